@@ -1,0 +1,683 @@
+"""Compile a (sliced) contraction tree into a static device plan.
+
+cotengra executes a tree eagerly: per pairwise step it materialises
+``transpose -> reshape -> matmul -> reshape -> transpose`` through a generic
+array API and allocates every intermediate (reference
+``cotengra/contract.py:364-411, 791-832``).  The MI355X executor instead
+compiles the tree ONCE into a flat list of *gather-GEMM* steps:
+
+    C[rowC(R) + colC(n)] = alpha * sum_k A[rowA(R) + kA(k)] * B[rowB(R) + kB(k) + colB(n)]
+
+where every index of the pairwise einsum belongs to exactly one of four
+groups -- batch/kept-left (rows ``R``), contracted (``k``), kept-right
+(``n``) -- and each operand's address is a *sum of per-group offset tables*.
+No operand is ever permuted or reshaped in memory: the axis permutation the
+reference performs with ``transpose`` + ``reshape`` copies is folded into the
+offset tables and realised inside the GEMM kernel's (coalesced, LDS-staged)
+load path.  The same classification as the reference's
+``_parse_eq_to_batch_matmul`` (contract.py:168-329) is used -- batch =
+on A, B and out; contracted = on A and B only; kept = on one operand and out
+-- but its output is addressing metadata instead of array ops.
+
+Slicing an index is likewise free: a sliced leaf is a strided view of the
+full input resident in HBM whose base offset depends on the slice id
+(reference ``core.py:3802-3819`` does the same with numpy views); the plan
+records per-leaf strides of the sliced indices and the executor's prologue
+kernel turns a slice id into base offsets on the device.
+
+Intermediates live in one arena whose offsets are assigned here from the
+traversal's liveness (the reference frees operands by ``temps.pop``,
+contract.py:806-807; its peak model is core.py:1299-1316).
+
+The plan is serialised to flat int64 arrays (see ``Plan.serialise``) and
+handed through the C ABI in ``include/ctg_hip.h``.
+"""
+
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass, field
+
+import numpy as np
+
+from .utils import eq_to_inputs_output, prod
+
+# ---- constants shared with csrc/ctg_common.h ------------------------------ #
+
+DTYPE_CODES = {"float32": 0, "float64": 1, "complex64": 2, "complex128": 3}
+DTYPE_ITEMSIZE = {"float32": 4, "float64": 8, "complex64": 8, "complex128": 16}
+
+KIND_SINGLE = 0  # out[o] = sum_s in[offO(o) + offS(s)]
+KIND_PAIR = 1  # gather-GEMM, see module docstring
+KIND_ACCUM = 2  # result[chunk + offR(o)] += src[o]
+
+KERNEL_VALU = 0  # one thread per output element, any dtype / any shape
+KERNEL_MFMA = 1  # LDS-tiled fp32-MFMA kernel (complex64 / float32)
+
+SPACE_INPUTS = 0
+SPACE_ARENA = 1
+SPACE_RESULT = 2
+
+STEP_WORDS = 48  # int64 words per serialised step record
+LO_MAX = 4096  # target size of the fast ('lo') level of a row table
+ARENA_ALIGN = 64  # elements; keeps every intermediate 256-B aligned
+
+# MFMA kernel limits (see csrc/ctg_pair_mfma.hip)
+MFMA_MAX_BATCH = 65535
+
+
+def _row_major_strides(shape):
+    strides = [1] * len(shape)
+    for i in range(len(shape) - 2, -1, -1):
+        strides[i] = strides[i + 1] * shape[i + 1]
+    return tuple(strides)
+
+
+def group_table(extents, strides):
+    """Flat offset table of an index group: entry ``i`` (row-major over
+    ``extents``, last fastest) is ``sum_j digit_j(i) * strides[j]``."""
+    table = np.zeros(1, dtype=np.int64)
+    for d, s in zip(extents, strides):
+        table = (table[:, None] + (np.arange(d, dtype=np.int64) * s)[None, :])
+        table = table.reshape(-1)
+    return table
+
+
+def split_point(extents, lo_max=LO_MAX):
+    """Number of trailing dims forming the 'lo' level of a two-level table:
+    the longest suffix whose product stays <= ``lo_max`` (at least one dim if
+    there is any)."""
+    lo = 1
+    n = 0
+    for d in reversed(extents):
+        if lo * d > lo_max and n > 0:
+            break
+        lo *= d
+        n += 1
+    return n, lo
+
+
+@dataclass
+class TensorRef:
+    """Where a tensor lives and how it is laid out.
+
+    ``inds`` may contain repeated labels only for raw leaves that still need
+    a SINGLE (diag/trace) preprocessing step."""
+
+    space: int
+    offset: int  # static element offset inside the space
+    leaf: int  # input number whose slice offset applies, or -1
+    inds: tuple
+    strides: tuple  # element strides per axis
+    size: int  # number of addressable elements (for bounds checks)
+
+    def stride_of(self, ix):
+        """Total stride of label ``ix`` (sum over repeats; 0 if absent)."""
+        return sum(s for i, s in zip(self.inds, self.strides) if i == ix)
+
+
+@dataclass
+class Step:
+    kind: int
+    kernel: int = KERNEL_VALU
+    a: TensorRef = None
+    b: TensorRef = None
+    c: TensorRef = None
+    # group extents
+    R: int = 1  # rows = batch * M   (VALU) ; M (MFMA)
+    Bt: int = 1  # batch (MFMA only; VALU folds it into R)
+    K: int = 1
+    N: int = 1
+    # two-level row tables: lo_size, per-operand (hi, lo) arrays
+    row_lo: int = 1
+    rows: dict = field(default_factory=dict)  # 'A','B','C' -> (hi, lo)
+    k_tabs: dict = field(default_factory=dict)  # 'A','B' -> flat
+    n_tabs: dict = field(default_factory=dict)  # 'B','C' -> flat
+    b_tabs: dict = field(default_factory=dict)  # 'A','B','C' -> flat (MFMA)
+    # bookkeeping for rooflines / debugging
+    macs: int = 0
+    elems_rw: int = 0
+    node: int = -1
+    label: str = ""
+    conj_free: bool = True
+
+
+class Arena:
+    """First-fit free-list allocator over element offsets."""
+
+    def __init__(self, align=ARENA_ALIGN):
+        self.align = align
+        self.free = []  # sorted list of (offset, size)
+        self.top = 0
+        self.peak = 0
+
+    def _round(self, n):
+        return (n + self.align - 1) // self.align * self.align
+
+    def alloc(self, n):
+        n = self._round(max(n, 1))
+        for i, (off, sz) in enumerate(self.free):
+            if sz >= n:
+                if sz == n:
+                    self.free.pop(i)
+                else:
+                    self.free[i] = (off + n, sz - n)
+                return off
+        # grow; merge with a trailing free block if it touches the top
+        if self.free and self.free[-1][0] + self.free[-1][1] == self.top:
+            off, sz = self.free.pop()
+            self.top = off + n
+        else:
+            off = self.top
+            self.top += n
+        self.peak = max(self.peak, self.top)
+        return off
+
+    def release(self, off, n):
+        n = self._round(max(n, 1))
+        self.free.append((off, n))
+        self.free.sort()
+        merged = []
+        for o, s in self.free:
+            if merged and merged[-1][0] + merged[-1][1] == o:
+                merged[-1] = (merged[-1][0], merged[-1][1] + s)
+            else:
+                merged.append((o, s))
+        self.free = merged
+
+
+class Plan:
+    """A compiled contraction: steps + tables + slice metadata."""
+
+    def __init__(self, dtype):
+        if dtype not in DTYPE_CODES:
+            raise ValueError(f"unsupported dtype {dtype}")
+        self.dtype = dtype
+        self.steps = []
+        self.input_sizes = []  # elements per (unsliced) input
+        self.input_offsets = []  # element offset of each input in the inputs space
+        self.arena_elems = 0
+        self.result_elems = 1
+        self.result_shape = ()
+        # slicing
+        self.slice_sizes = []  # extent per sliced index (1 if projected)
+        self.slice_fixed = []  # projected value or -1
+        self.slice_strides = None  # (n_inputs + 1, n_sliced) element strides
+        self.nslices = 1
+        # accounting
+        self.macs_per_slice = 0
+        self.elems_rw_per_slice = 0
+
+    # ------------------------------------------------------------------ #
+
+    @property
+    def itemsize(self):
+        return DTYPE_ITEMSIZE[self.dtype]
+
+    @property
+    def is_complex(self):
+        return self.dtype.startswith("complex")
+
+    def flops_per_slice(self):
+        """Real floating point operations per slice: 8 per complex
+        multiply-add, 2 per real one."""
+        return (8 if self.is_complex else 2) * self.macs_per_slice
+
+    def bytes_per_slice(self):
+        """Algorithmic bytes per slice: every operand read once and every
+        result written once, permutes assumed fused."""
+        return self.itemsize * self.elems_rw_per_slice
+
+    # ------------------------------------------------------------------ #
+
+    def serialise(self):
+        """Flatten to ``(header, steps, tables)`` int64 arrays for the C ABI.
+
+        tables is one blob; each step record stores word offsets into it.
+        Layout of a step record (STEP_WORDS int64 words):
+
+          0 kind            1 kernel
+          2 a.space  3 a.offset  4 a.leaf
+          5 b.space  6 b.offset  7 b.leaf
+          8 c.space  9 c.offset 10 c.leaf
+         11 R   12 Bt   13 K   14 N
+         15 row_lo   16 row_hi_len
+         17 rowA_hi 18 rowA_lo 19 rowB_hi 20 rowB_lo 21 rowC_hi 22 rowC_lo
+         23 kA   24 kB   25 nB   26 nC
+         27 bA   28 bB   29 bC
+         30 a.size 31 b.size 32 c.size      (bounds, elements)
+         33 macs    34 elems_rw   35 node
+         36.. reserved (0)
+        """
+        blobs = []
+        cursor = 0
+
+        def put(arr):
+            nonlocal cursor
+            arr = np.ascontiguousarray(arr, dtype=np.int64)
+            off = cursor
+            blobs.append(arr)
+            cursor += arr.size
+            return off
+
+        zero = put(np.zeros(1, dtype=np.int64))  # shared all-zero table
+
+        recs = np.zeros((len(self.steps), STEP_WORDS), dtype=np.int64)
+        for i, s in enumerate(self.steps):
+            r = recs[i]
+            r[0], r[1] = s.kind, s.kernel
+            for base, t in ((2, s.a), (5, s.b), (8, s.c)):
+                if t is not None:
+                    r[base : base + 3] = (t.space, t.offset, t.leaf)
+                else:
+                    r[base : base + 3] = (-1, 0, -1)
+            r[11], r[12], r[13], r[14] = s.R, s.Bt, s.K, s.N
+            r[15] = s.row_lo
+            hi_len = 1
+            for j, key in enumerate("ABC"):
+                if key in s.rows:
+                    hi, lo = s.rows[key]
+                    hi_len = len(hi)
+                    r[17 + 2 * j] = put(hi)
+                    r[18 + 2 * j] = put(lo)
+                else:
+                    r[17 + 2 * j] = -1
+                    r[18 + 2 * j] = -1
+            r[16] = hi_len
+            r[23] = put(s.k_tabs["A"]) if "A" in s.k_tabs else zero
+            r[24] = put(s.k_tabs["B"]) if "B" in s.k_tabs else zero
+            r[25] = put(s.n_tabs["B"]) if "B" in s.n_tabs else zero
+            r[26] = put(s.n_tabs["C"]) if "C" in s.n_tabs else zero
+            for j, key in enumerate("ABC"):
+                r[27 + j] = put(s.b_tabs[key]) if key in s.b_tabs else zero
+            r[30] = s.a.size if s.a is not None else 0
+            r[31] = s.b.size if s.b is not None else 0
+            r[32] = s.c.size if s.c is not None else 0
+            r[33], r[34], r[35] = s.macs, s.elems_rw, s.node
+
+        tables = np.concatenate(blobs) if blobs else np.zeros(1, np.int64)
+        n_in = len(self.input_sizes)
+        n_sl = len(self.slice_sizes)
+        slice_strides = (
+            np.ascontiguousarray(self.slice_strides, dtype=np.int64)
+            if n_sl
+            else np.zeros((n_in + 1, 0), dtype=np.int64)
+        )
+        return {
+            "dtype": DTYPE_CODES[self.dtype],
+            "input_sizes": np.asarray(self.input_sizes, dtype=np.int64),
+            "input_offsets": np.asarray(self.input_offsets, dtype=np.int64),
+            "arena_elems": int(self.arena_elems),
+            "result_elems": int(self.result_elems),
+            "steps": recs.reshape(-1),
+            "n_steps": len(self.steps),
+            "tables": tables,
+            "slice_sizes": np.asarray(self.slice_sizes, dtype=np.int64),
+            "slice_fixed": np.asarray(self.slice_fixed, dtype=np.int64),
+            "slice_strides": slice_strides.reshape(-1),
+        }
+
+    def describe_steps(self):
+        """Per-step rows for roofline tables (cf. the reference's
+        ``print_contractions``, core.py:3508)."""
+        rows = []
+        for i, s in enumerate(self.steps):
+            rows.append(
+                {
+                    "step": i,
+                    "kind": ("single", "pair", "accum")[s.kind],
+                    "kernel": ("valu", "mfma")[s.kernel],
+                    "R": s.R,
+                    "Bt": s.Bt,
+                    "K": s.K,
+                    "N": s.N,
+                    "macs": s.macs,
+                    "bytes": s.elems_rw * self.itemsize,
+                    "label": s.label,
+                }
+            )
+        return rows
+
+
+# --------------------------------------------------------------------------- #
+# step builders
+# --------------------------------------------------------------------------- #
+
+
+def _rows_two_level(extents, stride_lists, lo_max=LO_MAX):
+    """Two-level tables for a row group shared by several operands.
+
+    Returns ``(lo_size, [(hi, lo), ...])`` with
+    ``off(i) = hi[i // lo_size] + lo[i % lo_size]``."""
+    nlo, lo_size = split_point(extents, lo_max)
+    cut = len(extents) - nlo
+    out = []
+    for strides in stride_lists:
+        hi = group_table(extents[:cut], strides[:cut])
+        lo = group_table(extents[cut:], strides[cut:])
+        out.append((hi, lo))
+    return lo_size, out
+
+
+def choose_kernel(dtype, Bt, M, K, N):
+    """MFMA for complex64/float32 steps big enough to fill tiles; the VALU
+    kernel for everything else (tiny leaves, outer products, Hadamards,
+    skinny memory-bound steps, and the float64/complex128 parity mode)."""
+    if dtype not in ("complex64", "float32"):
+        return KERNEL_VALU
+    if Bt > MFMA_MAX_BATCH:
+        return KERNEL_VALU
+    if K >= 4 and N >= 8 and M >= 32 and (M * N * K) >= (1 << 15):
+        return KERNEL_MFMA
+    return KERNEL_VALU
+
+
+def build_pair_step(
+    dtype, size_dict, l, r, out_inds, out_ref_factory, node=-1, force_kernel=None
+):
+    """Lower one pairwise einsum ``l, r -> out_inds`` to a PAIR step.
+
+    ``out_ref_factory(inds, natural) -> TensorRef`` allocates the result;
+    ``natural`` is the kernel-preferred index order ``[batch, M, N]`` and the
+    factory may ignore it (the root must honour the user's output order).
+    """
+    l_set, r_set, o_set = set(l.inds), set(r.inds), set(out_inds)
+    if not o_set <= (l_set | r_set):
+        missing = o_set - (l_set | r_set)
+        raise ValueError(f"Output indices {missing} not found on any input.")
+
+    keep_l = [ix for ix in dict.fromkeys(l.inds) if ix in o_set and ix not in r_set]
+    keep_r = [ix for ix in dict.fromkeys(r.inds) if ix in o_set and ix not in l_set]
+    rows_l = prod(size_dict[ix] for ix in keep_l)
+    rows_r = prod(size_dict[ix] for ix in keep_r)
+    # the operand with more kept elements supplies the GEMM rows
+    if rows_r > rows_l:
+        A, B = r, l
+        keep_a, keep_b = keep_r, keep_l
+    else:
+        A, B = l, r
+        keep_a, keep_b = keep_l, keep_r
+    a_set, b_set = set(A.inds), set(B.inds)
+
+    a_order = list(dict.fromkeys(A.inds))
+    b_order = list(dict.fromkeys(B.inds))
+    batch = [ix for ix in a_order if ix in b_set and ix in o_set]
+    # contracted / summed: everything not in the output (an index living on
+    # one operand only is simply summed -- zero stride on the other operand)
+    con = [ix for ix in a_order if ix not in o_set]
+    con += [ix for ix in b_order if ix not in o_set and ix not in a_set]
+
+    ext = lambda g: [size_dict[ix] for ix in g]  # noqa: E731
+    Bt, M, K, N = (prod(ext(g)) for g in (batch, keep_a, con, keep_b))
+
+    natural = tuple(batch) + tuple(keep_a) + tuple(keep_b)
+    C = out_ref_factory(tuple(out_inds), natural)
+
+    kernel = force_kernel
+    if kernel is None:
+        kernel = choose_kernel(dtype, Bt, M, K, N)
+
+    step = Step(kind=KIND_PAIR, kernel=kernel, a=A, b=B, c=C, node=node)
+    step.K, step.N = K, N
+    step.k_tabs["A"] = group_table(ext(con), [A.stride_of(ix) for ix in con])
+    step.k_tabs["B"] = group_table(ext(con), [B.stride_of(ix) for ix in con])
+    step.n_tabs["B"] = group_table(ext(keep_b), [B.stride_of(ix) for ix in keep_b])
+    step.n_tabs["C"] = group_table(ext(keep_b), [C.stride_of(ix) for ix in keep_b])
+
+    if kernel == KERNEL_MFMA:
+        step.R, step.Bt = M, Bt
+        rows_g = keep_a
+        lo, tabs = _rows_two_level(
+            ext(rows_g),
+            [
+                [A.stride_of(ix) for ix in rows_g],
+                [C.stride_of(ix) for ix in rows_g],
+            ],
+        )
+        step.row_lo = lo
+        step.rows["A"], step.rows["C"] = tabs
+        for key, t in (("A", A), ("B", B), ("C", C)):
+            step.b_tabs[key] = group_table(
+                ext(batch), [t.stride_of(ix) for ix in batch]
+            )
+    else:
+        step.R, step.Bt = Bt * M, 1
+        rows_g = batch + keep_a
+        lo, tabs = _rows_two_level(
+            ext(rows_g),
+            [
+                [A.stride_of(ix) for ix in rows_g],
+                [B.stride_of(ix) if ix in batch else 0 for ix in rows_g],
+                [C.stride_of(ix) for ix in rows_g],
+            ],
+        )
+        step.row_lo = lo
+        step.rows["A"], step.rows["B"], step.rows["C"] = tabs
+
+    step.macs = Bt * M * K * N
+    step.elems_rw = (
+        prod(ext(dict.fromkeys(A.inds)))
+        + prod(ext(dict.fromkeys(B.inds)))
+        + Bt * M * N
+    )
+    step.label = (
+        f"{''.join(map(str, A.inds))},{''.join(map(str, B.inds))}"
+        f"->{''.join(map(str, C.inds))}"
+        if max(len(A.inds), len(B.inds)) <= 12
+        else f"b{Bt} m{M} k{K} n{N}"
+    )
+    return step
+
+
+def build_single_step(size_dict, src, out_inds, out_ref_factory, node=-1):
+    """Lower a single-term einsum (diagonals, traces, sums, transposes;
+    reference contract.py:62-119, 332-361) to a SINGLE step:
+    ``out[o] = sum_s src[offO(o) + offS(s)]`` where repeated labels simply
+    add their strides (a diagonal) and labels absent from the output are
+    summed."""
+    src_unique = list(dict.fromkeys(src.inds))
+    o_set = set(out_inds)
+    if not o_set <= set(src_unique):
+        raise ValueError("Output index not present on the input term.")
+    if len(set(out_inds)) != len(out_inds):
+        raise ValueError("Repeated output indices are not supported.")
+    summed = [ix for ix in src_unique if ix not in o_set]
+    ext = lambda g: [size_dict[ix] for ix in g]  # noqa: E731
+    C = out_ref_factory(tuple(out_inds), tuple(out_inds))
+
+    step = Step(kind=KIND_SINGLE, a=src, c=C, node=node)
+    rows_g = list(C.inds)  # iterate outputs in the result's memory order
+    step.R = prod(ext(rows_g))
+    lo, tabs = _rows_two_level(
+        ext(rows_g),
+        [
+            [src.stride_of(ix) for ix in rows_g],
+            [C.stride_of(ix) for ix in rows_g],
+        ],
+    )
+    step.row_lo = lo
+    step.rows["A"], step.rows["C"] = tabs
+    step.K = prod(ext(summed))
+    step.k_tabs["A"] = group_table(ext(summed), [src.stride_of(ix) for ix in summed])
+    step.macs = 0
+    step.elems_rw = step.R * step.K + step.R
+    step.label = (
+        f"{''.join(map(str, src.inds))}->{''.join(map(str, C.inds))}"
+        if len(src.inds) <= 16
+        else f"single r{step.R} s{step.K}"
+    )
+    return step
+
+
+# --------------------------------------------------------------------------- #
+# whole-tree compilation
+# --------------------------------------------------------------------------- #
+
+
+def compile_tree(tree, dtype, order=None, force_kernel=None):
+    """Compile ``tree`` (possibly sliced) into a :class:`Plan` that computes
+    ONE slice and accumulates it into the full result tensor.
+
+    The traversal order and the set of steps are exactly those of the
+    reference's ``extract_contractions`` (contract.py:573-651): optional
+    per-leaf single-term preprocessing, then one pairwise step per tree
+    node, bottom-up.
+    """
+    plan = Plan(dtype)
+    size_dict = tree.size_dict
+    N = tree.N
+
+    # -- inputs space: all (unsliced) inputs back to back, 64-element aligned
+    cursor = 0
+    for term in tree.inputs:
+        n = prod(size_dict[ix] for ix in term)
+        plan.input_sizes.append(n)
+        plan.input_offsets.append(cursor)
+        cursor += (n + ARENA_ALIGN - 1) // ARENA_ALIGN * ARENA_ALIGN
+
+    # -- result: the full output tensor (all slices accumulate into it)
+    plan.result_shape = tuple(size_dict[ix] for ix in tree.output)
+    plan.result_elems = prod(plan.result_shape)
+    full_out_strides = dict(
+        zip(tree.output, _row_major_strides(plan.result_shape))
+    )
+
+    # -- slicing metadata
+    sliced = list(tree.sliced_inds.values())
+    plan.nslices = tree.multiplicity
+    plan.slice_sizes = [si.size for si in sliced]
+    plan.slice_fixed = [(-1 if si.project is None else si.project) for si in sliced]
+    strides = np.zeros((N + 1, len(sliced)), dtype=np.int64)
+    for i, term in enumerate(tree.inputs):
+        shape = [size_dict[ix] for ix in term]
+        st = _row_major_strides(shape)
+        for j, si in enumerate(sliced):
+            strides[i, j] = sum(s for ix, s in zip(term, st) if ix == si.ind)
+    for j, si in enumerate(sliced):
+        strides[N, j] = full_out_strides.get(si.ind, 0)
+    plan.slice_strides = strides
+
+    arena = Arena()
+    arena_live = {}  # id(TensorRef) -> (offset, nelems)
+
+    def arena_factory(force_order=None):
+        def make(inds, natural):
+            order_ = force_order if force_order is not None else natural
+            shape = [size_dict[ix] for ix in order_]
+            n = prod(shape)
+            off = arena.alloc(n)
+            ref = TensorRef(
+                SPACE_ARENA, off, -1, tuple(order_), _row_major_strides(shape), n
+            )
+            arena_live[id(ref)] = (off, n)
+            return ref
+
+        return make
+
+    def release(ref):
+        if ref.space == SPACE_ARENA:
+            off, n = arena_live.pop(id(ref))
+            arena.release(off, n)
+
+    def add(step):
+        plan.steps.append(step)
+        plan.macs_per_slice += step.macs
+        plan.elems_rw_per_slice += step.elems_rw
+
+    # -- leaves: strided views of the resident inputs
+    tensors = {}
+    for i, term in enumerate(tree.inputs):
+        full_shape = [size_dict[ix] for ix in term]
+        st = _row_major_strides(full_shape)
+        kept = [(ix, s) for ix, s in zip(term, st) if ix not in tree.sliced_inds]
+        view = TensorRef(
+            SPACE_INPUTS,
+            plan.input_offsets[i],
+            i,
+            tuple(ix for ix, _ in kept),
+            tuple(s for _, s in kept),
+            plan.input_sizes[i],
+        )
+        legs = tree.get_legs(i)  # also fills tree.preprocessing lazily
+        if i in tree.preprocessing and N > 1:
+            step = build_single_step(
+                size_dict, view, tuple(legs), arena_factory(), node=i
+            )
+            add(step)
+            tensors[i] = step.c
+        else:
+            tensors[i] = view
+
+    root_order = tuple(ix for ix in tree.output if ix not in tree.sliced_inds)
+
+    if N == 1:
+        step = build_single_step(
+            size_dict, tensors[0], root_order, arena_factory(), node=tree.root
+        )
+        add(step)
+        final = step.c
+    else:
+        final = None
+        for p, l, r in tree.traverse(order=order):
+            is_root = p == tree.root
+            factory = arena_factory(root_order if is_root else None)
+            p_inds = root_order if is_root else tuple(tree.get_legs(p))
+            step = build_pair_step(
+                dtype,
+                size_dict,
+                tensors.pop(l),
+                tensors.pop(r),
+                p_inds,
+                factory,
+                node=p,
+                force_kernel=force_kernel,
+            )
+            add(step)
+            release(step.a)
+            release(step.b)
+            tensors[p] = step.c
+            final = step.c
+
+    # -- accumulate the slice into the full result at its chunk position
+    acc = Step(kind=KIND_ACCUM, a=final, node=-1, label="accumulate")
+    res = TensorRef(
+        SPACE_RESULT,
+        0,
+        N,  # pseudo-leaf N carries the chunk offset of outer-sliced indices
+        root_order,
+        tuple(full_out_strides[ix] for ix in root_order),
+        plan.result_elems,
+    )
+    acc.c = res
+    rows_g = list(final.inds)
+    ext = [size_dict[ix] for ix in rows_g]
+    acc.R = prod(ext)
+    lo, tabs = _rows_two_level(
+        ext,
+        [
+            [final.stride_of(ix) for ix in rows_g],
+            [res.stride_of(ix) for ix in rows_g],
+        ],
+    )
+    acc.row_lo = lo
+    acc.rows["A"], acc.rows["C"] = tabs
+    acc.elems_rw = 0
+    add(acc)
+    release(final)
+
+    plan.arena_elems = max(arena.peak, ARENA_ALIGN)
+    plan.inputs_elems = max(cursor, ARENA_ALIGN)
+    return plan
+
+
+def compile_pairwise(eq, shape_a, shape_b, dtype, force_kernel=None):
+    """Plan for a single public ``einsum(eq, a, b)`` call (reference
+    contract.py:414-459): a one-step tree over two inputs, including the
+    cases the tree never produces (indices summed from one operand, size-1
+    broadcast dims)."""
+    (ta, tb), out = eq_to_inputs_output(eq)
+    if len(ta) != len(shape_a):
+        raise ValueError(f"Term '{''.join(ta)}' does not match shape {shape_a}.")
+    if len(tb) != len(shape_b):
+        raise ValueError(f"Term '{''.join(tb)}' does not match shape {shape_b}.")
+    return (ta, tb), out
