@@ -1,0 +1,439 @@
+"""The whole-tree HIP contractor and the execution drivers behind
+``ContractionTree.contract / contract_core / contract_slice / gather_slices``.
+
+The reference offers two plug-in points for execution:
+per-op ``implementation=(einsum, tensordot)`` and the whole-tree backend
+``CuQuantumContractor`` chosen in ``make_contractor``
+(``cotengra/contract.py:840-1006``).  ``HipContractor`` fills the second slot
+for MI355X: it is built once from a tree, lazily set up on the first call
+(plan compilation + device residency), and then called with the arrays.
+
+Arrays may be numpy arrays (copied host->device once per call) or torch
+tensors already on a ROCm device (device-to-device copy into the executor's
+input space, result returned as a torch tensor on the same device).
+"""
+
+from __future__ import annotations
+
+import math
+import time
+
+import numpy as np
+
+from . import runtime
+from .plan import DTYPE_CODES, compile_tree
+from .utils import prod
+
+_SUPPORTED = tuple(DTYPE_CODES)
+
+
+def _is_torch(x):
+    return type(x).__module__.split(".")[0] == "torch"
+
+
+def _result_dtype(arrays):
+    names = []
+    for x in arrays:
+        dt = str(x.dtype).replace("torch.", "")
+        names.append(dt)
+    dt = np.result_type(*[np.dtype(n) for n in names]).name
+    if dt not in _SUPPORTED:
+        # integers / half precision are promoted like numpy would for matmul
+        dt = np.result_type(np.dtype(dt), np.float32).name
+        if dt not in _SUPPORTED:
+            raise TypeError(f"Unsupported array dtype {dt}.")
+    return dt
+
+
+class HipContractor:
+    """Callable performing the contraction of ``tree`` on an MI355X.
+
+    Parameters
+    ----------
+    tree : ContractionTree
+    order : str or callable, optional
+        Traversal order (``ContractionTree.traverse``).
+    strip_exponent, check_zero, progbar
+        Defaults that a call may override, as for the reference's
+        ``Contractor`` (contract.py:718-742).
+    handle_slicing : bool
+        True: calls take the *unsliced* arrays and return the full output
+        (all slices run and are gathered on the device).  False: calls take
+        arrays that were already sliced (``tree.contract_core`` semantics,
+        core.py:3724-3773).
+    device : int, optional
+        GPU ordinal for numpy inputs (torch inputs bring their own device).
+    """
+
+    def __init__(
+        self,
+        tree,
+        order=None,
+        strip_exponent=False,
+        check_zero=False,
+        progbar=False,
+        handle_slicing=True,
+        device=None,
+        force_kernel=None,
+    ):
+        if handle_slicing or not tree.sliced_inds:
+            self.tree = tree
+        else:
+            self.tree = _sliced_twin(tree)
+        self.order = order
+        self.strip_exponent = strip_exponent
+        self.check_zero = check_zero
+        self.progbar = progbar
+        self.device = device
+        self.force_kernel = force_kernel
+        self._plans = {}  # dtype -> (Plan, DevicePlan)
+        self._execs = {}  # (dtype, device, torch?) -> state dict
+
+    # ------------------------------------------------------------------ #
+
+    def get_plan(self, dtype):
+        try:
+            return self._plans[dtype]
+        except KeyError:
+            plan = compile_tree(
+                self.tree, dtype, order=self.order, force_kernel=self.force_kernel
+            )
+            entry = self._plans[dtype] = (plan, runtime.DevicePlan(plan))
+            return entry
+
+    def _get_exec(self, dtype, device, use_torch):
+        key = (dtype, device, use_torch)
+        try:
+            return self._execs[key]
+        except KeyError:
+            pass
+        plan, dplan = self.get_plan(dtype)
+        st = {"plan": plan}
+        if use_torch:
+            import torch
+
+            dev = torch.device("cuda", device)
+            res = torch.zeros(
+                plan.result_shape, dtype=getattr(torch, dtype), device=dev
+            )
+            stream = torch.cuda.current_stream(dev).cuda_stream
+            st["result"] = res
+            st["exec"] = runtime.Executor(
+                dplan, device=device, stream=stream, result_ptr=res.data_ptr()
+            )
+        else:
+            st["exec"] = runtime.Executor(dplan, device=device)
+        self._execs[key] = st
+        return st
+
+    def setup(self, *arrays):
+        """Make ``arrays`` resident and return the executor state (the
+        analogue of ``CuQuantumContractor.setup``, contract.py:883-899)."""
+        if len(arrays) != self.tree.N:
+            raise ValueError(
+                f"Expected {self.tree.N} arrays, got {len(arrays)}."
+            )
+        shapes = self.tree.get_shapes()
+        for i, (x, s) in enumerate(zip(arrays, shapes)):
+            if tuple(x.shape) != tuple(s):
+                raise ValueError(
+                    f"Array {i} has shape {tuple(x.shape)} but the tree "
+                    f"expects {tuple(s)}."
+                )
+        dtype = _result_dtype(arrays)
+        torch_in = [x for x in arrays if _is_torch(x) and x.is_cuda]
+        if torch_in:
+            import torch
+
+            device = torch_in[0].device.index or 0
+            st = self._get_exec(dtype, device, True)
+            tdt = getattr(torch, dtype)
+            keep = []
+            for x in arrays:
+                if not _is_torch(x):
+                    x = torch.as_tensor(np.asarray(x))
+                keep.append(
+                    x.to(device=torch_in[0].device, dtype=tdt).contiguous()
+                )
+            st["exec"].upload_device(
+                [t.data_ptr() for t in keep], [t.numel() for t in keep]
+            )
+            st["keep"] = keep
+        else:
+            device = self.device if self.device is not None else 0
+            st = self._get_exec(dtype, device, False)
+            host = [
+                x.detach().cpu().numpy() if _is_torch(x) else np.asarray(x)
+                for x in arrays
+            ]
+            st["exec"].upload_host(host)
+        return st
+
+    def _finish(self, st, strip_exponent, check_zero, index=None):
+        if "result" in st:
+            out = st["result"]
+            out = out[index] if index is not None else out
+            out = out.clone()
+            if not strip_exponent:
+                return out
+            import torch
+
+            factor = float(torch.max(torch.abs(out))) if out.numel() else 0.0
+        else:
+            out = st["exec"].download_result()
+            if index is not None:
+                out = out[index]
+            if out.ndim == 0 and not strip_exponent:
+                return out[()]
+            if not strip_exponent:
+                return out
+            factor = float(np.max(np.abs(out))) if out.size else 0.0
+        if factor == 0.0:
+            if check_zero:
+                return 0.0, float("-inf")
+            return out, float("-inf")
+        return out / factor, math.log10(factor)
+
+    def __call__(self, *arrays, **kwargs):
+        backend = kwargs.pop("backend", None)  # noqa: F841  (inferred from arrays)
+        kwargs.pop("progbar", None)
+        check_zero = kwargs.pop("check_zero", self.check_zero)
+        strip_exponent = kwargs.pop("strip_exponent", self.strip_exponent)
+        kwargs.pop("implementation", None)
+        if kwargs:
+            raise TypeError(f"Unknown keyword arguments: {kwargs}.")
+        st = self.setup(*arrays)
+        ex = st["exec"]
+        ex.zero_result()
+        ex.run_slices(0, self.tree.multiplicity, 1)
+        return self._finish(st, strip_exponent, check_zero)
+
+    def contract_slice(self, arrays, i, strip_exponent=False, check_zero=False):
+        """Output of slice ``i`` only (sliced output indices removed)."""
+        st = self.setup(*arrays)
+        ex = st["exec"]
+        ex.zero_result()
+        ex.run_slices(int(i), 1, 1)
+        loc = self.tree.slice_key(int(i))
+        index = tuple(loc.get(ix, slice(None)) for ix in self.tree.output)
+        return self._finish(st, strip_exponent, check_zero, index=index)
+
+    def profile(self, arrays, slice_id=0):
+        """Per-step milliseconds for one slice (see ``Plan.describe_steps``)."""
+        st = self.setup(*arrays)
+        return st["plan"], st["exec"].profile_slice(slice_id)
+
+    def close(self):
+        for st in self._execs.values():
+            st["exec"].close()
+        self._execs.clear()
+        for _, dplan in self._plans.values():
+            dplan.close()
+        self._plans.clear()
+
+
+def _sliced_twin(tree):
+    """The same contraction schedule seen from inside one slice: sliced
+    indices are removed from every term, nothing is sliced."""
+    from .tree import ContractionTree
+
+    twin = ContractionTree(
+        tree.get_inputs_sliced(), tree.get_output_sliced(), tree.size_dict
+    )
+    twin.children = dict(tree.children)
+    twin._extent = dict(tree._extent)
+    twin._next_ssa = tree._next_ssa
+    # indices sliced away no longer count as appearances
+    return twin
+
+
+def make_contractor(
+    tree,
+    order=None,
+    prefer_einsum=False,
+    strip_exponent=False,
+    check_zero=False,
+    implementation=None,
+    autojit=False,
+    progbar=False,
+    handle_slicing=False,
+):
+    """Reference ``make_contractor`` (contract.py:925-1006) with the MI355X
+    executor as the only engine.  ``prefer_einsum`` and ``autojit`` are
+    accepted for signature compatibility and have no effect: the plan never
+    distinguishes tensordot from einsum steps and is already compiled."""
+    if implementation not in (None, "auto", "hip"):
+        raise ValueError(
+            f"implementation={implementation!r} is not available: cotengra_amd "
+            "executes whole trees with its HIP backend ('hip')."
+        )
+    return HipContractor(
+        tree,
+        order=order,
+        strip_exponent=strip_exponent,
+        check_zero=check_zero,
+        progbar=progbar,
+        handle_slicing=handle_slicing,
+    )
+
+
+def _tree_contractor(tree, order=None):
+    """Cached slicing-aware contractor of a tree."""
+    key = ("hip-sliced", order if not callable(order) else id(order))
+    try:
+        return tree.contraction_cores[key]
+    except KeyError:
+        fn = tree.contraction_cores[key] = HipContractor(
+            tree, order=order, handle_slicing=True
+        )
+        return fn
+
+
+def contract_tree(
+    tree,
+    arrays,
+    order=None,
+    prefer_einsum=False,
+    strip_exponent=False,
+    check_zero=False,
+    backend=None,
+    implementation=None,
+    autojit="auto",
+    progbar=False,
+):
+    """``ContractionTree.contract`` (core.py:3943-4030): every slice runs on
+    the device and accumulates into the resident output tensor."""
+    if implementation not in (None, "auto", "hip"):
+        raise ValueError(f"implementation={implementation!r} is not available.")
+    fn = _tree_contractor(tree, order)
+    return fn(
+        *arrays,
+        strip_exponent=strip_exponent is not False,
+        check_zero=check_zero,
+    )
+
+
+def contract_slice(tree, arrays, i, **kwargs):
+    """``ContractionTree.contract_slice`` (core.py:3821-3823)."""
+    order = kwargs.pop("order", None)
+    strip_exponent = kwargs.pop("strip_exponent", False)
+    check_zero = kwargs.pop("check_zero", False)
+    for k in ("prefer_einsum", "backend", "implementation", "autojit", "progbar"):
+        kwargs.pop(k, None)
+    if kwargs:
+        raise TypeError(f"Unknown keyword arguments: {kwargs}.")
+    if not 0 <= i < tree.multiplicity:
+        raise IndexError(f"slice {i} out of range [0, {tree.multiplicity})")
+    fn = _tree_contractor(tree, order)
+    return fn.contract_slice(
+        arrays, i, strip_exponent=strip_exponent is not False, check_zero=check_zero
+    )
+
+
+def _add_maybe_stripped(x, y):
+    """Exponent-aware sum of two slice outputs (core.py:125-172)."""
+    xt, yt = isinstance(x, tuple), isinstance(y, tuple)
+    if not (xt or yt):
+        return x + y
+    xm, xe = x if xt else (x, 0.0)
+    ym, ye = y if yt else (y, 0.0)
+    e = max(xe, ye)
+    return xm * 10 ** (xe - e) + ym * 10 ** (ye - e), e
+
+
+def gather_slices(tree, slices, backend=None, progbar=False):
+    """Host-side gather of explicitly computed slice outputs
+    (core.py:3825-3882); ``tree.contract`` never needs it because the device
+    accumulates, but it is part of the public surface."""
+    output_pos = {
+        ix: i for i, ix in enumerate(tree.output) if ix in tree.sliced_inds
+    }
+    if not output_pos:
+        import functools
+
+        return functools.reduce(_add_maybe_stripped, slices)
+    chunks = {}
+    for i, s in enumerate(slices):
+        ks = tree.slice_key(i)
+        key = tuple(ks[ix] for ix in output_pos)
+        chunks[key] = _add_maybe_stripped(chunks[key], s) if key in chunks else s
+    if isinstance(next(iter(chunks.values())), tuple):
+        emax = max(v[1] for v in chunks.values())
+        chunks = {k: m * 10 ** (e - emax) for k, (m, e) in chunks.items()}
+    else:
+        emax = None
+    first = next(iter(chunks.values()))
+    if _is_torch(first):
+        import torch
+
+        stack_fn = lambda arrs, ax: torch.stack(arrs, ax)  # noqa: E731
+    else:
+        stack_fn = lambda arrs, ax: np.stack(arrs, ax)  # noqa: E731
+
+    def stack(loc, remaining):
+        if not remaining:
+            return chunks[loc]
+        arrs = [
+            stack(loc + (d,), remaining[1:])
+            for d in tree.sliced_inds[remaining[0]].sliced_range
+        ]
+        return stack_fn(arrs, output_pos[remaining[0]] - len(loc))
+
+    result = stack((), tuple(output_pos))
+    return (result, emax) if emax is not None else result
+
+
+def gen_output_chunks(tree, arrays, with_key=False, progbar=False, **contract_opts):
+    """core.py:3884-3941: one chunk per combination of outer sliced indices,
+    inner slices summed on the device."""
+    order = contract_opts.pop("order", None)
+    fn = _tree_contractor(tree, order)
+    stepsize = prod(si.size for si in tree.sliced_inds.values() if si.inner)
+    st = fn.setup(*arrays)
+    ex = st["exec"]
+    for o in range(tree.nslices // stepsize):
+        ex.zero_result()
+        ex.run_slices(o * stepsize, stepsize, 1)
+        loc = tree.slice_key(o * stepsize)
+        index = tuple(
+            loc[ix] if (ix in loc and ix in tree.output) else slice(None)
+            for ix in tree.output
+        )
+        chunk = fn._finish(st, False, False, index=index)
+        if with_key:
+            yield chunk, {ix: x for ix, x in loc.items() if ix in tree.output}
+        else:
+            yield chunk
+
+
+def benchmark_tree(
+    tree, dtype="float64", max_time=60, min_reps=3, max_reps=100, warmup=True,
+    **contract_opts,
+):
+    """``ContractionTree.benchmark`` (core.py:4092-4164) on the device: the
+    inputs are made resident once, then ``contract_slice`` work is timed."""
+    from .utils import make_arrays_from_inputs
+
+    arrays = make_arrays_from_inputs(tree.inputs, tree.size_dict, dtype=dtype)
+    fn = _tree_contractor(tree, contract_opts.pop("order", None))
+    st = fn.setup(*arrays)
+    ex = st["exec"]
+    for i in range(int(warmup)):
+        ex.run_slices(i % tree.nslices, 1, 1)
+    ex.sync()
+    t0 = ti = time.time()
+    i = 0
+    while (ti - t0 < max_time) or (i < min_reps):
+        ex.run_slices(i % tree.nslices, 1, 1)
+        ex.sync()
+        ti = time.time()
+        i += 1
+        if i >= max_reps:
+            break
+    time_per_slice = (ti - t0) / i
+    est_time_total = time_per_slice * tree.nslices
+    return {
+        "time_per_slice": time_per_slice,
+        "est_time_total": est_time_total,
+        "est_gigaflops": tree.total_flops(dtype=dtype) / (1e9 * est_time_total),
+    }

@@ -1,0 +1,160 @@
+// ctg_common.h -- structures shared by the host runtime and the gfx950 kernels.
+//
+// Addressing model (see cotengra_amd/plan.py): every operand of a step is
+//   base + *slice_offset + sum over index groups of an offset-table entry
+// where the tables are int64 element offsets living in one device blob.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace ctg {
+
+// word offsets of the serialised step record (must match plan.py: Plan.serialise)
+enum StepWord {
+    W_KIND = 0, W_KERNEL = 1,
+    W_A_SPACE = 2, W_A_OFF = 3, W_A_LEAF = 4,
+    W_B_SPACE = 5, W_B_OFF = 6, W_B_LEAF = 7,
+    W_C_SPACE = 8, W_C_OFF = 9, W_C_LEAF = 10,
+    W_R = 11, W_BT = 12, W_K = 13, W_N = 14,
+    W_ROW_LO = 15, W_ROW_HI_LEN = 16,
+    W_ROWA_HI = 17, W_ROWA_LO = 18, W_ROWB_HI = 19, W_ROWB_LO = 20,
+    W_ROWC_HI = 21, W_ROWC_LO = 22,
+    W_KA = 23, W_KB = 24, W_NB = 25, W_NC = 26,
+    W_BA = 27, W_BB = 28, W_BC = 29,
+    W_A_SIZE = 30, W_B_SIZE = 31, W_C_SIZE = 32,
+    W_MACS = 33, W_ELEMS = 34, W_NODE = 35,
+    W_K_LO = 36, W_KA_HI = 37, W_KB_HI = 38, W_K_HI_LEN = 39,
+    STEP_WORDS = 48
+};
+
+enum Kind { KIND_SINGLE = 0, KIND_PAIR = 1, KIND_ACCUM = 2 };
+enum Kernel { KERNEL_VALU = 0, KERNEL_MFMA = 1 };
+enum Space { SPACE_INPUTS = 0, SPACE_ARENA = 1, SPACE_RESULT = 2 };
+
+// Two-level row table: off(i) = hi[i / lo_size] + lo[i % lo_size].
+struct RowTab {
+    const int64_t* hi;
+    const int64_t* lo;
+};
+
+// Kernel arguments of every step kind.  Pointers are device pointers; `soff*`
+// point at the per-slice base offset of the operand (or at a constant 0).
+struct StepArgs {
+    const void* A;
+    const void* B;
+    void* C;
+    const int64_t* soffA;
+    const int64_t* soffB;
+    const int64_t* soffC;
+    int64_t R;   // rows (VALU: batch*M, MFMA: M)
+    int64_t Bt;  // batch (MFMA)
+    int64_t K;
+    int64_t N;
+    int64_t row_lo;      // size of the fast level of the row tables
+    int32_t row_lo_shift;  // log2(row_lo) if a power of two, else -1
+    RowTab rowA, rowB, rowC;
+    // contracted group, two-level as well: K = k_hi_len * k_lo
+    int64_t k_lo;
+    int64_t k_hi_len;
+    int32_t k_lo_shift;  // log2(k_lo) if a power of two, else -1
+    RowTab kA, kB;
+    const int64_t* nB;
+    const int64_t* nC;
+    const int64_t* bA;
+    const int64_t* bB;
+    const int64_t* bC;
+};
+
+__device__ __forceinline__ void split_k(const StepArgs& p, int64_t k, int64_t& hi, int64_t& lo) {
+    if (p.k_lo_shift >= 0) {
+        hi = k >> p.k_lo_shift;
+        lo = k & (p.k_lo - 1);
+    } else {
+        hi = k / p.k_lo;
+        lo = k - hi * p.k_lo;
+    }
+}
+
+__device__ __forceinline__ void split_row(const StepArgs& p, int64_t i, int64_t& hi, int64_t& lo) {
+    if (p.row_lo_shift >= 0) {
+        hi = i >> p.row_lo_shift;
+        lo = i & (p.row_lo - 1);
+    } else {
+        hi = i / p.row_lo;
+        lo = i - hi * p.row_lo;
+    }
+}
+
+// ---- complex arithmetic on plain structs (no thrust / hip_complex) -------- //
+
+template <typename F>
+struct cplx {
+    F re, im;
+};
+typedef cplx<float> c64;
+typedef cplx<double> c128;
+
+template <typename T> struct Acc;  // accumulate helper
+
+__device__ __forceinline__ float zero_of(float) { return 0.f; }
+__device__ __forceinline__ double zero_of(double) { return 0.0; }
+__device__ __forceinline__ c64 zero_of(c64) { return c64{0.f, 0.f}; }
+__device__ __forceinline__ c128 zero_of(c128) { return c128{0.0, 0.0}; }
+
+__device__ __forceinline__ void fma_acc(float& acc, float a, float b) { acc = fmaf(a, b, acc); }
+__device__ __forceinline__ void fma_acc(double& acc, double a, double b) { acc = fma(a, b, acc); }
+template <typename F>
+__device__ __forceinline__ void fma_acc(cplx<F>& acc, cplx<F> a, cplx<F> b) {
+    acc.re = fma(a.re, b.re, acc.re);
+    acc.re = fma(-a.im, b.im, acc.re);
+    acc.im = fma(a.re, b.im, acc.im);
+    acc.im = fma(a.im, b.re, acc.im);
+}
+
+__device__ __forceinline__ float add_of(float a, float b) { return a + b; }
+__device__ __forceinline__ double add_of(double a, double b) { return a + b; }
+template <typename F>
+__device__ __forceinline__ cplx<F> add_of(cplx<F> a, cplx<F> b) {
+    return cplx<F>{a.re + b.re, a.im + b.im};
+}
+
+// wave-wide (64 lanes) sum via cross-lane shuffles
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    return v;
+}
+template <typename F>
+__device__ __forceinline__ cplx<F> wave_sum(cplx<F> v) {
+    return cplx<F>{wave_sum(v.re), wave_sum(v.im)};
+}
+
+// ---- launchers implemented in the kernel translation units ---------------- //
+
+// dtype: 0 f32, 1 f64, 2 c64, 3 c128
+hipError_t launch_pair_valu(int dtype, const StepArgs& p, void* scratch, int64_t scratch_bytes,
+                            hipStream_t stream);
+hipError_t launch_pair_mfma(int dtype, const StepArgs& p, int flags, hipStream_t stream);
+hipError_t launch_single(int dtype, const StepArgs& p, hipStream_t stream);
+hipError_t launch_accum(int dtype, const StepArgs& p, hipStream_t stream);
+
+struct SliceMeta {
+    int64_t n_leaves;  // n_inputs + 1 (last = result chunk offset)
+    int64_t n_sliced;
+    const int64_t* sizes;    // [n_sliced]
+    const int64_t* fixed;    // [n_sliced]
+    const int64_t* strides;  // [n_leaves * n_sliced]
+};
+// soff[n_leaves] receives the per-leaf base offsets of slice `sid`; with sid < 0
+// the id is taken from the device counter state[0], which is then advanced by
+// state[1] (lets a captured graph walk over slices without host involvement)
+hipError_t launch_prologue(const SliceMeta& m, int64_t* state, int64_t* soff, int64_t sid,
+                           hipStream_t stream);
+
+}  // namespace ctg

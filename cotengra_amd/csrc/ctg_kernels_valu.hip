@@ -1,0 +1,303 @@
+// ctg_kernels_valu.hip -- the dtype-generic (f32/f64/c64/c128) gfx950 kernels.
+//
+//   pair_valu   : gather-GEMM, one thread per output element, k-loop in
+//                 registers.  Serves tiny tree steps, outer products /
+//                 Hadamards (reference contract.py:122-164, 398-400), skinny
+//                 HBM-bound steps and the f64/c128 parity mode.
+//   pair_kred   : same op when there are few outputs but a long contracted
+//                 dimension (the last steps of an amplitude contraction):
+//                 lanes run along k (coalesced) and a wavefront shuffle
+//                 reduction + fixed-order partial sum produce each output.
+//   single      : single-term einsum -- diagonals, traces, sums, transposes
+//                 (reference contract.py:62-119, 332-361).
+//   accum       : result[chunk] += slice (reference core.py:3842-3876).
+//   prologue    : slice id -> per-leaf base offsets (reference
+//                 core.py:3775-3819), advancing the on-device slice counter so
+//                 that a whole slice is a static launch sequence.
+//
+// All loads go through offset tables (ctg_common.h); wave = 64 lanes.
+#include "ctg_common.h"
+
+namespace ctg {
+
+// ------------------------------------------------------------------------- //
+// pair: thread per output
+// ------------------------------------------------------------------------- //
+
+template <typename T>
+__global__ __launch_bounds__(256) void pair_valu_kernel(StepArgs p, int tn_shift,
+                                                        int64_t col_tiles, int64_t n_tiles) {
+    const T* __restrict__ A = (const T*)p.A + *p.soffA;
+    const T* __restrict__ B = (const T*)p.B + *p.soffB;
+    T* __restrict__ C = (T*)p.C + *p.soffC;
+    const int TN = 1 << tn_shift;
+    const int TR = 256 >> tn_shift;
+    const int c = threadIdx.x & (TN - 1);
+    const int r = threadIdx.x >> tn_shift;
+
+    for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const int64_t rt = tile / col_tiles;
+        const int64_t ct = tile - rt * col_tiles;
+        const int64_t row = rt * TR + r;
+        const int64_t n = ct * TN + c;
+        if (row >= p.R || n >= p.N) continue;
+        int64_t hi, lo;
+        split_row(p, row, hi, lo);
+        const T* a = A + p.rowA.hi[hi] + p.rowA.lo[lo];
+        const T* b = B + p.rowB.hi[hi] + p.rowB.lo[lo] + p.nB[n];
+        T acc = zero_of(T{});
+        for (int64_t kh = 0; kh < p.k_hi_len; ++kh) {
+            const T* a2 = a + p.kA.hi[kh];
+            const T* b2 = b + p.kB.hi[kh];
+            for (int64_t kl = 0; kl < p.k_lo; ++kl) {
+                fma_acc(acc, a2[p.kA.lo[kl]], b2[p.kB.lo[kl]]);
+            }
+        }
+        C[p.rowC.hi[hi] + p.rowC.lo[lo] + p.nC[n]] = acc;
+    }
+}
+
+// ------------------------------------------------------------------------- //
+// pair: wavefront reduction along k
+// ------------------------------------------------------------------------- //
+
+// work item w = (output o, k-chunk g); one wave per item.
+template <typename T>
+__global__ __launch_bounds__(256) void pair_kred_kernel(StepArgs p, int64_t G, int64_t chunk,
+                                                        T* __restrict__ partial) {
+    const T* __restrict__ A = (const T*)p.A + *p.soffA;
+    const T* __restrict__ B = (const T*)p.B + *p.soffB;
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int64_t n_waves = (int64_t)gridDim.x * 4;
+    const int64_t items = p.R * p.N * G;
+
+    for (int64_t w = wave; w < items; w += n_waves) {
+        const int64_t o = w / G;
+        const int64_t g = w - o * G;
+        const int64_t row = o / p.N;
+        const int64_t n = o - row * p.N;
+        int64_t hi, lo;
+        split_row(p, row, hi, lo);
+        const T* a = A + p.rowA.hi[hi] + p.rowA.lo[lo];
+        const T* b = B + p.rowB.hi[hi] + p.rowB.lo[lo] + p.nB[n];
+        const int64_t k0 = g * chunk;
+        const int64_t k1 = (k0 + chunk < p.K) ? k0 + chunk : p.K;
+        T acc = zero_of(T{});
+        for (int64_t k = k0 + lane; k < k1; k += 64) {
+            int64_t kh, kl;
+            split_k(p, k, kh, kl);
+            fma_acc(acc, a[p.kA.hi[kh] + p.kA.lo[kl]], b[p.kB.hi[kh] + p.kB.lo[kl]]);
+        }
+        acc = wave_sum(acc);
+        if (lane == 0) partial[w] = acc;
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void pair_kred_finish_kernel(StepArgs p, int64_t G,
+                                                               const T* __restrict__ partial) {
+    T* __restrict__ C = (T*)p.C + *p.soffC;
+    const int64_t outs = p.R * p.N;
+    for (int64_t o = (int64_t)blockIdx.x * 256 + threadIdx.x; o < outs;
+         o += (int64_t)gridDim.x * 256) {
+        const int64_t row = o / p.N;
+        const int64_t n = o - row * p.N;
+        T acc = zero_of(T{});
+        for (int64_t g = 0; g < G; ++g) acc = add_of(acc, partial[o * G + g]);
+        int64_t hi, lo;
+        split_row(p, row, hi, lo);
+        C[p.rowC.hi[hi] + p.rowC.lo[lo] + p.nC[n]] = acc;
+    }
+}
+
+template <typename T>
+static hipError_t launch_pair_valu_t(const StepArgs& p, void* scratch, int64_t scratch_bytes,
+                                     hipStream_t stream) {
+    const int64_t outs = p.R * p.N;
+    // few outputs, long contraction -> lanes along k
+    if (p.K >= 256 && outs <= (1 << 15)) {
+        int64_t G = (p.K + 2047) / 2048;             // >= 2048 k per item keeps partial traffic low
+        const int64_t want = (1 << 14) / (outs > 0 ? outs : 1);  // ~16k waves fill the chip
+        if (G > want) G = want;
+        if (G < 1) G = 1;
+        const int64_t cap = scratch_bytes / (int64_t)sizeof(T) / (outs > 0 ? outs : 1);
+        if (G > cap) G = cap;
+        if (G >= 1) {
+            int64_t chunk = (p.K + G - 1) / G;
+            chunk = (chunk + 63) / 64 * 64;
+            G = (p.K + chunk - 1) / chunk;
+            const int64_t items = outs * G;
+            int64_t blocks = (items + 3) / 4;
+            if (blocks > 8192) blocks = 8192;
+            hipLaunchKernelGGL(pair_kred_kernel<T>, dim3((unsigned)blocks), dim3(256), 0, stream, p,
+                               G, chunk, (T*)scratch);
+            int64_t fblocks = (outs + 255) / 256;
+            if (fblocks > 4096) fblocks = 4096;
+            hipLaunchKernelGGL(pair_kred_finish_kernel<T>, dim3((unsigned)fblocks), dim3(256), 0,
+                               stream, p, G, (const T*)scratch);
+            return hipGetLastError();
+        }
+    }
+    int tn_shift = 0;
+    while ((1 << tn_shift) < p.N && tn_shift < 8) ++tn_shift;
+    const int64_t TN = 1 << tn_shift, TR = 256 >> tn_shift;
+    const int64_t col_tiles = (p.N + TN - 1) / TN;
+    const int64_t row_tiles = (p.R + TR - 1) / TR;
+    const int64_t n_tiles = col_tiles * row_tiles;
+    int64_t blocks = n_tiles;
+    if (blocks > (1 << 20)) blocks = 1 << 20;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(pair_valu_kernel<T>, dim3((unsigned)blocks), dim3(256), 0, stream, p, tn_shift,
+                       col_tiles, n_tiles);
+    return hipGetLastError();
+}
+
+hipError_t launch_pair_valu(int dtype, const StepArgs& p, void* scratch, int64_t scratch_bytes,
+                            hipStream_t stream) {
+    switch (dtype) {
+        case 0: return launch_pair_valu_t<float>(p, scratch, scratch_bytes, stream);
+        case 1: return launch_pair_valu_t<double>(p, scratch, scratch_bytes, stream);
+        case 2: return launch_pair_valu_t<c64>(p, scratch, scratch_bytes, stream);
+        case 3: return launch_pair_valu_t<c128>(p, scratch, scratch_bytes, stream);
+    }
+    return hipErrorInvalidValue;
+}
+
+// ------------------------------------------------------------------------- //
+// single-term einsum
+// ------------------------------------------------------------------------- //
+
+template <typename T>
+__global__ __launch_bounds__(256) void single_kernel(StepArgs p) {
+    const T* __restrict__ A = (const T*)p.A + *p.soffA;
+    T* __restrict__ C = (T*)p.C + *p.soffC;
+    for (int64_t row = (int64_t)blockIdx.x * 256 + threadIdx.x; row < p.R;
+         row += (int64_t)gridDim.x * 256) {
+        int64_t hi, lo;
+        split_row(p, row, hi, lo);
+        const T* a = A + p.rowA.hi[hi] + p.rowA.lo[lo];
+        T acc = zero_of(T{});
+        for (int64_t kh = 0; kh < p.k_hi_len; ++kh) {
+            const T* a2 = a + p.kA.hi[kh];
+            for (int64_t kl = 0; kl < p.k_lo; ++kl) acc = add_of(acc, a2[p.kA.lo[kl]]);
+        }
+        C[p.rowC.hi[hi] + p.rowC.lo[lo]] = acc;
+    }
+}
+
+// one wave per output when few outputs are reduced over many elements (full
+// traces): lanes along the summed group + wavefront reduction
+template <typename T>
+__global__ __launch_bounds__(256) void single_wave_kernel(StepArgs p) {
+    const T* __restrict__ A = (const T*)p.A + *p.soffA;
+    T* __restrict__ C = (T*)p.C + *p.soffC;
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    for (int64_t row = wave; row < p.R; row += (int64_t)gridDim.x * 4) {
+        int64_t hi, lo;
+        split_row(p, row, hi, lo);
+        const T* a = A + p.rowA.hi[hi] + p.rowA.lo[lo];
+        T acc = zero_of(T{});
+        for (int64_t k = lane; k < p.K; k += 64) {
+            int64_t kh, kl;
+            split_k(p, k, kh, kl);
+            acc = add_of(acc, a[p.kA.hi[kh] + p.kA.lo[kl]]);
+        }
+        acc = wave_sum(acc);
+        if (lane == 0) C[p.rowC.hi[hi] + p.rowC.lo[lo]] = acc;
+    }
+}
+
+template <typename T>
+static hipError_t launch_single_t(const StepArgs& p, hipStream_t stream) {
+    if (p.K >= 256 && p.R <= (1 << 14)) {
+        int64_t blocks = (p.R + 3) / 4;
+        if (blocks < 1) blocks = 1;
+        hipLaunchKernelGGL(single_wave_kernel<T>, dim3((unsigned)blocks), dim3(256), 0, stream, p);
+        return hipGetLastError();
+    }
+    int64_t blocks = (p.R + 255) / 256;
+    if (blocks > (1 << 20)) blocks = 1 << 20;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(single_kernel<T>, dim3((unsigned)blocks), dim3(256), 0, stream, p);
+    return hipGetLastError();
+}
+
+hipError_t launch_single(int dtype, const StepArgs& p, hipStream_t stream) {
+    switch (dtype) {
+        case 0: return launch_single_t<float>(p, stream);
+        case 1: return launch_single_t<double>(p, stream);
+        case 2: return launch_single_t<c64>(p, stream);
+        case 3: return launch_single_t<c128>(p, stream);
+    }
+    return hipErrorInvalidValue;
+}
+
+// ------------------------------------------------------------------------- //
+// accumulate a slice into the result tensor
+// ------------------------------------------------------------------------- //
+
+template <typename T>
+__global__ __launch_bounds__(256) void accum_kernel(StepArgs p) {
+    const T* __restrict__ A = (const T*)p.A + *p.soffA;
+    T* __restrict__ C = (T*)p.C + *p.soffC;
+    for (int64_t row = (int64_t)blockIdx.x * 256 + threadIdx.x; row < p.R;
+         row += (int64_t)gridDim.x * 256) {
+        int64_t hi, lo;
+        split_row(p, row, hi, lo);
+        T* c = C + p.rowC.hi[hi] + p.rowC.lo[lo];
+        *c = add_of(*c, A[p.rowA.hi[hi] + p.rowA.lo[lo]]);
+    }
+}
+
+hipError_t launch_accum(int dtype, const StepArgs& p, hipStream_t stream) {
+    int64_t blocks = (p.R + 255) / 256;
+    if (blocks > (1 << 20)) blocks = 1 << 20;
+    if (blocks < 1) blocks = 1;
+    switch (dtype) {
+        case 0: hipLaunchKernelGGL(accum_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, stream, p); break;
+        case 1: hipLaunchKernelGGL(accum_kernel<double>, dim3((unsigned)blocks), dim3(256), 0, stream, p); break;
+        case 2: hipLaunchKernelGGL(accum_kernel<c64>, dim3((unsigned)blocks), dim3(256), 0, stream, p); break;
+        case 3: hipLaunchKernelGGL(accum_kernel<c128>, dim3((unsigned)blocks), dim3(256), 0, stream, p); break;
+        default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------- //
+// slice prologue
+// ------------------------------------------------------------------------- //
+
+__global__ __launch_bounds__(256) void prologue_kernel(SliceMeta m, int64_t* state, int64_t* soff,
+                                                       int64_t sid_arg) {
+    const int64_t sid = sid_arg >= 0 ? sid_arg : state[0];
+    for (int64_t leaf = threadIdx.x; leaf < m.n_leaves; leaf += blockDim.x) {
+        int64_t rem = sid;
+        int64_t off = 0;
+        const int64_t* st = m.strides + leaf * m.n_sliced;
+        for (int64_t j = m.n_sliced - 1; j >= 0; --j) {
+            int64_t digit;
+            if (m.fixed[j] >= 0) {
+                digit = m.fixed[j];
+            } else {
+                const int64_t d = m.sizes[j];
+                const int64_t q = rem / d;
+                digit = rem - q * d;
+                rem = q;
+            }
+            off += digit * st[j];
+        }
+        soff[leaf] = off;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0 && sid_arg < 0) state[0] = sid + state[1];
+}
+
+hipError_t launch_prologue(const SliceMeta& m, int64_t* state, int64_t* soff, int64_t sid,
+                           hipStream_t stream) {
+    hipLaunchKernelGGL(prologue_kernel, dim3(1), dim3(256), 0, stream, m, state, soff, sid);
+    return hipGetLastError();
+}
+
+}  // namespace ctg

@@ -1,0 +1,261 @@
+// ctg_pair_mfma.hip -- complex64 gather-GEMM on the gfx950 fp32 matrix cores.
+//
+//   C[bC(b) + rowC(m) + nC(n)] = sum_k A[bA(b) + rowA(m) + kA(k)] * B[bB(b) + kB(k) + nB(n)]
+//
+// This one kernel replaces the reference's whole pairwise lowering
+// `transpose -> reshape -> matmul -> reshape -> transpose`
+// (cotengra/contract.py:364-411): the operand permutations are folded into
+// offset tables and realised in the global->LDS gather, so no operand is ever
+// copied just to be re-laid-out.
+//
+// Complex arithmetic on a real MFMA without wasted flops.  gfx950 has no
+// complex MFMA; v_mfma_f32_32x32x2_f32 computes D(32x32) += A'(32x2) B'(2x32)
+// in exact fp32.  For one complex k we feed
+//     A'[i][0] = Re a_ik            A'[i][1] = Im a_ik
+//     B'[0][2n] = Re b_kn  B'[0][2n+1] = Im b_kn
+//     B'[1][2n] = -Im b_kn B'[1][2n+1] = Re b_kn
+// so D[i][2n] / D[i][2n+1] accumulate Re / Im of sum_k a_ik b_kn: one
+// instruction = 32 rows x 16 complex columns x 1 complex k = 4096 real flops,
+// all of them useful (8 flops per complex multiply-add), and D is already in
+// interleaved complex layout for the store.
+//
+// Tiling: 256 threads = 4 waves (64 lanes each), block tile BM x BN complex,
+// BK complex per k-step, register-staged double buffering through LDS:
+// global gathers of step t+1 are in flight while the MFMAs of step t run.
+// LDS holds A as two planes (re, im) [BM][BK+4] and B transposed
+// [2*BN][BK+4] so every fragment is one aligned ds_read_b128 (4 k's).
+// The block-id -> tile map keeps all column tiles of a row tile on one XCD
+// (block b runs on XCD b % 8) so A is fetched from HBM once and re-read from
+// that XCD's L2.
+#include "ctg_common.h"
+
+namespace ctg {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+template <int BM, int BN, int BK, int WM, int WN>
+struct MfmaCfg {
+    static constexpr int kThreads = 256;
+    static constexpr int LD = BK + 4;               // padded k extent of an LDS row (floats)
+    static constexpr int WTM = BM / WM;             // wave tile rows
+    static constexpr int WTN = BN / WN;             // wave tile complex cols
+    static constexpr int FM = WTM / 32;             // MFMA tiles per wave along m
+    static constexpr int FN = WTN / 16;             // MFMA tiles per wave along n (16 complex = 32 real)
+    static constexpr int A_PER_T = BM * BK / kThreads;
+    static constexpr int B_PER_T = (BK * BN + kThreads - 1) / kThreads;
+    static constexpr int A_FLOATS = 2 * BM * LD;
+    static constexpr int B_FLOATS = 2 * BN * LD;
+    static_assert(WM * WN == 4, "4 waves per block");
+    static_assert(WTM % 32 == 0 && WTN % 16 == 0, "wave tile must hold whole MFMA tiles");
+    static_assert((BM * BK) % kThreads == 0, "A tile must divide over the block");
+    static_assert(BK % 4 == 0, "k-step is consumed 4 at a time");
+};
+
+template <typename Cfg, int BM, int BN, int BK, int WM, int WN>
+__global__ __launch_bounds__(256, 2) void pair_mfma_c64_kernel(StepArgs p, int64_t tiles_m,
+                                                               int64_t tiles_n, int flags) {
+    __shared__ __attribute__((aligned(16))) float lds[2 * (Cfg::A_FLOATS + Cfg::B_FLOATS)];
+    __shared__ int64_t rowC_s[BM];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+
+    // XCD-aware tile assignment
+    const int64_t bid = blockIdx.x;
+    const int64_t xcd = bid & 7, q = bid >> 3;
+    const int64_t tm = (q / tiles_n) * 8 + xcd;
+    const int64_t tn = q % tiles_n;
+    if (tm >= tiles_m) return;
+    const int64_t m0 = tm * BM, n0 = tn * BN;
+    const int64_t bz = blockIdx.z;
+
+    const c64* __restrict__ A = (const c64*)p.A + *p.soffA + p.bA[bz];
+    const c64* __restrict__ B = (const c64*)p.B + *p.soffB + p.bB[bz];
+    float* __restrict__ C = (float*)((c64*)p.C + *p.soffC + p.bC[bz]);
+
+    const bool a_kfast = flags & 1, b_kfast = flags & 2;
+
+    // --- per-thread gather coordinates (fixed for the whole kernel) --------
+    int a_r[Cfg::A_PER_T], a_c[Cfg::A_PER_T];
+    int64_t a_row[Cfg::A_PER_T];  // row offset or -1 if the row is outside M
+#pragma unroll
+    for (int j = 0; j < Cfg::A_PER_T; ++j) {
+        const int e = j * 256 + tid;
+        if (a_kfast) {
+            a_r[j] = e / BK;
+            a_c[j] = e % BK;
+        } else {
+            a_r[j] = e % BM;
+            a_c[j] = e / BM;
+        }
+        const int64_t m = m0 + a_r[j];
+        if (m < p.R) {
+            int64_t hi, lo;
+            split_row(p, m, hi, lo);
+            a_row[j] = p.rowA.hi[hi] + p.rowA.lo[lo];
+        } else {
+            a_row[j] = -1;
+        }
+    }
+    int b_k[Cfg::B_PER_T], b_n[Cfg::B_PER_T];
+    int64_t b_col[Cfg::B_PER_T];
+#pragma unroll
+    for (int j = 0; j < Cfg::B_PER_T; ++j) {
+        const int e = j * 256 + tid;
+        if (b_kfast) {
+            b_k[j] = e % BK;
+            b_n[j] = e / BK;
+        } else {
+            b_k[j] = e / BN;
+            b_n[j] = e % BN;
+        }
+        const int64_t n = n0 + b_n[j];
+        b_col[j] = (e < BK * BN && n < p.N) ? p.nB[n] : -1;
+    }
+    if (tid < BM) {
+        const int64_t m = m0 + tid;
+        int64_t off = -1;
+        if (m < p.R) {
+            int64_t hi, lo;
+            split_row(p, m, hi, lo);
+            off = p.rowC.hi[hi] + p.rowC.lo[lo];
+        }
+        rowC_s[tid] = off;
+    }
+
+    c64 a_reg[Cfg::A_PER_T], b_reg[Cfg::B_PER_T];
+
+    auto gather = [&](int64_t k0) {
+#pragma unroll
+        for (int j = 0; j < Cfg::A_PER_T; ++j) {
+            const int64_t k = k0 + a_c[j];
+            c64 v{0.f, 0.f};
+            if (a_row[j] >= 0 && k < p.K) {
+                int64_t kh, kl;
+                split_k(p, k, kh, kl);
+                v = A[a_row[j] + p.kA.hi[kh] + p.kA.lo[kl]];
+            }
+            a_reg[j] = v;
+        }
+#pragma unroll
+        for (int j = 0; j < Cfg::B_PER_T; ++j) {
+            const int64_t k = k0 + b_k[j];
+            c64 v{0.f, 0.f};
+            if (b_col[j] >= 0 && k < p.K) {
+                int64_t kh, kl;
+                split_k(p, k, kh, kl);
+                v = B[b_col[j] + p.kB.hi[kh] + p.kB.lo[kl]];
+            }
+            b_reg[j] = v;
+        }
+    };
+    auto stage = [&](int buf) {
+        float* As = lds + buf * (Cfg::A_FLOATS + Cfg::B_FLOATS);
+        float* Bs = As + Cfg::A_FLOATS;
+#pragma unroll
+        for (int j = 0; j < Cfg::A_PER_T; ++j) {
+            As[a_r[j] * Cfg::LD + a_c[j]] = a_reg[j].re;
+            As[BM * Cfg::LD + a_r[j] * Cfg::LD + a_c[j]] = a_reg[j].im;
+        }
+#pragma unroll
+        for (int j = 0; j < Cfg::B_PER_T; ++j) {
+            if (j * 256 + tid < BK * BN) {
+                Bs[(2 * b_n[j]) * Cfg::LD + b_k[j]] = b_reg[j].re;
+                Bs[(2 * b_n[j] + 1) * Cfg::LD + b_k[j]] = b_reg[j].im;
+            }
+        }
+    };
+
+    f32x16 acc[Cfg::FM][Cfg::FN];
+#pragma unroll
+    for (int i = 0; i < Cfg::FM; ++i)
+#pragma unroll
+        for (int j = 0; j < Cfg::FN; ++j)
+#pragma unroll
+            for (int t = 0; t < 16; ++t) acc[i][j][t] = 0.f;
+
+    const int kk = lane >> 5;     // 0: real part of a / first row of B', 1: imaginary part
+    const int l31 = lane & 31;
+    const bool negate = kk == 1 && (lane & 1) == 0;
+
+    const int64_t nk = (p.K + BK - 1) / BK;
+    gather(0);
+    stage(0);
+    __syncthreads();
+
+    for (int64_t kt = 0; kt < nk; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < nk) gather((kt + 1) * BK);
+
+        const float* As = lds + buf * (Cfg::A_FLOATS + Cfg::B_FLOATS);
+        const float* Bs = As + Cfg::A_FLOATS;
+        const float* a_base = As + kk * BM * Cfg::LD + (wm * Cfg::WTM + l31) * Cfg::LD;
+        const float* b_base = Bs + (2 * wn * Cfg::WTN + (l31 ^ kk)) * Cfg::LD;
+#pragma unroll
+        for (int kq = 0; kq < BK / 4; ++kq) {
+            f32x4 af[Cfg::FM], bf[Cfg::FN];
+#pragma unroll
+            for (int i = 0; i < Cfg::FM; ++i)
+                af[i] = *(const f32x4*)(a_base + i * 32 * Cfg::LD + kq * 4);
+#pragma unroll
+            for (int j = 0; j < Cfg::FN; ++j) {
+                f32x4 v = *(const f32x4*)(b_base + j * 32 * Cfg::LD + kq * 4);
+                bf[j] = negate ? -v : v;
+            }
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int i = 0; i < Cfg::FM; ++i)
+#pragma unroll
+                    for (int j = 0; j < Cfg::FN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][t], bf[j][t],
+                                                                        acc[i][j], 0, 0, 0);
+        }
+        if (kt + 1 < nk) stage(buf ^ 1);
+        __syncthreads();
+    }
+
+    // --- epilogue: D[row][2n+c], row = (reg&3) + 8*(reg>>2) + 4*(lane>>5) ------
+    const int c = lane & 1;
+#pragma unroll
+    for (int j = 0; j < Cfg::FN; ++j) {
+        const int64_t n = n0 + wn * Cfg::WTN + j * 16 + (l31 >> 1);
+        if (n >= p.N) continue;
+        const int64_t ncol = p.nC[n];
+#pragma unroll
+        for (int i = 0; i < Cfg::FM; ++i) {
+#pragma unroll
+            for (int t = 0; t < 16; ++t) {
+                const int row = wm * Cfg::WTM + i * 32 + (t & 3) + 8 * (t >> 2) + 4 * kk;
+                const int64_t ro = rowC_s[row];
+                if (ro >= 0) C[2 * (ro + ncol) + c] = acc[i][j][t];
+            }
+        }
+    }
+}
+
+template <int BM, int BN, int BK, int WM, int WN>
+static hipError_t launch_cfg(const StepArgs& p, int flags, hipStream_t stream) {
+    typedef MfmaCfg<BM, BN, BK, WM, WN> Cfg;
+    const int64_t tiles_m = (p.R + BM - 1) / BM;
+    const int64_t tiles_n = (p.N + BN - 1) / BN;
+    const int64_t gx = ((tiles_m + 7) / 8) * 8 * tiles_n;
+    if (gx > 0x7fffffffll) return hipErrorInvalidValue;
+    hipLaunchKernelGGL((pair_mfma_c64_kernel<Cfg, BM, BN, BK, WM, WN>), dim3((unsigned)gx, 1, (unsigned)p.Bt),
+                       dim3(256), 0, stream, p, tiles_m, tiles_n, flags);
+    return hipGetLastError();
+}
+
+// flags: bit0 = A's fastest-varying memory index is a contracted one,
+//        bit1 = B's fastest-varying memory index is a contracted one
+hipError_t launch_pair_mfma(int dtype, const StepArgs& p, int flags, hipStream_t stream) {
+    if (dtype != 2) return hipErrorInvalidValue;
+    if (p.N <= 16) return launch_cfg<128, 16, 16, 4, 1>(p, flags, stream);
+    if (p.N <= 32) return launch_cfg<128, 32, 16, 4, 1>(p, flags, stream);
+    return launch_cfg<128, 64, 16, 2, 2>(p, flags, stream);
+}
+
+}  // namespace ctg

@@ -1,0 +1,554 @@
+// ctg_runtime.hip -- host side of libctg_hip.so: plan validation, device
+// residency, the per-slice launch sequence and the C ABI of include/ctg_hip.h.
+//
+// One ctg_exec per GPU.  A slice is a fixed sequence of kernel launches
+// (prologue + one kernel per plan step); the slice id lives on the device and
+// is advanced by the prologue kernel, so the loop over slices needs no
+// host<->device traffic and no host synchronisation.
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/ctg_hip.h"
+#include "ctg_common.h"
+
+using namespace ctg;
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const char* fmt, ...) {
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                    \
+    do {                                                                                 \
+        hipError_t _e = (expr);                                                          \
+        if (_e != hipSuccess)                                                            \
+            return fail(_e == hipErrorOutOfMemory ? CTG_E_NOMEM : CTG_E_HIP, "%s failed: %s", \
+                        #expr, hipGetErrorString(_e));                                   \
+    } while (0)
+
+const int64_t kItemSize[4] = {4, 8, 8, 16};
+const int64_t kScratchBytes = 64ll << 20;
+
+int log2_exact(int64_t v) {
+    if (v <= 0 || (v & (v - 1))) return -1;
+    int s = 0;
+    while ((1ll << s) < v) ++s;
+    return s;
+}
+
+}  // namespace
+
+struct ctg_plan {
+    int dtype = 0;
+    int64_t n_inputs = 0;
+    std::vector<int64_t> input_sizes, input_offsets;
+    int64_t inputs_elems = 0, arena_elems = 0, result_elems = 0;
+    int64_t n_steps = 0;
+    std::vector<int64_t> steps;
+    std::vector<int64_t> tables;
+    int64_t n_sliced = 0;
+    std::vector<int64_t> slice_sizes, slice_fixed, slice_strides;
+    int64_t nslices = 1;
+    // per-leaf maximum slice offset (for bounds validation)
+    std::vector<int64_t> max_soff;
+};
+
+struct ctg_exec {
+    const ctg_plan* plan = nullptr;
+    int device = 0;
+    hipStream_t stream = nullptr;
+    char* d_inputs = nullptr;
+    char* d_arena = nullptr;
+    char* d_result = nullptr;
+    bool owns_result = false;
+    int64_t* d_tables = nullptr;
+    int64_t* d_misc = nullptr;  // [state(2) | zero(1) | soff(n_leaves) | sizes | fixed | strides]
+    int64_t* d_state = nullptr;
+    int64_t* d_zero = nullptr;
+    int64_t* d_soff = nullptr;
+    void* d_scratch = nullptr;
+    SliceMeta meta{};
+    std::vector<StepArgs> args;  // resolved per step
+    std::vector<int> flags;      // per step kernel hints
+    std::vector<hipEvent_t> events;
+};
+
+namespace {
+
+// max value of a table range [off, off+len)
+int64_t tab_max(const ctg_plan* p, int64_t off, int64_t len, int64_t* mn) {
+    int64_t mx = INT64_MIN;
+    *mn = INT64_MAX;
+    for (int64_t i = 0; i < len; ++i) {
+        mx = std::max(mx, p->tables[off + i]);
+        *mn = std::min(*mn, p->tables[off + i]);
+    }
+    return mx;
+}
+
+bool tab_ok(const ctg_plan* p, int64_t off, int64_t len) {
+    return off >= 0 && len >= 1 && off + len <= (int64_t)p->tables.size();
+}
+
+int64_t space_elems(const ctg_plan* p, int64_t space) {
+    switch (space) {
+        case SPACE_INPUTS: return p->inputs_elems;
+        case SPACE_ARENA: return p->arena_elems;
+        case SPACE_RESULT: return p->result_elems;
+    }
+    return -1;
+}
+
+int validate_plan(ctg_plan* p) {
+    if (p->dtype < 0 || p->dtype > 3) return fail(CTG_E_INVALID, "bad dtype %d", p->dtype);
+    if (p->n_inputs < 1) return fail(CTG_E_INVALID, "plan needs at least one input");
+    for (int64_t i = 0; i < p->n_inputs; ++i) {
+        if (p->input_sizes[i] < 1 || p->input_offsets[i] < 0 ||
+            p->input_offsets[i] + p->input_sizes[i] > p->inputs_elems)
+            return fail(CTG_E_BOUNDS, "input %lld does not fit the inputs space", (long long)i);
+    }
+    // slices
+    p->nslices = 1;
+    p->max_soff.assign(p->n_inputs + 1, 0);
+    for (int64_t j = 0; j < p->n_sliced; ++j) {
+        const int64_t d = p->slice_sizes[j], f = p->slice_fixed[j];
+        if (d < 1) return fail(CTG_E_INVALID, "bad slice size");
+        if (f >= 0 && d != 1) return fail(CTG_E_INVALID, "projected index must have size 1");
+        p->nslices *= d;
+        for (int64_t l = 0; l <= p->n_inputs; ++l) {
+            const int64_t st = p->slice_strides[l * p->n_sliced + j];
+            if (st < 0) return fail(CTG_E_INVALID, "negative slice stride");
+            p->max_soff[l] += st * (f >= 0 ? f : d - 1);
+        }
+    }
+    // steps
+    for (int64_t s = 0; s < p->n_steps; ++s) {
+        const int64_t* r = &p->steps[s * STEP_WORDS];
+        const int64_t kind = r[W_KIND];
+        if (kind < 0 || kind > 2) return fail(CTG_E_INVALID, "step %lld: bad kind", (long long)s);
+        if (r[W_KERNEL] < 0 || r[W_KERNEL] > 1)
+            return fail(CTG_E_INVALID, "step %lld: bad kernel", (long long)s);
+        if (r[W_KERNEL] == KERNEL_MFMA && (kind != KIND_PAIR || p->dtype != CTG_C64))
+            return fail(CTG_E_INVALID, "step %lld: MFMA kernel needs a complex64 pair step",
+                        (long long)s);
+        const int64_t R = r[W_R], Bt = r[W_BT], K = r[W_K], N = r[W_N];
+        const int64_t row_lo = r[W_ROW_LO], row_hi = r[W_ROW_HI_LEN];
+        const int64_t k_lo = r[W_K_LO], k_hi = r[W_K_HI_LEN];
+        if (R < 1 || Bt < 1 || K < 1 || N < 1 || row_lo < 1 || row_hi < 1 || k_lo < 1 || k_hi < 1)
+            return fail(CTG_E_INVALID, "step %lld: non-positive extent", (long long)s);
+        if (row_lo * row_hi != R) return fail(CTG_E_INVALID, "step %lld: row split != R", (long long)s);
+        if (k_lo * k_hi != K) return fail(CTG_E_INVALID, "step %lld: k split != K", (long long)s);
+        if (r[W_KERNEL] == KERNEL_MFMA && Bt > 65535)
+            return fail(CTG_E_INVALID, "step %lld: MFMA batch too large", (long long)s);
+
+        struct Op { int space_w, off_w, leaf_w, size_w; int64_t rhi, rlo, khi, klo, n, b; bool used; };
+        const bool pair = kind == KIND_PAIR, mfma = r[W_KERNEL] == KERNEL_MFMA;
+        Op ops[3] = {
+            {W_A_SPACE, W_A_OFF, W_A_LEAF, W_A_SIZE, r[W_ROWA_HI], r[W_ROWA_LO],
+             kind != KIND_ACCUM ? r[W_KA_HI] : -1, kind != KIND_ACCUM ? r[W_KA] : -1, -1,
+             mfma ? r[W_BA] : -1, true},
+            {W_B_SPACE, W_B_OFF, W_B_LEAF, W_B_SIZE, mfma ? -1 : r[W_ROWB_HI], mfma ? -1 : r[W_ROWB_LO],
+             r[W_KB_HI], r[W_KB], r[W_NB], mfma ? r[W_BB] : -1, pair},
+            {W_C_SPACE, W_C_OFF, W_C_LEAF, W_C_SIZE, r[W_ROWC_HI], r[W_ROWC_LO], -1, -1,
+             pair ? r[W_NC] : -1, mfma ? r[W_BC] : -1, true},
+        };
+        for (int o = 0; o < 3; ++o) {
+            const Op& op = ops[o];
+            if (!op.used) continue;
+            const int64_t space = r[op.space_w], off = r[op.off_w], leaf = r[op.leaf_w];
+            const int64_t cap = space_elems(p, space);
+            if (cap < 0) return fail(CTG_E_INVALID, "step %lld: bad space", (long long)s);
+            if (leaf < -1 || leaf > p->n_inputs)
+                return fail(CTG_E_INVALID, "step %lld: bad leaf", (long long)s);
+            if (o == 2 && space == SPACE_INPUTS)
+                return fail(CTG_E_INVALID, "step %lld: writes into the inputs space", (long long)s);
+            int64_t lo_addr = off, hi_addr = off + (leaf >= 0 ? p->max_soff[leaf] : 0);
+            struct { int64_t t, len; } tabs[6] = {
+                {op.rhi, row_hi}, {op.rlo, row_lo}, {op.khi, k_hi}, {op.klo, k_lo},
+                {op.n, N}, {op.b, Bt}};
+            for (auto& t : tabs) {
+                if (t.t < 0) continue;
+                if (!tab_ok(p, t.t, t.len))
+                    return fail(CTG_E_BOUNDS, "step %lld: table outside the blob", (long long)s);
+                int64_t mn;
+                const int64_t mx = tab_max(p, t.t, t.len, &mn);
+                hi_addr += mx;
+                lo_addr += mn;
+            }
+            if (lo_addr < 0 || hi_addr >= cap)
+                return fail(CTG_E_BOUNDS,
+                            "step %lld: operand %c addresses [%lld, %lld] outside its space of %lld elements",
+                            (long long)s, "ABC"[o], (long long)lo_addr, (long long)hi_addr, (long long)cap);
+        }
+    }
+    return CTG_OK;
+}
+
+void* space_ptr(const ctg_exec* e, int64_t space) {
+    switch (space) {
+        case SPACE_INPUTS: return e->d_inputs;
+        case SPACE_ARENA: return e->d_arena;
+        case SPACE_RESULT: return e->d_result;
+    }
+    return nullptr;
+}
+
+void resolve_args(ctg_exec* e) {
+    const ctg_plan* p = e->plan;
+    const int64_t isz = kItemSize[p->dtype];
+    e->args.resize(p->n_steps);
+    e->flags.assign(p->n_steps, 0);
+    const int64_t* T = e->d_tables;
+    for (int64_t s = 0; s < p->n_steps; ++s) {
+        const int64_t* r = &p->steps[s * STEP_WORDS];
+        StepArgs& a = e->args[s];
+        memset(&a, 0, sizeof(a));
+        auto ptr = [&](int sw, int ow) -> char* {
+            if (r[sw] < 0) return nullptr;
+            return (char*)space_ptr(e, r[sw]) + r[ow] * isz;
+        };
+        auto soff = [&](int lw) -> const int64_t* {
+            return r[lw] >= 0 ? e->d_soff + r[lw] : e->d_zero;
+        };
+        auto tab = [&](int w) -> const int64_t* { return r[w] >= 0 ? T + r[w] : e->d_zero; };
+        a.A = ptr(W_A_SPACE, W_A_OFF);
+        a.B = ptr(W_B_SPACE, W_B_OFF);
+        a.C = ptr(W_C_SPACE, W_C_OFF);
+        a.soffA = soff(W_A_LEAF);
+        a.soffB = soff(W_B_LEAF);
+        a.soffC = soff(W_C_LEAF);
+        a.R = r[W_R];
+        a.Bt = r[W_BT];
+        a.K = r[W_K];
+        a.N = r[W_N];
+        a.row_lo = r[W_ROW_LO];
+        a.row_lo_shift = log2_exact(a.row_lo);
+        a.rowA = RowTab{tab(W_ROWA_HI), tab(W_ROWA_LO)};
+        a.rowB = RowTab{tab(W_ROWB_HI), tab(W_ROWB_LO)};
+        a.rowC = RowTab{tab(W_ROWC_HI), tab(W_ROWC_LO)};
+        a.k_lo = r[W_K_LO];
+        a.k_hi_len = r[W_K_HI_LEN];
+        a.k_lo_shift = log2_exact(a.k_lo);
+        a.kA = RowTab{tab(W_KA_HI), tab(W_KA)};
+        a.kB = RowTab{tab(W_KB_HI), tab(W_KB)};
+        a.nB = tab(W_NB);
+        a.nC = tab(W_NC);
+        a.bA = tab(W_BA);
+        a.bB = tab(W_BB);
+        a.bC = tab(W_BC);
+        if (r[W_KIND] == KIND_PAIR && r[W_KERNEL] == KERNEL_MFMA) {
+            // which group holds the operand's fastest-varying memory index?
+            auto stride1 = [&](int w, int64_t len) -> int64_t {
+                if (len < 2 || r[w] < 0) return INT64_MAX;
+                const int64_t v = p->tables[r[w] + 1] - p->tables[r[w]];
+                return v < 0 ? -v : (v == 0 ? INT64_MAX : v);
+            };
+            const int64_t ak = stride1(W_KA, a.k_lo), am = stride1(W_ROWA_LO, a.row_lo);
+            const int64_t bk = stride1(W_KB, a.k_lo), bn = stride1(W_NB, a.N);
+            e->flags[s] = (ak < am ? 1 : 0) | (bk < bn ? 2 : 0);
+        }
+    }
+}
+
+int launch_step(ctg_exec* e, int64_t s) {
+    const ctg_plan* p = e->plan;
+    const int64_t* r = &p->steps[s * STEP_WORDS];
+    hipError_t err = hipSuccess;
+    switch (r[W_KIND]) {
+        case KIND_SINGLE: err = launch_single(p->dtype, e->args[s], e->stream); break;
+        case KIND_ACCUM: err = launch_accum(p->dtype, e->args[s], e->stream); break;
+        case KIND_PAIR:
+            if (r[W_KERNEL] == KERNEL_MFMA)
+                err = launch_pair_mfma(p->dtype, e->args[s], e->flags[s], e->stream);
+            else
+                err = launch_pair_valu(p->dtype, e->args[s], e->d_scratch, kScratchBytes, e->stream);
+            break;
+    }
+    if (err != hipSuccess)
+        return fail(CTG_E_HIP, "launch of step %lld failed: %s", (long long)s, hipGetErrorString(err));
+    return CTG_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int ctg_abi_version(void) { return CTG_ABI_VERSION; }
+
+const char* ctg_last_error(void) { return g_err.c_str(); }
+
+int ctg_plan_create(const ctg_plan_desc* d, ctg_plan** out) {
+    if (!d || !out) return fail(CTG_E_INVALID, "null argument");
+    if (d->n_inputs < 1 || d->n_steps < 0 || d->n_table_words < 1 || d->n_sliced < 0)
+        return fail(CTG_E_INVALID, "bad plan sizes");
+    if (!d->input_sizes || !d->input_offsets || !d->steps || !d->tables)
+        return fail(CTG_E_INVALID, "null plan array");
+    if (d->n_sliced > 0 && (!d->slice_sizes || !d->slice_fixed || !d->slice_strides))
+        return fail(CTG_E_INVALID, "null slice array");
+    ctg_plan* p = new ctg_plan();
+    p->dtype = d->dtype;
+    p->n_inputs = d->n_inputs;
+    p->input_sizes.assign(d->input_sizes, d->input_sizes + d->n_inputs);
+    p->input_offsets.assign(d->input_offsets, d->input_offsets + d->n_inputs);
+    p->inputs_elems = d->inputs_elems;
+    p->arena_elems = d->arena_elems;
+    p->result_elems = d->result_elems;
+    p->n_steps = d->n_steps;
+    p->steps.assign(d->steps, d->steps + d->n_steps * STEP_WORDS);
+    p->tables.assign(d->tables, d->tables + d->n_table_words);
+    p->n_sliced = d->n_sliced;
+    if (d->n_sliced) {
+        p->slice_sizes.assign(d->slice_sizes, d->slice_sizes + d->n_sliced);
+        p->slice_fixed.assign(d->slice_fixed, d->slice_fixed + d->n_sliced);
+        p->slice_strides.assign(d->slice_strides,
+                                d->slice_strides + (d->n_inputs + 1) * d->n_sliced);
+    }
+    if (p->inputs_elems < 1 || p->arena_elems < 1 || p->result_elems < 1) {
+        delete p;
+        return fail(CTG_E_INVALID, "empty buffer in plan");
+    }
+    const int rc = validate_plan(p);
+    if (rc != CTG_OK) {
+        delete p;
+        return rc;
+    }
+    *out = p;
+    return CTG_OK;
+}
+
+int ctg_plan_destroy(ctg_plan* plan) {
+    delete plan;
+    return CTG_OK;
+}
+
+int ctg_plan_nslices(const ctg_plan* plan, int64_t* nslices) {
+    if (!plan || !nslices) return fail(CTG_E_INVALID, "null argument");
+    *nslices = plan->nslices;
+    return CTG_OK;
+}
+
+int ctg_plan_workspace_bytes(const ctg_plan* p, int64_t bytes[4]) {
+    if (!p || !bytes) return fail(CTG_E_INVALID, "null argument");
+    const int64_t isz = kItemSize[p->dtype];
+    bytes[0] = p->inputs_elems * isz;
+    bytes[1] = p->arena_elems * isz;
+    bytes[2] = p->result_elems * isz;
+    bytes[3] = (int64_t)p->tables.size() * 8 + kScratchBytes +
+               8 * (3 + (p->n_inputs + 1) * (1 + p->n_sliced) + 2 * p->n_sliced);
+    return CTG_OK;
+}
+
+int ctg_exec_destroy(ctg_exec* e) {
+    if (!e) return CTG_OK;
+    (void)hipSetDevice(e->device);
+    if (e->stream) (void)hipStreamSynchronize(e->stream);
+    for (hipEvent_t ev : e->events) (void)hipEventDestroy(ev);
+    if (e->d_inputs) (void)hipFree(e->d_inputs);
+    if (e->d_arena) (void)hipFree(e->d_arena);
+    if (e->d_result && e->owns_result) (void)hipFree(e->d_result);
+    if (e->d_tables) (void)hipFree(e->d_tables);
+    if (e->d_misc) (void)hipFree(e->d_misc);
+    if (e->d_scratch) (void)hipFree(e->d_scratch);
+    delete e;
+    return CTG_OK;
+}
+
+int ctg_exec_create(const ctg_plan* p, int device, void* stream, void* ext_result, ctg_exec** out) {
+    if (!p || !out) return fail(CTG_E_INVALID, "null argument");
+    int ndev = 0;
+    HIP_TRY(hipGetDeviceCount(&ndev));
+    if (device < 0 || device >= ndev)
+        return fail(CTG_E_INVALID, "device %d not available (%d visible)", device, ndev);
+    HIP_TRY(hipSetDevice(device));
+    ctg_exec* e = new ctg_exec();
+    e->plan = p;
+    e->device = device;
+    e->stream = (hipStream_t)stream;
+    const int64_t isz = kItemSize[p->dtype];
+    auto bail = [&](int rc) {
+        std::string keep = g_err;
+        ctg_exec_destroy(e);
+        g_err = keep;
+        return rc;
+    };
+#define HIP_TRY_E(expr)                                                                         \
+    do {                                                                                        \
+        hipError_t _e = (expr);                                                                 \
+        if (_e != hipSuccess)                                                                   \
+            return bail(fail(_e == hipErrorOutOfMemory ? CTG_E_NOMEM : CTG_E_HIP, "%s failed: %s", \
+                             #expr, hipGetErrorString(_e)));                                    \
+    } while (0)
+    HIP_TRY_E(hipMalloc((void**)&e->d_inputs, p->inputs_elems * isz));
+    HIP_TRY_E(hipMalloc((void**)&e->d_arena, p->arena_elems * isz));
+    if (ext_result) {
+        e->d_result = (char*)ext_result;
+    } else {
+        HIP_TRY_E(hipMalloc((void**)&e->d_result, p->result_elems * isz));
+        e->owns_result = true;
+    }
+    HIP_TRY_E(hipMalloc((void**)&e->d_tables, p->tables.size() * 8));
+    HIP_TRY_E(hipMalloc(&e->d_scratch, kScratchBytes));
+    const int64_t n_leaves = p->n_inputs + 1;
+    const int64_t misc_words = 3 + n_leaves + 2 * p->n_sliced + n_leaves * p->n_sliced;
+    HIP_TRY_E(hipMalloc((void**)&e->d_misc, misc_words * 8));
+    std::vector<int64_t> misc(misc_words, 0);
+    int64_t* cur = e->d_misc;
+    e->d_state = cur;
+    cur += 2;
+    e->d_zero = cur;
+    cur += 1;
+    e->d_soff = cur;
+    cur += n_leaves;
+    int64_t* d_sizes = cur;
+    cur += p->n_sliced;
+    int64_t* d_fixed = cur;
+    cur += p->n_sliced;
+    int64_t* d_strides = cur;
+    for (int64_t j = 0; j < p->n_sliced; ++j) {
+        misc[(d_sizes - e->d_misc) + j] = p->slice_sizes[j];
+        misc[(d_fixed - e->d_misc) + j] = p->slice_fixed[j];
+    }
+    for (int64_t i = 0; i < n_leaves * p->n_sliced; ++i)
+        misc[(d_strides - e->d_misc) + i] = p->slice_strides[i];
+    misc[1] = 1;
+    HIP_TRY_E(hipMemcpy(e->d_misc, misc.data(), misc_words * 8, hipMemcpyHostToDevice));
+    HIP_TRY_E(hipMemcpy(e->d_tables, p->tables.data(), p->tables.size() * 8, hipMemcpyHostToDevice));
+    HIP_TRY_E(hipMemsetAsync(e->d_inputs, 0, p->inputs_elems * isz, e->stream));
+    HIP_TRY_E(hipMemsetAsync(e->d_result, 0, p->result_elems * isz, e->stream));
+    e->meta = SliceMeta{n_leaves, p->n_sliced, d_sizes, d_fixed, d_strides};
+    resolve_args(e);
+    *out = e;
+    return CTG_OK;
+#undef HIP_TRY_E
+}
+
+int ctg_exec_upload_inputs_host(ctg_exec* e, const void* const* ptrs) {
+    if (!e || !ptrs) return fail(CTG_E_INVALID, "null argument");
+    HIP_TRY(hipSetDevice(e->device));
+    const ctg_plan* p = e->plan;
+    const int64_t isz = kItemSize[p->dtype];
+    // stage all inputs in one pinned-free contiguous host buffer -> one copy
+    std::vector<char> staging((size_t)(p->inputs_elems * isz), 0);
+    for (int64_t i = 0; i < p->n_inputs; ++i) {
+        if (!ptrs[i]) return fail(CTG_E_INVALID, "input %lld is null", (long long)i);
+        memcpy(staging.data() + p->input_offsets[i] * isz, ptrs[i], p->input_sizes[i] * isz);
+    }
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    HIP_TRY(hipMemcpy(e->d_inputs, staging.data(), staging.size(), hipMemcpyHostToDevice));
+    return CTG_OK;
+}
+
+int ctg_exec_upload_inputs_device(ctg_exec* e, const void* const* ptrs) {
+    if (!e || !ptrs) return fail(CTG_E_INVALID, "null argument");
+    HIP_TRY(hipSetDevice(e->device));
+    const ctg_plan* p = e->plan;
+    const int64_t isz = kItemSize[p->dtype];
+    for (int64_t i = 0; i < p->n_inputs; ++i) {
+        if (!ptrs[i]) return fail(CTG_E_INVALID, "input %lld is null", (long long)i);
+        HIP_TRY(hipMemcpyAsync(e->d_inputs + p->input_offsets[i] * isz, ptrs[i],
+                               p->input_sizes[i] * isz, hipMemcpyDeviceToDevice, e->stream));
+    }
+    return CTG_OK;
+}
+
+int ctg_exec_zero_result(ctg_exec* e) {
+    if (!e) return fail(CTG_E_INVALID, "null argument");
+    HIP_TRY(hipSetDevice(e->device));
+    HIP_TRY(hipMemsetAsync(e->d_result, 0, e->plan->result_elems * kItemSize[e->plan->dtype],
+                           e->stream));
+    return CTG_OK;
+}
+
+int ctg_exec_run_slices(ctg_exec* e, int64_t first, int64_t count, int64_t stride) {
+    if (!e) return fail(CTG_E_INVALID, "null argument");
+    const ctg_plan* p = e->plan;
+    if (count < 0 || stride < 1 || first < 0 ||
+        (count > 0 && first + (count - 1) * stride >= p->nslices))
+        return fail(CTG_E_INVALID, "slice range [%lld + i*%lld, i<%lld) outside [0, %lld)",
+                    (long long)first, (long long)stride, (long long)count, (long long)p->nslices);
+    if (count == 0) return CTG_OK;
+    HIP_TRY(hipSetDevice(e->device));
+    for (int64_t i = 0; i < count; ++i) {
+        hipError_t err =
+            launch_prologue(e->meta, e->d_state, e->d_soff, first + i * stride, e->stream);
+        if (err != hipSuccess)
+            return fail(CTG_E_HIP, "prologue launch failed: %s", hipGetErrorString(err));
+        for (int64_t s = 0; s < p->n_steps; ++s) {
+            const int rc = launch_step(e, s);
+            if (rc != CTG_OK) return rc;
+        }
+    }
+    return CTG_OK;
+}
+
+int ctg_exec_profile_slice(ctg_exec* e, int64_t slice_id, float* ms) {
+    if (!e || !ms) return fail(CTG_E_INVALID, "null argument");
+    const ctg_plan* p = e->plan;
+    if (slice_id < 0 || slice_id >= p->nslices) return fail(CTG_E_INVALID, "slice id out of range");
+    HIP_TRY(hipSetDevice(e->device));
+    while ((int64_t)e->events.size() < p->n_steps + 1) {
+        hipEvent_t ev;
+        HIP_TRY(hipEventCreate(&ev));
+        e->events.push_back(ev);
+    }
+    hipError_t err = launch_prologue(e->meta, e->d_state, e->d_soff, slice_id, e->stream);
+    if (err != hipSuccess) return fail(CTG_E_HIP, "prologue launch failed: %s", hipGetErrorString(err));
+    HIP_TRY(hipEventRecord(e->events[0], e->stream));
+    for (int64_t s = 0; s < p->n_steps; ++s) {
+        const int rc = launch_step(e, s);
+        if (rc != CTG_OK) return rc;
+        HIP_TRY(hipEventRecord(e->events[s + 1], e->stream));
+    }
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    for (int64_t s = 0; s < p->n_steps; ++s)
+        HIP_TRY(hipEventElapsedTime(&ms[s], e->events[s], e->events[s + 1]));
+    return CTG_OK;
+}
+
+int ctg_exec_sync(ctg_exec* e) {
+    if (!e) return fail(CTG_E_INVALID, "null argument");
+    HIP_TRY(hipSetDevice(e->device));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    return CTG_OK;
+}
+
+int ctg_exec_result_ptr(ctg_exec* e, void** dev_ptr) {
+    if (!e || !dev_ptr) return fail(CTG_E_INVALID, "null argument");
+    *dev_ptr = e->d_result;
+    return CTG_OK;
+}
+
+int ctg_exec_download_result(ctg_exec* e, void* host_out) {
+    if (!e || !host_out) return fail(CTG_E_INVALID, "null argument");
+    HIP_TRY(hipSetDevice(e->device));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    HIP_TRY(hipMemcpy(host_out, e->d_result, e->plan->result_elems * kItemSize[e->plan->dtype],
+                      hipMemcpyDeviceToHost));
+    return CTG_OK;
+}
+
+int ctg_exec_download_arena(ctg_exec* e, int64_t offset, int64_t n, void* host_out) {
+    if (!e || !host_out) return fail(CTG_E_INVALID, "null argument");
+    if (offset < 0 || n < 0 || offset + n > e->plan->arena_elems)
+        return fail(CTG_E_BOUNDS, "arena range out of bounds");
+    const int64_t isz = kItemSize[e->plan->dtype];
+    HIP_TRY(hipSetDevice(e->device));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    HIP_TRY(hipMemcpy(host_out, e->d_arena + offset * isz, n * isz, hipMemcpyDeviceToHost));
+    return CTG_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,176 @@
+"""einsum-style front ends over the HIP executor.
+
+Mirrors the call shapes of the reference's high level API
+(``cotengra/interface.py``): ``einsum`` (:1038), ``einsum_tree`` (:875),
+``einsum_expression`` (:925), ``array_contract`` (:803),
+``array_contract_tree`` (:394), ``array_contract_expression`` (:673).
+
+Path *search* is out of scope for this package -- the reference's
+hyper-optimizers stay on the host unchanged and hand over a path or a tree
+(SURVEY.md section 2).  ``optimize`` therefore accepts an explicit path (list of
+pairs), a ``ContractionTree`` (ours, or any object exposing
+``inputs/output/size_dict/get_path()/sliced_inds`` such as the reference's
+tree), or the string ``"greedy"`` for the small built-in heuristic below that
+makes the front ends usable stand-alone.
+"""
+
+from __future__ import annotations
+
+import numpy as np
+
+from .contractor import HipContractor, _is_torch
+from .tree import ContractionTree
+from .utils import eq_to_inputs_output, prod, shapes_inputs_to_size_dict
+
+
+def greedy_path(inputs, output, size_dict):
+    """A plain greedy pairwise path (linear recycled ids): repeatedly contract
+    the pair of index-sharing tensors that minimises
+    ``size(result) - size(a) - size(b)``; leftover disconnected components are
+    combined smallest first.  Hyper-indices and output indices are kept until
+    their last appearance.  This is a convenience, not a port of the
+    reference's optimizers (``cotengra/pathfinders``)."""
+    terms = [frozenset(t) for t in inputs]
+    counts = {}
+    for t in list(terms) + [frozenset(output)]:
+        for ix in t:
+            counts[ix] = counts.get(ix, 0) + 1
+    # multiplicity-aware appearance count (repeated index on one term counts once
+    # here; the tree's preprocessing handles diagonals)
+    live = list(range(len(terms)))
+    tens = {i: terms[i] for i in live}
+    path = []
+
+    def size(t):
+        return prod(size_dict[ix] for ix in t)
+
+    def merged(a, b):
+        both = a | b
+        out = set()
+        for ix in both:
+            n = (ix in a) + (ix in b)
+            if counts[ix] - n > 0:
+                out.add(ix)
+        return frozenset(out)
+
+    next_id = len(terms)
+    while len(live) > 1:
+        best = None
+        for pi in range(len(live)):
+            for pj in range(pi + 1, len(live)):
+                a, b = tens[live[pi]], tens[live[pj]]
+                if not (a & b):
+                    continue
+                m = merged(a, b)
+                score = size(m) - size(a) - size(b)
+                if best is None or score < best[0]:
+                    best = (score, pi, pj, m)
+        if best is None:
+            # disconnected: outer product of the two smallest
+            order = sorted(range(len(live)), key=lambda p: size(tens[live[p]]))
+            pi, pj = sorted(order[:2])
+            m = merged(tens[live[pi]], tens[live[pj]])
+        else:
+            _, pi, pj, m = best
+        a, b = tens[live[pi]], tens[live[pj]]
+        for ix in a | b:
+            counts[ix] -= (ix in a) + (ix in b) - (ix in m)
+        path.append((pi, pj))
+        live.pop(pj)
+        live.pop(pi)
+        tens[next_id] = m
+        live.append(next_id)
+        next_id += 1
+    return tuple(path)
+
+
+def _as_tree(inputs, output, size_dict, optimize):
+    if isinstance(optimize, ContractionTree):
+        return optimize
+    if isinstance(optimize, str):
+        if optimize not in ("greedy", "auto"):
+            raise ValueError(
+                f"optimize={optimize!r}: only 'greedy' is built in; pass a path "
+                "or a tree found by cotengra's optimizers."
+            )
+        if len(inputs) == 1:
+            return ContractionTree(inputs, output, size_dict)
+        return ContractionTree.from_path(
+            inputs, output, size_dict, path=greedy_path(inputs, output, size_dict)
+        )
+    if hasattr(optimize, "get_path") and hasattr(optimize, "sliced_inds"):
+        # a foreign (e.g. reference cotengra) tree: adopt its path and slicing
+        tree = ContractionTree.from_path(
+            optimize.inputs, optimize.output, optimize.size_dict,
+            path=optimize.get_path(),
+        )
+        for ix in optimize.sliced_inds:
+            tree.remove_ind_(ix)
+        return tree
+    if len(inputs) == 1:
+        return ContractionTree(inputs, output, size_dict)
+    return ContractionTree.from_path(inputs, output, size_dict, path=optimize)
+
+
+def array_contract_tree(inputs, output, size_dict, optimize="greedy"):
+    """interface.py:394 -- build the tree for explicit index lists."""
+    return _as_tree(
+        [tuple(t) for t in inputs], tuple(output), dict(size_dict), optimize
+    )
+
+
+def einsum_tree(eq, *shapes, optimize="greedy"):
+    """interface.py:875."""
+    inputs, output = eq_to_inputs_output(eq)
+    size_dict = shapes_inputs_to_size_dict(shapes, inputs)
+    return array_contract_tree(inputs, output, size_dict, optimize)
+
+
+class ContractExpression:
+    """Reusable ``expr(*arrays)`` (the object ``_build_expression`` returns,
+    interface.py:585-667); sliced trees run all their slices on the device."""
+
+    def __init__(self, tree, strip_exponent=False, check_zero=False):
+        self.tree = tree
+        self.fn = HipContractor(
+            tree, strip_exponent=strip_exponent, check_zero=check_zero,
+            handle_slicing=True,
+        )
+
+    def __call__(self, *arrays, backend=None, **kwargs):
+        return self.fn(*arrays, **kwargs)
+
+
+def array_contract_expression(
+    inputs, output, size_dict=None, shapes=None, optimize="greedy",
+    strip_exponent=False, check_zero=False, **_ignored,
+):
+    """interface.py:673."""
+    inputs = [tuple(t) for t in inputs]
+    if size_dict is None:
+        size_dict = shapes_inputs_to_size_dict(shapes, inputs)
+    tree = array_contract_tree(inputs, output, size_dict, optimize)
+    return ContractExpression(tree, strip_exponent, check_zero)
+
+
+def einsum_expression(eq, *shapes, optimize="greedy", **kwargs):
+    """interface.py:925."""
+    inputs, output = eq_to_inputs_output(eq)
+    return array_contract_expression(
+        inputs, output, shapes=shapes, optimize=optimize, **kwargs
+    )
+
+
+def array_contract(arrays, inputs, output, optimize="greedy", **kwargs):
+    """interface.py:803."""
+    shapes = [tuple(x.shape) for x in arrays]
+    expr = array_contract_expression(
+        inputs, output, shapes=shapes, optimize=optimize, **kwargs
+    )
+    return expr(*arrays)
+
+
+def einsum(eq, *arrays, optimize="greedy", **kwargs):
+    """interface.py:1038 -- ``einsum(eq, *arrays)`` on the MI355X."""
+    inputs, output = eq_to_inputs_output(eq)
+    return array_contract(arrays, inputs, output, optimize=optimize, **kwargs)

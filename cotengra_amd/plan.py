@@ -131,7 +131,8 @@ class Step:
     # two-level row tables: lo_size, per-operand (hi, lo) arrays
     row_lo: int = 1
     rows: dict = field(default_factory=dict)  # 'A','B','C' -> (hi, lo)
-    k_tabs: dict = field(default_factory=dict)  # 'A','B' -> flat
+    k_lo: int = 1
+    k_tabs: dict = field(default_factory=dict)  # 'A','B' -> (hi, lo)
     n_tabs: dict = field(default_factory=dict)  # 'B','C' -> flat
     b_tabs: dict = field(default_factory=dict)  # 'A','B','C' -> flat (MFMA)
     # bookkeeping for rooflines / debugging
@@ -247,7 +248,8 @@ class Plan:
          27 bA   28 bB   29 bC
          30 a.size 31 b.size 32 c.size      (bounds, elements)
          33 macs    34 elems_rw   35 node
-         36.. reserved (0)
+         36 k_lo  37 kA_hi  38 kB_hi  39 k_hi_len   (23/24 hold the lo level)
+         40.. reserved (0)
         """
         blobs = []
         cursor = 0
@@ -284,8 +286,13 @@ class Plan:
                     r[17 + 2 * j] = -1
                     r[18 + 2 * j] = -1
             r[16] = hi_len
-            r[23] = put(s.k_tabs["A"]) if "A" in s.k_tabs else zero
-            r[24] = put(s.k_tabs["B"]) if "B" in s.k_tabs else zero
+            r[36], r[39] = s.k_lo, 1
+            r[23] = r[24] = r[37] = r[38] = zero
+            for key, w_lo, w_hi in (("A", 23, 37), ("B", 24, 38)):
+                if key in s.k_tabs:
+                    hi, lo = s.k_tabs[key]
+                    r[w_hi], r[w_lo] = put(hi), put(lo)
+                    r[39] = len(hi)
             r[25] = put(s.n_tabs["B"]) if "B" in s.n_tabs else zero
             r[26] = put(s.n_tabs["C"]) if "C" in s.n_tabs else zero
             for j, key in enumerate("ABC"):
@@ -363,7 +370,7 @@ def choose_kernel(dtype, Bt, M, K, N):
     """MFMA for complex64/float32 steps big enough to fill tiles; the VALU
     kernel for everything else (tiny leaves, outer products, Hadamards,
     skinny memory-bound steps, and the float64/complex128 parity mode)."""
-    if dtype not in ("complex64", "float32"):
+    if dtype != "complex64":
         return KERNEL_VALU
     if Bt > MFMA_MAX_BATCH:
         return KERNEL_VALU
@@ -419,8 +426,10 @@ def build_pair_step(
 
     step = Step(kind=KIND_PAIR, kernel=kernel, a=A, b=B, c=C, node=node)
     step.K, step.N = K, N
-    step.k_tabs["A"] = group_table(ext(con), [A.stride_of(ix) for ix in con])
-    step.k_tabs["B"] = group_table(ext(con), [B.stride_of(ix) for ix in con])
+    step.k_lo, (step.k_tabs["A"], step.k_tabs["B"]) = _rows_two_level(
+        ext(con),
+        [[A.stride_of(ix) for ix in con], [B.stride_of(ix) for ix in con]],
+    )
     step.n_tabs["B"] = group_table(ext(keep_b), [B.stride_of(ix) for ix in keep_b])
     step.n_tabs["C"] = group_table(ext(keep_b), [C.stride_of(ix) for ix in keep_b])
 
@@ -498,7 +507,9 @@ def build_single_step(size_dict, src, out_inds, out_ref_factory, node=-1):
     step.row_lo = lo
     step.rows["A"], step.rows["C"] = tabs
     step.K = prod(ext(summed))
-    step.k_tabs["A"] = group_table(ext(summed), [src.stride_of(ix) for ix in summed])
+    step.k_lo, (step.k_tabs["A"],) = _rows_two_level(
+        ext(summed), [[src.stride_of(ix) for ix in summed]]
+    )
     step.macs = 0
     step.elems_rw = step.R * step.K + step.R
     step.label = (

@@ -1,0 +1,272 @@
+"""ctypes binding of ``libctg_hip.so`` (C ABI: ``include/ctg_hip.h``).
+
+The HIP library is the only execution engine: if it is missing this module
+raises immediately -- there is no CPU fallback anywhere in the package.
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libctg_hip.so")
+ABI_VERSION = 1
+
+# every symbol include/ctg_hip.h declares
+SYMBOLS = (
+    "ctg_abi_version",
+    "ctg_last_error",
+    "ctg_plan_create",
+    "ctg_plan_destroy",
+    "ctg_plan_nslices",
+    "ctg_plan_workspace_bytes",
+    "ctg_exec_create",
+    "ctg_exec_destroy",
+    "ctg_exec_upload_inputs_host",
+    "ctg_exec_upload_inputs_device",
+    "ctg_exec_zero_result",
+    "ctg_exec_run_slices",
+    "ctg_exec_profile_slice",
+    "ctg_exec_sync",
+    "ctg_exec_result_ptr",
+    "ctg_exec_download_result",
+    "ctg_exec_download_arena",
+)
+
+
+class CtgError(RuntimeError):
+    """A call into libctg_hip.so failed."""
+
+
+class PlanDesc(C.Structure):
+    """Mirror of ``ctg_plan_desc``."""
+
+    _fields_ = [
+        ("dtype", C.c_int32),
+        ("n_inputs", C.c_int64),
+        ("input_sizes", C.POINTER(C.c_int64)),
+        ("input_offsets", C.POINTER(C.c_int64)),
+        ("inputs_elems", C.c_int64),
+        ("arena_elems", C.c_int64),
+        ("result_elems", C.c_int64),
+        ("n_steps", C.c_int64),
+        ("steps", C.POINTER(C.c_int64)),
+        ("n_table_words", C.c_int64),
+        ("tables", C.POINTER(C.c_int64)),
+        ("n_sliced", C.c_int64),
+        ("slice_sizes", C.POINTER(C.c_int64)),
+        ("slice_fixed", C.POINTER(C.c_int64)),
+        ("slice_strides", C.POINTER(C.c_int64)),
+    ]
+
+
+_lib = None
+
+
+def lib_path():
+    return _LIB_PATH
+
+
+def load():
+    """Load the shared library (once) and declare its prototypes."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(_LIB_PATH):
+        raise ImportError(
+            f"{_LIB_PATH} not found: build the HIP extension first "
+            "(python -c 'import __graft_entry__ as g; g.build()'). "
+            "cotengra_amd has no CPU fallback."
+        )
+    lib = C.CDLL(_LIB_PATH)
+    i64p = C.POINTER(C.c_int64)
+    vp = C.c_void_p
+    lib.ctg_abi_version.restype = C.c_int
+    lib.ctg_last_error.restype = C.c_char_p
+    protos = {
+        "ctg_plan_create": [C.POINTER(PlanDesc), C.POINTER(vp)],
+        "ctg_plan_destroy": [vp],
+        "ctg_plan_nslices": [vp, i64p],
+        "ctg_plan_workspace_bytes": [vp, i64p],
+        "ctg_exec_create": [vp, C.c_int, vp, vp, C.POINTER(vp)],
+        "ctg_exec_destroy": [vp],
+        "ctg_exec_upload_inputs_host": [vp, C.POINTER(vp)],
+        "ctg_exec_upload_inputs_device": [vp, C.POINTER(vp)],
+        "ctg_exec_zero_result": [vp],
+        "ctg_exec_run_slices": [vp, C.c_int64, C.c_int64, C.c_int64],
+        "ctg_exec_profile_slice": [vp, C.c_int64, C.POINTER(C.c_float)],
+        "ctg_exec_sync": [vp],
+        "ctg_exec_result_ptr": [vp, C.POINTER(vp)],
+        "ctg_exec_download_result": [vp, vp],
+        "ctg_exec_download_arena": [vp, C.c_int64, C.c_int64, vp],
+    }
+    for name, argtypes in protos.items():
+        fn = getattr(lib, name)
+        fn.argtypes = argtypes
+        fn.restype = C.c_int
+    if lib.ctg_abi_version() != ABI_VERSION:
+        raise ImportError(
+            f"libctg_hip.so ABI {lib.ctg_abi_version()} != expected {ABI_VERSION}; rebuild."
+        )
+    _lib = lib
+    return lib
+
+
+def _check(rc):
+    if rc != 0:
+        msg = load().ctg_last_error().decode("utf-8", "replace")
+        if rc == -1:
+            raise ValueError(msg)
+        if rc == -3:
+            raise MemoryError(msg)
+        raise CtgError(f"[{rc}] {msg}")
+
+
+def _i64p(arr):
+    return arr.ctypes.data_as(C.POINTER(C.c_int64))
+
+
+class DevicePlan:
+    """A validated plan inside the native library (host memory only)."""
+
+    def __init__(self, plan):
+        self.plan = plan
+        lib = load()
+        s = plan.serialise()
+        self._keep = s  # the C side deep-copies, but keep until created
+        d = PlanDesc()
+        d.dtype = s["dtype"]
+        d.n_inputs = len(s["input_sizes"])
+        d.input_sizes = _i64p(s["input_sizes"])
+        d.input_offsets = _i64p(s["input_offsets"])
+        d.inputs_elems = plan.inputs_elems
+        d.arena_elems = s["arena_elems"]
+        d.result_elems = s["result_elems"]
+        d.n_steps = s["n_steps"]
+        d.steps = _i64p(s["steps"])
+        d.n_table_words = len(s["tables"])
+        d.tables = _i64p(s["tables"])
+        d.n_sliced = len(s["slice_sizes"])
+        d.slice_sizes = _i64p(s["slice_sizes"])
+        d.slice_fixed = _i64p(s["slice_fixed"])
+        d.slice_strides = _i64p(s["slice_strides"])
+        handle = C.c_void_p()
+        _check(lib.ctg_plan_create(C.byref(d), C.byref(handle)))
+        self.handle = handle
+        self._keep = None
+
+    @property
+    def nslices(self):
+        n = C.c_int64()
+        _check(load().ctg_plan_nslices(self.handle, C.byref(n)))
+        return n.value
+
+    def workspace_bytes(self):
+        out = (C.c_int64 * 4)()
+        _check(load().ctg_plan_workspace_bytes(self.handle, out))
+        return dict(zip(("inputs", "arena", "result", "tables"), out))
+
+    def close(self):
+        if getattr(self, "handle", None):
+            load().ctg_plan_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Executor:
+    """One GPU's resident state for a plan: inputs, arena, tables, result."""
+
+    def __init__(self, dplan, device=0, stream=0, result_ptr=None):
+        self.dplan = dplan
+        self.plan = dplan.plan
+        self.device = int(device)
+        handle = C.c_void_p()
+        _check(
+            load().ctg_exec_create(
+                dplan.handle,
+                self.device,
+                C.c_void_p(int(stream) if stream else None),
+                C.c_void_p(int(result_ptr) if result_ptr else None),
+                C.byref(handle),
+            )
+        )
+        self.handle = handle
+
+    # -- inputs ---------------------------------------------------------- #
+
+    def upload_host(self, arrays):
+        """``arrays``: numpy arrays; converted to the plan dtype, C order."""
+        dt = np.dtype(self.plan.dtype)
+        keep = [np.ascontiguousarray(x, dtype=dt) for x in arrays]
+        self._check_sizes([x.size for x in keep])
+        ptrs = (C.c_void_p * len(keep))(*[x.ctypes.data for x in keep])
+        _check(load().ctg_exec_upload_inputs_host(self.handle, ptrs))
+
+    def upload_device(self, ptrs, sizes):
+        """``ptrs``: raw device addresses of contiguous tensors already in the
+        plan dtype."""
+        self._check_sizes(sizes)
+        arr = (C.c_void_p * len(ptrs))(*[int(p) for p in ptrs])
+        _check(load().ctg_exec_upload_inputs_device(self.handle, arr))
+
+    def _check_sizes(self, sizes):
+        want = list(self.plan.input_sizes)
+        if list(sizes) != want:
+            raise ValueError(
+                f"Input sizes {list(sizes)} do not match the plan's {want}."
+            )
+
+    # -- execution --------------------------------------------------------- #
+
+    def zero_result(self):
+        _check(load().ctg_exec_zero_result(self.handle))
+
+    def run_slices(self, first=0, count=None, stride=1):
+        if count is None:
+            count = (self.plan.nslices - first + stride - 1) // stride
+        _check(load().ctg_exec_run_slices(self.handle, first, count, stride))
+
+    def profile_slice(self, slice_id=0):
+        ms = (C.c_float * max(len(self.plan.steps), 1))()
+        _check(load().ctg_exec_profile_slice(self.handle, slice_id, ms))
+        return np.asarray(ms[: len(self.plan.steps)], dtype=np.float64)
+
+    def sync(self):
+        _check(load().ctg_exec_sync(self.handle))
+
+    def result_ptr(self):
+        p = C.c_void_p()
+        _check(load().ctg_exec_result_ptr(self.handle, C.byref(p)))
+        return p.value
+
+    def download_result(self):
+        out = np.empty(self.plan.result_shape, dtype=np.dtype(self.plan.dtype))
+        _check(load().ctg_exec_download_result(self.handle, C.c_void_p(out.ctypes.data)))
+        return out
+
+    def download_arena(self, offset, n):
+        out = np.empty(n, dtype=np.dtype(self.plan.dtype))
+        _check(
+            load().ctg_exec_download_arena(
+                self.handle, offset, n, C.c_void_p(out.ctypes.data)
+            )
+        )
+        return out
+
+    def close(self):
+        if getattr(self, "handle", None):
+            load().ctg_exec_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

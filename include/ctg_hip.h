@@ -1,0 +1,139 @@
+/* ctg_hip.h -- C ABI of the MI355X-native contraction-tree executor.
+ *
+ * This is the drop-in boundary for the execution path of jcmgray/cotengra
+ * (SURVEY.md section 8b).  cotengra itself is pure Python and has no FFI; the
+ * slot this library fills is the one the reference gives to a whole-tree
+ * native backend, `CuQuantumContractor` (reference cotengra/contract.py:840-922,
+ * selected in `make_contractor`, contract.py:986-992): built once from a tree,
+ * called with the input arrays, returns the contracted output.  Each entry
+ * point below cites the reference behaviour it replaces.
+ *
+ * Conventions: every function returns 0 on success and a negative CTG_E_*
+ * code on failure; `ctg_last_error()` returns a thread-local message for the
+ * last failure.  Handles are opaque.  Host buffers are borrowed for the
+ * duration of a call only and never written unless documented (the reference
+ * never mutates its inputs: contract.py:779-807 only drops references).  All
+ * device work is enqueued on the `stream` given at exec creation (a
+ * `hipStream_t` passed as `void*`; NULL = the default stream) and is
+ * asynchronous unless documented otherwise.  A `ctg_exec` is confined to one
+ * host thread at a time (one per GPU); plans are immutable and shareable.
+ *
+ * No torch / numpy / Python types appear anywhere in this interface.
+ */
+#ifndef CTG_HIP_H
+#define CTG_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CTG_ABI_VERSION 1
+
+/* element types of the tensors (reference tests cover all four:
+ * tests/test_compute.py:102-115) */
+enum { CTG_F32 = 0, CTG_F64 = 1, CTG_C64 = 2, CTG_C128 = 3 };
+
+enum {
+    CTG_OK = 0,
+    CTG_E_INVALID = -1, /* malformed plan / argument (ValueError in the reference) */
+    CTG_E_HIP = -2,     /* a HIP runtime call failed */
+    CTG_E_NOMEM = -3,   /* device allocation failed */
+    CTG_E_BOUNDS = -4   /* plan addresses outside a declared buffer */
+};
+
+#define CTG_STEP_WORDS 48
+
+/* Flat description of a compiled plan (produced by cotengra_amd/plan.py).
+ * It encodes what the reference keeps as the op list of
+ * `extract_contractions` (contract.py:573-651) plus the per-step index
+ * classification of `_parse_eq_to_batch_matmul` (contract.py:168-329), lowered
+ * to offset tables; and the slice bookkeeping of `SliceInfo` /
+ * `get_slice_strides` / `slice_key` (core.py:99-122, 3775-3800). */
+typedef struct ctg_plan_desc {
+    int32_t dtype;                /* CTG_F32 .. CTG_C128 */
+    int64_t n_inputs;
+    const int64_t* input_sizes;   /* [n_inputs] elements of each unsliced input */
+    const int64_t* input_offsets; /* [n_inputs] element offset inside the inputs space */
+    int64_t inputs_elems;         /* size of the inputs space */
+    int64_t arena_elems;          /* size of the intermediates arena */
+    int64_t result_elems;         /* size of the full output tensor */
+    int64_t n_steps;
+    const int64_t* steps;         /* [n_steps * CTG_STEP_WORDS], layout in plan.py */
+    int64_t n_table_words;
+    const int64_t* tables;        /* offset-table blob addressed by the step records */
+    int64_t n_sliced;
+    const int64_t* slice_sizes;   /* [n_sliced] extent (1 when projected) */
+    const int64_t* slice_fixed;   /* [n_sliced] projected value or -1 */
+    const int64_t* slice_strides; /* [(n_inputs+1) * n_sliced] element strides; row
+                                     n_inputs is the output tensor (outer slices) */
+} ctg_plan_desc;
+
+typedef struct ctg_plan ctg_plan;
+typedef struct ctg_exec ctg_exec;
+
+/* Library / error --------------------------------------------------------- */
+int ctg_abi_version(void);
+const char* ctg_last_error(void);
+
+/* Plan: host-only, needs no GPU.  Replaces building a `Contractor` from
+ * `extract_contractions(tree)` (contract.py:994-1000).  The descriptor is
+ * validated (kinds, table ranges, that every address stays inside its
+ * buffer) and deep-copied. */
+int ctg_plan_create(const ctg_plan_desc* desc, ctg_plan** out);
+int ctg_plan_destroy(ctg_plan* plan);
+/* number of independent slices = prod(slice_sizes) (core.py:403-408) */
+int ctg_plan_nslices(const ctg_plan* plan, int64_t* nslices);
+/* device bytes an exec will allocate: [0] inputs [1] arena [2] result
+ * [3] tables+misc */
+int ctg_plan_workspace_bytes(const ctg_plan* plan, int64_t bytes[4]);
+
+/* Exec: one per GPU.  Owns inputs space, arena, tables; the result buffer is
+ * either owned or caller-provided device memory (`ext_result`, e.g. memory a
+ * collective library will reduce in place).  Replaces the lazy `setup(*arrays)`
+ * of the whole-tree backend (contract.py:883-899). */
+int ctg_exec_create(const ctg_plan* plan, int device, void* stream,
+                    void* ext_result, ctg_exec** out);
+int ctg_exec_destroy(ctg_exec* exec);
+
+/* Make the (unsliced) input tensors resident: `ptrs[i]` points to
+ * input_sizes[i] contiguous row-major elements.  Replaces passing `*arrays`
+ * to the contractor (contract.py:718, 779-780) / `reset_operands`
+ * (contract.py:916).  `_host` synchronises the stream before returning;
+ * `_device` enqueues device-to-device copies. */
+int ctg_exec_upload_inputs_host(ctg_exec* exec, const void* const* ptrs);
+int ctg_exec_upload_inputs_device(ctg_exec* exec, const void* const* ptrs);
+
+/* result <- 0 (start of a `gather_slices` reduction, core.py:3842-3844) */
+int ctg_exec_zero_result(ctg_exec* exec);
+
+/* Contract slices first, first+stride, ... (count of them) and ACCUMULATE each
+ * into the result tensor at its chunk position: the slice loop of
+ * `ContractionTree.contract` (core.py:4015-4030) fused with `gather_slices`
+ * (core.py:3825-3882), or with count=1 `contract_slice` (core.py:3821-3823);
+ * `stride = world_size` gives the round-robin of `contract_mpi`
+ * (core.py:4068-4076).  Slice-to-leaf indexing (`slice_arrays`,
+ * core.py:3802-3819) happens on the device. */
+int ctg_exec_run_slices(ctg_exec* exec, int64_t first, int64_t count, int64_t stride);
+
+/* Same as run_slices(slice_id, 1, 1) but brackets every step with events and
+ * returns its duration in milliseconds (`ms[n_steps]`); synchronous.  Serves
+ * the role of `tree.print_contractions` + `tree.benchmark`
+ * (core.py:3508, 4092-4164) for per-step rooflines. */
+int ctg_exec_profile_slice(ctg_exec* exec, int64_t slice_id, float* ms);
+
+int ctg_exec_sync(ctg_exec* exec);
+/* device address of the result tensor (result_elems elements, row-major in
+ * the tree's output index order) */
+int ctg_exec_result_ptr(ctg_exec* exec, void** dev_ptr);
+/* synchronous copy of the result to host memory */
+int ctg_exec_download_result(ctg_exec* exec, void* host_out);
+/* debugging aid: copy `n` elements of the arena starting at element `offset`
+ * to the host (synchronous) */
+int ctg_exec_download_arena(ctg_exec* exec, int64_t offset, int64_t n, void* host_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CTG_HIP_H */

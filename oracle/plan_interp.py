@@ -22,6 +22,11 @@ def _rows(step, key):
     return (hi[:, None] + lo[None, :]).reshape(-1)
 
 
+def _ks(step, key):
+    hi, lo = step.k_tabs[key]
+    return (hi[:, None] + lo[None, :]).reshape(-1)
+
+
 def slice_offsets(plan, slice_id):
     """Base offset per input (and pseudo-input N = result chunk) for a slice:
     mixed-radix decode of ``slice_id`` over the sliced indices, most
@@ -66,7 +71,7 @@ def run_plan(plan, arrays, slice_ids=None, result=None):
         for step in plan.steps:
             if step.kind == P.KIND_SINGLE:
                 src, dst = spaces[step.a.space], spaces[step.c.space]
-                ia = base(step.a) + _rows(step, "A")[:, None] + step.k_tabs["A"][None, :]
+                ia = base(step.a) + _rows(step, "A")[:, None] + _ks(step, "A")[None, :]
                 ic = base(step.c) + _rows(step, "C")
                 dst[ic] = src[ia].sum(axis=1)
             elif step.kind == P.KIND_ACCUM:
@@ -76,7 +81,7 @@ def run_plan(plan, arrays, slice_ids=None, result=None):
                 dst[ic] += src[ia]
             elif step.kind == P.KIND_PAIR:
                 A, B, C = (spaces[t.space] for t in (step.a, step.b, step.c))
-                kA, kB = step.k_tabs["A"], step.k_tabs["B"]
+                kA, kB = _ks(step, "A"), _ks(step, "B")
                 nB, nC = step.n_tabs["B"], step.n_tabs["C"]
                 if step.kernel == P.KERNEL_MFMA:
                     rA, rC = _rows(step, "A"), _rows(step, "C")
