@@ -27,6 +27,19 @@ from .utils import prod
 _SUPPORTED = tuple(DTYPE_CODES)
 
 
+def _current_device():
+    """The process's current ROCm device (one process per GPU sets it with
+    ``torch.cuda.set_device(LOCAL_RANK)``); 0 without torch."""
+    try:
+        import torch
+
+        if torch.cuda.is_available():
+            return torch.cuda.current_device()
+    except ImportError:
+        pass
+    return 0
+
+
 def _is_torch(x):
     return type(x).__module__.split(".")[0] == "torch"
 
@@ -160,7 +173,7 @@ class HipContractor:
             )
             st["keep"] = keep
         else:
-            device = self.device if self.device is not None else 0
+            device = self.device if self.device is not None else _current_device()
             st = self._get_exec(dtype, device, False)
             host = [
                 x.detach().cpu().numpy() if _is_torch(x) else np.asarray(x)

@@ -140,7 +140,8 @@ __device__ __forceinline__ cplx<F> wave_sum(cplx<F> v) {
 // dtype: 0 f32, 1 f64, 2 c64, 3 c128
 hipError_t launch_pair_valu(int dtype, const StepArgs& p, void* scratch, int64_t scratch_bytes,
                             hipStream_t stream);
-hipError_t launch_pair_mfma(int dtype, const StepArgs& p, int flags, hipStream_t stream);
+hipError_t launch_pair_mfma(int dtype, const StepArgs& p, int flags, void* scratch,
+                            int64_t scratch_bytes, hipStream_t stream);
 hipError_t launch_single(int dtype, const StepArgs& p, hipStream_t stream);
 hipError_t launch_accum(int dtype, const StepArgs& p, hipStream_t stream);
 

@@ -54,7 +54,9 @@ struct MfmaCfg {
 
 template <typename Cfg, int BM, int BN, int BK, int WM, int WN>
 __global__ __launch_bounds__(256, 2) void pair_mfma_c64_kernel(StepArgs p, int64_t tiles_m,
-                                                               int64_t tiles_n, int flags) {
+                                                               int64_t tiles_n, int flags,
+                                                               int64_t k_chunk,
+                                                               float* __restrict__ partial) {
     __shared__ __attribute__((aligned(16))) float lds[2 * (Cfg::A_FLOATS + Cfg::B_FLOATS)];
     __shared__ int64_t rowC_s[BM];
 
@@ -181,14 +183,19 @@ __global__ __launch_bounds__(256, 2) void pair_mfma_c64_kernel(StepArgs p, int64
     const int l31 = lane & 31;
     const bool negate = kk == 1 && (lane & 1) == 0;
 
-    const int64_t nk = (p.K + BK - 1) / BK;
-    gather(0);
+    // split-K: blockIdx.y owns k in [k_begin, k_end); partial tiles go to scratch
+    const int64_t k_begin = (int64_t)blockIdx.y * k_chunk;
+    const int64_t k_end_raw = k_begin + k_chunk;
+    const int64_t k_end = k_end_raw < p.K ? k_end_raw : p.K;
+    const int64_t nk = (k_end - k_begin + BK - 1) / BK;
+    // gather() masks with p.K; chunks are multiples of BK so no overlap occurs
+    gather(k_begin);
     stage(0);
     __syncthreads();
 
     for (int64_t kt = 0; kt < nk; ++kt) {
         const int buf = kt & 1;
-        if (kt + 1 < nk) gather((kt + 1) * BK);
+        if (kt + 1 < nk) gather(k_begin + (kt + 1) * BK);
 
         const float* As = lds + buf * (Cfg::A_FLOATS + Cfg::B_FLOATS);
         const float* Bs = As + Cfg::A_FLOATS;
@@ -220,6 +227,23 @@ __global__ __launch_bounds__(256, 2) void pair_mfma_c64_kernel(StepArgs p, int64
 
     // --- epilogue: D[row][2n+c], row = (reg&3) + 8*(reg>>2) + 4*(lane>>5) ------
     const int c = lane & 1;
+    if (partial != nullptr) {
+        // dense fp32 slab [batch][split][tiles_m*BM][2*tiles_n*BN]
+        const int64_t ldp = 2 * tiles_n * BN;
+        float* slab = partial + ((bz * gridDim.y + blockIdx.y) * (tiles_m * BM)) * ldp;
+#pragma unroll
+        for (int j = 0; j < Cfg::FN; ++j) {
+            const int64_t col = 2 * (n0 + wn * Cfg::WTN + j * 16) + l31;
+#pragma unroll
+            for (int i = 0; i < Cfg::FM; ++i)
+#pragma unroll
+                for (int t = 0; t < 16; ++t) {
+                    const int64_t row = m0 + wm * Cfg::WTM + i * 32 + (t & 3) + 8 * (t >> 2) + 4 * kk;
+                    slab[row * ldp + col] = acc[i][j][t];
+                }
+        }
+        return;
+    }
 #pragma unroll
     for (int j = 0; j < Cfg::FN; ++j) {
         const int64_t n = n0 + wn * Cfg::WTN + j * 16 + (l31 >> 1);
@@ -237,25 +261,76 @@ __global__ __launch_bounds__(256, 2) void pair_mfma_c64_kernel(StepArgs p, int64
     }
 }
 
+// sum the split-K slabs in a fixed order and scatter into C
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(StepArgs p, int64_t S, int64_t Mpad,
+                                                            int64_t ldp,
+                                                            const float* __restrict__ partial) {
+    const int64_t per_b = p.R * p.N;
+    const int64_t total = per_b * p.Bt;
+    for (int64_t o = (int64_t)blockIdx.x * 256 + threadIdx.x; o < total;
+         o += (int64_t)gridDim.x * 256) {
+        const int64_t b = o / per_b;
+        const int64_t rem = o - b * per_b;
+        const int64_t m = rem / p.N;
+        const int64_t n = rem - m * p.N;
+        float re = 0.f, im = 0.f;
+        for (int64_t s = 0; s < S; ++s) {
+            const float2 v = *(const float2*)(partial + ((b * S + s) * Mpad + m) * ldp + 2 * n);
+            re += v.x;
+            im += v.y;
+        }
+        int64_t hi, lo;
+        split_row(p, m, hi, lo);
+        c64* C = (c64*)p.C + *p.soffC + p.bC[b];
+        C[p.rowC.hi[hi] + p.rowC.lo[lo] + p.nC[n]] = c64{re, im};
+    }
+}
+
 template <int BM, int BN, int BK, int WM, int WN>
-static hipError_t launch_cfg(const StepArgs& p, int flags, hipStream_t stream) {
+static hipError_t launch_cfg(const StepArgs& p, int flags, void* scratch, int64_t scratch_bytes,
+                             hipStream_t stream) {
     typedef MfmaCfg<BM, BN, BK, WM, WN> Cfg;
     const int64_t tiles_m = (p.R + BM - 1) / BM;
     const int64_t tiles_n = (p.N + BN - 1) / BN;
     const int64_t gx = ((tiles_m + 7) / 8) * 8 * tiles_n;
     if (gx > 0x7fffffffll) return hipErrorInvalidValue;
-    hipLaunchKernelGGL((pair_mfma_c64_kernel<Cfg, BM, BN, BK, WM, WN>), dim3((unsigned)gx, 1, (unsigned)p.Bt),
-                       dim3(256), 0, stream, p, tiles_m, tiles_n, flags);
+    // split-K when the output alone cannot fill the chip but K is long
+    const int64_t tiles = tiles_m * tiles_n * p.Bt;
+    const int64_t nk_total = (p.K + BK - 1) / BK;
+    int64_t S = 1;
+    if (tiles < 512 && nk_total >= 16) {
+        S = (1024 + tiles - 1) / tiles;
+        if (S > nk_total / 4) S = nk_total / 4;
+        const int64_t slab_bytes = tiles_m * BM * tiles_n * BN * 8 * p.Bt;
+        if (S * slab_bytes > scratch_bytes) S = scratch_bytes / slab_bytes;
+        if (S > 65535) S = 65535;
+        if (S < 1) S = 1;
+    }
+    int64_t k_chunk = p.K;
+    if (S > 1) {
+        k_chunk = ((nk_total + S - 1) / S) * BK;
+        S = (p.K + k_chunk - 1) / k_chunk;
+    }
+    hipLaunchKernelGGL((pair_mfma_c64_kernel<Cfg, BM, BN, BK, WM, WN>),
+                       dim3((unsigned)gx, (unsigned)S, (unsigned)p.Bt), dim3(256), 0, stream, p, tiles_m,
+                       tiles_n, flags, k_chunk, S > 1 ? (float*)scratch : (float*)nullptr);
+    if (S > 1) {
+        int64_t blocks = (p.R * p.N * p.Bt + 255) / 256;
+        if (blocks > 4096) blocks = 4096;
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, p, S,
+                           tiles_m * BM, 2 * tiles_n * BN, (const float*)scratch);
+    }
     return hipGetLastError();
 }
 
 // flags: bit0 = A's fastest-varying memory index is a contracted one,
 //        bit1 = B's fastest-varying memory index is a contracted one
-hipError_t launch_pair_mfma(int dtype, const StepArgs& p, int flags, hipStream_t stream) {
+hipError_t launch_pair_mfma(int dtype, const StepArgs& p, int flags, void* scratch,
+                            int64_t scratch_bytes, hipStream_t stream) {
     if (dtype != 2) return hipErrorInvalidValue;
-    if (p.N <= 16) return launch_cfg<128, 16, 16, 4, 1>(p, flags, stream);
-    if (p.N <= 32) return launch_cfg<128, 32, 16, 4, 1>(p, flags, stream);
-    return launch_cfg<128, 64, 16, 2, 2>(p, flags, stream);
+    if (p.N <= 16) return launch_cfg<128, 16, 16, 4, 1>(p, flags, scratch, scratch_bytes, stream);
+    if (p.N <= 32) return launch_cfg<128, 32, 16, 4, 1>(p, flags, scratch, scratch_bytes, stream);
+    return launch_cfg<128, 64, 16, 2, 2>(p, flags, scratch, scratch_bytes, stream);
 }
 
 }  // namespace ctg

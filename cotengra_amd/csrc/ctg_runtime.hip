@@ -272,7 +272,8 @@ int launch_step(ctg_exec* e, int64_t s) {
         case KIND_ACCUM: err = launch_accum(p->dtype, e->args[s], e->stream); break;
         case KIND_PAIR:
             if (r[W_KERNEL] == KERNEL_MFMA)
-                err = launch_pair_mfma(p->dtype, e->args[s], e->flags[s], e->stream);
+                err = launch_pair_mfma(p->dtype, e->args[s], e->flags[s], e->d_scratch, kScratchBytes,
+                                       e->stream);
             else
                 err = launch_pair_valu(p->dtype, e->args[s], e->d_scratch, kScratchBytes, e->stream);
             break;

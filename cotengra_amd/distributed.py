@@ -1,0 +1,89 @@
+"""Slice-parallel contraction over the GPUs of one node.
+
+The reference's only distributed execution is ``ContractionTree.contract_mpi``
+(``cotengra/core.py:4032-4090``): ranks take slices round-robin
+(``range(rank, nslices, size)``, :4070), sum them locally, and meet in ONE
+``Allreduce`` / ``Reduce`` of the output tensor (:4081, :4089).  Here the
+ranks are one process per MI355X, the local loop and sum run on the device
+inside ``ctg_exec_run_slices(first=rank, stride=world)``, and the single
+collective is an RCCL (``torch.distributed`` backend "nccl") all-reduce or
+reduce over xGMI of the resident result tensor.  There is no other
+inter-GPU traffic: inputs are tiny and replicated, the plan is identical.
+
+``executor_factory`` exists so the world-size-2 CPU tests (gloo) can inject a
+numpy executor; the product default is the HIP contractor.
+"""
+
+from __future__ import annotations
+
+import numpy as np
+
+
+def slices_of_rank(nslices, rank, world):
+    """Round-robin partition of ``contract_mpi`` (core.py:4070)."""
+    return range(rank, nslices, world)
+
+
+def contract_distributed(
+    tree, arrays, group=None, root=None, executor_factory=None, order=None
+):
+    """Contract all slices of ``tree`` across the ranks of ``group``.
+
+    Returns the full output on every rank (``root=None``, all-reduce) or only
+    on ``root`` (others get ``None``), like ``contract_mpi``.
+    """
+    import torch
+    import torch.distributed as dist
+
+    if not dist.is_initialized():
+        raise RuntimeError("torch.distributed is not initialised.")
+    if not set(tree.sliced_inds).isdisjoint(set(tree.output)):
+        # same restriction as the reference (core.py:4051-4055)
+        raise NotImplementedError(
+            "Sliced and output indices overlap - only a simple sum of result "
+            "slices is supported."
+        )
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    if tree.multiplicity < world:
+        # core.py:4062-4066
+        raise ValueError(
+            f"Need to have more slices than processes, but have "
+            f"{tree.multiplicity} and {world} respectively."
+        )
+
+    mine = slices_of_rank(tree.multiplicity, rank, world)
+
+    if executor_factory is None:
+        from .contractor import _tree_contractor
+
+        fn = _tree_contractor(tree, order)
+        st = fn.setup(*[_to_local_device(x) for x in arrays])
+        ex = st["exec"]
+        ex.zero_result()
+        ex.run_slices(rank, len(mine), world)
+        if "result" in st:
+            partial = st["result"]
+        else:
+            partial = torch.as_tensor(ex.download_result())
+    else:
+        partial = torch.as_tensor(
+            np.ascontiguousarray(executor_factory(tree, arrays, mine))
+        )
+
+    partial = partial.contiguous()
+    # complex tensors are reduced as pairs of reals (portable across backends)
+    buf = torch.view_as_real(partial) if partial.is_complex() else partial
+    if root is None:
+        dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group)
+        return partial
+    dist.reduce(buf, dst=root, op=dist.ReduceOp.SUM, group=group)
+    return partial if rank == root else None
+
+
+def _to_local_device(x):
+    """numpy inputs are uploaded by the executor; torch inputs must live on
+    this rank's GPU."""
+    if type(x).__module__.split(".")[0] == "torch" and not x.is_cuda:
+        return x.numpy()
+    return x

@@ -1,0 +1,56 @@
+"""Kernel-level GPU parity: single pairwise contractions with shuffled index
+layouts against numpy.einsum (complex128 accumulate), sized to hit every MFMA
+tile configuration, split-K, the k-reduction kernel, batch (hyper) indices,
+ragged tile edges and non-power-of-two extents."""
+import numpy as np
+import pytest
+
+import cotengra_amd as ca
+from cotengra_amd.interface import einsum
+
+pytestmark = pytest.mark.gpu
+
+CASES = [
+    # eq, sizes
+    ("abcd,cdef->abef", dict(a=16, b=32, c=8, d=4, e=8, f=8)),        # N=64 config
+    ("abcd,cdef->abef", dict(a=64, b=32, c=4, d=4, e=4, f=4)),        # N=16 config
+    ("abcd,cdef->feba", dict(a=64, b=32, c=4, d=4, e=8, f=4)),        # N=32, scattered output
+    ("dacb,fdce->abef", dict(a=16, b=32, c=8, d=4, e=8, f=8)),        # permuted operands
+    ("abk,kc->abc", dict(a=8, b=4, k=65536, c=32)),                   # split-K (32 x 65536 x 32)
+    ("ak,kb->ab", dict(a=2, k=1 << 18, b=2)),                         # k-reduction kernel
+    ("k,k->", dict(k=1 << 20)),                                       # dot product
+    ("xab,xbc->xac", dict(x=5, a=96, b=24, c=40)),                    # batch + ragged
+    ("axb,bxc->xca", dict(x=3, a=130, b=17, c=33)),                   # ragged everything
+    ("abc,cd->abd", dict(a=81, b=27, c=9, d=27)),                     # powers of three
+    ("ab,cd->abcd", dict(a=64, b=64, c=8, d=8)),                      # outer product
+    ("ab,ab->ab", dict(a=512, b=300)),                                # Hadamard
+    ("abc,bcd->ad", dict(a=4096, b=32, c=32, d=256)),                 # K=1024 GEMM
+    ("abcdefgh,hgfeij->abcdij", dict(a=8, b=8, c=8, d=8, e=2, f=2, g=2, h=2, i=4, j=4)),
+]
+
+
+@pytest.mark.parametrize("dtype", ["complex64", "complex128", "float32", "float64"])
+@pytest.mark.parametrize("case", range(len(CASES)))
+def test_pairwise(case, dtype):
+    eq, sizes = CASES[case]
+    if dtype in ("complex128", "float64", "float32") and case in (4, 12):
+        pytest.skip("large case only exercised on the complex64 MFMA path")
+    (ta, tb), out = ca.eq_to_inputs_output(eq)
+    rng = np.random.default_rng(case)
+    def mk(t):
+        shape = [sizes[i] for i in t]
+        x = rng.normal(size=shape)
+        if "complex" in dtype:
+            x = x + 1j * rng.normal(size=shape)
+        return x.astype(dtype)
+    a, b = mk(ta), mk(tb)
+    hi = "complex128" if "complex" in dtype else "float64"
+    ref = np.einsum(eq, a.astype(hi), b.astype(hi), optimize=True)
+    got = einsum(eq, a, b, optimize=[(0, 1)])
+    assert np.shape(got) == np.shape(ref)
+    scale = np.abs(ref).max()
+    tol = 3e-5 if dtype in ("complex64", "float32") else 1e-12
+    # long single-precision reductions accumulate rounding ~ sqrt(K) eps
+    if dtype in ("complex64", "float32") and case in (4, 5, 6):
+        tol = 3e-4
+    assert np.abs(np.asarray(got) - ref).max() <= tol * scale
