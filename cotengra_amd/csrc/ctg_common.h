@@ -135,12 +135,30 @@ __device__ __forceinline__ cplx<F> wave_sum(cplx<F> v) {
     return cplx<F>{wave_sum(v.re), wave_sum(v.im)};
 }
 
+// ---- MFMA kernel hints built on the host per step (ctg_runtime.hip) -------- //
+
+constexpr int MFMA_BM = 128;  // rows of a block tile
+constexpr int MFMA_BK = 16;   // complex k per step
+
+// ordA: [256][BM*BK/256] packed (r << 4 | c): the tile elements a thread
+// gathers, in ascending memory order across the lanes of each load
+// instruction; with vecA entries (2j, 2j+1) are adjacent in memory (one
+// 16-byte load).  ordB: [256][ceil(BK*BN/256)] packed (n << 4 | k).
+struct MfmaHints {
+    const uint16_t* ordA;
+    const uint16_t* ordB;
+    int bn;    // column tile: 16, 32 or 64
+    int vecA;  // 1: pairs of A elements are contiguous + aligned, tiles are full
+};
+
+inline int mfma_pick_bn(int64_t N) { return N <= 16 ? 16 : (N <= 32 ? 32 : 64); }
+
 // ---- launchers implemented in the kernel translation units ---------------- //
 
 // dtype: 0 f32, 1 f64, 2 c64, 3 c128
 hipError_t launch_pair_valu(int dtype, const StepArgs& p, void* scratch, int64_t scratch_bytes,
                             hipStream_t stream);
-hipError_t launch_pair_mfma(int dtype, const StepArgs& p, int flags, void* scratch,
+hipError_t launch_pair_mfma(int dtype, const StepArgs& p, const MfmaHints& h, void* scratch,
                             int64_t scratch_bytes, hipStream_t stream);
 hipError_t launch_single(int dtype, const StepArgs& p, hipStream_t stream);
 hipError_t launch_accum(int dtype, const StepArgs& p, hipStream_t stream);

@@ -24,6 +24,18 @@
 // global gathers of step t+1 are in flight while the MFMAs of step t run.
 // LDS holds A as two planes (re, im) [BM][BK+4] and B transposed
 // [2*BN][BK+4] so every fragment is one aligned ds_read_b128 (4 k's).
+//
+// Coalescing of the gather.  Which tile element a lane fetches is given by a
+// per-step *order table* built on the host (ctg_runtime.hip): the BM x BK
+// tile elements sorted by their memory offset.  Lane l of load instruction j
+// takes sorted element j*256 + l, so a wave always walks memory in ascending
+// address order whatever index permutation the step encodes -- the HBM-side
+// equivalent of the LDS-staged transpose.  When adjacent sorted elements are
+// adjacent in memory (always the case for the big operand of power-of-two
+// networks) each lane moves two complex numbers with one 16-byte load.
+// Offsets come from LDS, not from global tables: row offsets are resolved once
+// per tile, k offsets by 2*BK threads one k-step ahead (3-slot ring).
+//
 // The block-id -> tile map keeps all column tiles of a row tile on one XCD
 // (block b runs on XCD b % 8) so A is fetched from HBM once and re-read from
 // that XCD's L2.
@@ -34,31 +46,36 @@ namespace ctg {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-template <int BM, int BN, int BK, int WM, int WN>
+template <int BM_, int BN_, int BK_, int WM_, int WN_>
 struct MfmaCfg {
+    static constexpr int BM = BM_, BN = BN_, BK = BK_, WM = WM_, WN = WN_;
     static constexpr int kThreads = 256;
-    static constexpr int LD = BK + 4;               // padded k extent of an LDS row (floats)
-    static constexpr int WTM = BM / WM;             // wave tile rows
-    static constexpr int WTN = BN / WN;             // wave tile complex cols
-    static constexpr int FM = WTM / 32;             // MFMA tiles per wave along m
-    static constexpr int FN = WTN / 16;             // MFMA tiles per wave along n (16 complex = 32 real)
+    static constexpr int LD = BK + 4;    // padded k extent of an LDS row (floats)
+    static constexpr int WTM = BM / WM;  // wave tile rows
+    static constexpr int WTN = BN / WN;  // wave tile complex cols
+    static constexpr int FM = WTM / 32;  // MFMA tiles per wave along m
+    static constexpr int FN = WTN / 16;  // MFMA tiles per wave along n (16 complex = 32 real)
     static constexpr int A_PER_T = BM * BK / kThreads;
     static constexpr int B_PER_T = (BK * BN + kThreads - 1) / kThreads;
     static constexpr int A_FLOATS = 2 * BM * LD;
     static constexpr int B_FLOATS = 2 * BN * LD;
     static_assert(WM * WN == 4, "4 waves per block");
     static_assert(WTM % 32 == 0 && WTN % 16 == 0, "wave tile must hold whole MFMA tiles");
-    static_assert((BM * BK) % kThreads == 0, "A tile must divide over the block");
+    static_assert((BM * BK) % (2 * kThreads) == 0, "A tile must divide over the block in pairs");
+    static_assert(BK == MFMA_BK && BM == MFMA_BM, "tile constants shared with the host");
     static_assert(BK % 4 == 0, "k-step is consumed 4 at a time");
 };
 
-template <typename Cfg, int BM, int BN, int BK, int WM, int WN>
-__global__ __launch_bounds__(256, 2) void pair_mfma_c64_kernel(StepArgs p, int64_t tiles_m,
-                                                               int64_t tiles_n, int flags,
+template <typename Cfg, bool VEC_A>
+__global__ __launch_bounds__(256, 2) void pair_mfma_c64_kernel(StepArgs p, MfmaHints h,
+                                                               int64_t tiles_m, int64_t tiles_n,
                                                                int64_t k_chunk,
                                                                float* __restrict__ partial) {
+    constexpr int BM = Cfg::BM, BN = Cfg::BN, BK = Cfg::BK, WN = Cfg::WN, LD = Cfg::LD;
     __shared__ __attribute__((aligned(16))) float lds[2 * (Cfg::A_FLOATS + Cfg::B_FLOATS)];
+    __shared__ int64_t rowA_s[BM];
     __shared__ int64_t rowC_s[BM];
+    __shared__ int64_t kofs_s[3][2][BK];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -78,79 +95,99 @@ __global__ __launch_bounds__(256, 2) void pair_mfma_c64_kernel(StepArgs p, int64
     const c64* __restrict__ B = (const c64*)p.B + *p.soffB + p.bB[bz];
     float* __restrict__ C = (float*)((c64*)p.C + *p.soffC + p.bC[bz]);
 
-    const bool a_kfast = flags & 1, b_kfast = flags & 2;
+    // split-K: blockIdx.y owns k in [k_begin, k_end); partial tiles go to scratch
+    const int64_t k_begin = (int64_t)blockIdx.y * k_chunk;
+    const int64_t k_end_raw = k_begin + k_chunk;
+    const int64_t k_end = k_end_raw < p.K ? k_end_raw : p.K;
+    const int64_t nk = (k_end - k_begin + BK - 1) / BK;
 
-    // --- per-thread gather coordinates (fixed for the whole kernel) --------
-    int a_r[Cfg::A_PER_T], a_c[Cfg::A_PER_T];
-    int64_t a_row[Cfg::A_PER_T];  // row offset or -1 if the row is outside M
-#pragma unroll
-    for (int j = 0; j < Cfg::A_PER_T; ++j) {
-        const int e = j * 256 + tid;
-        if (a_kfast) {
-            a_r[j] = e / BK;
-            a_c[j] = e % BK;
-        } else {
-            a_r[j] = e % BM;
-            a_c[j] = e / BM;
-        }
-        const int64_t m = m0 + a_r[j];
-        if (m < p.R) {
-            int64_t hi, lo;
-            split_row(p, m, hi, lo);
-            a_row[j] = p.rowA.hi[hi] + p.rowA.lo[lo];
-        } else {
-            a_row[j] = -1;
-        }
-    }
-    int b_k[Cfg::B_PER_T], b_n[Cfg::B_PER_T];
-    int64_t b_col[Cfg::B_PER_T];
-#pragma unroll
-    for (int j = 0; j < Cfg::B_PER_T; ++j) {
-        const int e = j * 256 + tid;
-        if (b_kfast) {
-            b_k[j] = e % BK;
-            b_n[j] = e / BK;
-        } else {
-            b_k[j] = e / BN;
-            b_n[j] = e % BN;
-        }
-        const int64_t n = n0 + b_n[j];
-        b_col[j] = (e < BK * BN && n < p.N) ? p.nB[n] : -1;
-    }
+    // --- offsets into LDS ---------------------------------------------------
     if (tid < BM) {
         const int64_t m = m0 + tid;
-        int64_t off = -1;
+        int64_t oa = -1, oc = -1;
         if (m < p.R) {
             int64_t hi, lo;
             split_row(p, m, hi, lo);
-            off = p.rowC.hi[hi] + p.rowC.lo[lo];
+            oa = p.rowA.hi[hi] + p.rowA.lo[lo];
+            oc = p.rowC.hi[hi] + p.rowC.lo[lo];
         }
-        rowC_s[tid] = off;
+        rowA_s[tid] = oa;
+        rowC_s[tid] = oc;
     }
+    auto fill_kofs = [&](int64_t step) {  // executed by threads tid < 2*BK
+        const int which = tid / BK, c = tid % BK;
+        const int64_t k = k_begin + step * BK + c;
+        int64_t off = -1;
+        if (k < p.K) {
+            int64_t kh, kl;
+            split_k(p, k, kh, kl);
+            off = which ? p.kB.hi[kh] + p.kB.lo[kl] : p.kA.hi[kh] + p.kA.lo[kl];
+        }
+        kofs_s[step % 3][which][c] = off;
+    };
+    if (tid < 2 * BK) {
+        fill_kofs(0);
+        if (nk > 1) fill_kofs(1);
+    }
+
+    // --- per-thread gather coordinates (sorted-by-address order tables) ------
+    int a_lds[Cfg::A_PER_T], a_c[Cfg::A_PER_T], a_r[Cfg::A_PER_T];
+    {
+        const uint16_t* oa = h.ordA + tid * Cfg::A_PER_T;
+#pragma unroll
+        for (int j = 0; j < Cfg::A_PER_T; ++j) {
+            const int v = oa[j];
+            a_r[j] = v >> 4;
+            a_c[j] = v & 15;
+            a_lds[j] = a_r[j] * LD + a_c[j];
+        }
+    }
+    int b_k[Cfg::B_PER_T], b_lds[Cfg::B_PER_T];
+    int64_t b_col[Cfg::B_PER_T];
+    {
+        const uint16_t* ob = h.ordB + tid * Cfg::B_PER_T;
+#pragma unroll
+        for (int j = 0; j < Cfg::B_PER_T; ++j) {
+            const int v = ob[j];
+            const int nn = v >> 4;
+            b_k[j] = v & 15;
+            b_lds[j] = 2 * nn * LD + b_k[j];
+            const int64_t n = n0 + nn;
+            b_col[j] = (j * 256 + tid < BK * BN && n < p.N) ? p.nB[n] : -1;
+        }
+    }
+    __syncthreads();
+    int64_t a_row[Cfg::A_PER_T];
+#pragma unroll
+    for (int j = 0; j < Cfg::A_PER_T; ++j) a_row[j] = rowA_s[a_r[j]];
 
     c64 a_reg[Cfg::A_PER_T], b_reg[Cfg::B_PER_T];
 
-    auto gather = [&](int64_t k0) {
+    auto gather = [&](int64_t step) {
+        const int64_t* ka = kofs_s[step % 3][0];
+        const int64_t* kb = kofs_s[step % 3][1];
+        if (VEC_A) {
+            // sorted elements (2j, 2j+1) are adjacent in memory and the tile is full
 #pragma unroll
-        for (int j = 0; j < Cfg::A_PER_T; ++j) {
-            const int64_t k = k0 + a_c[j];
-            c64 v{0.f, 0.f};
-            if (a_row[j] >= 0 && k < p.K) {
-                int64_t kh, kl;
-                split_k(p, k, kh, kl);
-                v = A[a_row[j] + p.kA.hi[kh] + p.kA.lo[kl]];
+            for (int j = 0; j < Cfg::A_PER_T; j += 2) {
+                const f32x4 v = *(const f32x4*)(A + a_row[j] + ka[a_c[j]]);
+                a_reg[j] = c64{v[0], v[1]};
+                a_reg[j + 1] = c64{v[2], v[3]};
             }
-            a_reg[j] = v;
+        } else {
+#pragma unroll
+            for (int j = 0; j < Cfg::A_PER_T; ++j) {
+                const int64_t ko = ka[a_c[j]];
+                c64 v{0.f, 0.f};
+                if (a_row[j] >= 0 && ko >= 0) v = A[a_row[j] + ko];
+                a_reg[j] = v;
+            }
         }
 #pragma unroll
         for (int j = 0; j < Cfg::B_PER_T; ++j) {
-            const int64_t k = k0 + b_k[j];
+            const int64_t ko = kb[b_k[j]];
             c64 v{0.f, 0.f};
-            if (b_col[j] >= 0 && k < p.K) {
-                int64_t kh, kl;
-                split_k(p, k, kh, kl);
-                v = B[b_col[j] + p.kB.hi[kh] + p.kB.lo[kl]];
-            }
+            if (b_col[j] >= 0 && ko >= 0) v = B[b_col[j] + ko];
             b_reg[j] = v;
         }
     };
@@ -159,14 +196,14 @@ __global__ __launch_bounds__(256, 2) void pair_mfma_c64_kernel(StepArgs p, int64
         float* Bs = As + Cfg::A_FLOATS;
 #pragma unroll
         for (int j = 0; j < Cfg::A_PER_T; ++j) {
-            As[a_r[j] * Cfg::LD + a_c[j]] = a_reg[j].re;
-            As[BM * Cfg::LD + a_r[j] * Cfg::LD + a_c[j]] = a_reg[j].im;
+            As[a_lds[j]] = a_reg[j].re;
+            As[BM * LD + a_lds[j]] = a_reg[j].im;
         }
 #pragma unroll
         for (int j = 0; j < Cfg::B_PER_T; ++j) {
             if (j * 256 + tid < BK * BN) {
-                Bs[(2 * b_n[j]) * Cfg::LD + b_k[j]] = b_reg[j].re;
-                Bs[(2 * b_n[j] + 1) * Cfg::LD + b_k[j]] = b_reg[j].im;
+                Bs[b_lds[j]] = b_reg[j].re;
+                Bs[b_lds[j] + LD] = b_reg[j].im;
             }
         }
     };
@@ -179,37 +216,31 @@ __global__ __launch_bounds__(256, 2) void pair_mfma_c64_kernel(StepArgs p, int64
 #pragma unroll
             for (int t = 0; t < 16; ++t) acc[i][j][t] = 0.f;
 
-    const int kk = lane >> 5;     // 0: real part of a / first row of B', 1: imaginary part
+    const int kk = lane >> 5;  // 0: real part of a / first row of B', 1: imaginary part
     const int l31 = lane & 31;
     const bool negate = kk == 1 && (lane & 1) == 0;
 
-    // split-K: blockIdx.y owns k in [k_begin, k_end); partial tiles go to scratch
-    const int64_t k_begin = (int64_t)blockIdx.y * k_chunk;
-    const int64_t k_end_raw = k_begin + k_chunk;
-    const int64_t k_end = k_end_raw < p.K ? k_end_raw : p.K;
-    const int64_t nk = (k_end - k_begin + BK - 1) / BK;
-    // gather() masks with p.K; chunks are multiples of BK so no overlap occurs
-    gather(k_begin);
+    gather(0);
     stage(0);
     __syncthreads();
 
     for (int64_t kt = 0; kt < nk; ++kt) {
         const int buf = kt & 1;
-        if (kt + 1 < nk) gather(k_begin + (kt + 1) * BK);
+        if (kt + 2 < nk && tid < 2 * BK) fill_kofs(kt + 2);
+        if (kt + 1 < nk) gather(kt + 1);
 
         const float* As = lds + buf * (Cfg::A_FLOATS + Cfg::B_FLOATS);
         const float* Bs = As + Cfg::A_FLOATS;
-        const float* a_base = As + kk * BM * Cfg::LD + (wm * Cfg::WTM + l31) * Cfg::LD;
-        const float* b_base = Bs + (2 * wn * Cfg::WTN + (l31 ^ kk)) * Cfg::LD;
+        const float* a_base = As + kk * BM * LD + (wm * Cfg::WTM + l31) * LD;
+        const float* b_base = Bs + (2 * wn * Cfg::WTN + (l31 ^ kk)) * LD;
 #pragma unroll
         for (int kq = 0; kq < BK / 4; ++kq) {
             f32x4 af[Cfg::FM], bf[Cfg::FN];
 #pragma unroll
-            for (int i = 0; i < Cfg::FM; ++i)
-                af[i] = *(const f32x4*)(a_base + i * 32 * Cfg::LD + kq * 4);
+            for (int i = 0; i < Cfg::FM; ++i) af[i] = *(const f32x4*)(a_base + i * 32 * LD + kq * 4);
 #pragma unroll
             for (int j = 0; j < Cfg::FN; ++j) {
-                f32x4 v = *(const f32x4*)(b_base + j * 32 * Cfg::LD + kq * 4);
+                f32x4 v = *(const f32x4*)(b_base + j * 32 * LD + kq * 4);
                 bf[j] = negate ? -v : v;
             }
 #pragma unroll
@@ -226,7 +257,6 @@ __global__ __launch_bounds__(256, 2) void pair_mfma_c64_kernel(StepArgs p, int64
     }
 
     // --- epilogue: D[row][2n+c], row = (reg&3) + 8*(reg>>2) + 4*(lane>>5) ------
-    const int c = lane & 1;
     if (partial != nullptr) {
         // dense fp32 slab [batch][split][tiles_m*BM][2*tiles_n*BN]
         const int64_t ldp = 2 * tiles_n * BN;
@@ -244,18 +274,28 @@ __global__ __launch_bounds__(256, 2) void pair_mfma_c64_kernel(StepArgs p, int64
         }
         return;
     }
+    // pair up rows (t, t+1): even lanes end up with (re, im) of row t, odd lanes
+    // with (re, im) of row t+1, so every lane stores one whole complex number
+    const bool odd = lane & 1;
 #pragma unroll
     for (int j = 0; j < Cfg::FN; ++j) {
         const int64_t n = n0 + wn * Cfg::WTN + j * 16 + (l31 >> 1);
-        if (n >= p.N) continue;
-        const int64_t ncol = p.nC[n];
+        const bool n_ok = n < p.N;
+        const int64_t ncol = n_ok ? p.nC[n] : 0;
 #pragma unroll
         for (int i = 0; i < Cfg::FM; ++i) {
 #pragma unroll
-            for (int t = 0; t < 16; ++t) {
-                const int row = wm * Cfg::WTM + i * 32 + (t & 3) + 8 * (t >> 2) + 4 * kk;
+            for (int t = 0; t < 16; t += 2) {
+                const float send = odd ? acc[i][j][t] : acc[i][j][t + 1];
+                const float recv = __shfl_xor(send, 1, 64);
+                const int row = wm * Cfg::WTM + i * 32 + (t & 3) + 8 * (t >> 2) + 4 * kk + (odd ? 1 : 0);
                 const int64_t ro = rowC_s[row];
-                if (ro >= 0) C[2 * (ro + ncol) + c] = acc[i][j][t];
+                if (n_ok && ro >= 0) {
+                    float2 v;
+                    v.x = odd ? recv : acc[i][j][t];
+                    v.y = odd ? acc[i][j][t + 1] : recv;
+                    *(float2*)(C + 2 * (ro + ncol)) = v;
+                }
             }
         }
     }
@@ -286,10 +326,10 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(StepArgs p, int64_t 
     }
 }
 
-template <int BM, int BN, int BK, int WM, int WN>
-static hipError_t launch_cfg(const StepArgs& p, int flags, void* scratch, int64_t scratch_bytes,
-                             hipStream_t stream) {
-    typedef MfmaCfg<BM, BN, BK, WM, WN> Cfg;
+template <typename Cfg>
+static hipError_t launch_cfg(const StepArgs& p, const MfmaHints& h, void* scratch,
+                             int64_t scratch_bytes, hipStream_t stream) {
+    constexpr int BM = Cfg::BM, BN = Cfg::BN, BK = Cfg::BK;
     const int64_t tiles_m = (p.R + BM - 1) / BM;
     const int64_t tiles_n = (p.N + BN - 1) / BN;
     const int64_t gx = ((tiles_m + 7) / 8) * 8 * tiles_n;
@@ -311,9 +351,14 @@ static hipError_t launch_cfg(const StepArgs& p, int flags, void* scratch, int64_
         k_chunk = ((nk_total + S - 1) / S) * BK;
         S = (p.K + k_chunk - 1) / k_chunk;
     }
-    hipLaunchKernelGGL((pair_mfma_c64_kernel<Cfg, BM, BN, BK, WM, WN>),
-                       dim3((unsigned)gx, (unsigned)S, (unsigned)p.Bt), dim3(256), 0, stream, p, tiles_m,
-                       tiles_n, flags, k_chunk, S > 1 ? (float*)scratch : (float*)nullptr);
+    const dim3 grid((unsigned)gx, (unsigned)S, (unsigned)p.Bt);
+    float* part = S > 1 ? (float*)scratch : (float*)nullptr;
+    if (h.vecA)
+        hipLaunchKernelGGL((pair_mfma_c64_kernel<Cfg, true>), grid, dim3(256), 0, stream, p, h,
+                           tiles_m, tiles_n, k_chunk, part);
+    else
+        hipLaunchKernelGGL((pair_mfma_c64_kernel<Cfg, false>), grid, dim3(256), 0, stream, p, h,
+                           tiles_m, tiles_n, k_chunk, part);
     if (S > 1) {
         int64_t blocks = (p.R * p.N * p.Bt + 255) / 256;
         if (blocks > 4096) blocks = 4096;
@@ -323,14 +368,15 @@ static hipError_t launch_cfg(const StepArgs& p, int flags, void* scratch, int64_
     return hipGetLastError();
 }
 
-// flags: bit0 = A's fastest-varying memory index is a contracted one,
-//        bit1 = B's fastest-varying memory index is a contracted one
-hipError_t launch_pair_mfma(int dtype, const StepArgs& p, int flags, void* scratch,
+hipError_t launch_pair_mfma(int dtype, const StepArgs& p, const MfmaHints& h, void* scratch,
                             int64_t scratch_bytes, hipStream_t stream) {
     if (dtype != 2) return hipErrorInvalidValue;
-    if (p.N <= 16) return launch_cfg<128, 16, 16, 4, 1>(p, flags, scratch, scratch_bytes, stream);
-    if (p.N <= 32) return launch_cfg<128, 32, 16, 4, 1>(p, flags, scratch, scratch_bytes, stream);
-    return launch_cfg<128, 64, 16, 2, 2>(p, flags, scratch, scratch_bytes, stream);
+    switch (h.bn) {
+        case 16: return launch_cfg<MfmaCfg<128, 16, 16, 4, 1>>(p, h, scratch, scratch_bytes, stream);
+        case 32: return launch_cfg<MfmaCfg<128, 32, 16, 4, 1>>(p, h, scratch, scratch_bytes, stream);
+        case 64: return launch_cfg<MfmaCfg<128, 64, 16, 2, 2>>(p, h, scratch, scratch_bytes, stream);
+    }
+    return hipErrorInvalidValue;
 }
 
 }  // namespace ctg

@@ -82,7 +82,8 @@ struct ctg_exec {
     void* d_scratch = nullptr;
     SliceMeta meta{};
     std::vector<StepArgs> args;  // resolved per step
-    std::vector<int> flags;      // per step kernel hints
+    std::vector<MfmaHints> hints;  // per step kernel hints (MFMA steps)
+    uint16_t* d_ord = nullptr;     // order tables of all MFMA steps
     std::vector<hipEvent_t> events;
 };
 
@@ -210,7 +211,7 @@ void resolve_args(ctg_exec* e) {
     const ctg_plan* p = e->plan;
     const int64_t isz = kItemSize[p->dtype];
     e->args.resize(p->n_steps);
-    e->flags.assign(p->n_steps, 0);
+    e->hints.assign(p->n_steps, MfmaHints{nullptr, nullptr, 0, 0});
     const int64_t* T = e->d_tables;
     for (int64_t s = 0; s < p->n_steps; ++s) {
         const int64_t* r = &p->steps[s * STEP_WORDS];
@@ -249,18 +250,133 @@ void resolve_args(ctg_exec* e) {
         a.bA = tab(W_BA);
         a.bB = tab(W_BB);
         a.bC = tab(W_BC);
-        if (r[W_KIND] == KIND_PAIR && r[W_KERNEL] == KERNEL_MFMA) {
-            // which group holds the operand's fastest-varying memory index?
-            auto stride1 = [&](int w, int64_t len) -> int64_t {
-                if (len < 2 || r[w] < 0) return INT64_MAX;
-                const int64_t v = p->tables[r[w] + 1] - p->tables[r[w]];
-                return v < 0 ? -v : (v == 0 ? INT64_MAX : v);
-            };
-            const int64_t ak = stride1(W_KA, a.k_lo), am = stride1(W_ROWA_LO, a.row_lo);
-            const int64_t bk = stride1(W_KB, a.k_lo), bn = stride1(W_NB, a.N);
-            e->flags[s] = (ak < am ? 1 : 0) | (bk < bn ? 2 : 0);
+    }
+}
+
+// ---- MFMA gather order tables -------------------------------------------- //
+
+// offset of entry i of a two-level table (host copy)
+int64_t tab2(const ctg_plan* p, int64_t hi_w, int64_t lo_w, int64_t lo_size, int64_t i) {
+    return p->tables[hi_w + i / lo_size] + p->tables[lo_w + i % lo_size];
+}
+
+// true if lo[t*B + r] - lo[t*B] == lo[r] for every tile t: tile-local offsets
+// do not depend on the tile, so the order found on tile 0 holds everywhere
+bool tile_additive(const ctg_plan* p, int64_t lo_w, int64_t lo_size, int64_t total, int B) {
+    if (total % B) return false;
+    if (lo_size % B) return false;
+    for (int64_t t = 0; t < lo_size / B; ++t)
+        for (int r = 0; r < B; ++r)
+            if (p->tables[lo_w + t * B + r] - p->tables[lo_w + t * B] != p->tables[lo_w + r])
+                return false;
+    return true;
+}
+
+bool all_even(const ctg_plan* p, int64_t w, int64_t len, int64_t stride = 1) {
+    for (int64_t i = 0; i < len; i += stride)
+        if (p->tables[w + i] & 1) return false;
+    return true;
+}
+
+// Build the order tables of one MFMA step; appends to `blob`, returns offsets.
+void build_mfma_order(const ctg_plan* p, const int64_t* r, int bn, std::vector<uint16_t>& blob,
+                      size_t* offA, size_t* offB, int* vecA) {
+    const int BM = MFMA_BM, BK = MFMA_BK;
+    const int64_t R = r[W_R], K = r[W_K], N = r[W_N];
+    const int64_t BIG = INT64_MAX / 4;
+    // ---- A tile ----
+    {
+        const int n_el = BM * BK, per_t = n_el / 256;
+        std::vector<int64_t> off(n_el);
+        std::vector<int> idx(n_el);
+        for (int rr = 0; rr < BM; ++rr)
+            for (int c = 0; c < BK; ++c) {
+                const int i = rr * BK + c;
+                idx[i] = i;
+                off[i] = (rr < R && c < K)
+                             ? tab2(p, r[W_ROWA_HI], r[W_ROWA_LO], r[W_ROW_LO], rr) +
+                                   tab2(p, r[W_KA_HI], r[W_KA], r[W_K_LO], c)
+                             : BIG + i;
+            }
+        std::stable_sort(idx.begin(), idx.end(), [&](int x, int y) { return off[x] < off[y]; });
+        bool vec = (R % BM == 0) && (K % BK == 0);
+        for (int q = 0; vec && q < n_el / 2; ++q) {
+            const int64_t o0 = off[idx[2 * q]], o1 = off[idx[2 * q + 1]];
+            if (o1 != o0 + 1 || (o0 & 1)) vec = false;
+        }
+        // the pairing must hold for every tile / k-step and keep 16-byte alignment
+        vec = vec && tile_additive(p, r[W_ROWA_LO], r[W_ROW_LO], R, BM) &&
+              tile_additive(p, r[W_KA], r[W_K_LO], K, BK);
+        vec = vec && all_even(p, r[W_ROWA_HI], r[W_ROW_HI_LEN]) &&
+              all_even(p, r[W_ROWA_LO], r[W_ROW_LO], BM) && all_even(p, r[W_KA_HI], r[W_K_HI_LEN]) &&
+              all_even(p, r[W_KA], r[W_K_LO], BK) && all_even(p, r[W_BA], r[W_BT]) &&
+              (r[W_A_OFF] % 2 == 0);
+        if (vec && r[W_A_LEAF] >= 0)
+            for (int64_t j = 0; j < p->n_sliced; ++j)
+                if (p->slice_strides[r[W_A_LEAF] * p->n_sliced + j] & 1) vec = false;
+        *vecA = vec ? 1 : 0;
+        *offA = blob.size();
+        blob.resize(blob.size() + n_el);
+        uint16_t* out = blob.data() + *offA;
+        auto pack = [&](int i) { return (uint16_t)(((i / BK) << 4) | (i % BK)); };
+        for (int tid = 0; tid < 256; ++tid) {
+            if (vec) {
+                for (int jj = 0; jj < per_t / 2; ++jj) {
+                    const int q = jj * 256 + tid;
+                    out[tid * per_t + 2 * jj] = pack(idx[2 * q]);
+                    out[tid * per_t + 2 * jj + 1] = pack(idx[2 * q + 1]);
+                }
+            } else {
+                for (int j = 0; j < per_t; ++j) out[tid * per_t + j] = pack(idx[j * 256 + tid]);
+            }
         }
     }
+    // ---- B tile ----
+    {
+        const int n_el = BK * bn, per_t = (n_el + 255) / 256;
+        std::vector<int64_t> off(n_el);
+        std::vector<int> idx(n_el);
+        for (int n = 0; n < bn; ++n)
+            for (int c = 0; c < BK; ++c) {
+                const int i = n * BK + c;
+                idx[i] = i;
+                off[i] = (n < N && c < K)
+                             ? p->tables[r[W_NB] + n] + tab2(p, r[W_KB_HI], r[W_KB], r[W_K_LO], c)
+                             : BIG + i;
+            }
+        std::stable_sort(idx.begin(), idx.end(), [&](int x, int y) { return off[x] < off[y]; });
+        *offB = blob.size();
+        blob.resize(blob.size() + 256 * per_t, 0);
+        uint16_t* out = blob.data() + *offB;
+        for (int tid = 0; tid < 256; ++tid)
+            for (int j = 0; j < per_t; ++j) {
+                const int e = j * 256 + tid;
+                out[tid * per_t + j] =
+                    e < n_el ? (uint16_t)(((idx[e] / BK) << 4) | (idx[e] % BK)) : (uint16_t)0;
+            }
+    }
+}
+
+int build_hints(ctg_exec* e) {
+    const ctg_plan* p = e->plan;
+    std::vector<uint16_t> blob;
+    std::vector<size_t> offA(p->n_steps, 0), offB(p->n_steps, 0);
+    for (int64_t s = 0; s < p->n_steps; ++s) {
+        const int64_t* r = &p->steps[s * STEP_WORDS];
+        if (r[W_KIND] != KIND_PAIR || r[W_KERNEL] != KERNEL_MFMA) continue;
+        MfmaHints& h = e->hints[s];
+        h.bn = mfma_pick_bn(r[W_N]);
+        build_mfma_order(p, r, h.bn, blob, &offA[s], &offB[s], &h.vecA);
+    }
+    if (blob.empty()) return CTG_OK;
+    HIP_TRY(hipMalloc((void**)&e->d_ord, blob.size() * sizeof(uint16_t)));
+    HIP_TRY(hipMemcpy(e->d_ord, blob.data(), blob.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+    for (int64_t s = 0; s < p->n_steps; ++s) {
+        if (e->hints[s].bn == 0) continue;
+        e->hints[s].ordA = e->d_ord + offA[s];
+        e->hints[s].ordB = e->d_ord + offB[s];
+    }
+    return CTG_OK;
 }
 
 int launch_step(ctg_exec* e, int64_t s) {
@@ -272,7 +388,7 @@ int launch_step(ctg_exec* e, int64_t s) {
         case KIND_ACCUM: err = launch_accum(p->dtype, e->args[s], e->stream); break;
         case KIND_PAIR:
             if (r[W_KERNEL] == KERNEL_MFMA)
-                err = launch_pair_mfma(p->dtype, e->args[s], e->flags[s], e->d_scratch, kScratchBytes,
+                err = launch_pair_mfma(p->dtype, e->args[s], e->hints[s], e->d_scratch, kScratchBytes,
                                        e->stream);
             else
                 err = launch_pair_valu(p->dtype, e->args[s], e->d_scratch, kScratchBytes, e->stream);
@@ -363,6 +479,7 @@ int ctg_exec_destroy(ctg_exec* e) {
     if (e->d_tables) (void)hipFree(e->d_tables);
     if (e->d_misc) (void)hipFree(e->d_misc);
     if (e->d_scratch) (void)hipFree(e->d_scratch);
+    if (e->d_ord) (void)hipFree(e->d_ord);
     delete e;
     return CTG_OK;
 }
@@ -431,6 +548,10 @@ int ctg_exec_create(const ctg_plan* p, int device, void* stream, void* ext_resul
     HIP_TRY_E(hipMemsetAsync(e->d_result, 0, p->result_elems * isz, e->stream));
     e->meta = SliceMeta{n_leaves, p->n_sliced, d_sizes, d_fixed, d_strides};
     resolve_args(e);
+    {
+        const int rc = build_hints(e);
+        if (rc != CTG_OK) return bail(rc);
+    }
     *out = e;
     return CTG_OK;
 #undef HIP_TRY_E
