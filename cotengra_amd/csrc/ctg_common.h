@@ -149,7 +149,14 @@ struct MfmaHints {
     const uint16_t* ordB;
     int bn;    // column tile: 16, 32 or 64
     int vecA;  // 1: pairs of A elements are contiguous + aligned, tiles are full
+    int stream;      // 1: tall-skinny streaming kernel (row tile 32, B resident in LDS)
+    int additive32;  // 1: row offsets are tile-additive for 32-row groups
 };
+
+// steps the streaming kernel takes: short contraction, few columns, many rows
+inline bool mfma_use_stream(int64_t R, int64_t Bt, int64_t K, int64_t N) {
+    return Bt == 1 && K <= 128 && N <= 64 && R >= 8192;
+}
 
 inline int mfma_pick_bn(int64_t N) { return N <= 16 ? 16 : (N <= 32 ? 32 : 64); }
 

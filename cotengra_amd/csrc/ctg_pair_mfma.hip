@@ -368,9 +368,318 @@ static hipError_t launch_cfg(const StepArgs& p, const MfmaHints& h, void* scratc
     return hipGetLastError();
 }
 
+
+// ------------------------------------------------------------------------- //
+// Streaming variant for tall-skinny steps (K <= 128, N <= 64, R huge): the
+// HBM-bound majority of a sliced Sycamore contraction.
+//
+// B (K x N, a few KB) is gathered into LDS once per block in MFMA fragment
+// layout.  Every wave then streams its own 32-row groups of A completely on
+// its own: 16-byte gathers in ascending address order -> wave-private LDS
+// transpose -> fragments -> MFMA -> 8-byte stores.  There is no block barrier
+// in the loop, so the 8-12 waves of a CU overlap each other's memory latency,
+// and row/k offsets never touch global tables inside the loop (tile-additive
+// offsets: one scalar base per group + per-lane constants).
+// ------------------------------------------------------------------------- //
+
+template <int FN, bool VEC, bool ADD>
+__global__ __launch_bounds__(256) void pair_mfma_stream_kernel(StepArgs p, MfmaHints h, int KP,
+                                                               int64_t n_groups) {
+    constexpr int LD = MFMA_BK + 4;
+    constexpr int PER_T = 32 * MFMA_BK / 64;  // A elements per lane per chunk (8)
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int LDB = KP + 4;
+    float* Bs = (float*)smem;                                   // [2*16*FN][LDB]
+    int64_t* kofs_s = (int64_t*)(Bs + 2 * 16 * FN * LDB);       // [KP]
+    float* As_all = (float*)(kofs_s + KP);                      // [4 waves][2][32][LD]
+    int64_t* rows_all = (int64_t*)(As_all + 4 * 2 * 32 * LD);   // [4 waves][2][32] (general path)
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // provably wave-uniform
+    const int kk = lane >> 5;
+    const int l31 = lane & 31;
+    const bool odd = lane & 1;
+    const bool negate = kk == 1 && !odd;
+
+    const c64* __restrict__ A = (const c64*)p.A + *p.soffA;
+    const c64* __restrict__ B = (const c64*)p.B + *p.soffB;
+    float* __restrict__ C = (float*)((c64*)p.C + *p.soffC);
+
+    // ---- B and the k offsets of A into LDS (once per block) -----------------
+    for (int e = tid; e < KP * 16 * FN; e += 256) {
+        const int n = e / KP, k = e - n * KP;
+        c64 v{0.f, 0.f};
+        if (n < p.N && k < p.K) {
+            int64_t kh, kl;
+            split_k(p, k, kh, kl);
+            v = B[p.nB[n] + p.kB.hi[kh] + p.kB.lo[kl]];
+        }
+        Bs[(2 * n) * LDB + k] = v.re;
+        Bs[(2 * n + 1) * LDB + k] = v.im;
+    }
+    for (int k = tid; k < KP; k += 256) {
+        int64_t off = -1;
+        if (k < p.K) {
+            int64_t kh, kl;
+            split_k(p, k, kh, kl);
+            off = p.kA.hi[kh] + p.kA.lo[kl];
+        }
+        kofs_s[k] = off;
+    }
+
+    // ---- per-lane constants ---------------------------------------------------
+    // a_pk[j] = (row << 16) | lds offset of element j; column = lds offset % LD
+    int a_pk[PER_T];
+    int a_delta[PER_T];  // ADD: row offset relative to the group base (host-checked < 2^31)
+    {
+        const uint16_t* oa = h.ordA + lane * PER_T;
+#pragma unroll
+        for (int j = 0; j < PER_T; ++j) {
+            const int v = oa[j];
+            const int r = v >> 4, c = v & 15;
+            a_pk[j] = (r << 16) | (r * LD + c);
+            if (ADD) a_delta[j] = (int)p.rowA.lo[r];
+        }
+    }
+    // rows this lane stores in the epilogue: 8 (paired) rows per MFMA tile
+    int c_delta[8];
+    if (ADD) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int t = 2 * u;
+            c_delta[u] = (int)p.rowC.lo[(t & 3) + 8 * (t >> 2) + 4 * kk + (odd ? 1 : 0)];
+        }
+    }
+    int64_t ncol[FN];
+    bool n_ok[FN];
+#pragma unroll
+    for (int j = 0; j < FN; ++j) {
+        const int64_t n = j * 16 + (l31 >> 1);
+        n_ok[j] = n < p.N;
+        ncol[j] = n_ok[j] ? p.nC[n] : 0;
+    }
+    __syncthreads();
+
+    float* As = As_all + wave * (2 * 32 * LD);
+    const int n_chunks = KP / MFMA_BK;
+    const int64_t wave_g = (int64_t)blockIdx.x * 4 + wave;
+    const int64_t n_waves = (int64_t)gridDim.x * 4;
+
+    // ---- task stream: (group, chunk) pairs, gathers two tasks ahead ----------
+    // Two register sets alternate (R0/R1) so that 2 x 4 KB per wave are always
+    // in flight while the matrix cores work on the task before.
+    int64_t a_base_off = 0;  // ADD: scalar row base of the group being gathered
+
+    auto resolve_rows_a = [&](int64_t g) {
+        const int64_t m0 = g * 32;
+        if (ADD) {
+            int64_t hi, lo;
+            split_row(p, m0, hi, lo);
+            a_base_off = p.rowA.hi[hi] + p.rowA.lo[lo];
+        }
+    };
+    auto gather = [&](c64 (&a_reg)[PER_T], int64_t g, int chunk) {
+        const int64_t* ka = kofs_s + chunk * MFMA_BK;
+        const int64_t m0 = g * 32;
+        if (VEC) {
+#pragma unroll
+            for (int j = 0; j < PER_T; j += 2) {
+                const int r = a_pk[j] >> 16, c = (a_pk[j] & 0xffff) - r * LD;
+                int64_t ro;
+                if (ADD) {
+                    ro = a_base_off + a_delta[j];
+                } else {
+                    int64_t hi, lo;
+                    split_row(p, m0 + r, hi, lo);
+                    ro = p.rowA.hi[hi] + p.rowA.lo[lo];
+                }
+                const f32x4 v = *(const f32x4*)(A + ro + ka[c]);
+                a_reg[j] = c64{v[0], v[1]};
+                a_reg[j + 1] = c64{v[2], v[3]};
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < PER_T; ++j) {
+                const int r = a_pk[j] >> 16, c = (a_pk[j] & 0xffff) - r * LD;
+                int64_t ro = -1;
+                if (ADD) {
+                    ro = a_base_off + a_delta[j];
+                } else if (m0 + r < p.R) {
+                    int64_t hi, lo;
+                    split_row(p, m0 + r, hi, lo);
+                    ro = p.rowA.hi[hi] + p.rowA.lo[lo];
+                }
+                const int64_t ko = ka[c];
+                c64 v{0.f, 0.f};
+                if (ro >= 0 && ko >= 0) v = A[ro + ko];
+                a_reg[j] = v;
+            }
+        }
+    };
+
+    f32x16 acc[FN];
+    const int64_t my_groups = wave_g < n_groups ? (n_groups - wave_g + n_waves - 1) / n_waves : 0;
+    const int64_t n_tasks = my_groups * n_chunks;
+
+    // cursor of the next task to ISSUE
+    int64_t ig = wave_g;
+    int ic = 0;
+    int64_t issued = 0;
+    auto issue = [&](c64 (&a_reg)[PER_T]) {
+        if (issued < n_tasks) {
+            if (ic == 0) resolve_rows_a(ig);
+            gather(a_reg, ig, ic);
+            ++issued;
+            if (++ic == n_chunks) {
+                ic = 0;
+                ig += n_waves;
+            }
+        }
+    };
+    // cursor of the task being CONSUMED
+    int64_t cg = wave_g;
+    int cc = 0;
+    auto consume = [&](c64 (&a_reg)[PER_T]) {
+        if (cc == 0) {
+#pragma unroll
+            for (int j = 0; j < FN; ++j)
+#pragma unroll
+                for (int t = 0; t < 16; ++t) acc[j][t] = 0.f;
+        }
+        // registers -> wave-private LDS (transpose to fragment layout)
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int j = 0; j < PER_T; ++j) {
+            const int o = a_pk[j] & 0xffff;
+            As[o] = a_reg[j].re;
+            As[32 * LD + o] = a_reg[j].im;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        // refill this register set two tasks ahead
+        issue(a_reg);
+        const bool last = cc == n_chunks - 1;
+        // C row base of this group: scalar loads hidden behind the MFMAs below
+        int64_t c_base = 0;
+        if (ADD && last) {
+            int64_t hi, lo;
+            split_row(p, cg * 32, hi, lo);
+            c_base = p.rowC.hi[hi] + p.rowC.lo[lo];
+        }
+        const float* a_base = As + kk * 32 * LD + l31 * LD;
+        const float* b_base = Bs + (l31 ^ kk) * LDB + cc * MFMA_BK;
+        const int k_left = (int)p.K - cc * MFMA_BK;
+        const int nq = k_left >= MFMA_BK ? MFMA_BK / 4 : (k_left + 3) / 4;
+        for (int kq = 0; kq < nq; ++kq) {
+            const f32x4 af = *(const f32x4*)(a_base + kq * 4);
+            f32x4 bf[FN];
+#pragma unroll
+            for (int j = 0; j < FN; ++j) {
+                const f32x4 v = *(const f32x4*)(b_base + j * 32 * LDB + kq * 4);
+                bf[j] = negate ? -v : v;
+            }
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int j = 0; j < FN; ++j)
+                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[t], bf[j][t], acc[j], 0, 0, 0);
+        }
+        if (last) {
+            // epilogue: pair rows (t, t+1) so each lane stores whole complex numbers
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int t = 2 * u;
+                int64_t ro;
+                if (ADD) {
+                    ro = c_base + c_delta[u];
+                } else {
+                    const int64_t m = cg * 32 + (t & 3) + 8 * (t >> 2) + 4 * kk + (odd ? 1 : 0);
+                    ro = -1;
+                    if (m < p.R) {
+                        int64_t hi, lo;
+                        split_row(p, m, hi, lo);
+                        ro = p.rowC.hi[hi] + p.rowC.lo[lo];
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < FN; ++j) {
+                    const float send = odd ? acc[j][t] : acc[j][t + 1];
+                    const float recv = __shfl_xor(send, 1, 64);
+                    if (n_ok[j] && ro >= 0) {
+                        float2 v;
+                        v.x = odd ? recv : acc[j][t];
+                        v.y = odd ? acc[j][t + 1] : recv;
+                        *(float2*)(C + 2 * (ro + ncol[j])) = v;
+                    }
+                }
+            }
+            cc = 0;
+            cg += n_waves;
+        } else {
+            ++cc;
+        }
+    };
+
+    c64 r0[PER_T], r1[PER_T];
+    issue(r0);
+    issue(r1);
+    for (int64_t t = 0; t < n_tasks; t += 2) {
+        consume(r0);
+        if (t + 1 < n_tasks) consume(r1);
+    }
+    (void)rows_all;
+}
+
+template <int FN, bool VEC, bool ADD>
+static hipError_t launch_stream_t(const StepArgs& p, const MfmaHints& h, int KP, size_t smem,
+                                  hipStream_t stream) {
+    auto kern = pair_mfma_stream_kernel<FN, VEC, ADD>;
+    static int blocks_per_cu[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};  // by KP / 16
+    int& bpc = blocks_per_cu[KP / 16];
+    if (bpc == 0) {
+        if (smem > 48 * 1024) {
+            // opt in to more than the default dynamic LDS (the CU has 160 KiB)
+            hipError_t e = hipFuncSetAttribute((const void*)kern,
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, 120 * 1024);
+            if (e != hipSuccess) return e;
+        }
+        int n = 0;
+        hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kern, 256, smem);
+        if (e != hipSuccess) return e;
+        bpc = n < 1 ? 1 : (n > 8 ? 8 : n);
+    }
+    const int64_t n_groups = (p.R + 31) / 32;
+    int64_t blocks = (n_groups + 3) / 4;
+    const int64_t cap = 256ll * bpc;  // persistent: exactly the resident blocks
+    if (blocks > cap) blocks = cap;
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), smem, stream, p, h, KP, n_groups);
+    return hipGetLastError();
+}
+
+template <int FN>
+static hipError_t launch_stream(const StepArgs& p, const MfmaHints& h, hipStream_t stream) {
+    const int KP = (int)((p.K + MFMA_BK - 1) / MFMA_BK) * MFMA_BK;
+    const int LDB = KP + 4;
+    const size_t smem = (size_t)2 * 16 * FN * LDB * 4 + (size_t)KP * 8 +
+                        (size_t)4 * 2 * 32 * (MFMA_BK + 4) * 4 + (size_t)4 * 64 * 8;
+    if (h.vecA && h.additive32) return launch_stream_t<FN, true, true>(p, h, KP, smem, stream);
+    if (h.additive32) return launch_stream_t<FN, false, true>(p, h, KP, smem, stream);
+    return launch_stream_t<FN, false, false>(p, h, KP, smem, stream);
+}
+
 hipError_t launch_pair_mfma(int dtype, const StepArgs& p, const MfmaHints& h, void* scratch,
                             int64_t scratch_bytes, hipStream_t stream) {
     if (dtype != 2) return hipErrorInvalidValue;
+    if (h.stream) {
+        switch (h.bn) {
+            case 16: return launch_stream<1>(p, h, stream);
+            case 32: return launch_stream<2>(p, h, stream);
+            case 64: return launch_stream<4>(p, h, stream);
+        }
+        return hipErrorInvalidValue;
+    }
     switch (h.bn) {
         case 16: return launch_cfg<MfmaCfg<128, 16, 16, 4, 1>>(p, h, scratch, scratch_bytes, stream);
         case 32: return launch_cfg<MfmaCfg<128, 32, 16, 4, 1>>(p, h, scratch, scratch_bytes, stream);

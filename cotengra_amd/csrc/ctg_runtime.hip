@@ -211,7 +211,7 @@ void resolve_args(ctg_exec* e) {
     const ctg_plan* p = e->plan;
     const int64_t isz = kItemSize[p->dtype];
     e->args.resize(p->n_steps);
-    e->hints.assign(p->n_steps, MfmaHints{nullptr, nullptr, 0, 0});
+    e->hints.assign(p->n_steps, MfmaHints{nullptr, nullptr, 0, 0, 0, 0});
     const int64_t* T = e->d_tables;
     for (int64_t s = 0; s < p->n_steps; ++s) {
         const int64_t* r = &p->steps[s * STEP_WORDS];
@@ -279,14 +279,15 @@ bool all_even(const ctg_plan* p, int64_t w, int64_t len, int64_t stride = 1) {
 }
 
 // Build the order tables of one MFMA step; appends to `blob`, returns offsets.
-void build_mfma_order(const ctg_plan* p, const int64_t* r, int bn, std::vector<uint16_t>& blob,
-                      size_t* offA, size_t* offB, int* vecA) {
-    const int BM = MFMA_BM, BK = MFMA_BK;
+void build_mfma_order(const ctg_plan* p, const int64_t* r, int bn, int BM,
+                      std::vector<uint16_t>& blob, size_t* offA, size_t* offB, int* vecA) {
+    const int BK = MFMA_BK;
+    const int T = BM == 32 ? 64 : 256;  // threads sharing one tile gather
     const int64_t R = r[W_R], K = r[W_K], N = r[W_N];
     const int64_t BIG = INT64_MAX / 4;
     // ---- A tile ----
     {
-        const int n_el = BM * BK, per_t = n_el / 256;
+        const int n_el = BM * BK, per_t = n_el / T;
         std::vector<int64_t> off(n_el);
         std::vector<int> idx(n_el);
         for (int rr = 0; rr < BM; ++rr)
@@ -319,15 +320,15 @@ void build_mfma_order(const ctg_plan* p, const int64_t* r, int bn, std::vector<u
         blob.resize(blob.size() + n_el);
         uint16_t* out = blob.data() + *offA;
         auto pack = [&](int i) { return (uint16_t)(((i / BK) << 4) | (i % BK)); };
-        for (int tid = 0; tid < 256; ++tid) {
+        for (int tid = 0; tid < T; ++tid) {
             if (vec) {
                 for (int jj = 0; jj < per_t / 2; ++jj) {
-                    const int q = jj * 256 + tid;
+                    const int q = jj * T + tid;
                     out[tid * per_t + 2 * jj] = pack(idx[2 * q]);
                     out[tid * per_t + 2 * jj + 1] = pack(idx[2 * q + 1]);
                 }
             } else {
-                for (int j = 0; j < per_t; ++j) out[tid * per_t + j] = pack(idx[j * 256 + tid]);
+                for (int j = 0; j < per_t; ++j) out[tid * per_t + j] = pack(idx[j * T + tid]);
             }
         }
     }
@@ -366,7 +367,17 @@ int build_hints(ctg_exec* e) {
         if (r[W_KIND] != KIND_PAIR || r[W_KERNEL] != KERNEL_MFMA) continue;
         MfmaHints& h = e->hints[s];
         h.bn = mfma_pick_bn(r[W_N]);
-        build_mfma_order(p, r, h.bn, blob, &offA[s], &offB[s], &h.vecA);
+        h.stream = mfma_use_stream(r[W_R], r[W_BT], r[W_K], r[W_N]) ? 1 : 0;
+        h.additive32 = (h.stream && tile_additive(p, r[W_ROWA_LO], r[W_ROW_LO], r[W_R], 32) &&
+                        tile_additive(p, r[W_ROWC_LO], r[W_ROW_LO], r[W_R], 32))
+                           ? 1
+                           : 0;
+        // the kernel keeps the 32 tile-local row offsets in 32-bit registers
+        for (int rr = 0; h.additive32 && rr < 32; ++rr) {
+            const int64_t a = p->tables[r[W_ROWA_LO] + rr], c = p->tables[r[W_ROWC_LO] + rr];
+            if (a < 0 || a > INT32_MAX || c < 0 || c > INT32_MAX) h.additive32 = 0;
+        }
+        build_mfma_order(p, r, h.bn, h.stream ? 32 : MFMA_BM, blob, &offA[s], &offB[s], &h.vecA);
     }
     if (blob.empty()) return CTG_OK;
     HIP_TRY(hipMalloc((void**)&e->d_ord, blob.size() * sizeof(uint16_t)));

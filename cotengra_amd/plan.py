@@ -376,6 +376,10 @@ def choose_kernel(dtype, Bt, M, K, N):
         return KERNEL_VALU
     if K >= 4 and N >= 8 and M >= 32 and (M * N * K) >= (1 << 15):
         return KERNEL_MFMA
+    # tall-skinny streaming kernel: HBM-bound, so padding N up to an MFMA tile
+    # costs nothing (csrc/ctg_common.h: mfma_use_stream)
+    if Bt == 1 and 4 <= K <= 128 and N <= 64 and M >= 8192:
+        return KERNEL_MFMA
     return KERNEL_VALU
 
 

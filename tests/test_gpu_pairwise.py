@@ -26,6 +26,13 @@ CASES = [
     ("ab,ab->ab", dict(a=512, b=300)),                                # Hadamard
     ("abc,bcd->ad", dict(a=4096, b=32, c=32, d=256)),                 # K=1024 GEMM
     ("abcdefgh,hgfeij->abcdij", dict(a=8, b=8, c=8, d=8, e=2, f=2, g=2, h=2, i=4, j=4)),
+    # tall-skinny streaming kernel (R >= 8192, K <= 128, N <= 64)
+    ("abck,kn->abcn", dict(a=32, b=32, c=16, k=16, n=16)),            # 15: contiguous k
+    ("kabc,nk->cban", dict(a=32, b=32, c=16, k=32, n=32)),            # 16: k slowest, scattered out
+    ("akbc,kn->abcn", dict(a=64, b=16, c=16, k=128, n=64)),           # 17: K=128, N=64 (large LDS)
+    ("abkc,kn->abcn", dict(a=40, b=25, c=10, k=12, n=5)),             # 18: ragged R/K/N (general path)
+    ("abcdefghijklmnop,dhlp->abcefgijkmno", {ix: 2 for ix in "abcdefghijklmnop"}),  # 19: bit-permuted
+    ("abcdefghijklmnop,pdxhyl->xabcefygijkmno", {ix: 2 for ix in "abcdefghijklmnopxy"}),  # 20
 ]
 
 
@@ -33,7 +40,7 @@ CASES = [
 @pytest.mark.parametrize("case", range(len(CASES)))
 def test_pairwise(case, dtype):
     eq, sizes = CASES[case]
-    if dtype in ("complex128", "float64", "float32") and case in (4, 12):
+    if dtype in ("complex128", "float64", "float32") and case in (4, 12, 17):
         pytest.skip("large case only exercised on the complex64 MFMA path")
     (ta, tb), out = ca.eq_to_inputs_output(eq)
     rng = np.random.default_rng(case)
