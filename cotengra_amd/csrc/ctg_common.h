@@ -151,6 +151,7 @@ struct MfmaHints {
     int vecA;  // 1: pairs of A elements are contiguous + aligned, tiles are full
     int stream;      // 1: tall-skinny streaming kernel (row tile 32, B resident in LDS)
     int additive32;  // 1: row offsets are tile-additive for 32-row groups
+    int fast;        // 1: full tiles + tile-additive 32-bit offsets (tiled fast path)
 };
 
 // steps the streaming kernel takes: short contraction, few columns, many rows

@@ -114,7 +114,12 @@ __global__ __launch_bounds__(256, 2) void pair_mfma_c64_kernel(StepArgs p, MfmaH
         rowA_s[tid] = oa;
         rowC_s[tid] = oc;
     }
-    auto fill_kofs = [&](int64_t step) {  // executed by threads tid < 2*BK
+    // k offsets of a future step: fetched from the global tables into a register
+    // (kofs_fetch) early in an iteration and written to the LDS ring
+    // (kofs_commit) only after that iteration's MFMAs, so the table-load latency
+    // never sits on the critical path of the wave that does it.
+    int64_t kofs_val = -1;
+    auto kofs_fetch = [&](int64_t step) {  // executed by threads tid < 2*BK
         const int which = tid / BK, c = tid % BK;
         const int64_t k = k_begin + step * BK + c;
         int64_t off = -1;
@@ -123,11 +128,17 @@ __global__ __launch_bounds__(256, 2) void pair_mfma_c64_kernel(StepArgs p, MfmaH
             split_k(p, k, kh, kl);
             off = which ? p.kB.hi[kh] + p.kB.lo[kl] : p.kA.hi[kh] + p.kA.lo[kl];
         }
-        kofs_s[step % 3][which][c] = off;
+        kofs_val = off;
+    };
+    auto kofs_commit = [&](int64_t step) { kofs_s[step % 3][tid / BK][tid % BK] = kofs_val; };
+    auto fill_kofs = [&](int64_t step) {
+        kofs_fetch(step);
+        kofs_commit(step);
     };
     if (tid < 2 * BK) {
         fill_kofs(0);
         if (nk > 1) fill_kofs(1);
+        if (nk > 2) fill_kofs(2);
     }
 
     // --- per-thread gather coordinates (sorted-by-address order tables) ------
@@ -220,14 +231,21 @@ __global__ __launch_bounds__(256, 2) void pair_mfma_c64_kernel(StepArgs p, MfmaH
     const int l31 = lane & 31;
     const bool negate = kk == 1 && (lane & 1) == 0;
 
+    // software pipeline: at the top of iteration kt the registers already hold
+    // tile kt+1 (gathered a full iteration ago, so no wait), it is written to
+    // the other LDS buffer and the gather of tile kt+2 is issued -- both
+    // asynchronous to the MFMAs of tile kt that follow.
     gather(0);
     stage(0);
+    if (nk > 1) gather(1);
     __syncthreads();
 
     for (int64_t kt = 0; kt < nk; ++kt) {
         const int buf = kt & 1;
-        if (kt + 2 < nk && tid < 2 * BK) fill_kofs(kt + 2);
-        if (kt + 1 < nk) gather(kt + 1);
+        if (kt + 1 < nk) stage(buf ^ 1);
+        const bool kofs_mine = kt + 3 < nk && tid < 2 * BK;
+        if (kofs_mine) kofs_fetch(kt + 3);
+        if (kt + 2 < nk) gather(kt + 2);
 
         const float* As = lds + buf * (Cfg::A_FLOATS + Cfg::B_FLOATS);
         const float* Bs = As + Cfg::A_FLOATS;
@@ -252,7 +270,7 @@ __global__ __launch_bounds__(256, 2) void pair_mfma_c64_kernel(StepArgs p, MfmaH
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][t], bf[j][t],
                                                                         acc[i][j], 0, 0, 0);
         }
-        if (kt + 1 < nk) stage(buf ^ 1);
+        if (kofs_mine) kofs_commit(kt + 3);
         __syncthreads();
     }
 
@@ -296,6 +314,206 @@ __global__ __launch_bounds__(256, 2) void pair_mfma_c64_kernel(StepArgs p, MfmaH
                     v.y = odd ? acc[i][j][t + 1] : recv;
                     *(float2*)(C + 2 * (ro + ncol)) = v;
                 }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------- //
+// Fast path of the tiled kernel for the steps that carry the flops of a
+// power-of-two network: full tiles and tile-additive offset tables (checked on
+// the host, MfmaHints::fast).  Every address is then
+//     [uniform 64-bit base in SGPRs] + [per-lane 32-bit constant]
+// -- the per-lane constants are computed once per block, the bases once per
+// tile / k-step with scalar loads -- so the inner loop carries no 64-bit
+// vector arithmetic, no LDS offset lookups, no bounds checks and no branches:
+// 4 x 16-byte A loads + B loads + LDS traffic + 64 MFMAs per wave per k-step.
+// ------------------------------------------------------------------------- //
+
+template <typename Cfg, bool VEC_A>
+__global__ __launch_bounds__(256, 2) void pair_mfma_fast_kernel(StepArgs p, MfmaHints h,
+                                                                int64_t tiles_m, int64_t tiles_n,
+                                                                int64_t k_chunk,
+                                                                float* __restrict__ partial) {
+    constexpr int BM = Cfg::BM, BN = Cfg::BN, BK = Cfg::BK, WN = Cfg::WN, LD = Cfg::LD;
+    constexpr int NA = VEC_A ? Cfg::A_PER_T / 2 : Cfg::A_PER_T;  // A load instructions per thread
+    __shared__ __attribute__((aligned(16))) float lds[2 * (Cfg::A_FLOATS + Cfg::B_FLOATS)];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+
+    const int64_t bid = blockIdx.x;
+    const int64_t xcd = bid & 7, q = bid >> 3;
+    const int64_t tm = (q / tiles_n) * 8 + xcd;
+    const int64_t tn = q % tiles_n;
+    if (tm >= tiles_m) return;
+    const int64_t m0 = tm * BM, n0 = tn * BN;
+    const int64_t bz = blockIdx.z;
+
+    // ---- uniform bases ---------------------------------------------------------
+    int64_t rhi, rlo;
+    split_row(p, m0, rhi, rlo);
+    const c64* __restrict__ A = (const c64*)p.A + *p.soffA + p.bA[bz] + p.rowA.hi[rhi] + p.rowA.lo[rlo];
+    const c64* __restrict__ B = (const c64*)p.B + *p.soffB + p.bB[bz] + p.nB[n0];
+    float* __restrict__ C =
+        (float*)((c64*)p.C + *p.soffC + p.bC[bz] + p.rowC.hi[rhi] + p.rowC.lo[rlo] + p.nC[n0]);
+
+    const int64_t k_begin = (int64_t)blockIdx.y * k_chunk;
+    const int64_t k_end_raw = k_begin + k_chunk;
+    const int64_t k_end = k_end_raw < p.K ? k_end_raw : p.K;
+    const int64_t nk = (k_end - k_begin) / BK;
+
+    // ---- per-lane constants -----------------------------------------------------
+    unsigned a_off[NA];          // element offset of the load relative to the bases
+    int a_lds[Cfg::A_PER_T];     // LDS float offset of each element
+    {
+        const uint16_t* oa = h.ordA + tid * Cfg::A_PER_T;
+#pragma unroll
+        for (int j = 0; j < Cfg::A_PER_T; ++j) {
+            const int v = oa[j];
+            const int r = v >> 4, c = v & 15;
+            a_lds[j] = r * LD + c;
+            if (!VEC_A || (j & 1) == 0)
+                a_off[VEC_A ? j / 2 : j] = (unsigned)(p.rowA.lo[r] + p.kA.lo[c]);
+        }
+    }
+    unsigned b_off[Cfg::B_PER_T];
+    int b_lds[Cfg::B_PER_T];
+    {
+        const uint16_t* ob = h.ordB + tid * Cfg::B_PER_T;
+#pragma unroll
+        for (int j = 0; j < Cfg::B_PER_T; ++j) {
+            const int v = ob[j];
+            const int nn = v >> 4, c = v & 15;
+            b_lds[j] = 2 * nn * LD + c;
+            b_off[j] = (unsigned)(p.nB[nn] + p.kB.lo[c]);
+        }
+    }
+
+    c64 a_reg[Cfg::A_PER_T], b_reg[Cfg::B_PER_T];
+
+    auto gather = [&](int64_t step) {
+        int64_t kh, kl;
+        split_k(p, k_begin + step * BK, kh, kl);   // uniform -> scalar loads
+        const c64* Ak = A + p.kA.hi[kh] + p.kA.lo[kl];
+        const c64* Bk = B + p.kB.hi[kh] + p.kB.lo[kl];
+        if (VEC_A) {
+#pragma unroll
+            for (int j = 0; j < NA; ++j) {
+                const f32x4 v = *(const f32x4*)(Ak + a_off[j]);
+                a_reg[2 * j] = c64{v[0], v[1]};
+                a_reg[2 * j + 1] = c64{v[2], v[3]};
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < NA; ++j) a_reg[j] = Ak[a_off[j]];
+        }
+#pragma unroll
+        for (int j = 0; j < Cfg::B_PER_T; ++j)
+            if (Cfg::B_PER_T * 256 == BK * BN || j * 256 + tid < BK * BN) b_reg[j] = Bk[b_off[j]];
+    };
+    auto stage = [&](int buf) {
+        float* As = lds + buf * (Cfg::A_FLOATS + Cfg::B_FLOATS);
+        float* Bs = As + Cfg::A_FLOATS;
+#pragma unroll
+        for (int j = 0; j < Cfg::A_PER_T; ++j) {
+            As[a_lds[j]] = a_reg[j].re;
+            As[BM * LD + a_lds[j]] = a_reg[j].im;
+        }
+#pragma unroll
+        for (int j = 0; j < Cfg::B_PER_T; ++j) {
+            if (Cfg::B_PER_T * 256 == BK * BN || j * 256 + tid < BK * BN) {
+                Bs[b_lds[j]] = b_reg[j].re;
+                Bs[b_lds[j] + LD] = b_reg[j].im;
+            }
+        }
+    };
+
+    f32x16 acc[Cfg::FM][Cfg::FN];
+#pragma unroll
+    for (int i = 0; i < Cfg::FM; ++i)
+#pragma unroll
+        for (int j = 0; j < Cfg::FN; ++j)
+#pragma unroll
+            for (int t = 0; t < 16; ++t) acc[i][j][t] = 0.f;
+
+    const int kk = lane >> 5;
+    const int l31 = lane & 31;
+    // sign bit to flip on the B fragment: -Im b for lanes (row 1 of B', even column)
+    const unsigned sign = (kk == 1 && (lane & 1) == 0) ? 0x80000000u : 0u;
+
+    gather(0);
+    stage(0);
+    if (nk > 1) gather(1);
+    __syncthreads();
+
+    for (int64_t kt = 0; kt < nk; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < nk) stage(buf ^ 1);
+        if (kt + 2 < nk) gather(kt + 2);
+
+        const float* As = lds + buf * (Cfg::A_FLOATS + Cfg::B_FLOATS);
+        const float* Bs = As + Cfg::A_FLOATS;
+        const float* a_base = As + kk * BM * LD + (wm * Cfg::WTM + l31) * LD;
+        const float* b_base = Bs + (2 * wn * Cfg::WTN + (l31 ^ kk)) * LD;
+#pragma unroll
+        for (int kq = 0; kq < BK / 4; ++kq) {
+            f32x4 af[Cfg::FM], bf[Cfg::FN];
+#pragma unroll
+            for (int i = 0; i < Cfg::FM; ++i) af[i] = *(const f32x4*)(a_base + i * 32 * LD + kq * 4);
+#pragma unroll
+            for (int j = 0; j < Cfg::FN; ++j) {
+                typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+                u32x4 v = *(const u32x4*)(b_base + j * 32 * LD + kq * 4);
+                v ^= sign;
+                bf[j] = __builtin_bit_cast(f32x4, v);
+            }
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int i = 0; i < Cfg::FM; ++i)
+#pragma unroll
+                    for (int j = 0; j < Cfg::FN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][t], bf[j][t],
+                                                                        acc[i][j], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+
+    if (partial != nullptr) {
+        const int64_t ldp = 2 * tiles_n * BN;
+        float* slab = partial + ((bz * gridDim.y + blockIdx.y) * (tiles_m * BM)) * ldp;
+#pragma unroll
+        for (int j = 0; j < Cfg::FN; ++j) {
+            const int64_t col = 2 * (n0 + wn * Cfg::WTN + j * 16) + l31;
+#pragma unroll
+            for (int i = 0; i < Cfg::FM; ++i)
+#pragma unroll
+                for (int t = 0; t < 16; ++t) {
+                    const int64_t row = m0 + wm * Cfg::WTM + i * 32 + (t & 3) + 8 * (t >> 2) + 4 * kk;
+                    slab[row * ldp + col] = acc[i][j][t];
+                }
+        }
+        return;
+    }
+    const bool odd = lane & 1;
+#pragma unroll
+    for (int i = 0; i < Cfg::FM; ++i) {
+#pragma unroll
+        for (int t = 0; t < 16; t += 2) {
+            const int row = wm * Cfg::WTM + i * 32 + (t & 3) + 8 * (t >> 2) + 4 * kk + (odd ? 1 : 0);
+            const unsigned ro = (unsigned)p.rowC.lo[row];
+#pragma unroll
+            for (int j = 0; j < Cfg::FN; ++j) {
+                const unsigned co = (unsigned)p.nC[wn * Cfg::WTN + j * 16 + (l31 >> 1)];
+                const float send = odd ? acc[i][j][t] : acc[i][j][t + 1];
+                const float recv = __shfl_xor(send, 1, 64);
+                float2 v;
+                v.x = odd ? recv : acc[i][j][t];
+                v.y = odd ? acc[i][j][t + 1] : recv;
+                *(float2*)(C + 2 * (size_t)(ro + co)) = v;
             }
         }
     }
@@ -353,7 +571,13 @@ static hipError_t launch_cfg(const StepArgs& p, const MfmaHints& h, void* scratc
     }
     const dim3 grid((unsigned)gx, (unsigned)S, (unsigned)p.Bt);
     float* part = S > 1 ? (float*)scratch : (float*)nullptr;
-    if (h.vecA)
+    if (h.fast && h.vecA)
+        hipLaunchKernelGGL((pair_mfma_fast_kernel<Cfg, true>), grid, dim3(256), 0, stream, p, h,
+                           tiles_m, tiles_n, k_chunk, part);
+    else if (h.fast)
+        hipLaunchKernelGGL((pair_mfma_fast_kernel<Cfg, false>), grid, dim3(256), 0, stream, p, h,
+                           tiles_m, tiles_n, k_chunk, part);
+    else if (h.vecA)
         hipLaunchKernelGGL((pair_mfma_c64_kernel<Cfg, true>), grid, dim3(256), 0, stream, p, h,
                            tiles_m, tiles_n, k_chunk, part);
     else

@@ -211,7 +211,7 @@ void resolve_args(ctg_exec* e) {
     const ctg_plan* p = e->plan;
     const int64_t isz = kItemSize[p->dtype];
     e->args.resize(p->n_steps);
-    e->hints.assign(p->n_steps, MfmaHints{nullptr, nullptr, 0, 0, 0, 0});
+    e->hints.assign(p->n_steps, MfmaHints{nullptr, nullptr, 0, 0, 0, 0, 0});
     const int64_t* T = e->d_tables;
     for (int64_t s = 0; s < p->n_steps; ++s) {
         const int64_t* r = &p->steps[s * STEP_WORDS];
@@ -358,6 +358,41 @@ void build_mfma_order(const ctg_plan* p, const int64_t* r, int bn, int BM,
     }
 }
 
+// flat-table variant of tile_additive
+bool flat_additive(const ctg_plan* p, int64_t w, int64_t total, int B) {
+    if (total % B) return false;
+    for (int64_t t = 0; t < total / B; ++t)
+        for (int r = 0; r < B; ++r)
+            if (p->tables[w + t * B + r] - p->tables[w + t * B] != p->tables[w + r]) return false;
+    return true;
+}
+
+// conditions of pair_mfma_fast_kernel: full tiles, tile-additive tables, and
+// tile-local offsets that fit 32 bits
+bool mfma_fast_ok(const ctg_plan* p, const int64_t* r, int bn) {
+    const int BM = MFMA_BM, BK = MFMA_BK;
+    const int64_t R = r[W_R], K = r[W_K], N = r[W_N];
+    if (R % BM || K % BK || N % bn) return false;
+    if (!tile_additive(p, r[W_ROWA_LO], r[W_ROW_LO], R, BM)) return false;
+    if (!tile_additive(p, r[W_ROWC_LO], r[W_ROW_LO], R, BM)) return false;
+    if (!tile_additive(p, r[W_KA], r[W_K_LO], K, BK)) return false;
+    if (!tile_additive(p, r[W_KB], r[W_K_LO], K, BK)) return false;
+    if (!flat_additive(p, r[W_NB], N, bn) || !flat_additive(p, r[W_NC], N, bn)) return false;
+    auto mx = [&](int64_t w, int n) {
+        int64_t m = 0;
+        for (int i = 0; i < n; ++i) {
+            if (p->tables[w + i] < 0) return (int64_t)INT64_MAX / 4;
+            m = std::max(m, p->tables[w + i]);
+        }
+        return m;
+    };
+    const int64_t lim = (int64_t)1 << 31;
+    if (mx(r[W_ROWA_LO], BM) + mx(r[W_KA], BK) >= lim) return false;
+    if (mx(r[W_NB], bn) + mx(r[W_KB], BK) >= lim) return false;
+    if (mx(r[W_ROWC_LO], BM) + mx(r[W_NC], bn) >= lim) return false;
+    return true;
+}
+
 int build_hints(ctg_exec* e) {
     const ctg_plan* p = e->plan;
     std::vector<uint16_t> blob;
@@ -378,6 +413,7 @@ int build_hints(ctg_exec* e) {
             if (a < 0 || a > INT32_MAX || c < 0 || c > INT32_MAX) h.additive32 = 0;
         }
         build_mfma_order(p, r, h.bn, h.stream ? 32 : MFMA_BM, blob, &offA[s], &offB[s], &h.vecA);
+        h.fast = (!h.stream && mfma_fast_ok(p, r, h.bn)) ? 1 : 0;
     }
     if (blob.empty()) return CTG_OK;
     HIP_TRY(hipMalloc((void**)&e->d_ord, blob.size() * sizeof(uint16_t)));
