@@ -331,13 +331,20 @@ __global__ __launch_bounds__(256, 2) void pair_mfma_c64_kernel(StepArgs p, MfmaH
 // ------------------------------------------------------------------------- //
 
 template <typename Cfg, bool VEC_A>
-__global__ __launch_bounds__(256, 2) void pair_mfma_fast_kernel(StepArgs p, MfmaHints h,
+__global__ __launch_bounds__(256, 3) void pair_mfma_fast_kernel(StepArgs p, MfmaHints h,
                                                                 int64_t tiles_m, int64_t tiles_n,
                                                                 int64_t k_chunk,
                                                                 float* __restrict__ partial) {
-    constexpr int BM = Cfg::BM, BN = Cfg::BN, BK = Cfg::BK, WN = Cfg::WN, LD = Cfg::LD;
+    constexpr int BM = Cfg::BM, BN = Cfg::BN, BK = Cfg::BK, WN = Cfg::WN;
     constexpr int NA = VEC_A ? Cfg::A_PER_T / 2 : Cfg::A_PER_T;  // A load instructions per thread
-    __shared__ __attribute__((aligned(16))) float lds[2 * (Cfg::A_FLOATS + Cfg::B_FLOATS)];
+    // Unpadded LDS rows of BK floats with an XOR swizzle of the four 16-byte
+    // columns by (row >> 2) & 3: fragment reads (ds_read_b128 over 16 rows)
+    // stay conflict-free and a block needs 48 KB instead of 60 KB, which lets
+    // three blocks share a CU (12 waves feeding the matrix cores).
+    constexpr int LD = BK;
+    constexpr int AF = 2 * BM * LD, BF = 2 * BN * LD;
+    __shared__ __attribute__((aligned(16))) float lds[2 * (AF + BF)];
+    auto swz = [](int row, int c) { return row * LD + ((((c >> 2) ^ (row >> 2)) & 3) << 2) + (c & 3); };
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -374,20 +381,21 @@ __global__ __launch_bounds__(256, 2) void pair_mfma_fast_kernel(StepArgs p, Mfma
         for (int j = 0; j < Cfg::A_PER_T; ++j) {
             const int v = oa[j];
             const int r = v >> 4, c = v & 15;
-            a_lds[j] = r * LD + c;
+            a_lds[j] = swz(r, c);
             if (!VEC_A || (j & 1) == 0)
                 a_off[VEC_A ? j / 2 : j] = (unsigned)(p.rowA.lo[r] + p.kA.lo[c]);
         }
     }
     unsigned b_off[Cfg::B_PER_T];
-    int b_lds[Cfg::B_PER_T];
+    int b_lds[Cfg::B_PER_T], b_lds2[Cfg::B_PER_T];
     {
         const uint16_t* ob = h.ordB + tid * Cfg::B_PER_T;
 #pragma unroll
         for (int j = 0; j < Cfg::B_PER_T; ++j) {
             const int v = ob[j];
             const int nn = v >> 4, c = v & 15;
-            b_lds[j] = 2 * nn * LD + c;
+            b_lds[j] = swz(2 * nn, c);
+            b_lds2[j] = swz(2 * nn + 1, c);
             b_off[j] = (unsigned)(p.nB[nn] + p.kB.lo[c]);
         }
     }
@@ -415,8 +423,8 @@ __global__ __launch_bounds__(256, 2) void pair_mfma_fast_kernel(StepArgs p, Mfma
             if (Cfg::B_PER_T * 256 == BK * BN || j * 256 + tid < BK * BN) b_reg[j] = Bk[b_off[j]];
     };
     auto stage = [&](int buf) {
-        float* As = lds + buf * (Cfg::A_FLOATS + Cfg::B_FLOATS);
-        float* Bs = As + Cfg::A_FLOATS;
+        float* As = lds + buf * (AF + BF);
+        float* Bs = As + AF;
 #pragma unroll
         for (int j = 0; j < Cfg::A_PER_T; ++j) {
             As[a_lds[j]] = a_reg[j].re;
@@ -426,7 +434,7 @@ __global__ __launch_bounds__(256, 2) void pair_mfma_fast_kernel(StepArgs p, Mfma
         for (int j = 0; j < Cfg::B_PER_T; ++j) {
             if (Cfg::B_PER_T * 256 == BK * BN || j * 256 + tid < BK * BN) {
                 Bs[b_lds[j]] = b_reg[j].re;
-                Bs[b_lds[j] + LD] = b_reg[j].im;
+                Bs[b_lds2[j]] = b_reg[j].im;
             }
         }
     };
@@ -454,19 +462,23 @@ __global__ __launch_bounds__(256, 2) void pair_mfma_fast_kernel(StepArgs p, Mfma
         if (kt + 1 < nk) stage(buf ^ 1);
         if (kt + 2 < nk) gather(kt + 2);
 
-        const float* As = lds + buf * (Cfg::A_FLOATS + Cfg::B_FLOATS);
-        const float* Bs = As + Cfg::A_FLOATS;
-        const float* a_base = As + kk * BM * LD + (wm * Cfg::WTM + l31) * LD;
-        const float* b_base = Bs + (2 * wn * Cfg::WTN + (l31 ^ kk)) * LD;
+        const float* As = lds + buf * (AF + BF);
+        const float* Bs = As + AF;
+        // rows of this lane's fragments; i*32 / j*32 do not change (row >> 2) & 3
+        const int a_row = wm * Cfg::WTM + l31;
+        const int b_row = 2 * wn * Cfg::WTN + (l31 ^ kk);
+        const float* a_base = As + kk * BM * LD + a_row * LD;
+        const float* b_base = Bs + b_row * LD;
+        const int a_sw = (a_row >> 2) & 3, b_sw = (b_row >> 2) & 3;
 #pragma unroll
         for (int kq = 0; kq < BK / 4; ++kq) {
             f32x4 af[Cfg::FM], bf[Cfg::FN];
 #pragma unroll
-            for (int i = 0; i < Cfg::FM; ++i) af[i] = *(const f32x4*)(a_base + i * 32 * LD + kq * 4);
+            for (int i = 0; i < Cfg::FM; ++i) af[i] = *(const f32x4*)(a_base + i * 32 * LD + ((kq ^ a_sw) << 2));
 #pragma unroll
             for (int j = 0; j < Cfg::FN; ++j) {
                 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-                u32x4 v = *(const u32x4*)(b_base + j * 32 * LD + kq * 4);
+                u32x4 v = *(const u32x4*)(b_base + j * 32 * LD + ((kq ^ b_sw) << 2));
                 v ^= sign;
                 bf[j] = __builtin_bit_cast(f32x4, v);
             }
