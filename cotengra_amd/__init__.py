@@ -17,3 +17,14 @@ from .utils import (  # noqa: F401
 )
 
 __version__ = "0.1.0"
+from . import interface, plan  # noqa: F401,E402
+from .contractor import HipContractor, make_contractor  # noqa: F401,E402
+from .interface import (  # noqa: F401,E402
+    array_contract,
+    array_contract_expression,
+    array_contract_tree,
+    einsum,
+    einsum_expression,
+    einsum_tree,
+    greedy_path,
+)

@@ -128,7 +128,8 @@ int validate_plan(ctg_plan* p) {
         const int64_t d = p->slice_sizes[j], f = p->slice_fixed[j];
         if (d < 1) return fail(CTG_E_INVALID, "bad slice size");
         if (f >= 0 && d != 1) return fail(CTG_E_INVALID, "projected index must have size 1");
-        p->nslices *= d;
+        // saturate: trees narrowed for tests can have more than 2^63 slices
+        p->nslices = (p->nslices > INT64_MAX / d) ? INT64_MAX : p->nslices * d;
         for (int64_t l = 0; l <= p->n_inputs; ++l) {
             const int64_t st = p->slice_strides[l * p->n_sliced + j];
             if (st < 0) return fail(CTG_E_INVALID, "negative slice stride");

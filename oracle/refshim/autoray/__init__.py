@@ -39,10 +39,6 @@ def do(name, *args, like=None, **kwargs):
     if name == "astype":
         x, dtype = args
         return _np.asarray(x).astype(dtype)
-    if name == "einsum":
-        # force the reference onto its own matmul/transpose/sum lowering
-        # (contract.py:338-341 catches ImportError and falls through)
-        raise ImportError("einsum deliberately absent from the shim")
     return getattr(_np, name)(*args, **kwargs)
 
 

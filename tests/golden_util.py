@@ -1,0 +1,64 @@
+"""Shared loader for the committed golden fixtures (tests/golden/)."""
+import json
+import os
+
+import numpy as np
+
+import cotengra_amd as ca
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+_CASES = None
+_EXPECTED = None
+
+
+def load():
+    global _CASES, _EXPECTED
+    if _CASES is None:
+        with open(os.path.join(HERE, "golden", "golden_cases.json"), encoding="utf-8") as f:
+            _CASES = json.load(f)["cases"]
+        _EXPECTED = np.load(os.path.join(HERE, "golden", "golden_expected.npz"))
+    return _CASES, _EXPECTED
+
+
+def cases(kind=None):
+    cs, _ = load()
+    return [c for c in cs if kind is None or c["kind"] == kind]
+
+
+def expected(key):
+    _, ex = load()
+    return ex[key]
+
+
+def tree_of(case):
+    inputs = [tuple(t) for t in case["inputs"]]
+    output = tuple(case["output"])
+    if len(inputs) > 1:
+        tree = ca.ContractionTree.from_path(inputs, output, case["size_dict"], path=case["path"])
+    else:
+        tree = ca.ContractionTree(inputs, output, case["size_dict"])
+    for ind, project in case["sliced"]:
+        tree.remove_ind_(ind, project=project)
+    return tree
+
+
+def arrays_of(case, dtype, tree=None):
+    inputs = [tuple(t) for t in case["inputs"]] if tree is None else tree.inputs
+    return ca.make_arrays_from_inputs(
+        inputs, case["size_dict"], seed=case["seed"], dtype=dtype, rescale=case.get("rescale", False)
+    )
+
+
+def eq_tree_and_arrays(case, dtype):
+    inputs, output = ca.eq_to_inputs_output(case["eq"])
+    tree = ca.array_contract_tree(inputs, output, case["size_dict"],
+                                  optimize=case["path"] if len(inputs) > 1 else "greedy")
+    arrays = ca.make_arrays_from_inputs(inputs, case["size_dict"], seed=case["seed"], dtype=dtype)
+    return tree, arrays
+
+
+def relerr(x, ref):
+    x, ref = np.asarray(x), np.asarray(ref)
+    assert x.shape == ref.shape, (x.shape, ref.shape)
+    scale = max(float(np.abs(ref).max()) if ref.size else 0.0, 1e-300)
+    return float(np.abs(x - ref).max() / scale) if ref.size else 0.0

@@ -1,0 +1,134 @@
+"""GPU parity proper: the HIP path (Python host -> C ABI -> gfx950 kernels)
+against the golden vectors frozen from the real reference, plus the oracle on
+the same seeded inputs where no golden exists.
+
+Tolerances: double precision 1e-10 relative to max|ref| (bit-level agreement
+is not defined for floating point; the reference's own gate is 5e-6,
+tests/test_compute.py:113); single precision 2e-4 (reference gate 5e-3).
+"""
+import numpy as np
+import pytest
+
+from cotengra_amd.contractor import HipContractor
+from oracle import contract_ref as orc
+
+import golden_util as G
+
+pytestmark = pytest.mark.gpu
+
+TREE_CASES = G.cases("tree")
+EQ_CASES = G.cases("eq")
+TOL = {"float32": 2e-4, "complex64": 2e-4, "float64": 1e-10, "complex128": 1e-10}
+LOW = {"complex128": "complex64", "float64": "float32"}
+
+
+def check(got, ref, dtype):
+    got = np.asarray(got.cpu()) if hasattr(got, "cpu") else np.asarray(got)
+    assert G.relerr(got, ref) < TOL[dtype], (G.relerr(got, ref), dtype)
+
+
+@pytest.mark.parametrize("case", TREE_CASES, ids=[c["name"] for c in TREE_CASES])
+def test_tree_cases(case):
+    tree = G.tree_of(case)
+    for dt in case["dtypes"]:
+        arrays = G.arrays_of(case, dt, tree)
+        for run_dt in (dt, LOW[dt]):
+            xs = [a.astype(run_dt) for a in arrays]
+            if case["slice_ids"]:
+                for i in case["slice_ids"]:
+                    if i >= 2**62:
+                        continue  # beyond the int64 slice ids of the C ABI
+                    got = tree.contract_slice(xs, i)
+                    check(got, G.expected(f"{case['name']}/{dt}/slice{i}"), run_dt)
+            else:
+                got = tree.contract(xs)
+                check(got, G.expected(f"{case['name']}/{dt}"), run_dt)
+
+
+@pytest.mark.parametrize("case", EQ_CASES, ids=[c["name"] for c in EQ_CASES])
+def test_reference_test_equations(case):
+    for dt in ("complex128", "float64"):
+        tree, arrays = G.eq_tree_and_arrays(case, dt)
+        for run_dt in (dt, LOW[dt]):
+            got = tree.contract([a.astype(run_dt) for a in arrays])
+            check(got, G.expected(f"{case['name']}/{dt}"), run_dt)
+
+
+def test_projected_slices_sum_to_total():
+    """sum_j remove_ind(ix, project=j) == total (tests/test_tree.py:315-335)."""
+    parts = [c for c in TREE_CASES if c["name"].startswith("project_") and c["name"] != "project_total"]
+    total = next(c for c in TREE_CASES if c["name"] == "project_total")
+    acc = 0
+    for c in parts:
+        tree = G.tree_of(c)
+        acc = acc + np.asarray(tree.contract(G.arrays_of(c, "complex128", tree)))
+    check(acc, G.expected("project_total/complex128"), "complex128")
+
+
+def test_torch_device_inputs_and_expression_api():
+    import torch
+
+    import cotengra_amd as ca
+
+    case = next(c for c in TREE_CASES if c["name"] == "lattice4x4_sliced")
+    tree = G.tree_of(case)
+    arrays = G.arrays_of(case, "complex128", tree)
+    dev = [torch.as_tensor(a, device="cuda") for a in arrays]
+    out = tree.contract(dev)
+    assert out.is_cuda
+    check(out, G.expected("lattice4x4_sliced/complex128"), "complex128")
+    expr = ca.array_contract_expression(tree.inputs, tree.output, tree.size_dict, optimize=tree)
+    check(expr(*arrays), G.expected("lattice4x4_sliced/complex128"), "complex128")
+    # contract_core takes already-sliced arrays (core.py:3724-3773)
+    sl = tree.slice_arrays(arrays, 1)
+    got = tree.contract_core(sl)
+    check(got, orc.contract_slice(tree, arrays, 1), "complex128")
+    # gen_output_chunks / gather_slices round trip
+    slices = [tree.contract_slice(arrays, i) for i in range(tree.nslices)]
+    check(tree.gather_slices(slices), G.expected("lattice4x4_sliced/complex128"), "complex128")
+
+
+def test_strip_exponent_and_chunks():
+    case = next(c for c in TREE_CASES if c["name"].endswith("_outsliced") and c["stats"]["nslices"] > 1)
+    tree = G.tree_of(case)
+    arrays = G.arrays_of(case, "complex128", tree)
+    ref = G.expected(f"{case['name']}/complex128")
+    m, e = tree.contract(arrays, strip_exponent=True)
+    check(np.asarray(m) * 10.0**e, ref, "complex128")
+    y = sum((np.abs(np.asarray(ch)) ** 2).sum() for ch in tree.gen_output_chunks(arrays))
+    assert abs(y - (np.abs(ref) ** 2).sum()) <= 1e-9 * (np.abs(ref) ** 2).sum()
+
+
+def test_full_size_properties_m20():
+    """Size-independent checks at the benchmark's full slice width (2^30):
+    (1) slicing identity -- a slice of the tree equals the sum of the two
+    slices obtained by slicing one more index; (2) linearity in one input."""
+    import cotengra_amd as ca
+    import os
+
+    rec = ca.load_network(os.path.join(os.path.dirname(__file__), "golden", "trees", "sycamore_m20_w30.json"))
+    tree = ca.tree_from_record(rec)
+    arrays = ca.make_arrays_from_inputs(tree.inputs, tree.size_dict, seed=42, dtype="complex64", rescale=True)
+    coarse = HipContractor(tree)
+    full = np.asarray(coarse.contract_slice(arrays, 5))
+    # linearity: scaling one input tensor scales the slice amplitude
+    arrays2 = list(arrays)
+    arrays2[7] = arrays[7] * np.complex64(0.5 - 2.0j)
+    lin = np.asarray(coarse.contract_slice(arrays2, 5))
+    coarse.close()
+    assert abs(lin - full * (0.5 - 2.0j)) <= 2e-4 * abs(full) * abs(0.5 - 2.0j)
+    # one more sliced index: fine slices 2*5, 2*5+1 ... in the finer tree's numbering
+    big = max((p for p, _, _ in tree.traverse()), key=tree.get_size)
+    ix = next(iter(tree.get_legs(big)))
+    fine = tree.remove_ind(ix)
+    key = tree.slice_key(5)
+    ids = []
+    for v in range(tree.size_dict[ix]):
+        k = dict(key)
+        k[ix] = v
+        strides = ca.get_slice_strides(fine.sliced_inds)
+        ids.append(sum(k[s] * st for s, st in zip(fine.sliced_inds, strides)))
+    fc = HipContractor(fine)
+    parts = sum(np.asarray(fc.contract_slice(arrays, i)) for i in ids)
+    fc.close()
+    assert abs(parts - full) <= 2e-4 * abs(full)
