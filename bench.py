@@ -91,13 +91,15 @@ def main():
     if args.gpus != world and world > 1:
         raise SystemExit(f"--gpus {args.gpus} != WORLD_SIZE {world}")
     dist = None
-    if world > 1:
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1 or "RANK" in os.environ:
+        # launched by torch.distributed.run: one process per GPU over RCCL
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world)
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+        os.environ.setdefault("MASTER_PORT", "29500")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     import cotengra_amd as ca
     from cotengra_amd.contractor import HipContractor

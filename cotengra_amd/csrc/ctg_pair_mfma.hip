@@ -82,12 +82,18 @@ __global__ __launch_bounds__(256, 2) void pair_mfma_c64_kernel(StepArgs p, MfmaH
     const int wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
 
-    // XCD-aware tile assignment
+    // XCD-aware work assignment (block b runs on XCD b % 8): a unit is a
+    // (row tile, k-split) pair; all column tiles of a unit sit on one XCD (they
+    // share the A panel in that XCD's L2) and consecutive units go to
+    // different XCDs -- including the k-splits of a single row tile.
+    const int64_t S_split = k_chunk;  // number of k-splits (1 = none)
     const int64_t bid = blockIdx.x;
     const int64_t xcd = bid & 7, q = bid >> 3;
-    const int64_t tm = (q / tiles_n) * 8 + xcd;
+    const int64_t unit = (q / tiles_n) * 8 + xcd;
     const int64_t tn = q % tiles_n;
-    if (tm >= tiles_m) return;
+    if (unit >= tiles_m * S_split) return;
+    const int64_t tm = unit % tiles_m;
+    const int64_t ksplit = unit / tiles_m;
     const int64_t m0 = tm * BM, n0 = tn * BN;
     const int64_t bz = blockIdx.z;
 
@@ -95,11 +101,13 @@ __global__ __launch_bounds__(256, 2) void pair_mfma_c64_kernel(StepArgs p, MfmaH
     const c64* __restrict__ B = (const c64*)p.B + *p.soffB + p.bB[bz];
     float* __restrict__ C = (float*)((c64*)p.C + *p.soffC + p.bC[bz]);
 
-    // split-K: blockIdx.y owns k in [k_begin, k_end); partial tiles go to scratch
-    const int64_t k_begin = (int64_t)blockIdx.y * k_chunk;
-    const int64_t k_end_raw = k_begin + k_chunk;
-    const int64_t k_end = k_end_raw < p.K ? k_end_raw : p.K;
-    const int64_t nk = (k_end - k_begin + BK - 1) / BK;
+    // split-K: the k-steps are dealt out cyclically -- block y of S takes steps
+    // y, y+S, y+2S, ... -- so that the blocks running at the same time sweep
+    // one contiguous window of K together (streaming-like page / DRAM-row
+    // locality; contiguous chunks per block thrash address translation when
+    // the chunks are megabytes apart).  Partial tiles go to scratch.
+    const int64_t nk_total = (p.K + BK - 1) / BK;
+    const int64_t nk = (nk_total - ksplit + S_split - 1) / S_split;
 
     // --- offsets into LDS ---------------------------------------------------
     if (tid < BM) {
@@ -121,7 +129,7 @@ __global__ __launch_bounds__(256, 2) void pair_mfma_c64_kernel(StepArgs p, MfmaH
     int64_t kofs_val = -1;
     auto kofs_fetch = [&](int64_t step) {  // executed by threads tid < 2*BK
         const int which = tid / BK, c = tid % BK;
-        const int64_t k = k_begin + step * BK + c;
+        const int64_t k = (step * S_split + ksplit) * BK + c;
         int64_t off = -1;
         if (k < p.K) {
             int64_t kh, kl;
@@ -278,7 +286,7 @@ __global__ __launch_bounds__(256, 2) void pair_mfma_c64_kernel(StepArgs p, MfmaH
     if (partial != nullptr) {
         // dense fp32 slab [batch][split][tiles_m*BM][2*tiles_n*BN]
         const int64_t ldp = 2 * tiles_n * BN;
-        float* slab = partial + ((bz * gridDim.y + blockIdx.y) * (tiles_m * BM)) * ldp;
+        float* slab = partial + ((bz * S_split + ksplit) * (tiles_m * BM)) * ldp;
 #pragma unroll
         for (int j = 0; j < Cfg::FN; ++j) {
             const int64_t col = 2 * (n0 + wn * Cfg::WTN + j * 16) + l31;
@@ -351,11 +359,15 @@ __global__ __launch_bounds__(256, 3) void pair_mfma_fast_kernel(StepArgs p, Mfma
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WN, wn = wave % WN;
 
+    // (row tile, k-split) units spread over the XCDs: see the general kernel
+    const int64_t S_split = k_chunk;
     const int64_t bid = blockIdx.x;
     const int64_t xcd = bid & 7, q = bid >> 3;
-    const int64_t tm = (q / tiles_n) * 8 + xcd;
+    const int64_t unit = (q / tiles_n) * 8 + xcd;
     const int64_t tn = q % tiles_n;
-    if (tm >= tiles_m) return;
+    if (unit >= tiles_m * S_split) return;
+    const int64_t tm = unit % tiles_m;
+    const int64_t ksplit = unit / tiles_m;
     const int64_t m0 = tm * BM, n0 = tn * BN;
     const int64_t bz = blockIdx.z;
 
@@ -367,10 +379,10 @@ __global__ __launch_bounds__(256, 3) void pair_mfma_fast_kernel(StepArgs p, Mfma
     float* __restrict__ C =
         (float*)((c64*)p.C + *p.soffC + p.bC[bz] + p.rowC.hi[rhi] + p.rowC.lo[rlo] + p.nC[n0]);
 
-    const int64_t k_begin = (int64_t)blockIdx.y * k_chunk;
-    const int64_t k_end_raw = k_begin + k_chunk;
-    const int64_t k_end = k_end_raw < p.K ? k_end_raw : p.K;
-    const int64_t nk = (k_end - k_begin) / BK;
+    // split-K: cyclic distribution of the k-steps over blockIdx.y (see the
+    // general kernel)
+    const int64_t nk_total = p.K / BK;
+    const int64_t nk = (nk_total - ksplit + S_split - 1) / S_split;
 
     // ---- per-lane constants -----------------------------------------------------
     unsigned a_off[NA];          // element offset of the load relative to the bases
@@ -404,7 +416,7 @@ __global__ __launch_bounds__(256, 3) void pair_mfma_fast_kernel(StepArgs p, Mfma
 
     auto gather = [&](int64_t step) {
         int64_t kh, kl;
-        split_k(p, k_begin + step * BK, kh, kl);   // uniform -> scalar loads
+        split_k(p, (step * S_split + ksplit) * BK, kh, kl);   // uniform -> scalar loads
         const c64* Ak = A + p.kA.hi[kh] + p.kA.lo[kl];
         const c64* Bk = B + p.kB.hi[kh] + p.kB.lo[kl];
         if (VEC_A) {
@@ -496,7 +508,7 @@ __global__ __launch_bounds__(256, 3) void pair_mfma_fast_kernel(StepArgs p, Mfma
 
     if (partial != nullptr) {
         const int64_t ldp = 2 * tiles_n * BN;
-        float* slab = partial + ((bz * gridDim.y + blockIdx.y) * (tiles_m * BM)) * ldp;
+        float* slab = partial + ((bz * S_split + ksplit) * (tiles_m * BM)) * ldp;
 #pragma unroll
         for (int j = 0; j < Cfg::FN; ++j) {
             const int64_t col = 2 * (n0 + wn * Cfg::WTN + j * 16) + l31;
@@ -531,28 +543,50 @@ __global__ __launch_bounds__(256, 3) void pair_mfma_fast_kernel(StepArgs p, Mfma
     }
 }
 
-// sum the split-K slabs in a fixed order and scatter into C
+// sum the split-K slabs in a fixed order and scatter into C.  A block reduces
+// 32 outputs: 8 thread groups each add every 8th slab (loads unrolled so many
+// are in flight), then the 8 partial sums are combined in a fixed order.
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(StepArgs p, int64_t S, int64_t Mpad,
                                                             int64_t ldp,
                                                             const float* __restrict__ partial) {
+    __shared__ float2 part[8][32];
+    const int ox = threadIdx.x & 31, sy = threadIdx.x >> 5;
     const int64_t per_b = p.R * p.N;
     const int64_t total = per_b * p.Bt;
-    for (int64_t o = (int64_t)blockIdx.x * 256 + threadIdx.x; o < total;
-         o += (int64_t)gridDim.x * 256) {
-        const int64_t b = o / per_b;
-        const int64_t rem = o - b * per_b;
-        const int64_t m = rem / p.N;
-        const int64_t n = rem - m * p.N;
+    for (int64_t o0 = (int64_t)blockIdx.x * 32; o0 < total; o0 += (int64_t)gridDim.x * 32) {
+        const int64_t o = o0 + ox;
+        const bool ok = o < total;
+        int64_t b = 0, m = 0, n = 0;
         float re = 0.f, im = 0.f;
-        for (int64_t s = 0; s < S; ++s) {
-            const float2 v = *(const float2*)(partial + ((b * S + s) * Mpad + m) * ldp + 2 * n);
-            re += v.x;
-            im += v.y;
+        if (ok) {
+            b = o / per_b;
+            const int64_t rem = o - b * per_b;
+            m = rem / p.N;
+            n = rem - m * p.N;
+            const float* src = partial + (b * S * Mpad + m) * ldp + 2 * n;
+            const int64_t slab = Mpad * ldp;
+#pragma unroll 8
+            for (int64_t s = sy; s < S; s += 8) {
+                const float2 v = *(const float2*)(src + s * slab);
+                re += v.x;
+                im += v.y;
+            }
         }
-        int64_t hi, lo;
-        split_row(p, m, hi, lo);
-        c64* C = (c64*)p.C + *p.soffC + p.bC[b];
-        C[p.rowC.hi[hi] + p.rowC.lo[lo] + p.nC[n]] = c64{re, im};
+        part[sy][ox] = make_float2(re, im);
+        __syncthreads();
+        if (sy == 0 && ok) {
+            float r2 = 0.f, i2 = 0.f;
+#pragma unroll
+            for (int g = 0; g < 8; ++g) {
+                r2 += part[g][ox].x;
+                i2 += part[g][ox].y;
+            }
+            int64_t hi, lo;
+            split_row(p, m, hi, lo);
+            c64* C = (c64*)p.C + *p.soffC + p.bC[b];
+            C[p.rowC.hi[hi] + p.rowC.lo[lo] + p.nC[n]] = c64{r2, i2};
+        }
+        __syncthreads();
     }
 }
 
@@ -562,8 +596,6 @@ static hipError_t launch_cfg(const StepArgs& p, const MfmaHints& h, void* scratc
     constexpr int BM = Cfg::BM, BN = Cfg::BN, BK = Cfg::BK;
     const int64_t tiles_m = (p.R + BM - 1) / BM;
     const int64_t tiles_n = (p.N + BN - 1) / BN;
-    const int64_t gx = ((tiles_m + 7) / 8) * 8 * tiles_n;
-    if (gx > 0x7fffffffll) return hipErrorInvalidValue;
     // split-K when the output alone cannot fill the chip but K is long
     const int64_t tiles = tiles_m * tiles_n * p.Bt;
     const int64_t nk_total = (p.K + BK - 1) / BK;
@@ -576,12 +608,11 @@ static hipError_t launch_cfg(const StepArgs& p, const MfmaHints& h, void* scratc
         if (S > 65535) S = 65535;
         if (S < 1) S = 1;
     }
-    int64_t k_chunk = p.K;
-    if (S > 1) {
-        k_chunk = ((nk_total + S - 1) / S) * BK;
-        S = (p.K + k_chunk - 1) / k_chunk;
-    }
-    const dim3 grid((unsigned)gx, (unsigned)S, (unsigned)p.Bt);
+    if (S > nk_total) S = nk_total;
+    const int64_t k_chunk = S;  // the kernels' k_chunk argument carries the split count
+    const int64_t gx = ((tiles_m * S + 7) / 8) * 8 * tiles_n;
+    if (gx > 0x7fffffffll) return hipErrorInvalidValue;
+    const dim3 grid((unsigned)gx, 1, (unsigned)p.Bt);
     float* part = S > 1 ? (float*)scratch : (float*)nullptr;
     if (h.fast && h.vecA)
         hipLaunchKernelGGL((pair_mfma_fast_kernel<Cfg, true>), grid, dim3(256), 0, stream, p, h,
@@ -596,8 +627,8 @@ static hipError_t launch_cfg(const StepArgs& p, const MfmaHints& h, void* scratc
         hipLaunchKernelGGL((pair_mfma_c64_kernel<Cfg, false>), grid, dim3(256), 0, stream, p, h,
                            tiles_m, tiles_n, k_chunk, part);
     if (S > 1) {
-        int64_t blocks = (p.R * p.N * p.Bt + 255) / 256;
-        if (blocks > 4096) blocks = 4096;
+        int64_t blocks = (p.R * p.N * p.Bt + 31) / 32;
+        if (blocks > 8192) blocks = 8192;
         hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, p, S,
                            tiles_m * BM, 2 * tiles_n * BN, (const float*)scratch);
     }

@@ -64,6 +64,8 @@ ARENA_ALIGN = 64  # elements; keeps every intermediate 256-B aligned
 
 # MFMA kernel limits (see csrc/ctg_pair_mfma.hip)
 MFMA_MAX_BATCH = 65535
+# both operands at least this big (elements) => neither is cache resident
+INTERLEAVE_MIN_ELEMS = 1 << 22
 
 
 def _row_major_strides(shape):
@@ -417,6 +419,30 @@ def build_pair_step(
     # one operand only is simply summed -- zero stride on the other operand)
     con = [ix for ix in a_order if ix not in o_set]
     con += [ix for ix in b_order if ix not in o_set and ix not in a_set]
+    # Order of the contracted group = which k's share a k-step of the kernels.
+    # Following A's memory order makes A's tile gathers contiguous; when B is
+    # too large to live in cache as well, interleave the fastest-varying
+    # contracted indices of both operands so that each k-step covers the low
+    # address bits of BOTH (64-128 B runs on each side instead of 8 B on one).
+    size_a = prod(size_dict[ix] for ix in a_order)
+    size_b = prod(size_dict[ix] for ix in b_order)
+    if min(size_a, size_b) >= INTERLEAVE_MIN_ELEMS and len(con) > 2:
+        fast_a = sorted((ix for ix in con if ix in a_set), key=A.stride_of)
+        fast_b = sorted((ix for ix in con if ix in b_set), key=B.stride_of)
+        merged = []
+        ia = ib = 0
+        take_a = True
+        while ia < len(fast_a) or ib < len(fast_b):
+            src, pos = (fast_a, ia) if (take_a and ia < len(fast_a)) or ib >= len(fast_b) else (fast_b, ib)
+            ix = src[pos]
+            if src is fast_a:
+                ia += 1
+            else:
+                ib += 1
+            if ix not in merged:
+                merged.append(ix)
+                take_a = not take_a
+        con = merged[::-1]  # tables put the LAST index fastest
 
     ext = lambda g: [size_dict[ix] for ix in g]  # noqa: E731
     Bt, M, K, N = (prod(ext(g)) for g in (batch, keep_a, con, keep_b))
