@@ -66,6 +66,15 @@ struct StepArgs {
     const int64_t* bC;
 };
 
+// Tell the compiler a 64-bit value is wave-uniform so that loads indexed by it
+// become scalar loads (s_load: own counter, no vmcnt drain of the vector
+// memory pipeline).  Only call with values that ARE uniform across the wave.
+__device__ __forceinline__ int64_t uniform64(int64_t v) {
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)(v & 0xffffffffll));
+    const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)((unsigned long long)v >> 32));
+    return (int64_t)(((unsigned long long)hi << 32) | lo);
+}
+
 __device__ __forceinline__ void split_k(const StepArgs& p, int64_t k, int64_t& hi, int64_t& lo) {
     if (p.k_lo_shift >= 0) {
         hi = k >> p.k_lo_shift;
@@ -152,6 +161,7 @@ struct MfmaHints {
     int stream;      // 1: tall-skinny streaming kernel (row tile 32, B resident in LDS)
     int additive32;  // 1: row offsets are tile-additive for 32-row groups
     int fast;        // 1: full tiles + tile-additive 32-bit offsets (tiled fast path)
+    int exp;         // experiment switches (env CTG_EXP, 0 in production)
 };
 
 // steps the streaming kernel takes: short contraction, few columns, many rows
@@ -183,5 +193,7 @@ struct SliceMeta {
 // state[1] (lets a captured graph walk over slices without host involvement)
 hipError_t launch_prologue(const SliceMeta& m, int64_t* state, int64_t* soff, int64_t sid,
                            hipStream_t stream);
+// state[0] = next, state[1] = stride (device-side slice counter of a graph replay)
+hipError_t launch_set_state(int64_t* state, int64_t next, int64_t stride, hipStream_t stream);
 
 }  // namespace ctg

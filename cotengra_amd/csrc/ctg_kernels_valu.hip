@@ -294,6 +294,16 @@ __global__ __launch_bounds__(256) void prologue_kernel(SliceMeta m, int64_t* sta
     if (threadIdx.x == 0 && sid_arg < 0) state[0] = sid + state[1];
 }
 
+__global__ void set_state_kernel(int64_t* state, int64_t next, int64_t stride) {
+    state[0] = next;
+    state[1] = stride;
+}
+
+hipError_t launch_set_state(int64_t* state, int64_t next, int64_t stride, hipStream_t stream) {
+    hipLaunchKernelGGL(set_state_kernel, dim3(1), dim3(1), 0, stream, state, next, stride);
+    return hipGetLastError();
+}
+
 hipError_t launch_prologue(const SliceMeta& m, int64_t* state, int64_t* soff, int64_t sid,
                            hipStream_t stream) {
     hipLaunchKernelGGL(prologue_kernel, dim3(1), dim3(256), 0, stream, m, state, soff, sid);

@@ -59,6 +59,8 @@ struct MfmaCfg {
     static constexpr int B_PER_T = (BK * BN + kThreads - 1) / kThreads;
     static constexpr int A_FLOATS = 2 * BM * LD;
     static constexpr int B_FLOATS = 2 * BN * LD;
+    // blocks per CU the fast kernel is compiled for (LDS: 2*(BM+BN)*2*BK*4 bytes)
+    static constexpr int FAST_BLOCKS = BN >= 128 ? 2 : 3;
     static_assert(WM * WN == 4, "4 waves per block");
     static_assert(WTM % 32 == 0 && WTN % 16 == 0, "wave tile must hold whole MFMA tiles");
     static_assert((BM * BK) % (2 * kThreads) == 0, "A tile must divide over the block in pairs");
@@ -339,7 +341,7 @@ __global__ __launch_bounds__(256, 2) void pair_mfma_c64_kernel(StepArgs p, MfmaH
 // ------------------------------------------------------------------------- //
 
 template <typename Cfg, bool VEC_A>
-__global__ __launch_bounds__(256, 3) void pair_mfma_fast_kernel(StepArgs p, MfmaHints h,
+__global__ __launch_bounds__(256, Cfg::FAST_BLOCKS) void pair_mfma_fast_kernel(StepArgs p, MfmaHints h,
                                                                 int64_t tiles_m, int64_t tiles_n,
                                                                 int64_t k_chunk,
                                                                 float* __restrict__ partial) {
@@ -416,7 +418,9 @@ __global__ __launch_bounds__(256, 3) void pair_mfma_fast_kernel(StepArgs p, Mfma
 
     auto gather = [&](int64_t step) {
         int64_t kh, kl;
-        split_k(p, (step * S_split + ksplit) * BK, kh, kl);   // uniform -> scalar loads
+        split_k(p, uniform64((step * S_split + ksplit) * BK), kh, kl);   // scalar loads
+        kh = uniform64(kh);
+        kl = uniform64(kl);
         const c64* Ak = A + p.kA.hi[kh] + p.kA.lo[kl];
         const c64* Bk = B + p.kB.hi[kh] + p.kB.lo[kl];
         if (VEC_A) {
@@ -523,21 +527,31 @@ __global__ __launch_bounds__(256, 3) void pair_mfma_fast_kernel(StepArgs p, Mfma
         return;
     }
     const bool odd = lane & 1;
+    // all store offsets first (one batch of table loads, one wait), then stores
+    unsigned ro[Cfg::FM][8], co[Cfg::FN];
+#pragma unroll
+    for (int i = 0; i < Cfg::FM; ++i)
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int t = 2 * u;
+            ro[i][u] = (unsigned)p.rowC.lo[wm * Cfg::WTM + i * 32 + (t & 3) + 8 * (t >> 2) + 4 * kk +
+                                           (odd ? 1 : 0)];
+        }
+#pragma unroll
+    for (int j = 0; j < Cfg::FN; ++j) co[j] = (unsigned)p.nC[wn * Cfg::WTN + j * 16 + (l31 >> 1)];
 #pragma unroll
     for (int i = 0; i < Cfg::FM; ++i) {
 #pragma unroll
-        for (int t = 0; t < 16; t += 2) {
-            const int row = wm * Cfg::WTM + i * 32 + (t & 3) + 8 * (t >> 2) + 4 * kk + (odd ? 1 : 0);
-            const unsigned ro = (unsigned)p.rowC.lo[row];
+        for (int u = 0; u < 8; ++u) {
+            const int t = 2 * u;
 #pragma unroll
             for (int j = 0; j < Cfg::FN; ++j) {
-                const unsigned co = (unsigned)p.nC[wn * Cfg::WTN + j * 16 + (l31 >> 1)];
                 const float send = odd ? acc[i][j][t] : acc[i][j][t + 1];
                 const float recv = __shfl_xor(send, 1, 64);
                 float2 v;
                 v.x = odd ? recv : acc[i][j][t];
                 v.y = odd ? acc[i][j][t + 1] : recv;
-                *(float2*)(C + 2 * (size_t)(ro + co)) = v;
+                *(float2*)(C + 2 * (size_t)(ro[i][u] + co[j])) = v;
             }
         }
     }
@@ -620,7 +634,9 @@ static hipError_t launch_cfg(const StepArgs& p, const MfmaHints& h, void* scratc
     else if (h.fast)
         hipLaunchKernelGGL((pair_mfma_fast_kernel<Cfg, false>), grid, dim3(256), 0, stream, p, h,
                            tiles_m, tiles_n, k_chunk, part);
-    else if (h.vecA)
+    else if constexpr (Cfg::BN >= 128) {
+        return hipErrorInvalidValue;  // the 128-wide tile exists for the fast path only
+    } else if (h.vecA)
         hipLaunchKernelGGL((pair_mfma_c64_kernel<Cfg, true>), grid, dim3(256), 0, stream, p, h,
                            tiles_m, tiles_n, k_chunk, part);
     else
@@ -742,8 +758,8 @@ __global__ __launch_bounds__(256) void pair_mfma_stream_kernel(StepArgs p, MfmaH
         const int64_t m0 = g * 32;
         if (ADD) {
             int64_t hi, lo;
-            split_row(p, m0, hi, lo);
-            a_base_off = p.rowA.hi[hi] + p.rowA.lo[lo];
+            split_row(p, uniform64(m0), hi, lo);
+            a_base_off = p.rowA.hi[uniform64(hi)] + p.rowA.lo[uniform64(lo)];
         }
     };
     auto gather = [&](c64 (&a_reg)[PER_T], int64_t g, int chunk) {
@@ -832,14 +848,14 @@ __global__ __launch_bounds__(256) void pair_mfma_stream_kernel(StepArgs p, MfmaH
         int64_t c_base = 0;
         if (ADD && last) {
             int64_t hi, lo;
-            split_row(p, cg * 32, hi, lo);
-            c_base = p.rowC.hi[hi] + p.rowC.lo[lo];
+            split_row(p, uniform64(cg * 32), hi, lo);
+            c_base = p.rowC.hi[uniform64(hi)] + p.rowC.lo[uniform64(lo)];
         }
         const float* a_base = As + kk * 32 * LD + l31 * LD;
         const float* b_base = Bs + (l31 ^ kk) * LDB + cc * MFMA_BK;
         const int k_left = (int)p.K - cc * MFMA_BK;
         const int nq = k_left >= MFMA_BK ? MFMA_BK / 4 : (k_left + 3) / 4;
-        for (int kq = 0; kq < nq; ++kq) {
+        for (int kq = 0; kq < ((h.exp & 2) ? 1 : nq); ++kq) {
             const f32x4 af = *(const f32x4*)(a_base + kq * 4);
             f32x4 bf[FN];
 #pragma unroll
@@ -874,11 +890,16 @@ __global__ __launch_bounds__(256) void pair_mfma_stream_kernel(StepArgs p, MfmaH
                 for (int j = 0; j < FN; ++j) {
                     const float send = odd ? acc[j][t] : acc[j][t + 1];
                     const float recv = __shfl_xor(send, 1, 64);
-                    if (n_ok[j] && ro >= 0) {
+                    if (n_ok[j] && ro >= 0 && !(h.exp & 1)) {
                         float2 v;
                         v.x = odd ? recv : acc[j][t];
                         v.y = odd ? acc[j][t + 1] : recv;
-                        *(float2*)(C + 2 * (ro + ncol[j])) = v;
+                        if (h.exp & 4) {
+                            typedef float f32x2 __attribute__((ext_vector_type(2)));
+                            f32x2 w = {v.x, v.y};
+                            __builtin_nontemporal_store(w, (f32x2*)(C + 2 * (ro + ncol[j])));
+                        } else
+                            *(float2*)(C + 2 * (ro + ncol[j])) = v;
                     }
                 }
             }
@@ -951,6 +972,7 @@ hipError_t launch_pair_mfma(int dtype, const StepArgs& p, const MfmaHints& h, vo
         case 16: return launch_cfg<MfmaCfg<128, 16, 16, 4, 1>>(p, h, scratch, scratch_bytes, stream);
         case 32: return launch_cfg<MfmaCfg<128, 32, 16, 4, 1>>(p, h, scratch, scratch_bytes, stream);
         case 64: return launch_cfg<MfmaCfg<128, 64, 16, 2, 2>>(p, h, scratch, scratch_bytes, stream);
+        case 128: return launch_cfg<MfmaCfg<128, 128, 16, 2, 2>>(p, h, scratch, scratch_bytes, stream);
     }
     return hipErrorInvalidValue;
 }

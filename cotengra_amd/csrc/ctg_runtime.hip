@@ -8,6 +8,7 @@
 #include <algorithm>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -85,6 +86,13 @@ struct ctg_exec {
     std::vector<MfmaHints> hints;  // per step kernel hints (MFMA steps)
     uint16_t* d_ord = nullptr;     // order tables of all MFMA steps
     std::vector<hipEvent_t> events;
+    // slice graph: the launch sequence of one slice captured once and replayed,
+    // the slice id advancing on the device (prologue kernel)
+    hipStream_t gstream = nullptr;
+    hipGraphExec_t gexec = nullptr;
+    hipEvent_t ev_in = nullptr, ev_out = nullptr;
+    bool warm = false;
+    bool graph_off = false;
 };
 
 namespace {
@@ -212,7 +220,7 @@ void resolve_args(ctg_exec* e) {
     const ctg_plan* p = e->plan;
     const int64_t isz = kItemSize[p->dtype];
     e->args.resize(p->n_steps);
-    e->hints.assign(p->n_steps, MfmaHints{nullptr, nullptr, 0, 0, 0, 0, 0});
+    e->hints.assign(p->n_steps, MfmaHints{nullptr, nullptr, 0, 0, 0, 0, 0, 0});
     const int64_t* T = e->d_tables;
     for (int64_t s = 0; s < p->n_steps; ++s) {
         const int64_t* r = &p->steps[s * STEP_WORDS];
@@ -403,7 +411,13 @@ int build_hints(ctg_exec* e) {
         if (r[W_KIND] != KIND_PAIR || r[W_KERNEL] != KERNEL_MFMA) continue;
         MfmaHints& h = e->hints[s];
         h.bn = mfma_pick_bn(r[W_N]);
+        h.exp = getenv("CTG_EXP") ? atoi(getenv("CTG_EXP")) : 0;
         h.stream = mfma_use_stream(r[W_R], r[W_BT], r[W_K], r[W_N]) ? 1 : 0;
+        // big square-ish GEMMs: 128x128 tiles (fast path only) halve the LDS
+        // traffic and barriers per flop
+        if (!h.stream && r[W_N] % 128 == 0 && r[W_R] * r[W_N] >= (1ll << 22) && r[W_K] >= 256 &&
+            mfma_fast_ok(p, r, 128))
+            h.bn = 128;
         h.additive32 = (h.stream && tile_additive(p, r[W_ROWA_LO], r[W_ROW_LO], r[W_R], 32) &&
                         tile_additive(p, r[W_ROWC_LO], r[W_ROW_LO], r[W_R], 32))
                            ? 1
@@ -427,19 +441,19 @@ int build_hints(ctg_exec* e) {
     return CTG_OK;
 }
 
-int launch_step(ctg_exec* e, int64_t s) {
+int launch_step(ctg_exec* e, int64_t s, hipStream_t stream) {
     const ctg_plan* p = e->plan;
     const int64_t* r = &p->steps[s * STEP_WORDS];
     hipError_t err = hipSuccess;
     switch (r[W_KIND]) {
-        case KIND_SINGLE: err = launch_single(p->dtype, e->args[s], e->stream); break;
-        case KIND_ACCUM: err = launch_accum(p->dtype, e->args[s], e->stream); break;
+        case KIND_SINGLE: err = launch_single(p->dtype, e->args[s], stream); break;
+        case KIND_ACCUM: err = launch_accum(p->dtype, e->args[s], stream); break;
         case KIND_PAIR:
             if (r[W_KERNEL] == KERNEL_MFMA)
                 err = launch_pair_mfma(p->dtype, e->args[s], e->hints[s], e->d_scratch, kScratchBytes,
-                                       e->stream);
+                                       stream);
             else
-                err = launch_pair_valu(p->dtype, e->args[s], e->d_scratch, kScratchBytes, e->stream);
+                err = launch_pair_valu(p->dtype, e->args[s], e->d_scratch, kScratchBytes, stream);
             break;
     }
     if (err != hipSuccess)
@@ -521,6 +535,11 @@ int ctg_exec_destroy(ctg_exec* e) {
     (void)hipSetDevice(e->device);
     if (e->stream) (void)hipStreamSynchronize(e->stream);
     for (hipEvent_t ev : e->events) (void)hipEventDestroy(ev);
+    if (e->gstream) (void)hipStreamSynchronize(e->gstream);
+    if (e->gexec) (void)hipGraphExecDestroy(e->gexec);
+    if (e->ev_in) (void)hipEventDestroy(e->ev_in);
+    if (e->ev_out) (void)hipEventDestroy(e->ev_out);
+    if (e->gstream) (void)hipStreamDestroy(e->gstream);
     if (e->d_inputs) (void)hipFree(e->d_inputs);
     if (e->d_arena) (void)hipFree(e->d_arena);
     if (e->d_result && e->owns_result) (void)hipFree(e->d_result);
@@ -595,6 +614,12 @@ int ctg_exec_create(const ctg_plan* p, int device, void* stream, void* ext_resul
     HIP_TRY_E(hipMemsetAsync(e->d_inputs, 0, p->inputs_elems * isz, e->stream));
     HIP_TRY_E(hipMemsetAsync(e->d_result, 0, p->result_elems * isz, e->stream));
     e->meta = SliceMeta{n_leaves, p->n_sliced, d_sizes, d_fixed, d_strides};
+    // Replaying a captured slice graph measured SLOWER than eager launches on
+    // ROCm 7.2 / MI355X (C2: 622 vs 523 us per contraction, m20: 92.0 vs 91.4
+    // ms per slice): the host already runs ahead of the device and the tiny
+    // kernels are bound by their dependent-load latency, not by launch cost.
+    // The path stays available behind CTG_GRAPH=1.
+    e->graph_off = getenv("CTG_GRAPH") == nullptr;
     resolve_args(e);
     {
         const int rc = build_hints(e);
@@ -651,16 +676,62 @@ int ctg_exec_run_slices(ctg_exec* e, int64_t first, int64_t count, int64_t strid
                     (long long)first, (long long)stride, (long long)count, (long long)p->nslices);
     if (count == 0) return CTG_OK;
     HIP_TRY(hipSetDevice(e->device));
-    for (int64_t i = 0; i < count; ++i) {
-        hipError_t err =
-            launch_prologue(e->meta, e->d_state, e->d_soff, first + i * stride, e->stream);
+    auto eager = [&](int64_t sid) -> int {
+        hipError_t err = launch_prologue(e->meta, e->d_state, e->d_soff, sid, e->stream);
         if (err != hipSuccess)
             return fail(CTG_E_HIP, "prologue launch failed: %s", hipGetErrorString(err));
         for (int64_t s = 0; s < p->n_steps; ++s) {
-            const int rc = launch_step(e, s);
+            const int rc = launch_step(e, s, e->stream);
             if (rc != CTG_OK) return rc;
         }
+        return CTG_OK;
+    };
+    int64_t i = 0;
+    if (!e->graph_off && (count >= 2 || e->warm)) {
+        if (!e->warm) {  // first slice eagerly: lets the launchers do their one-time setup
+            const int rc = eager(first);
+            if (rc != CTG_OK) return rc;
+            e->warm = true;
+            i = 1;
+        }
+        if (!e->gexec) {
+            // capture one slice; any failure just disables the graph path
+            bool ok = hipStreamCreateWithFlags(&e->gstream, hipStreamNonBlocking) == hipSuccess &&
+                      hipEventCreateWithFlags(&e->ev_in, hipEventDisableTiming) == hipSuccess &&
+                      hipEventCreateWithFlags(&e->ev_out, hipEventDisableTiming) == hipSuccess;
+            hipGraph_t graph = nullptr;
+            if (ok) ok = hipStreamBeginCapture(e->gstream, hipStreamCaptureModeThreadLocal) == hipSuccess;
+            if (ok) {
+                bool launched = launch_prologue(e->meta, e->d_state, e->d_soff, -1, e->gstream) == hipSuccess;
+                for (int64_t s = 0; launched && s < p->n_steps; ++s)
+                    launched = launch_step(e, s, e->gstream) == CTG_OK;
+                ok = hipStreamEndCapture(e->gstream, &graph) == hipSuccess && launched && graph;
+            }
+            if (ok) ok = hipGraphInstantiate(&e->gexec, graph, nullptr, nullptr, 0) == hipSuccess;
+            if (graph) (void)hipGraphDestroy(graph);
+            if (!ok) {
+                (void)hipGetLastError();
+                e->gexec = nullptr;
+                e->graph_off = true;
+            }
+        }
+        if (e->gexec && i < count) {
+            HIP_TRY(hipEventRecord(e->ev_in, e->stream));
+            HIP_TRY(hipStreamWaitEvent(e->gstream, e->ev_in, 0));
+            hipError_t err = launch_set_state(e->d_state, first + i * stride, stride, e->gstream);
+            if (err != hipSuccess)
+                return fail(CTG_E_HIP, "state launch failed: %s", hipGetErrorString(err));
+            for (; i < count; ++i) HIP_TRY(hipGraphLaunch(e->gexec, e->gstream));
+            HIP_TRY(hipEventRecord(e->ev_out, e->gstream));
+            HIP_TRY(hipStreamWaitEvent(e->stream, e->ev_out, 0));
+            return CTG_OK;
+        }
     }
+    for (; i < count; ++i) {
+        const int rc = eager(first + i * stride);
+        if (rc != CTG_OK) return rc;
+    }
+    e->warm = true;
     return CTG_OK;
 }
 
@@ -678,7 +749,7 @@ int ctg_exec_profile_slice(ctg_exec* e, int64_t slice_id, float* ms) {
     if (err != hipSuccess) return fail(CTG_E_HIP, "prologue launch failed: %s", hipGetErrorString(err));
     HIP_TRY(hipEventRecord(e->events[0], e->stream));
     for (int64_t s = 0; s < p->n_steps; ++s) {
-        const int rc = launch_step(e, s);
+        const int rc = launch_step(e, s, e->stream);
         if (rc != CTG_OK) return rc;
         HIP_TRY(hipEventRecord(e->events[s + 1], e->stream));
     }
