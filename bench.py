@@ -155,27 +155,51 @@ def main():
         rows = plan.describe_steps()
         for r, m in zip(rows, ms):
             r["ms"] = float(m)
+        names = ex.step_kernels()
+        for r, nm in zip(rows, names):
+            r["kernel_name"] = nm
+        # dominant kernel = the kernel symbol with the largest share of slice time
+        by_name = {}
+        for r in rows:
+            d = by_name.setdefault(r["kernel_name"], {"ms": 0.0, "flops": 0.0, "bytes": 0.0, "n": 0})
+            d["ms"] += r["ms"]
+            d["flops"] += 8.0 * r["macs"]
+            d["bytes"] += r["bytes"]
+            d["n"] += 1
+        dom_name, dom = max(by_name.items(), key=lambda kv: kv[1]["ms"])
+        achieved = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
         mf = [r for r in rows if r["kernel"] == "mfma"]
-        dom_flops = sum(8.0 * r["macs"] for r in mf)
-        dom_ms = sum(r["ms"] for r in mf)
-        achieved = dom_flops / (dom_ms * 1e-3) / 1e12 if dom_ms > 0 else 0.0
+        all_flops = sum(8.0 * r["macs"] for r in mf)
+        all_ms = sum(r["ms"] for r in mf)
         roofline = {
             "bound": "mfma",
-            "kernel": "pair_mfma_c64_kernel (all launches of one slice)",
+            "kernel": dom_name,
             "achieved": achieved,
             "peak": PEAK_MFMA_F32_TFLOPS,
             "unit": "TFLOP/s",
             "frac": achieved / PEAK_MFMA_F32_TFLOPS,
-            "launches_per_slice": len(mf),
-            "avg_launch_ms": dom_ms / max(len(mf), 1),
-            "flops_per_launch": dom_flops / max(len(mf), 1),
-            "share_of_slice_time": dom_ms / max(float(ms.sum()), 1e-9),
+            "launches_per_slice": dom["n"],
+            "avg_launch_ms": dom["ms"] / dom["n"],
+            "flops_per_launch": dom["flops"] / dom["n"],
+            "algorithmic_bytes_per_launch": dom["bytes"] / dom["n"],
+            "share_of_slice_time": dom["ms"] / max(float(ms.sum()), 1e-9),
             "traffic": None,
+            "all_mfma_kernels": {
+                "achieved": all_flops / (all_ms * 1e-3) / 1e12,
+                "frac": all_flops / (all_ms * 1e-3) / 1e12 / PEAK_MFMA_F32_TFLOPS,
+                "launches_per_slice": len(mf),
+                "share_of_slice_time": all_ms / max(float(ms.sum()), 1e-9),
+            },
+            "by_kernel_ms": {k: round(v["ms"], 3) for k, v in sorted(by_name.items(), key=lambda kv: -kv[1]["ms"])},
         }
         pmc = os.path.join(ROOT, "profiles", "pmc_summary.json")
         if os.path.exists(pmc):
             try:
-                roofline["traffic"] = json.load(open(pmc)).get("hbm_bytes_per_launch")
+                pm = json.load(open(pmc))
+                kv = pm.get("kernels", {}).get(dom_name)
+                if kv:
+                    roofline["traffic"] = kv["hbm_bytes_per_launch"]
+                roofline["traffic_all_mfma_per_launch"] = pm.get("hbm_bytes_per_launch")
             except Exception:
                 pass
         if args.dump_steps:

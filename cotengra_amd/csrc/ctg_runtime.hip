@@ -759,6 +759,32 @@ int ctg_exec_profile_slice(ctg_exec* e, int64_t slice_id, float* ms) {
     return CTG_OK;
 }
 
+int ctg_exec_step_kernel(ctg_exec* e, int64_t step, char* buf, int64_t buflen) {
+    if (!e || !buf || buflen < 1) return fail(CTG_E_INVALID, "null argument");
+    const ctg_plan* p = e->plan;
+    if (step < 0 || step >= p->n_steps) return fail(CTG_E_INVALID, "step out of range");
+    const int64_t* r = &p->steps[step * STEP_WORDS];
+    char name[128];
+    if (r[W_KIND] == KIND_SINGLE) {
+        snprintf(name, sizeof(name), "single_kernel");
+    } else if (r[W_KIND] == KIND_ACCUM) {
+        snprintf(name, sizeof(name), "accum_kernel");
+    } else if (r[W_KERNEL] == KERNEL_MFMA) {
+        const MfmaHints& h = e->hints[step];
+        if (h.stream)
+            snprintf(name, sizeof(name), "pair_mfma_stream_kernel<%d,%s,%s>", h.bn / 16,
+                     (h.vecA && h.additive32) ? "true" : "false", h.additive32 ? "true" : "false");
+        else
+            snprintf(name, sizeof(name), "%s<128,%d,16>,%s",
+                     h.fast ? "pair_mfma_fast_kernel" : "pair_mfma_c64_kernel", h.bn,
+                     h.vecA ? "true" : "false");
+    } else {
+        snprintf(name, sizeof(name), "pair_valu_kernel");
+    }
+    snprintf(buf, (size_t)buflen, "%s", name);
+    return CTG_OK;
+}
+
 int ctg_exec_sync(ctg_exec* e) {
     if (!e) return fail(CTG_E_INVALID, "null argument");
     HIP_TRY(hipSetDevice(e->device));

@@ -29,6 +29,7 @@ SYMBOLS = (
     "ctg_exec_zero_result",
     "ctg_exec_run_slices",
     "ctg_exec_profile_slice",
+    "ctg_exec_step_kernel",
     "ctg_exec_sync",
     "ctg_exec_result_ptr",
     "ctg_exec_download_result",
@@ -97,6 +98,7 @@ def load():
         "ctg_exec_zero_result": [vp],
         "ctg_exec_run_slices": [vp, C.c_int64, C.c_int64, C.c_int64],
         "ctg_exec_profile_slice": [vp, C.c_int64, C.POINTER(C.c_float)],
+        "ctg_exec_step_kernel": [vp, C.c_int64, C.c_char_p, C.c_int64],
         "ctg_exec_sync": [vp],
         "ctg_exec_result_ptr": [vp, C.POINTER(vp)],
         "ctg_exec_download_result": [vp, vp],
@@ -237,6 +239,15 @@ class Executor:
         ms = (C.c_float * max(len(self.plan.steps), 1))()
         _check(load().ctg_exec_profile_slice(self.handle, slice_id, ms))
         return np.asarray(ms[: len(self.plan.steps)], dtype=np.float64)
+
+    def step_kernels(self):
+        """Kernel name per plan step (as rocprof reports it, shortened)."""
+        buf = C.create_string_buffer(160)
+        names = []
+        for s in range(len(self.plan.steps)):
+            _check(load().ctg_exec_step_kernel(self.handle, s, buf, 160))
+            names.append(buf.value.decode())
+        return names
 
     def sync(self):
         _check(load().ctg_exec_sync(self.handle))

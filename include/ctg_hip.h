@@ -123,6 +123,11 @@ int ctg_exec_run_slices(ctg_exec* exec, int64_t first, int64_t count, int64_t st
  * (core.py:3508, 4092-4164) for per-step rooflines. */
 int ctg_exec_profile_slice(ctg_exec* exec, int64_t slice_id, float* ms);
 
+/* Name of the kernel that executes plan step `step` on this executor (e.g.
+ * "pair_mfma_fast_kernel<128,128,16>"), NUL-terminated into `buf`; lets a
+ * profile attribute per-step timings to rocprof kernel names. */
+int ctg_exec_step_kernel(ctg_exec* exec, int64_t step, char* buf, int64_t buflen);
+
 int ctg_exec_sync(ctg_exec* exec);
 /* device address of the result tensor (result_elems elements, row-major in
  * the tree's output index order) */
