@@ -36,9 +36,9 @@
 // Offsets come from LDS, not from global tables: row offsets are resolved once
 // per tile, k offsets by 2*BK threads one k-step ahead (3-slot ring).
 //
-// The block-id -> tile map keeps all column tiles of a row tile on one XCD
-// (block b runs on XCD b % 8) so A is fetched from HBM once and re-read from
-// that XCD's L2.
+// The block-id -> tile map (map_tile) hands 8x8 patches of tiles to one XCD at a
+// time (block b runs on XCD b % 8) so A and B k-slices are shared through that
+// XCD's L2 instead of being re-fetched per tile.
 #include "ctg_common.h"
 
 namespace ctg {
@@ -68,6 +68,44 @@ struct MfmaCfg {
     static_assert(BK % 4 == 0, "k-step is consumed 4 at a time");
 };
 
+
+// XCD-aware work assignment of the tiled kernels.  Block b runs on XCD b % 8
+// (each XCD has its own 4 MB L2).  A unit is a (row tile, k-split) pair.  The
+// (unit, column tile) grid is cut into patches of PM x PN = 64 tiles; a patch
+// is handed to ONE XCD as 64 consecutive blocks, which run concurrently and
+// step through K roughly together -- so each A k-slice is fetched once per PN
+// column tiles and each B k-slice once per PM row tiles from that XCD's L2
+// instead of once per tile from HBM / Infinity Cache.  Consecutive patches go
+// to different XCDs (also spreads the k-splits of a single row tile).
+struct TileMap {
+    int64_t unit, tn;
+    bool valid;
+};
+__device__ __forceinline__ void patch_shape(int64_t tiles_n, int& PM, int& PN) {
+    PN = tiles_n >= 8 ? 8 : (tiles_n >= 4 ? 4 : (tiles_n >= 2 ? 2 : 1));
+    PM = 64 / PN;
+}
+__device__ __forceinline__ TileMap map_tile(int64_t bid, int64_t units, int64_t tiles_n) {
+    int PM, PN;
+    patch_shape(tiles_n, PM, PN);
+    const int64_t npn = (tiles_n + PN - 1) / PN;
+    const int64_t xcd = bid & 7, q = bid >> 3;
+    const int64_t pid = (q >> 6) * 8 + xcd;  // patch index
+    const int within = (int)(q & 63);
+    const int64_t pm = pid / npn, pn = pid - pm * npn;
+    TileMap t;
+    t.unit = pm * PM + within / PN;
+    t.tn = pn * PN + within % PN;
+    t.valid = t.unit < units && t.tn < tiles_n;
+    return t;
+}
+static int64_t tile_grid_blocks(int64_t units, int64_t tiles_n) {
+    const int PN = tiles_n >= 8 ? 8 : (tiles_n >= 4 ? 4 : (tiles_n >= 2 ? 2 : 1));
+    const int PM = 64 / PN;
+    const int64_t patches = ((units + PM - 1) / PM) * ((tiles_n + PN - 1) / PN);
+    return ((patches + 7) / 8) * 8 * 64;
+}
+
 template <typename Cfg, bool VEC_A>
 __global__ __launch_bounds__(256, 2) void pair_mfma_c64_kernel(StepArgs p, MfmaHints h,
                                                                int64_t tiles_m, int64_t tiles_n,
@@ -84,18 +122,12 @@ __global__ __launch_bounds__(256, 2) void pair_mfma_c64_kernel(StepArgs p, MfmaH
     const int wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
 
-    // XCD-aware work assignment (block b runs on XCD b % 8): a unit is a
-    // (row tile, k-split) pair; all column tiles of a unit sit on one XCD (they
-    // share the A panel in that XCD's L2) and consecutive units go to
-    // different XCDs -- including the k-splits of a single row tile.
     const int64_t S_split = k_chunk;  // number of k-splits (1 = none)
-    const int64_t bid = blockIdx.x;
-    const int64_t xcd = bid & 7, q = bid >> 3;
-    const int64_t unit = (q / tiles_n) * 8 + xcd;
-    const int64_t tn = q % tiles_n;
-    if (unit >= tiles_m * S_split) return;
-    const int64_t tm = unit % tiles_m;
-    const int64_t ksplit = unit / tiles_m;
+    const TileMap tmap = map_tile(blockIdx.x, tiles_m * S_split, tiles_n);
+    if (!tmap.valid) return;
+    const int64_t tn = tmap.tn;
+    const int64_t tm = tmap.unit % tiles_m;
+    const int64_t ksplit = tmap.unit / tiles_m;
     const int64_t m0 = tm * BM, n0 = tn * BN;
     const int64_t bz = blockIdx.z;
 
@@ -361,15 +393,12 @@ __global__ __launch_bounds__(256, Cfg::FAST_BLOCKS) void pair_mfma_fast_kernel(S
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WN, wn = wave % WN;
 
-    // (row tile, k-split) units spread over the XCDs: see the general kernel
     const int64_t S_split = k_chunk;
-    const int64_t bid = blockIdx.x;
-    const int64_t xcd = bid & 7, q = bid >> 3;
-    const int64_t unit = (q / tiles_n) * 8 + xcd;
-    const int64_t tn = q % tiles_n;
-    if (unit >= tiles_m * S_split) return;
-    const int64_t tm = unit % tiles_m;
-    const int64_t ksplit = unit / tiles_m;
+    const TileMap tmap = map_tile(blockIdx.x, tiles_m * S_split, tiles_n);
+    if (!tmap.valid) return;
+    const int64_t tn = tmap.tn;
+    const int64_t tm = tmap.unit % tiles_m;
+    const int64_t ksplit = tmap.unit / tiles_m;
     const int64_t m0 = tm * BM, n0 = tn * BN;
     const int64_t bz = blockIdx.z;
 
@@ -624,7 +653,7 @@ static hipError_t launch_cfg(const StepArgs& p, const MfmaHints& h, void* scratc
     }
     if (S > nk_total) S = nk_total;
     const int64_t k_chunk = S;  // the kernels' k_chunk argument carries the split count
-    const int64_t gx = ((tiles_m * S + 7) / 8) * 8 * tiles_n;
+    const int64_t gx = tile_grid_blocks(tiles_m * S, tiles_n);
     if (gx > 0x7fffffffll) return hipErrorInvalidValue;
     const dim3 grid((unsigned)gx, 1, (unsigned)p.Bt);
     float* part = S > 1 ? (float*)scratch : (float*)nullptr;
