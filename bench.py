@@ -112,6 +112,7 @@ def main():
     fn = HipContractor(tree, handle_slicing=True)
     st = fn.setup(*[torch.as_tensor(a, device=dev) for a in arrays])
     ex, plan = st["exec"], st["plan"]
+    ex.set_strip_exponent(False)
     result = st["result"]
     nsl = tree.nslices
 

@@ -15,7 +15,6 @@ input space, result returned as a torch tensor on the same device).
 
 from __future__ import annotations
 
-import math
 import time
 
 import numpy as np
@@ -183,29 +182,27 @@ class HipContractor:
         return st
 
     def _finish(self, st, strip_exponent, check_zero, index=None):
+        """Fetch the result; with ``strip_exponent`` return ``(mantissa,
+        exponent)`` as accumulated on the device (reference contract.py:834-835
+        and core.py:125-172)."""
         if "result" in st:
             out = st["result"]
             out = out[index] if index is not None else out
             out = out.clone()
-            if not strip_exponent:
-                return out
-            import torch
-
-            factor = float(torch.max(torch.abs(out))) if out.numel() else 0.0
         else:
             out = st["exec"].download_result()
             if index is not None:
                 out = out[index]
             if out.ndim == 0 and not strip_exponent:
                 return out[()]
-            if not strip_exponent:
-                return out
-            factor = float(np.max(np.abs(out))) if out.size else 0.0
-        if factor == 0.0:
-            if check_zero:
-                return 0.0, float("-inf")
-            return out, float("-inf")
-        return out / factor, math.log10(factor)
+        if not strip_exponent:
+            return out
+        exponent, zero = st["exec"].get_exponent()
+        if zero and check_zero and exponent == float("-inf"):
+            return 0.0, float("-inf")
+        if not _is_torch(out) and out.ndim == 0:
+            out = out[()]
+        return out, exponent
 
     def __call__(self, *arrays, **kwargs):
         backend = kwargs.pop("backend", None)  # noqa: F841  (inferred from arrays)
@@ -217,6 +214,7 @@ class HipContractor:
             raise TypeError(f"Unknown keyword arguments: {kwargs}.")
         st = self.setup(*arrays)
         ex = st["exec"]
+        ex.set_strip_exponent(strip_exponent, check_zero)
         ex.zero_result()
         ex.run_slices(0, self.tree.multiplicity, 1)
         return self._finish(st, strip_exponent, check_zero)
@@ -225,6 +223,7 @@ class HipContractor:
         """Output of slice ``i`` only (sliced output indices removed)."""
         st = self.setup(*arrays)
         ex = st["exec"]
+        ex.set_strip_exponent(strip_exponent, check_zero)
         ex.zero_result()
         ex.run_slices(int(i), 1, 1)
         loc = self.tree.slice_key(int(i))
@@ -404,6 +403,7 @@ def gen_output_chunks(tree, arrays, with_key=False, progbar=False, **contract_op
     stepsize = prod(si.size for si in tree.sliced_inds.values() if si.inner)
     st = fn.setup(*arrays)
     ex = st["exec"]
+    ex.set_strip_exponent(False)
     for o in range(tree.nslices // stepsize):
         ex.zero_result()
         ex.run_slices(o * stepsize, stepsize, 1)
@@ -431,6 +431,7 @@ def benchmark_tree(
     fn = _tree_contractor(tree, contract_opts.pop("order", None))
     st = fn.setup(*arrays)
     ex = st["exec"]
+    ex.set_strip_exponent(False)
     for i in range(int(warmup)):
         ex.run_slices(i % tree.nslices, 1, 1)
     ex.sync()

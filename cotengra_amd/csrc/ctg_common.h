@@ -25,6 +25,7 @@ enum StepWord {
     W_A_SIZE = 30, W_B_SIZE = 31, W_C_SIZE = 32,
     W_MACS = 33, W_ELEMS = 34, W_NODE = 35,
     W_K_LO = 36, W_KA_HI = 37, W_KB_HI = 38, W_K_HI_LEN = 39,
+    W_A_PROD = 40, W_B_PROD = 41,  // step that produced the operand (-1: input / preprocessing)
     STEP_WORDS = 48
 };
 
@@ -64,7 +65,20 @@ struct StepArgs {
     const int64_t* bA;
     const int64_t* bB;
     const int64_t* bC;
+    // strip_exponent (reference contract.py:816-829): max|.| of the operands'
+    // producers; the step stores alpha * (A . B) with alpha = 1 / (facA * facB),
+    // i.e. the contraction of the normalised operands.  nullptr = feature off.
+    const double* facA;
+    const double* facB;
+    int32_t check_zero;
 };
+
+__device__ __forceinline__ double step_alpha(const StepArgs& p) {
+    if (p.facA == nullptr) return 1.0;
+    const double f = (*p.facA) * (*p.facB);
+    if (f == 0.0 && p.check_zero) return 0.0;
+    return 1.0 / f;  // inf -> nan downstream, like the reference without check_zero
+}
 
 // Tell the compiler a 64-bit value is wave-uniform so that loads indexed by it
 // become scalar loads (s_load: own counter, no vmcnt drain of the vector
@@ -121,6 +135,19 @@ __device__ __forceinline__ void fma_acc(cplx<F>& acc, cplx<F> a, cplx<F> b) {
     acc.im = fma(a.im, b.re, acc.im);
 }
 
+__device__ __forceinline__ float scale_of(float a, double s) { return a * (float)s; }
+__device__ __forceinline__ double scale_of(double a, double s) { return a * s; }
+__device__ __forceinline__ cplx<float> scale_of(cplx<float> a, double s) {
+    return cplx<float>{a.re * (float)s, a.im * (float)s};
+}
+__device__ __forceinline__ cplx<double> scale_of(cplx<double> a, double s) {
+    return cplx<double>{a.re * s, a.im * s};
+}
+__device__ __forceinline__ double abs_of(float a) { return fabs((double)a); }
+__device__ __forceinline__ double abs_of(double a) { return fabs(a); }
+__device__ __forceinline__ double abs_of(cplx<float> a) { return hypot((double)a.re, (double)a.im); }
+__device__ __forceinline__ double abs_of(cplx<double> a) { return hypot(a.re, a.im); }
+
 __device__ __forceinline__ float add_of(float a, float b) { return a + b; }
 __device__ __forceinline__ double add_of(double a, double b) { return a + b; }
 template <typename F>
@@ -171,6 +198,16 @@ inline bool mfma_use_stream(int64_t R, int64_t Bt, int64_t K, int64_t N) {
 
 inline int mfma_pick_bn(int64_t N) { return N <= 16 ? 16 : (N <= 32 ? 32 : 64); }
 
+// exponent state of a strip_exponent run (device memory)
+struct StripState {
+    double E;       // running exponent of the result tensor (-inf: empty)
+    double e_slice; // exponent of the slice just computed
+    double coefM;   // rescale of the existing result  = 10^(E - E')
+    double coefm;   // scale of the incoming slice      = 10^(e_slice - E') / fac_root
+    int32_t zero;   // a zero intermediate was met (check_zero)
+    int32_t pad;
+};
+
 // ---- launchers implemented in the kernel translation units ---------------- //
 
 // dtype: 0 f32, 1 f64, 2 c64, 3 c128
@@ -179,7 +216,13 @@ hipError_t launch_pair_valu(int dtype, const StepArgs& p, void* scratch, int64_t
 hipError_t launch_pair_mfma(int dtype, const StepArgs& p, const MfmaHints& h, void* scratch,
                             int64_t scratch_bytes, hipStream_t stream);
 hipError_t launch_single(int dtype, const StepArgs& p, hipStream_t stream);
-hipError_t launch_accum(int dtype, const StepArgs& p, hipStream_t stream);
+hipError_t launch_accum(int dtype, const StepArgs& p, const StripState* st, hipStream_t stream);
+
+hipError_t launch_maxabs(int dtype, const void* x, int64_t n, double* fac, hipStream_t stream);
+// e_slice = sum_s log10(fac[s]) over the listed steps; coefficients for the accumulate
+hipError_t launch_strip_prepare(const double* fac, const int32_t* counted, int64_t n_steps,
+                                int64_t root_step, int check_zero, StripState* st, hipStream_t stream);
+hipError_t launch_rescale(int dtype, void* result, int64_t n, const StripState* st, hipStream_t stream);
 
 struct SliceMeta {
     int64_t n_leaves;  // n_inputs + 1 (last = result chunk offset)
@@ -187,6 +230,8 @@ struct SliceMeta {
     const int64_t* sizes;    // [n_sliced]
     const int64_t* fixed;    // [n_sliced]
     const int64_t* strides;  // [n_leaves * n_sliced]
+    double* fac;             // strip_exponent: per-step max|.| scalars, zeroed per slice (or null)
+    int64_t n_fac;
 };
 // soff[n_leaves] receives the per-leaf base offsets of slice `sid`; with sid < 0
 // the id is taken from the device counter state[0], which is then advanced by

@@ -30,6 +30,7 @@ __global__ __launch_bounds__(256) void pair_valu_kernel(StepArgs p, int tn_shift
     const T* __restrict__ A = (const T*)p.A + *p.soffA;
     const T* __restrict__ B = (const T*)p.B + *p.soffB;
     T* __restrict__ C = (T*)p.C + *p.soffC;
+    const double alpha = step_alpha(p);
     const int TN = 1 << tn_shift;
     const int TR = 256 >> tn_shift;
     const int c = threadIdx.x & (TN - 1);
@@ -53,7 +54,7 @@ __global__ __launch_bounds__(256) void pair_valu_kernel(StepArgs p, int tn_shift
                 fma_acc(acc, a2[p.kA.lo[kl]], b2[p.kB.lo[kl]]);
             }
         }
-        C[p.rowC.hi[hi] + p.rowC.lo[lo] + p.nC[n]] = acc;
+        C[p.rowC.hi[hi] + p.rowC.lo[lo] + p.nC[n]] = scale_of(acc, alpha);
     }
 }
 
@@ -98,6 +99,7 @@ template <typename T>
 __global__ __launch_bounds__(256) void pair_kred_finish_kernel(StepArgs p, int64_t G,
                                                                const T* __restrict__ partial) {
     T* __restrict__ C = (T*)p.C + *p.soffC;
+    const double alpha = step_alpha(p);
     const int64_t outs = p.R * p.N;
     for (int64_t o = (int64_t)blockIdx.x * 256 + threadIdx.x; o < outs;
          o += (int64_t)gridDim.x * 256) {
@@ -107,7 +109,7 @@ __global__ __launch_bounds__(256) void pair_kred_finish_kernel(StepArgs p, int64
         for (int64_t g = 0; g < G; ++g) acc = add_of(acc, partial[o * G + g]);
         int64_t hi, lo;
         split_row(p, row, hi, lo);
-        C[p.rowC.hi[hi] + p.rowC.lo[lo] + p.nC[n]] = acc;
+        C[p.rowC.hi[hi] + p.rowC.lo[lo] + p.nC[n]] = scale_of(acc, alpha);
     }
 }
 
@@ -239,27 +241,124 @@ hipError_t launch_single(int dtype, const StepArgs& p, hipStream_t stream) {
 // ------------------------------------------------------------------------- //
 
 template <typename T>
-__global__ __launch_bounds__(256) void accum_kernel(StepArgs p) {
+__global__ __launch_bounds__(256) void accum_kernel(StepArgs p, const StripState* st) {
     const T* __restrict__ A = (const T*)p.A + *p.soffA;
     T* __restrict__ C = (T*)p.C + *p.soffC;
+    const double coef = st ? st->coefm : 1.0;
     for (int64_t row = (int64_t)blockIdx.x * 256 + threadIdx.x; row < p.R;
          row += (int64_t)gridDim.x * 256) {
         int64_t hi, lo;
         split_row(p, row, hi, lo);
         T* c = C + p.rowC.hi[hi] + p.rowC.lo[lo];
-        *c = add_of(*c, A[p.rowA.hi[hi] + p.rowA.lo[lo]]);
+        const T a = A[p.rowA.hi[hi] + p.rowA.lo[lo]];
+        *c = add_of(*c, st ? scale_of(a, coef) : a);
     }
 }
 
-hipError_t launch_accum(int dtype, const StepArgs& p, hipStream_t stream) {
+hipError_t launch_accum(int dtype, const StepArgs& p, const StripState* st, hipStream_t stream) {
     int64_t blocks = (p.R + 255) / 256;
     if (blocks > (1 << 20)) blocks = 1 << 20;
     if (blocks < 1) blocks = 1;
     switch (dtype) {
-        case 0: hipLaunchKernelGGL(accum_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, stream, p); break;
-        case 1: hipLaunchKernelGGL(accum_kernel<double>, dim3((unsigned)blocks), dim3(256), 0, stream, p); break;
-        case 2: hipLaunchKernelGGL(accum_kernel<c64>, dim3((unsigned)blocks), dim3(256), 0, stream, p); break;
-        case 3: hipLaunchKernelGGL(accum_kernel<c128>, dim3((unsigned)blocks), dim3(256), 0, stream, p); break;
+        case 0: hipLaunchKernelGGL(accum_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, stream, p, st); break;
+        case 1: hipLaunchKernelGGL(accum_kernel<double>, dim3((unsigned)blocks), dim3(256), 0, stream, p, st); break;
+        case 2: hipLaunchKernelGGL(accum_kernel<c64>, dim3((unsigned)blocks), dim3(256), 0, stream, p, st); break;
+        case 3: hipLaunchKernelGGL(accum_kernel<c128>, dim3((unsigned)blocks), dim3(256), 0, stream, p, st); break;
+        default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------- //
+// strip_exponent support (reference contract.py:816-829, core.py:125-172)
+// ------------------------------------------------------------------------- //
+
+// fac = max |x_i|: wavefront max + one atomicMax per wave on the bit pattern of
+// the non-negative double (order preserving)
+template <typename T>
+__global__ __launch_bounds__(256) void maxabs_kernel(const T* __restrict__ x, int64_t n, double* fac) {
+    double m = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const double a = abs_of(x[i]);
+        m = a > m || a != a ? a : m;  // propagate nan
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const double other = __shfl_down(m, o, 64);
+        m = other > m || other != other ? other : m;
+    }
+    if ((threadIdx.x & 63) == 0)
+        atomicMax((unsigned long long*)fac, (unsigned long long)__double_as_longlong(m));
+}
+
+hipError_t launch_maxabs(int dtype, const void* x, int64_t n, double* fac, hipStream_t stream) {
+    int64_t blocks = (n + 256 * 8 - 1) / (256 * 8);
+    if (blocks > 2048) blocks = 2048;
+    if (blocks < 1) blocks = 1;
+    switch (dtype) {
+        case 0: hipLaunchKernelGGL(maxabs_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, stream, (const float*)x, n, fac); break;
+        case 1: hipLaunchKernelGGL(maxabs_kernel<double>, dim3((unsigned)blocks), dim3(256), 0, stream, (const double*)x, n, fac); break;
+        case 2: hipLaunchKernelGGL(maxabs_kernel<c64>, dim3((unsigned)blocks), dim3(256), 0, stream, (const c64*)x, n, fac); break;
+        case 3: hipLaunchKernelGGL(maxabs_kernel<c128>, dim3((unsigned)blocks), dim3(256), 0, stream, (const c128*)x, n, fac); break;
+        default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+// slice exponent and the coefficients of the exponent-aware accumulate
+// (AdderWithMaybeExponentStripped, core.py:125-172): E' = max(E, e),
+// result = result * 10^(E-E') + slice * 10^(e-E') / fac_root
+__global__ void strip_prepare_kernel(const double* fac, const int32_t* counted, int64_t n_steps,
+                                     int64_t root_step, int check_zero, StripState* st) {
+    double e = 0.0;
+    bool zero = false;
+    for (int64_t s = 0; s < n_steps; ++s) {
+        if (!counted[s]) continue;
+        const double f = fac[s];
+        if (f == 0.0) zero = true;
+        e += log10(f);
+    }
+    const double froot = root_step >= 0 ? fac[root_step] : 1.0;
+    const double inf = __longlong_as_double(0x7ff0000000000000ll);
+    if (zero && check_zero) e = -inf;
+    const double E = st->E;
+    const double En = e > E ? e : E;  // nan e (not check_zero) compares false: keeps E, coefm nan below
+    st->e_slice = e;
+    st->zero = zero ? 1 : 0;
+    if (En == -inf) {
+        st->coefM = 1.0;
+        st->coefm = 0.0;
+    } else {
+        st->coefM = E == -inf ? 0.0 : pow(10.0, E - En);
+        st->coefm = (zero && check_zero) ? 0.0 : pow(10.0, e - En) / froot;
+    }
+    st->E = En;
+}
+
+hipError_t launch_strip_prepare(const double* fac, const int32_t* counted, int64_t n_steps,
+                                int64_t root_step, int check_zero, StripState* st, hipStream_t stream) {
+    hipLaunchKernelGGL(strip_prepare_kernel, dim3(1), dim3(1), 0, stream, fac, counted, n_steps,
+                       root_step, check_zero, st);
+    return hipGetLastError();
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void rescale_kernel(T* __restrict__ x, int64_t n, const StripState* st) {
+    const double c = st->coefM;
+    if (c == 1.0) return;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
+        x[i] = c == 0.0 ? zero_of(T{}) : scale_of(x[i], c);
+}
+
+hipError_t launch_rescale(int dtype, void* result, int64_t n, const StripState* st, hipStream_t stream) {
+    int64_t blocks = (n + 255) / 256;
+    if (blocks > 65536) blocks = 65536;
+    if (blocks < 1) blocks = 1;
+    switch (dtype) {
+        case 0: hipLaunchKernelGGL(rescale_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, stream, (float*)result, n, st); break;
+        case 1: hipLaunchKernelGGL(rescale_kernel<double>, dim3((unsigned)blocks), dim3(256), 0, stream, (double*)result, n, st); break;
+        case 2: hipLaunchKernelGGL(rescale_kernel<c64>, dim3((unsigned)blocks), dim3(256), 0, stream, (c64*)result, n, st); break;
+        case 3: hipLaunchKernelGGL(rescale_kernel<c128>, dim3((unsigned)blocks), dim3(256), 0, stream, (c128*)result, n, st); break;
         default: return hipErrorInvalidValue;
     }
     return hipGetLastError();
@@ -290,6 +389,8 @@ __global__ __launch_bounds__(256) void prologue_kernel(SliceMeta m, int64_t* sta
         }
         soff[leaf] = off;
     }
+    if (m.fac)
+        for (int64_t i = threadIdx.x; i < m.n_fac; i += blockDim.x) m.fac[i] = 0.0;
     __syncthreads();
     if (threadIdx.x == 0 && sid_arg < 0) state[0] = sid + state[1];
 }

@@ -337,6 +337,7 @@ __global__ __launch_bounds__(256, 2) void pair_mfma_c64_kernel(StepArgs p, MfmaH
     // pair up rows (t, t+1): even lanes end up with (re, im) of row t, odd lanes
     // with (re, im) of row t+1, so every lane stores one whole complex number
     const bool odd = lane & 1;
+    const float alpha = (float)step_alpha(p);
 #pragma unroll
     for (int j = 0; j < Cfg::FN; ++j) {
         const int64_t n = n0 + wn * Cfg::WTN + j * 16 + (l31 >> 1);
@@ -354,6 +355,8 @@ __global__ __launch_bounds__(256, 2) void pair_mfma_c64_kernel(StepArgs p, MfmaH
                     float2 v;
                     v.x = odd ? recv : acc[i][j][t];
                     v.y = odd ? acc[i][j][t + 1] : recv;
+                    v.x *= alpha;
+                    v.y *= alpha;
                     *(float2*)(C + 2 * (ro + ncol)) = v;
                 }
             }
@@ -556,6 +559,7 @@ __global__ __launch_bounds__(256, Cfg::FAST_BLOCKS) void pair_mfma_fast_kernel(S
         return;
     }
     const bool odd = lane & 1;
+    const float alpha = (float)step_alpha(p);
     // all store offsets first (one batch of table loads, one wait), then stores
     unsigned ro[Cfg::FM][8], co[Cfg::FN];
 #pragma unroll
@@ -580,6 +584,8 @@ __global__ __launch_bounds__(256, Cfg::FAST_BLOCKS) void pair_mfma_fast_kernel(S
                 float2 v;
                 v.x = odd ? recv : acc[i][j][t];
                 v.y = odd ? acc[i][j][t + 1] : recv;
+                v.x *= alpha;
+                v.y *= alpha;
                 *(float2*)(C + 2 * (size_t)(ro[i][u] + co[j])) = v;
             }
         }
@@ -593,6 +599,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(StepArgs p, int64_t 
                                                             int64_t ldp,
                                                             const float* __restrict__ partial) {
     __shared__ float2 part[8][32];
+    const float alpha = (float)step_alpha(p);
     const int ox = threadIdx.x & 31, sy = threadIdx.x >> 5;
     const int64_t per_b = p.R * p.N;
     const int64_t total = per_b * p.Bt;
@@ -627,7 +634,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(StepArgs p, int64_t 
             int64_t hi, lo;
             split_row(p, m, hi, lo);
             c64* C = (c64*)p.C + *p.soffC + p.bC[b];
-            C[p.rowC.hi[hi] + p.rowC.lo[lo] + p.nC[n]] = c64{r2, i2};
+            C[p.rowC.hi[hi] + p.rowC.lo[lo] + p.nC[n]] = c64{r2 * alpha, i2 * alpha};
         }
         __syncthreads();
     }
@@ -774,6 +781,7 @@ __global__ __launch_bounds__(256) void pair_mfma_stream_kernel(StepArgs p, MfmaH
     __syncthreads();
 
     float* As = As_all + wave * (2 * 32 * LD);
+    const float alpha = (float)step_alpha(p);
     const int n_chunks = KP / MFMA_BK;
     const int64_t wave_g = (int64_t)blockIdx.x * 4 + wave;
     const int64_t n_waves = (int64_t)gridDim.x * 4;
@@ -884,7 +892,7 @@ __global__ __launch_bounds__(256) void pair_mfma_stream_kernel(StepArgs p, MfmaH
         const float* b_base = Bs + (l31 ^ kk) * LDB + cc * MFMA_BK;
         const int k_left = (int)p.K - cc * MFMA_BK;
         const int nq = k_left >= MFMA_BK ? MFMA_BK / 4 : (k_left + 3) / 4;
-        for (int kq = 0; kq < ((h.exp & 2) ? 1 : nq); ++kq) {
+        for (int kq = 0; kq < nq; ++kq) {
             const f32x4 af = *(const f32x4*)(a_base + kq * 4);
             f32x4 bf[FN];
 #pragma unroll
@@ -919,16 +927,13 @@ __global__ __launch_bounds__(256) void pair_mfma_stream_kernel(StepArgs p, MfmaH
                 for (int j = 0; j < FN; ++j) {
                     const float send = odd ? acc[j][t] : acc[j][t + 1];
                     const float recv = __shfl_xor(send, 1, 64);
-                    if (n_ok[j] && ro >= 0 && !(h.exp & 1)) {
+                    if (n_ok[j] && ro >= 0) {
                         float2 v;
                         v.x = odd ? recv : acc[j][t];
                         v.y = odd ? acc[j][t + 1] : recv;
-                        if (h.exp & 4) {
-                            typedef float f32x2 __attribute__((ext_vector_type(2)));
-                            f32x2 w = {v.x, v.y};
-                            __builtin_nontemporal_store(w, (f32x2*)(C + 2 * (ro + ncol[j])));
-                        } else
-                            *(float2*)(C + 2 * (ro + ncol[j])) = v;
+                        v.x *= alpha;
+                        v.y *= alpha;
+                        *(float2*)(C + 2 * (ro + ncol[j])) = v;
                     }
                 }
             }

@@ -7,6 +7,7 @@
 // host<->device traffic and no host synchronisation.
 #include <algorithm>
 #include <cstdarg>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -93,6 +94,12 @@ struct ctg_exec {
     hipEvent_t ev_in = nullptr, ev_out = nullptr;
     bool warm = false;
     bool graph_off = false;
+    // strip_exponent state
+    int strip = 0, check_zero = 0;
+    double* d_fac = nullptr;        // [n_steps + 1] max|.| per pair step; last = constant 1.0
+    int32_t* d_counted = nullptr;   // [n_steps] 1 for pair steps
+    StripState* d_strip = nullptr;
+    int64_t root_step = -1;
 };
 
 namespace {
@@ -259,6 +266,15 @@ void resolve_args(ctg_exec* e) {
         a.bA = tab(W_BA);
         a.bB = tab(W_BB);
         a.bC = tab(W_BC);
+        a.facA = a.facB = nullptr;
+        a.check_zero = e->check_zero;
+        if (e->strip && r[W_KIND] == KIND_PAIR) {
+            auto fac = [&](int w) -> const double* {
+                return (r[w] >= 0 && r[w] < p->n_steps) ? e->d_fac + r[w] : e->d_fac + p->n_steps;
+            };
+            a.facA = fac(W_A_PROD);
+            a.facB = fac(W_B_PROD);
+        }
     }
 }
 
@@ -447,7 +463,17 @@ int launch_step(ctg_exec* e, int64_t s, hipStream_t stream) {
     hipError_t err = hipSuccess;
     switch (r[W_KIND]) {
         case KIND_SINGLE: err = launch_single(p->dtype, e->args[s], stream); break;
-        case KIND_ACCUM: err = launch_accum(p->dtype, e->args[s], stream); break;
+        case KIND_ACCUM:
+            if (e->strip) {
+                err = launch_strip_prepare(e->d_fac, e->d_counted, p->n_steps, e->root_step,
+                                           e->check_zero, e->d_strip, stream);
+                if (err == hipSuccess)
+                    err = launch_rescale(p->dtype, e->d_result, p->result_elems, e->d_strip, stream);
+                if (err == hipSuccess) err = launch_accum(p->dtype, e->args[s], e->d_strip, stream);
+            } else {
+                err = launch_accum(p->dtype, e->args[s], nullptr, stream);
+            }
+            break;
         case KIND_PAIR:
             if (r[W_KERNEL] == KERNEL_MFMA)
                 err = launch_pair_mfma(p->dtype, e->args[s], e->hints[s], e->d_scratch, kScratchBytes,
@@ -455,6 +481,11 @@ int launch_step(ctg_exec* e, int64_t s, hipStream_t stream) {
             else
                 err = launch_pair_valu(p->dtype, e->args[s], e->d_scratch, kScratchBytes, stream);
             break;
+    }
+    if (err == hipSuccess && e->strip && r[W_KIND] == KIND_PAIR) {
+        // factor = max|p| of the freshly written intermediate (contiguous in the arena)
+        const char* c = (const char*)space_ptr(e, r[W_C_SPACE]) + r[W_C_OFF] * kItemSize[p->dtype];
+        err = launch_maxabs(p->dtype, c, r[W_C_SIZE], e->d_fac + s, stream);
     }
     if (err != hipSuccess)
         return fail(CTG_E_HIP, "launch of step %lld failed: %s", (long long)s, hipGetErrorString(err));
@@ -547,6 +578,9 @@ int ctg_exec_destroy(ctg_exec* e) {
     if (e->d_misc) (void)hipFree(e->d_misc);
     if (e->d_scratch) (void)hipFree(e->d_scratch);
     if (e->d_ord) (void)hipFree(e->d_ord);
+    if (e->d_fac) (void)hipFree(e->d_fac);
+    if (e->d_counted) (void)hipFree(e->d_counted);
+    if (e->d_strip) (void)hipFree(e->d_strip);
     delete e;
     return CTG_OK;
 }
@@ -613,7 +647,25 @@ int ctg_exec_create(const ctg_plan* p, int device, void* stream, void* ext_resul
     HIP_TRY_E(hipMemcpy(e->d_tables, p->tables.data(), p->tables.size() * 8, hipMemcpyHostToDevice));
     HIP_TRY_E(hipMemsetAsync(e->d_inputs, 0, p->inputs_elems * isz, e->stream));
     HIP_TRY_E(hipMemsetAsync(e->d_result, 0, p->result_elems * isz, e->stream));
-    e->meta = SliceMeta{n_leaves, p->n_sliced, d_sizes, d_fixed, d_strides};
+    e->meta = SliceMeta{n_leaves, p->n_sliced, d_sizes, d_fixed, d_strides, nullptr, 0};
+    {
+        std::vector<double> fac(p->n_steps + 1, 0.0);
+        fac[p->n_steps] = 1.0;
+        std::vector<int32_t> counted(std::max<int64_t>(p->n_steps, 1), 0);
+        for (int64_t st = 0; st < p->n_steps; ++st) {
+            const int64_t* r = &p->steps[st * STEP_WORDS];
+            if (r[W_KIND] == KIND_PAIR) {
+                counted[st] = 1;
+                e->root_step = st;  // the last pair step produces the slice output
+            }
+        }
+        HIP_TRY_E(hipMalloc((void**)&e->d_fac, fac.size() * sizeof(double)));
+        HIP_TRY_E(hipMalloc((void**)&e->d_counted, counted.size() * sizeof(int32_t)));
+        HIP_TRY_E(hipMalloc((void**)&e->d_strip, sizeof(StripState)));
+        HIP_TRY_E(hipMemcpy(e->d_fac, fac.data(), fac.size() * sizeof(double), hipMemcpyHostToDevice));
+        HIP_TRY_E(hipMemcpy(e->d_counted, counted.data(), counted.size() * sizeof(int32_t),
+                            hipMemcpyHostToDevice));
+    }
     // Replaying a captured slice graph measured SLOWER than eager launches on
     // ROCm 7.2 / MI355X (C2: 622 vs 523 us per contraction, m20: 92.0 vs 91.4
     // ms per slice): the host already runs ahead of the device and the tiny
@@ -664,6 +716,44 @@ int ctg_exec_zero_result(ctg_exec* e) {
     HIP_TRY(hipSetDevice(e->device));
     HIP_TRY(hipMemsetAsync(e->d_result, 0, e->plan->result_elems * kItemSize[e->plan->dtype],
                            e->stream));
+    StripState init{};
+    init.E = -HUGE_VAL;
+    init.e_slice = -HUGE_VAL;
+    init.coefM = 1.0;
+    init.coefm = 0.0;
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    HIP_TRY(hipMemcpy(e->d_strip, &init, sizeof(init), hipMemcpyHostToDevice));
+    return CTG_OK;
+}
+
+int ctg_exec_set_strip_exponent(ctg_exec* e, int strip, int check_zero) {
+    if (!e) return fail(CTG_E_INVALID, "null argument");
+    HIP_TRY(hipSetDevice(e->device));
+    strip = strip ? 1 : 0;
+    check_zero = check_zero ? 1 : 0;
+    if (strip == e->strip && check_zero == e->check_zero) return CTG_OK;
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    e->strip = strip;
+    e->check_zero = check_zero;
+    e->meta.fac = strip ? e->d_fac : nullptr;
+    e->meta.n_fac = strip ? e->plan->n_steps : 0;
+    resolve_args(e);
+    // a captured slice graph embeds the old arguments
+    if (e->gexec) {
+        (void)hipGraphExecDestroy(e->gexec);
+        e->gexec = nullptr;
+    }
+    return CTG_OK;
+}
+
+int ctg_exec_get_exponent(ctg_exec* e, double* exponent, int* zero) {
+    if (!e || !exponent) return fail(CTG_E_INVALID, "null argument");
+    HIP_TRY(hipSetDevice(e->device));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    StripState st{};
+    HIP_TRY(hipMemcpy(&st, e->d_strip, sizeof(st), hipMemcpyDeviceToHost));
+    *exponent = st.E;
+    if (zero) *zero = st.zero;
     return CTG_OK;
 }
 

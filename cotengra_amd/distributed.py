@@ -60,6 +60,7 @@ def contract_distributed(
         fn = _tree_contractor(tree, order)
         st = fn.setup(*[_to_local_device(x) for x in arrays])
         ex = st["exec"]
+        ex.set_strip_exponent(False)
         ex.zero_result()
         ex.run_slices(rank, len(mine), world)
         if "result" in st:

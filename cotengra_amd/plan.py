@@ -142,7 +142,10 @@ class Step:
     elems_rw: int = 0
     node: int = -1
     label: str = ""
-    conj_free: bool = True
+    # index of the pair step that produced operand a / b (-1: input or
+    # preprocessing output, whose scale factor is 1) -- strip_exponent
+    a_prod: int = -1
+    b_prod: int = -1
 
 
 class Arena:
@@ -251,7 +254,8 @@ class Plan:
          30 a.size 31 b.size 32 c.size      (bounds, elements)
          33 macs    34 elems_rw   35 node
          36 k_lo  37 kA_hi  38 kB_hi  39 k_hi_len   (23/24 hold the lo level)
-         40.. reserved (0)
+         40 a.producer step  41 b.producer step   (-1: scale factor 1)
+         42.. reserved (0)
         """
         blobs = []
         cursor = 0
@@ -303,6 +307,7 @@ class Plan:
             r[31] = s.b.size if s.b is not None else 0
             r[32] = s.c.size if s.c is not None else 0
             r[33], r[34], r[35] = s.macs, s.elems_rw, s.node
+            r[40], r[41] = s.a_prod, s.b_prod
 
         tables = np.concatenate(blobs) if blobs else np.zeros(1, np.int64)
         n_in = len(self.input_sizes)
@@ -620,7 +625,13 @@ def compile_tree(tree, dtype, order=None, force_kernel=None):
             off, n = arena_live.pop(id(ref))
             arena.release(off, n)
 
+    producer = {}  # id(TensorRef) -> index of the pair step that wrote it
+
     def add(step):
+        if step.kind == KIND_PAIR:
+            step.a_prod = producer.get(id(step.a), -1)
+            step.b_prod = producer.get(id(step.b), -1)
+            producer[id(step.c)] = len(plan.steps)
         plan.steps.append(step)
         plan.macs_per_slice += step.macs
         plan.elems_rw_per_slice += step.elems_rw

@@ -27,6 +27,8 @@ SYMBOLS = (
     "ctg_exec_upload_inputs_host",
     "ctg_exec_upload_inputs_device",
     "ctg_exec_zero_result",
+    "ctg_exec_set_strip_exponent",
+    "ctg_exec_get_exponent",
     "ctg_exec_run_slices",
     "ctg_exec_profile_slice",
     "ctg_exec_step_kernel",
@@ -96,6 +98,8 @@ def load():
         "ctg_exec_upload_inputs_host": [vp, C.POINTER(vp)],
         "ctg_exec_upload_inputs_device": [vp, C.POINTER(vp)],
         "ctg_exec_zero_result": [vp],
+        "ctg_exec_set_strip_exponent": [vp, C.c_int, C.c_int],
+        "ctg_exec_get_exponent": [vp, C.POINTER(C.c_double), C.POINTER(C.c_int)],
         "ctg_exec_run_slices": [vp, C.c_int64, C.c_int64, C.c_int64],
         "ctg_exec_profile_slice": [vp, C.c_int64, C.POINTER(C.c_float)],
         "ctg_exec_step_kernel": [vp, C.c_int64, C.c_char_p, C.c_int64],
@@ -229,6 +233,14 @@ class Executor:
 
     def zero_result(self):
         _check(load().ctg_exec_zero_result(self.handle))
+
+    def set_strip_exponent(self, strip, check_zero=False):
+        _check(load().ctg_exec_set_strip_exponent(self.handle, int(bool(strip)), int(bool(check_zero))))
+
+    def get_exponent(self):
+        e, z = C.c_double(), C.c_int()
+        _check(load().ctg_exec_get_exponent(self.handle, C.byref(e), C.byref(z)))
+        return e.value, bool(z.value)
 
     def run_slices(self, first=0, count=None, stride=1):
         if count is None:

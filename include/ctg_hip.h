@@ -108,6 +108,17 @@ int ctg_exec_upload_inputs_device(ctg_exec* exec, const void* const* ptrs);
 /* result <- 0 (start of a `gather_slices` reduction, core.py:3842-3844) */
 int ctg_exec_zero_result(ctg_exec* exec);
 
+/* strip_exponent / check_zero of the reference's Contractor (contract.py:
+ * 674-683, 816-829): after every pairwise step the intermediate is normalised
+ * by factor = max|p| and log10(factor) accumulated.  On the device the
+ * normalisation is lazy (the consumer's epilogue multiplies by 1/(fac_l fac_r))
+ * and slices are combined with the exponent-aware adder of core.py:125-172.
+ * With strip on, the result tensor holds the mantissa and ctg_exec_get_exponent
+ * returns the base-10 exponent E (result = mantissa * 10^E; E = -inf and
+ * *zero = 1 when check_zero met a zero intermediate in every slice). */
+int ctg_exec_set_strip_exponent(ctg_exec* exec, int strip_exponent, int check_zero);
+int ctg_exec_get_exponent(ctg_exec* exec, double* exponent, int* zero);
+
 /* Contract slices first, first+stride, ... (count of them) and ACCUMULATE each
  * into the result tensor at its chunk position: the slice loop of
  * `ContractionTree.contract` (core.py:4015-4030) fused with `gather_slices`
