@@ -26,6 +26,7 @@ enum StepWord {
     W_MACS = 33, W_ELEMS = 34, W_NODE = 35,
     W_K_LO = 36, W_KA_HI = 37, W_KB_HI = 38, W_K_HI_LEN = 39,
     W_A_PROD = 40, W_B_PROD = 41,  // step that produced the operand (-1: input / preprocessing)
+    W_INVARIANT = 42,              // 1: does not depend on sliced inputs, run once per upload
     STEP_WORDS = 48
 };
 
@@ -230,7 +231,8 @@ struct SliceMeta {
     const int64_t* sizes;    // [n_sliced]
     const int64_t* fixed;    // [n_sliced]
     const int64_t* strides;  // [n_leaves * n_sliced]
-    double* fac;             // strip_exponent: per-step max|.| scalars, zeroed per slice (or null)
+    double* fac;             // strip_exponent: per-step max|.| scalars (or null)
+    const int32_t* fac_zero; // [n_fac] 1: zero the scalar at slice start (per-slice pair steps)
     int64_t n_fac;
 };
 // soff[n_leaves] receives the per-leaf base offsets of slice `sid`; with sid < 0

@@ -390,7 +390,8 @@ __global__ __launch_bounds__(256) void prologue_kernel(SliceMeta m, int64_t* sta
         soff[leaf] = off;
     }
     if (m.fac)
-        for (int64_t i = threadIdx.x; i < m.n_fac; i += blockDim.x) m.fac[i] = 0.0;
+        for (int64_t i = threadIdx.x; i < m.n_fac; i += blockDim.x)
+            if (m.fac_zero[i]) m.fac[i] = 0.0;
     __syncthreads();
     if (threadIdx.x == 0 && sid_arg < 0) state[0] = sid + state[1];
 }

@@ -98,6 +98,10 @@ struct ctg_exec {
     int strip = 0, check_zero = 0;
     double* d_fac = nullptr;        // [n_steps + 1] max|.| per pair step; last = constant 1.0
     int32_t* d_counted = nullptr;   // [n_steps] 1 for pair steps
+    int32_t* d_fac_zero = nullptr;  // [n_steps] 1 for per-slice pair steps
+    // slice-invariant steps: executed once per upload / option change
+    std::vector<char> invariant;
+    bool invariants_ready = false;
     StripState* d_strip = nullptr;
     int64_t root_step = -1;
 };
@@ -492,6 +496,30 @@ int launch_step(ctg_exec* e, int64_t s, hipStream_t stream) {
     return CTG_OK;
 }
 
+// Slice-invariant steps (no sliced input below them): once per upload.  Their
+// strip_exponent factors are computed here too and kept across slices.
+int run_invariants(ctg_exec* e) {
+    if (e->invariants_ready) return CTG_OK;
+    const ctg_plan* p = e->plan;
+    bool any = false;
+    for (int64_t s = 0; s < p->n_steps; ++s) any = any || e->invariant[s];
+    if (any) {
+        // invariant operands are never slice dependent, but kernels read *soff
+        hipError_t err = launch_prologue(e->meta, e->d_state, e->d_soff, 0, e->stream);
+        if (err != hipSuccess)
+            return fail(CTG_E_HIP, "prologue launch failed: %s", hipGetErrorString(err));
+        if (e->strip)
+            HIP_TRY(hipMemsetAsync(e->d_fac, 0, p->n_steps * sizeof(double), e->stream));
+        for (int64_t s = 0; s < p->n_steps; ++s) {
+            if (!e->invariant[s]) continue;
+            const int rc = launch_step(e, s, e->stream);
+            if (rc != CTG_OK) return rc;
+        }
+    }
+    e->invariants_ready = true;
+    return CTG_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -580,6 +608,7 @@ int ctg_exec_destroy(ctg_exec* e) {
     if (e->d_ord) (void)hipFree(e->d_ord);
     if (e->d_fac) (void)hipFree(e->d_fac);
     if (e->d_counted) (void)hipFree(e->d_counted);
+    if (e->d_fac_zero) (void)hipFree(e->d_fac_zero);
     if (e->d_strip) (void)hipFree(e->d_strip);
     delete e;
     return CTG_OK;
@@ -647,18 +676,25 @@ int ctg_exec_create(const ctg_plan* p, int device, void* stream, void* ext_resul
     HIP_TRY_E(hipMemcpy(e->d_tables, p->tables.data(), p->tables.size() * 8, hipMemcpyHostToDevice));
     HIP_TRY_E(hipMemsetAsync(e->d_inputs, 0, p->inputs_elems * isz, e->stream));
     HIP_TRY_E(hipMemsetAsync(e->d_result, 0, p->result_elems * isz, e->stream));
-    e->meta = SliceMeta{n_leaves, p->n_sliced, d_sizes, d_fixed, d_strides, nullptr, 0};
+    e->meta = SliceMeta{n_leaves, p->n_sliced, d_sizes, d_fixed, d_strides, nullptr, nullptr, 0};
     {
         std::vector<double> fac(p->n_steps + 1, 0.0);
         fac[p->n_steps] = 1.0;
         std::vector<int32_t> counted(std::max<int64_t>(p->n_steps, 1), 0);
+        std::vector<int32_t> fac_zero(std::max<int64_t>(p->n_steps, 1), 0);
+        e->invariant.assign(p->n_steps, 0);
         for (int64_t st = 0; st < p->n_steps; ++st) {
             const int64_t* r = &p->steps[st * STEP_WORDS];
+            e->invariant[st] = r[W_INVARIANT] != 0 && r[W_KIND] != KIND_ACCUM;
             if (r[W_KIND] == KIND_PAIR) {
                 counted[st] = 1;
+                fac_zero[st] = e->invariant[st] ? 0 : 1;
                 e->root_step = st;  // the last pair step produces the slice output
             }
         }
+        HIP_TRY_E(hipMalloc((void**)&e->d_fac_zero, fac_zero.size() * sizeof(int32_t)));
+        HIP_TRY_E(hipMemcpy(e->d_fac_zero, fac_zero.data(), fac_zero.size() * sizeof(int32_t),
+                            hipMemcpyHostToDevice));
         HIP_TRY_E(hipMalloc((void**)&e->d_fac, fac.size() * sizeof(double)));
         HIP_TRY_E(hipMalloc((void**)&e->d_counted, counted.size() * sizeof(int32_t)));
         HIP_TRY_E(hipMalloc((void**)&e->d_strip, sizeof(StripState)));
@@ -695,6 +731,7 @@ int ctg_exec_upload_inputs_host(ctg_exec* e, const void* const* ptrs) {
     }
     HIP_TRY(hipStreamSynchronize(e->stream));
     HIP_TRY(hipMemcpy(e->d_inputs, staging.data(), staging.size(), hipMemcpyHostToDevice));
+    e->invariants_ready = false;
     return CTG_OK;
 }
 
@@ -708,6 +745,7 @@ int ctg_exec_upload_inputs_device(ctg_exec* e, const void* const* ptrs) {
         HIP_TRY(hipMemcpyAsync(e->d_inputs + p->input_offsets[i] * isz, ptrs[i],
                                p->input_sizes[i] * isz, hipMemcpyDeviceToDevice, e->stream));
     }
+    e->invariants_ready = false;
     return CTG_OK;
 }
 
@@ -736,7 +774,9 @@ int ctg_exec_set_strip_exponent(ctg_exec* e, int strip, int check_zero) {
     e->strip = strip;
     e->check_zero = check_zero;
     e->meta.fac = strip ? e->d_fac : nullptr;
+    e->meta.fac_zero = e->d_fac_zero;
     e->meta.n_fac = strip ? e->plan->n_steps : 0;
+    e->invariants_ready = false;  // their stored scale changes with the option
     resolve_args(e);
     // a captured slice graph embeds the old arguments
     if (e->gexec) {
@@ -766,11 +806,16 @@ int ctg_exec_run_slices(ctg_exec* e, int64_t first, int64_t count, int64_t strid
                     (long long)first, (long long)stride, (long long)count, (long long)p->nslices);
     if (count == 0) return CTG_OK;
     HIP_TRY(hipSetDevice(e->device));
+    {
+        const int rc = run_invariants(e);
+        if (rc != CTG_OK) return rc;
+    }
     auto eager = [&](int64_t sid) -> int {
         hipError_t err = launch_prologue(e->meta, e->d_state, e->d_soff, sid, e->stream);
         if (err != hipSuccess)
             return fail(CTG_E_HIP, "prologue launch failed: %s", hipGetErrorString(err));
         for (int64_t s = 0; s < p->n_steps; ++s) {
+            if (e->invariant[s]) continue;
             const int rc = launch_step(e, s, e->stream);
             if (rc != CTG_OK) return rc;
         }
@@ -794,7 +839,7 @@ int ctg_exec_run_slices(ctg_exec* e, int64_t first, int64_t count, int64_t strid
             if (ok) {
                 bool launched = launch_prologue(e->meta, e->d_state, e->d_soff, -1, e->gstream) == hipSuccess;
                 for (int64_t s = 0; launched && s < p->n_steps; ++s)
-                    launched = launch_step(e, s, e->gstream) == CTG_OK;
+                    if (!e->invariant[s]) launched = launch_step(e, s, e->gstream) == CTG_OK;
                 ok = hipStreamEndCapture(e->gstream, &graph) == hipSuccess && launched && graph;
             }
             if (ok) ok = hipGraphInstantiate(&e->gexec, graph, nullptr, nullptr, 0) == hipSuccess;
@@ -835,12 +880,18 @@ int ctg_exec_profile_slice(ctg_exec* e, int64_t slice_id, float* ms) {
         HIP_TRY(hipEventCreate(&ev));
         e->events.push_back(ev);
     }
+    {
+        const int rc = run_invariants(e);
+        if (rc != CTG_OK) return rc;
+    }
     hipError_t err = launch_prologue(e->meta, e->d_state, e->d_soff, slice_id, e->stream);
     if (err != hipSuccess) return fail(CTG_E_HIP, "prologue launch failed: %s", hipGetErrorString(err));
     HIP_TRY(hipEventRecord(e->events[0], e->stream));
     for (int64_t s = 0; s < p->n_steps; ++s) {
-        const int rc = launch_step(e, s, e->stream);
-        if (rc != CTG_OK) return rc;
+        if (!e->invariant[s]) {  // invariant steps cost nothing per slice: 0 ms
+            const int rc = launch_step(e, s, e->stream);
+            if (rc != CTG_OK) return rc;
+        }
         HIP_TRY(hipEventRecord(e->events[s + 1], e->stream));
     }
     HIP_TRY(hipStreamSynchronize(e->stream));

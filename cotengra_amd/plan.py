@@ -146,6 +146,9 @@ class Step:
     # preprocessing output, whose scale factor is 1) -- strip_exponent
     a_prod: int = -1
     b_prod: int = -1
+    # True if the step does not depend on any sliced input: it is executed once
+    # per upload instead of once per slice and its output is never recycled
+    invariant: bool = False
 
 
 class Arena:
@@ -255,7 +258,8 @@ class Plan:
          33 macs    34 elems_rw   35 node
          36 k_lo  37 kA_hi  38 kB_hi  39 k_hi_len   (23/24 hold the lo level)
          40 a.producer step  41 b.producer step   (-1: scale factor 1)
-         42.. reserved (0)
+         42 slice-invariant (run once per upload, output persistent)
+         43.. reserved (0)
         """
         blobs = []
         cursor = 0
@@ -308,6 +312,7 @@ class Plan:
             r[32] = s.c.size if s.c is not None else 0
             r[33], r[34], r[35] = s.macs, s.elems_rw, s.node
             r[40], r[41] = s.a_prod, s.b_prod
+            r[42] = 1 if s.invariant else 0
 
         tables = np.concatenate(blobs) if blobs else np.zeros(1, np.int64)
         n_in = len(self.input_sizes)
@@ -606,22 +611,38 @@ def compile_tree(tree, dtype, order=None, force_kernel=None):
     arena = Arena()
     arena_live = {}  # id(TensorRef) -> (offset, nelems)
 
-    def arena_factory(force_order=None):
+    # Slice-invariant subtrees: a node none of whose
+    # leaves is sliced evaluates to the same tensor in every slice; the
+    # reference recomputes it per slice (core.py:3821-3823), here it is
+    # computed once per upload.  Its output lives in memory that per-slice
+    # steps never recycle.  Only meaningful for sliced trees.
+    use_invariants = tree.multiplicity > 1
+    persistent = set()  # id(TensorRef) of invariant outputs
+    persistent_refs = []
+    parena = Arena()
+
+    def arena_factory(force_order=None, invariant=False):
         def make(inds, natural):
             order_ = force_order if force_order is not None else natural
             shape = [size_dict[ix] for ix in order_]
             n = prod(shape)
-            off = arena.alloc(n)
+            # invariant outputs live in their own region placed behind the
+            # per-slice arena (relocated below once its peak is known): they
+            # must survive the per-slice recycling of every later slice
+            off = (parena if invariant else arena).alloc(n)
             ref = TensorRef(
                 SPACE_ARENA, off, -1, tuple(order_), _row_major_strides(shape), n
             )
             arena_live[id(ref)] = (off, n)
+            if invariant:
+                persistent.add(id(ref))
+                persistent_refs.append(ref)
             return ref
 
         return make
 
     def release(ref):
-        if ref.space == SPACE_ARENA:
+        if ref.space == SPACE_ARENA and id(ref) not in persistent:
             off, n = arena_live.pop(id(ref))
             arena.release(off, n)
 
@@ -638,6 +659,7 @@ def compile_tree(tree, dtype, order=None, force_kernel=None):
 
     # -- leaves: strided views of the resident inputs
     tensors = {}
+    depends = {}  # node -> does it depend on a sliced input?
     for i, term in enumerate(tree.inputs):
         full_shape = [size_dict[ix] for ix in term]
         st = _row_major_strides(full_shape)
@@ -651,10 +673,13 @@ def compile_tree(tree, dtype, order=None, force_kernel=None):
             plan.input_sizes[i],
         )
         legs = tree.get_legs(i)  # also fills tree.preprocessing lazily
+        depends[i] = (i in tree.sliced_inputs) or not use_invariants
         if i in tree.preprocessing and N > 1:
+            inv = not depends[i]
             step = build_single_step(
-                size_dict, view, tuple(legs), arena_factory(), node=i
+                size_dict, view, tuple(legs), arena_factory(invariant=inv), node=i
             )
+            step.invariant = inv
             add(step)
             tensors[i] = step.c
         else:
@@ -672,7 +697,9 @@ def compile_tree(tree, dtype, order=None, force_kernel=None):
         final = None
         for p, l, r in tree.traverse(order=order):
             is_root = p == tree.root
-            factory = arena_factory(root_order if is_root else None)
+            depends[p] = depends[l] or depends[r] or is_root
+            inv = not depends[p]
+            factory = arena_factory(root_order if is_root else None, invariant=inv)
             p_inds = root_order if is_root else tuple(tree.get_legs(p))
             step = build_pair_step(
                 dtype,
@@ -684,6 +711,7 @@ def compile_tree(tree, dtype, order=None, force_kernel=None):
                 node=p,
                 force_kernel=force_kernel,
             )
+            step.invariant = inv
             add(step)
             release(step.a)
             release(step.b)
@@ -717,7 +745,10 @@ def compile_tree(tree, dtype, order=None, force_kernel=None):
     add(acc)
     release(final)
 
-    plan.arena_elems = max(arena.peak, ARENA_ALIGN)
+    slice_peak = max(arena.peak, ARENA_ALIGN)
+    for ref in persistent_refs:
+        ref.offset += slice_peak
+    plan.arena_elems = slice_peak + parena.peak
     plan.inputs_elems = max(cursor, ARENA_ALIGN)
     return plan
 

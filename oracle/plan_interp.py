@@ -59,6 +59,7 @@ def run_plan(plan, arrays, slice_ids=None, result=None):
     if slice_ids is None:
         slice_ids = range(plan.nslices)
 
+    first = True
     for sid in slice_ids:
         soff = slice_offsets(plan, sid)
 
@@ -69,6 +70,8 @@ def run_plan(plan, arrays, slice_ids=None, result=None):
             return b
 
         for step in plan.steps:
+            if step.invariant and not first:
+                continue  # computed once, output persistent (like the executor)
             if step.kind == P.KIND_SINGLE:
                 src, dst = spaces[step.a.space], spaces[step.c.space]
                 ia = base(step.a) + _rows(step, "A")[:, None] + _ks(step, "A")[None, :]
@@ -98,4 +101,5 @@ def run_plan(plan, arrays, slice_ids=None, result=None):
                     C[ic] = np.einsum("rk,rkn->rn", A[ia], B[ib])
             else:
                 raise ValueError(f"bad step kind {step.kind}")
+        first = False
     return result.reshape(plan.result_shape)
