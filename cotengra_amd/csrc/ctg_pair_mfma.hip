@@ -701,7 +701,7 @@ static hipError_t launch_cfg(const StepArgs& p, const MfmaHints& h, void* scratc
 // offsets: one scalar base per group + per-lane constants).
 // ------------------------------------------------------------------------- //
 
-template <int FN, bool VEC, bool ADD>
+template <int FN, bool VEC, bool ADD, bool SHORTK>
 __global__ __launch_bounds__(256) void pair_mfma_stream_kernel(StepArgs p, MfmaHints h, int KP,
                                                                int64_t n_groups) {
     constexpr int LD = MFMA_BK + 4;
@@ -756,6 +756,11 @@ __global__ __launch_bounds__(256) void pair_mfma_stream_kernel(StepArgs p, MfmaH
 #pragma unroll
         for (int j = 0; j < PER_T; ++j) {
             const int v = oa[j];
+            if (SHORTK && (v & 0x8000)) {  // short-K padding: nothing to gather for this slot
+                a_pk[j] = -1;
+                if (ADD) a_delta[j] = 0;
+                continue;
+            }
             const int r = v >> 4, c = v & 15;
             a_pk[j] = (r << 16) | (r * LD + c);
             if (ADD) a_delta[j] = (int)p.rowA.lo[r];
@@ -781,6 +786,9 @@ __global__ __launch_bounds__(256) void pair_mfma_stream_kernel(StepArgs p, MfmaH
     __syncthreads();
 
     float* As = As_all + wave * (2 * 32 * LD);
+    // columns never gathered (k >= K of a short contraction) must read as zero
+    if (SHORTK)
+        for (int i = lane; i < 2 * 32 * LD; i += 64) As[i] = 0.f;
     const float alpha = (float)step_alpha(p);
     const int n_chunks = KP / MFMA_BK;
     const int64_t wave_g = (int64_t)blockIdx.x * 4 + wave;
@@ -805,6 +813,7 @@ __global__ __launch_bounds__(256) void pair_mfma_stream_kernel(StepArgs p, MfmaH
         if (VEC) {
 #pragma unroll
             for (int j = 0; j < PER_T; j += 2) {
+                if (SHORTK && a_pk[j] < 0) continue;  // wave-uniform (depends on j only)
                 const int r = a_pk[j] >> 16, c = (a_pk[j] & 0xffff) - r * LD;
                 int64_t ro;
                 if (ADD) {
@@ -821,6 +830,7 @@ __global__ __launch_bounds__(256) void pair_mfma_stream_kernel(StepArgs p, MfmaH
         } else {
 #pragma unroll
             for (int j = 0; j < PER_T; ++j) {
+                if (SHORTK && a_pk[j] < 0) continue;
                 const int r = a_pk[j] >> 16, c = (a_pk[j] & 0xffff) - r * LD;
                 int64_t ro = -1;
                 if (ADD) {
@@ -871,6 +881,7 @@ __global__ __launch_bounds__(256) void pair_mfma_stream_kernel(StepArgs p, MfmaH
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
         for (int j = 0; j < PER_T; ++j) {
+            if (SHORTK && a_pk[j] < 0) continue;
             const int o = a_pk[j] & 0xffff;
             As[o] = a_reg[j].re;
             As[32 * LD + o] = a_reg[j].im;
@@ -954,10 +965,10 @@ __global__ __launch_bounds__(256) void pair_mfma_stream_kernel(StepArgs p, MfmaH
     (void)rows_all;
 }
 
-template <int FN, bool VEC, bool ADD>
+template <int FN, bool VEC, bool ADD, bool SHORTK>
 static hipError_t launch_stream_t(const StepArgs& p, const MfmaHints& h, int KP, size_t smem,
                                   hipStream_t stream) {
-    auto kern = pair_mfma_stream_kernel<FN, VEC, ADD>;
+    auto kern = pair_mfma_stream_kernel<FN, VEC, ADD, SHORTK>;
     static int blocks_per_cu[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};  // by KP / 16
     int& bpc = blocks_per_cu[KP / 16];
     if (bpc == 0) {
@@ -986,9 +997,14 @@ static hipError_t launch_stream(const StepArgs& p, const MfmaHints& h, hipStream
     const int LDB = KP + 4;
     const size_t smem = (size_t)2 * 16 * FN * LDB * 4 + (size_t)KP * 8 +
                         (size_t)4 * 2 * 32 * (MFMA_BK + 4) * 4 + (size_t)4 * 64 * 8;
-    if (h.vecA && h.additive32) return launch_stream_t<FN, true, true>(p, h, KP, smem, stream);
-    if (h.additive32) return launch_stream_t<FN, false, true>(p, h, KP, smem, stream);
-    return launch_stream_t<FN, false, false>(p, h, KP, smem, stream);
+    if (p.K < MFMA_BK) {  // short contraction: order table holds only the real columns
+        if (h.vecA && h.additive32) return launch_stream_t<FN, true, true, true>(p, h, KP, smem, stream);
+        if (h.additive32) return launch_stream_t<FN, false, true, true>(p, h, KP, smem, stream);
+        return launch_stream_t<FN, false, false, true>(p, h, KP, smem, stream);
+    }
+    if (h.vecA && h.additive32) return launch_stream_t<FN, true, true, false>(p, h, KP, smem, stream);
+    if (h.additive32) return launch_stream_t<FN, false, true, false>(p, h, KP, smem, stream);
+    return launch_stream_t<FN, false, false, false>(p, h, KP, smem, stream);
 }
 
 hipError_t launch_pair_mfma(int dtype, const StepArgs& p, const MfmaHints& h, void* scratch,

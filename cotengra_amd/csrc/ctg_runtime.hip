@@ -329,14 +329,19 @@ void build_mfma_order(const ctg_plan* p, const int64_t* r, int bn, int BM,
                              : BIG + i;
             }
         std::stable_sort(idx.begin(), idx.end(), [&](int x, int y) { return off[x] < off[y]; });
-        bool vec = (R % BM == 0) && (K % BK == 0);
-        for (int q = 0; vec && q < n_el / 2; ++q) {
+        // streaming kernel with a short contraction (K < 16, one chunk): only the
+        // 32*K real elements are gathered (they sort first), all lanes stay busy
+        const bool short_k = BM == 32 && K < BK;
+        int n_valid = 0;
+        for (int i = 0; i < n_el; ++i) n_valid += off[i] < BIG ? 1 : 0;
+        bool vec = (R % BM == 0) && (short_k ? (K % 4 == 0) : (K % BK == 0));
+        for (int q = 0; vec && q < n_valid / 2; ++q) {
             const int64_t o0 = off[idx[2 * q]], o1 = off[idx[2 * q + 1]];
             if (o1 != o0 + 1 || (o0 & 1)) vec = false;
         }
         // the pairing must hold for every tile / k-step and keep 16-byte alignment
         vec = vec && tile_additive(p, r[W_ROWA_LO], r[W_ROW_LO], R, BM) &&
-              tile_additive(p, r[W_KA], r[W_K_LO], K, BK);
+              (short_k || tile_additive(p, r[W_KA], r[W_K_LO], K, BK));
         vec = vec && all_even(p, r[W_ROWA_HI], r[W_ROW_HI_LEN]) &&
               all_even(p, r[W_ROWA_LO], r[W_ROW_LO], BM) && all_even(p, r[W_KA_HI], r[W_K_HI_LEN]) &&
               all_even(p, r[W_KA], r[W_K_LO], BK) && all_even(p, r[W_BA], r[W_BT]) &&
@@ -349,12 +354,14 @@ void build_mfma_order(const ctg_plan* p, const int64_t* r, int bn, int BM,
         blob.resize(blob.size() + n_el);
         uint16_t* out = blob.data() + *offA;
         auto pack = [&](int i) { return (uint16_t)(((i / BK) << 4) | (i % BK)); };
+        const uint16_t kSkip = 0x8000;  // entry the kernel must not gather (short-K padding)
         for (int tid = 0; tid < T; ++tid) {
             if (vec) {
                 for (int jj = 0; jj < per_t / 2; ++jj) {
                     const int q = jj * T + tid;
-                    out[tid * per_t + 2 * jj] = pack(idx[2 * q]);
-                    out[tid * per_t + 2 * jj + 1] = pack(idx[2 * q + 1]);
+                    const bool live = 2 * q + 1 < n_valid;
+                    out[tid * per_t + 2 * jj] = live ? pack(idx[2 * q]) : kSkip;
+                    out[tid * per_t + 2 * jj + 1] = live ? pack(idx[2 * q + 1]) : kSkip;
                 }
             } else {
                 for (int j = 0; j < per_t; ++j) out[tid * per_t + j] = pack(idx[j * T + tid]);
@@ -913,8 +920,9 @@ int ctg_exec_step_kernel(ctg_exec* e, int64_t step, char* buf, int64_t buflen) {
     } else if (r[W_KERNEL] == KERNEL_MFMA) {
         const MfmaHints& h = e->hints[step];
         if (h.stream)
-            snprintf(name, sizeof(name), "pair_mfma_stream_kernel<%d,%s,%s>", h.bn / 16,
-                     (h.vecA && h.additive32) ? "true" : "false", h.additive32 ? "true" : "false");
+            snprintf(name, sizeof(name), "pair_mfma_stream_kernel<%d,%s,%s,%s>", h.bn / 16,
+                     (h.vecA && h.additive32) ? "true" : "false", h.additive32 ? "true" : "false",
+                     r[W_K] < MFMA_BK ? "true" : "false");
         else
             snprintf(name, sizeof(name), "%s<128,%d,16>,%s",
                      h.fast ? "pair_mfma_fast_kernel" : "pair_mfma_c64_kernel", h.bn,

@@ -33,6 +33,11 @@ CASES = [
     ("abkc,kn->abcn", dict(a=40, b=25, c=10, k=12, n=5)),             # 18: ragged R/K/N (general path)
     ("abcdefghijklmnop,dhlp->abcefgijkmno", {ix: 2 for ix in "abcdefghijklmnop"}),  # 19: bit-permuted
     ("abcdefghijklmnop,pdxhyl->xabcefygijkmno", {ix: 2 for ix in "abcdefghijklmnopxy"}),  # 20
+    # short contractions in the streaming kernel (only the real K columns are gathered)
+    ("abck,kn->abcn", dict(a=32, b=32, c=16, k=8, n=4)),              # 21: K=8
+    ("akbc,kn->abcn", dict(a=32, b=32, c=16, k=4, n=64)),             # 22: K=4, N=64
+    ("abcdefghijklmnop,dhpxy->abcefgijklmnoxy", {ix: 2 for ix in "abcdefghijklmnopxy"}),  # 23: K=8 bits
+    ("abkc,kn->abcn", dict(a=32, b=32, c=16, k=12, n=16)),            # 24: K=12
 ]
 
 
