@@ -27,4 +27,5 @@ from .interface import (  # noqa: F401,E402
     einsum_expression,
     einsum_tree,
     greedy_path,
+    tensordot,
 )

@@ -189,7 +189,6 @@ struct MfmaHints {
     int stream;      // 1: tall-skinny streaming kernel (row tile 32, B resident in LDS)
     int additive32;  // 1: row offsets are tile-additive for 32-row groups
     int fast;        // 1: full tiles + tile-additive 32-bit offsets (tiled fast path)
-    int exp;         // experiment switches (env CTG_EXP, 0 in production)
 };
 
 // steps the streaming kernel takes: short contraction, few columns, many rows

@@ -231,7 +231,7 @@ void resolve_args(ctg_exec* e) {
     const ctg_plan* p = e->plan;
     const int64_t isz = kItemSize[p->dtype];
     e->args.resize(p->n_steps);
-    e->hints.assign(p->n_steps, MfmaHints{nullptr, nullptr, 0, 0, 0, 0, 0, 0});
+    e->hints.assign(p->n_steps, MfmaHints{nullptr, nullptr, 0, 0, 0, 0, 0});
     const int64_t* T = e->d_tables;
     for (int64_t s = 0; s < p->n_steps; ++s) {
         const int64_t* r = &p->steps[s * STEP_WORDS];
@@ -438,7 +438,6 @@ int build_hints(ctg_exec* e) {
         if (r[W_KIND] != KIND_PAIR || r[W_KERNEL] != KERNEL_MFMA) continue;
         MfmaHints& h = e->hints[s];
         h.bn = mfma_pick_bn(r[W_N]);
-        h.exp = getenv("CTG_EXP") ? atoi(getenv("CTG_EXP")) : 0;
         h.stream = mfma_use_stream(r[W_R], r[W_BT], r[W_K], r[W_N]) ? 1 : 0;
         // big square-ish GEMMs: 128x128 tiles (fast path only) halve the LDS
         // traffic and barriers per flop

@@ -170,6 +170,42 @@ def array_contract(arrays, inputs, output, optimize="greedy", **kwargs):
     return expr(*arrays)
 
 
+def tensordot(a, b, axes=2, **kwargs):
+    """Pairwise ``tensordot`` on the MI355X with numpy semantics -- the
+    second callable of the reference's per-op plug-in pair
+    ``implementation=(einsum, tensordot)`` (contract.py:521-570, 775-776):
+    output axes are ``[free-a..., free-b...]``."""
+    nda, ndb = len(a.shape), len(b.shape)
+    try:
+        axes_a, axes_b = tuple(map(int, axes[0])), tuple(map(int, axes[1]))
+    except (TypeError, IndexError):
+        k = int(axes)
+        axes_a, axes_b = tuple(range(nda - k, nda)), tuple(range(k))
+    if len(axes_a) != len(axes_b):
+        raise ValueError(f"Axes should have the same length, got {axes_a} and {axes_b}.")
+    axes_a = tuple(x % nda for x in axes_a)
+    axes_b = tuple(x % ndb for x in axes_b)
+    from .utils import get_symbol
+
+    ia = [get_symbol(i) for i in range(nda)]
+    ib, nxt = [], nda
+    for j in range(ndb):
+        if j in axes_b:
+            x = axes_a[axes_b.index(j)]
+            if a.shape[x] != b.shape[j]:
+                raise ValueError(
+                    f"Dimension mismatch between axes {x} of {tuple(a.shape)} and {j} of "
+                    f"{tuple(b.shape)}: {a.shape[x]} != {b.shape[j]}."
+                )
+            ib.append(ia[x])
+        else:
+            ib.append(get_symbol(nxt))
+            nxt += 1
+    out = [s for i, s in enumerate(ia) if i not in axes_a] + [s for j, s in enumerate(ib) if j not in axes_b]
+    eq = f"{''.join(ia)},{''.join(ib)}->{''.join(out)}"
+    return einsum(eq, a, b, optimize=[(0, 1)], **kwargs)
+
+
 def einsum(eq, *arrays, optimize="greedy", **kwargs):
     """interface.py:1038 -- ``einsum(eq, *arrays)`` on the MI355X."""
     inputs, output = eq_to_inputs_output(eq)

@@ -35,12 +35,11 @@ handed through the C ABI in ``include/ctg_hip.h``.
 
 from __future__ import annotations
 
-import math
 from dataclasses import dataclass, field
 
 import numpy as np
 
-from .utils import eq_to_inputs_output, prod
+from .utils import prod
 
 # ---- constants shared with csrc/ctg_common.h ------------------------------ #
 
@@ -751,16 +750,3 @@ def compile_tree(tree, dtype, order=None, force_kernel=None):
     plan.arena_elems = slice_peak + parena.peak
     plan.inputs_elems = max(cursor, ARENA_ALIGN)
     return plan
-
-
-def compile_pairwise(eq, shape_a, shape_b, dtype, force_kernel=None):
-    """Plan for a single public ``einsum(eq, a, b)`` call (reference
-    contract.py:414-459): a one-step tree over two inputs, including the
-    cases the tree never produces (indices summed from one operand, size-1
-    broadcast dims)."""
-    (ta, tb), out = eq_to_inputs_output(eq)
-    if len(ta) != len(shape_a):
-        raise ValueError(f"Term '{''.join(ta)}' does not match shape {shape_a}.")
-    if len(tb) != len(shape_b):
-        raise ValueError(f"Term '{''.join(tb)}' does not match shape {shape_b}.")
-    return (ta, tb), out

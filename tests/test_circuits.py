@@ -1,0 +1,116 @@
+"""qsim -> amplitude network front end (cotengra_amd/circuits.py) and the
+Sycamore m10 configuration (BASELINE.json configs[2]): network built from the
+reference's qsim gate list, tree + slicing found by the reference's optimizer,
+golden amplitude computed by the reference (tests/golden/gen/make_m10.py)."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import cotengra_amd as ca
+from cotengra_amd.circuits import circuit_to_network, gate_matrix, parse_qsim
+from oracle import contract_ref as orc
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+M10_TREE = os.path.join(HERE, "golden", "trees", "sycamore_m10.json")
+M10_ARRAYS = os.path.join(HERE, "golden", "sycamore_m10_arrays.npz")
+M10_EXPECTED = os.path.join(HERE, "golden", "sycamore_m10_expected.npz")
+
+QSIM = """4
+0 hz_1_2 0
+0 x_1_2 1
+0 y_1_2 2
+0 x_1_2 3
+1 rz 0 0.3
+1 rz 1 -1.1
+1 fs 0 1 1.5157741664069029 0.5567125777723744
+2 y_1_2 0
+2 hz_1_2 1
+2 x_1_2 2
+3 rz 1 2.0
+3 rz 2 0.7
+3 fs 1 2 1.2 -0.4
+3 fs 0 3 0.9 0.2
+4 x_1_2 0
+4 y_1_2 3
+"""
+
+
+def statevector(n, gates):
+    psi = np.zeros([2] * n, complex)
+    psi[(0,) * n] = 1
+    for name, qs, ps in gates:
+        U = gate_matrix(name, ps)
+        if len(qs) == 1:
+            psi = np.moveaxis(np.tensordot(U, psi, axes=([1], [qs[0]])), 0, qs[0])
+        else:
+            psi = np.moveaxis(
+                np.tensordot(U.reshape(2, 2, 2, 2), psi, axes=([2, 3], [qs[0], qs[1]])), [0, 1], list(qs))
+    return psi
+
+
+def test_gates_are_unitary():
+    for name, ps in (("x_1_2", ()), ("y_1_2", ()), ("hz_1_2", ()), ("rz", (0.37,)), ("fs", (1.1, -0.6))):
+        U = gate_matrix(name, ps)
+        assert np.allclose(U @ U.conj().T, np.eye(len(U)))
+    # sqrt gates square to X, Y, W up to a global phase
+    X = np.array([[0, 1], [1, 0]]); Y = np.array([[0, -1j], [1j, 0]])
+    for name, P in (("x_1_2", X), ("y_1_2", Y), ("hz_1_2", (X + Y) / np.sqrt(2))):
+        U2 = gate_matrix(name) @ gate_matrix(name)
+        ph = U2[0, 1] / P[0, 1]
+        assert abs(abs(ph) - 1) < 1e-12 and np.allclose(U2, ph * P)
+
+
+@pytest.mark.parametrize("simplify", [False, True])
+def test_network_amplitudes_match_statevector(simplify):
+    n, gates = parse_qsim(QSIM)
+    assert n == 4 and len(gates) == 16
+    psi = statevector(n, gates)
+    assert abs(np.vdot(psi, psi) - 1) < 1e-12
+    for bits in ("0000", "1010", "0111", "1111"):
+        inputs, output, sd, arrays = circuit_to_network(n, gates, bits, simplify=simplify)
+        if simplify:
+            assert all(len(t) >= 3 for t in inputs) or len(inputs) == 1
+        tree = ca.array_contract_tree(inputs, output, sd)
+        amp = orc.contract(tree, arrays)
+        assert abs(amp - psi[tuple(int(b) for b in bits)]) < 1e-13
+
+
+def m10():
+    rec = ca.load_network(M10_TREE)
+    tree = ca.tree_from_record(rec)
+    z = np.load(M10_ARRAYS)
+    arrays = [z[f"t{i}"] for i in range(tree.N)]
+    return rec, tree, arrays, np.load(M10_EXPECTED)
+
+
+needs_m10 = pytest.mark.skipif(not os.path.exists(M10_EXPECTED), reason="m10 fixture not generated")
+
+
+@needs_m10
+def test_m10_fixture_oracle_slices():
+    rec, tree, arrays, exp = m10()
+    assert tree.N == 170 and tree.nslices >= 64 and rec["stats"]["nslices"] == tree.nslices
+    assert sorted(len(t) for t in tree.inputs)[0] >= 3
+    got = orc.contract_slice(tree, arrays, 1)
+    assert abs(got - exp["slice1"]) <= 1e-12 * abs(exp["slice1"])
+
+
+@needs_m10
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", ["complex128", "complex64"])
+def test_m10_full_amplitude_on_gpu(dtype):
+    """All slices of the m10 amplitude on the device vs the reference's full
+    CPU contraction (the north-star gate: 1e-5 relative, both precisions)."""
+    rec, tree, arrays, exp = m10()
+    xs = [a.astype(dtype) for a in arrays]
+    amp = complex(np.asarray(tree.contract(xs)))
+    ref = complex(exp["amplitude"])
+    assert abs(amp - ref) <= (1e-10 if dtype == "complex128" else 1e-5) * abs(ref)
+    for key in exp.files:
+        if key.startswith("slice"):
+            i = int(key[5:])
+            got = complex(np.asarray(tree.contract_slice(xs, i)))
+            tol = 1e-10 if dtype == "complex128" else 2e-4
+            assert abs(got - complex(exp[key])) <= tol * abs(exp[key])

@@ -66,3 +66,19 @@ def test_pairwise(case, dtype):
     if dtype in ("complex64", "float32") and case in (4, 5, 6):
         tol = 3e-4
     assert np.abs(np.asarray(got) - ref).max() <= tol * scale
+
+
+def test_tensordot_numpy_semantics():
+    from cotengra_amd.interface import tensordot
+
+    rng = np.random.default_rng(3)
+    a = rng.normal(size=(4, 2, 3)) + 1j * rng.normal(size=(4, 2, 3))
+    b = rng.normal(size=(3, 4, 5)) + 1j * rng.normal(size=(3, 4, 5))
+    for axes in (((0, 2), (1, 0)), ((2,), (0,)), 0, ((-1,), (0,))):
+        got = np.asarray(tensordot(a, b, axes))
+        ref = np.tensordot(a, b, axes)
+        assert got.shape == ref.shape and np.abs(got - ref).max() < 1e-12 * np.abs(ref).max()
+    c = rng.normal(size=(3, 5, 4))
+    assert np.allclose(np.asarray(tensordot(a.real, c, 1)), np.tensordot(a.real, c, 1))
+    with pytest.raises(ValueError):
+        tensordot(a, b, ((0,), (0,)))
