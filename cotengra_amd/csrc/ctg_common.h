@@ -217,6 +217,8 @@ hipError_t launch_pair_valu(int dtype, const StepArgs& p, void* scratch, int64_t
                             hipStream_t stream);
 hipError_t launch_pair_mfma(int dtype, const StepArgs& p, const MfmaHints& h, void* scratch,
                             int64_t scratch_bytes, hipStream_t stream);
+// complex128 on the FP64 matrix cores (ctg_pair_mfma_f64.hip)
+hipError_t launch_pair_mfma_c128(const StepArgs& p, int flags, hipStream_t stream);
 hipError_t launch_single(int dtype, const StepArgs& p, hipStream_t stream);
 hipError_t launch_accum(int dtype, const StepArgs& p, const StripState* st, hipStream_t stream);
 

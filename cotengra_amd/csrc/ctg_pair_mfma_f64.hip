@@ -1,0 +1,221 @@
+// ctg_pair_mfma_f64.hip -- complex128 gather-GEMM on the gfx950 FP64 matrix cores
+// (v_mfma_f64_16x16x4_f64, 78.6 TFLOP/s peak): the double-precision parity mode
+// of the contraction path (the reference's tests run every case in complex128 /
+// float64 as well, tests/test_compute.py:102-115).
+//
+//   C[bC(b) + rowC(m) + nC(n)] = sum_k A[bA(b) + rowA(m) + kA(k)] * B[bB(b) + kB(k) + nB(n)]
+//
+// Same formulation as the complex64 kernel: one MFMA consumes 4 real k = 2
+// complex k with A' = (Re, Im) pairs along k and B' = [[Re, Im], [-Im, Re]]
+// interleaved along the 16 real columns (8 complex columns), so no flop is
+// wasted and D is interleaved complex.  Block tile 64 x 32 complex, 8 complex
+// k per step, 4 waves as 2 x 2 (wave tile 32 x 16 = 2 x 2 MFMA tiles),
+// register-staged double buffering, bounds masks everywhere (general shapes),
+// row offsets and the k offsets of the next steps resolved into LDS.
+#include "ctg_common.h"
+
+namespace ctg {
+
+typedef double f64x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+constexpr int BM = 64, BN = 32, BK = 8, LD = BK + 1;
+constexpr int A_DBL = 2 * BM * LD, B_DBL = 2 * BN * LD;
+}  // namespace
+
+__global__ __launch_bounds__(256, 2) void pair_mfma_c128_kernel(StepArgs p, int flags,
+                                                               int64_t tiles_m, int64_t tiles_n) {
+    __shared__ double lds[2 * (A_DBL + B_DBL)];
+    __shared__ int64_t rowA_s[BM];
+    __shared__ int64_t rowC_s[BM];
+    __shared__ int64_t kofs_s[3][2][BK];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+
+    // XCD-aware: consecutive row tiles on different XCDs, column tiles of a row
+    // tile on the same one (they share the A panel through that XCD's L2)
+    const int64_t bid = blockIdx.x;
+    const int64_t xcd = bid & 7, q = bid >> 3;
+    const int64_t tm = (q / tiles_n) * 8 + xcd;
+    const int64_t tn = q % tiles_n;
+    if (tm >= tiles_m) return;
+    const int64_t m0 = tm * BM, n0 = tn * BN;
+    const int64_t bz = blockIdx.z;
+
+    const c128* __restrict__ A = (const c128*)p.A + *p.soffA + p.bA[bz];
+    const c128* __restrict__ B = (const c128*)p.B + *p.soffB + p.bB[bz];
+    double* __restrict__ C = (double*)((c128*)p.C + *p.soffC + p.bC[bz]);
+    const bool a_kfast = flags & 1, b_kfast = flags & 2;
+    const int64_t nk = (p.K + BK - 1) / BK;
+
+    if (tid < BM) {
+        const int64_t m = m0 + tid;
+        int64_t oa = -1, oc = -1;
+        if (m < p.R) {
+            int64_t hi, lo;
+            split_row(p, m, hi, lo);
+            oa = p.rowA.hi[hi] + p.rowA.lo[lo];
+            oc = p.rowC.hi[hi] + p.rowC.lo[lo];
+        }
+        rowA_s[tid] = oa;
+        rowC_s[tid] = oc;
+    }
+    int64_t kofs_val = -1;
+    auto kofs_fetch = [&](int64_t step) {  // threads tid < 2*BK
+        const int which = tid / BK, c = tid % BK;
+        const int64_t k = step * BK + c;
+        int64_t off = -1;
+        if (k < p.K) {
+            int64_t kh, kl;
+            split_k(p, k, kh, kl);
+            off = which ? p.kB.hi[kh] + p.kB.lo[kl] : p.kA.hi[kh] + p.kA.lo[kl];
+        }
+        kofs_val = off;
+    };
+    auto kofs_commit = [&](int64_t step) { kofs_s[step % 3][tid / BK][tid % BK] = kofs_val; };
+    if (tid < 2 * BK) {
+        for (int s = 0; s < 3 && s < nk; ++s) {
+            kofs_fetch(s);
+            kofs_commit(s);
+        }
+    }
+
+    // ---- gather coordinates: 2 A elements + 1 B element per thread per step ----
+    int a_r[2], a_c[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int e = j * 256 + tid;
+        if (a_kfast) {
+            a_r[j] = e / BK;
+            a_c[j] = e % BK;
+        } else {
+            a_r[j] = e % BM;
+            a_c[j] = e / BM;
+        }
+    }
+    int b_k, b_n;
+    if (b_kfast) {
+        b_k = tid % BK;
+        b_n = tid / BK;
+    } else {
+        b_k = tid / BN;
+        b_n = tid % BN;
+    }
+    const int64_t b_col = (n0 + b_n < p.N) ? p.nB[n0 + b_n] : -1;
+    __syncthreads();
+    int64_t a_row[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) a_row[j] = rowA_s[a_r[j]];
+
+    c128 a_reg[2], b_reg;
+    auto gather = [&](int64_t step) {
+        const int64_t* ka = kofs_s[step % 3][0];
+        const int64_t* kb = kofs_s[step % 3][1];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int64_t ko = ka[a_c[j]];
+            c128 v{0.0, 0.0};
+            if (a_row[j] >= 0 && ko >= 0) v = A[a_row[j] + ko];
+            a_reg[j] = v;
+        }
+        const int64_t ko = kb[b_k];
+        c128 v{0.0, 0.0};
+        if (b_col >= 0 && ko >= 0) v = B[b_col + ko];
+        b_reg = v;
+    };
+    auto stage = [&](int buf) {
+        double* As = lds + buf * (A_DBL + B_DBL);
+        double* Bs = As + A_DBL;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            As[a_r[j] * LD + a_c[j]] = a_reg[j].re;
+            As[BM * LD + a_r[j] * LD + a_c[j]] = a_reg[j].im;
+        }
+        Bs[(2 * b_n) * LD + b_k] = b_reg.re;
+        Bs[(2 * b_n + 1) * LD + b_k] = b_reg.im;
+    };
+
+    f64x4 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) acc[i][j][t] = 0.0;
+
+    // fragment coordinates of v_mfma_f64_16x16x4_f64: lane -> (i16, k4)
+    const int i16 = lane & 15, k4 = lane >> 4;
+    const int part = k4 & 1;       // 0: Re a / first B' row of the pair, 1: Im a / second
+    const int kc_in = k4 >> 1;     // which of the MFMA's two complex k
+    const int cc = i16 & 1;        // B'/D column parity: 0 = real part, 1 = imaginary part
+    const bool negate = part == 1 && cc == 0;
+
+    gather(0);
+    stage(0);
+    if (nk > 1) gather(1);
+    __syncthreads();
+
+    for (int64_t kt = 0; kt < nk; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < nk) stage(buf ^ 1);
+        const bool kofs_mine = kt + 3 < nk && tid < 2 * BK;
+        if (kofs_mine) kofs_fetch(kt + 3);
+        if (kt + 2 < nk) gather(kt + 2);
+
+        const double* As = lds + buf * (A_DBL + B_DBL);
+        const double* Bs = As + A_DBL;
+        const double* a_base = As + part * BM * LD + (wm * 32 + i16) * LD + kc_in;
+        const double* b_base = Bs + (2 * (wn * 16 + (i16 >> 1)) + (cc ^ part)) * LD + kc_in;
+#pragma unroll
+        for (int kq = 0; kq < BK / 2; ++kq) {
+            double af[2], bf[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) af[i] = a_base[i * 16 * LD + 2 * kq];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const double v = b_base[j * 16 * LD + 2 * kq];
+                bf[j] = negate ? -v : v;
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[i], bf[j], acc[i][j], 0, 0, 0);
+        }
+        if (kofs_mine) kofs_commit(kt + 3);
+        __syncthreads();
+    }
+
+    // D: col = lane & 15 (complex column = col >> 1, part = col & 1), row = (lane >> 4) + 4 * reg
+    const double alpha = step_alpha(p);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int64_t n = n0 + wn * 16 + j * 8 + (i16 >> 1);
+        if (n >= p.N) continue;
+        const int64_t ncol = p.nC[n];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int row = wm * 32 + i * 16 + k4 + 4 * t;
+                const int64_t ro = rowC_s[row];
+                if (ro >= 0) C[2 * (ro + ncol) + cc] = acc[i][j][t] * alpha;
+            }
+    }
+}
+
+// flags: bit0 = A's fastest-varying memory index is a contracted one, bit1 = same for B
+hipError_t launch_pair_mfma_c128(const StepArgs& p, int flags, hipStream_t stream) {
+    const int64_t tiles_m = (p.R + BM - 1) / BM;
+    const int64_t tiles_n = (p.N + BN - 1) / BN;
+    const int64_t gx = ((tiles_m + 7) / 8) * 8 * tiles_n;
+    if (gx > 0x7fffffffll || p.Bt > 65535) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(pair_mfma_c128_kernel, dim3((unsigned)gx, 1, (unsigned)p.Bt), dim3(256), 0, stream,
+                       p, flags, tiles_m, tiles_n);
+    return hipGetLastError();
+}
+
+}  // namespace ctg

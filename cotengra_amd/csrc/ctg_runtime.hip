@@ -162,8 +162,9 @@ int validate_plan(ctg_plan* p) {
         if (kind < 0 || kind > 2) return fail(CTG_E_INVALID, "step %lld: bad kind", (long long)s);
         if (r[W_KERNEL] < 0 || r[W_KERNEL] > 1)
             return fail(CTG_E_INVALID, "step %lld: bad kernel", (long long)s);
-        if (r[W_KERNEL] == KERNEL_MFMA && (kind != KIND_PAIR || p->dtype != CTG_C64))
-            return fail(CTG_E_INVALID, "step %lld: MFMA kernel needs a complex64 pair step",
+        if (r[W_KERNEL] == KERNEL_MFMA &&
+            (kind != KIND_PAIR || (p->dtype != CTG_C64 && p->dtype != CTG_C128)))
+            return fail(CTG_E_INVALID, "step %lld: MFMA kernel needs a complex64/complex128 pair step",
                         (long long)s);
         const int64_t R = r[W_R], Bt = r[W_BT], K = r[W_K], N = r[W_N];
         const int64_t row_lo = r[W_ROW_LO], row_hi = r[W_ROW_HI_LEN];
@@ -437,6 +438,19 @@ int build_hints(ctg_exec* e) {
         const int64_t* r = &p->steps[s * STEP_WORDS];
         if (r[W_KIND] != KIND_PAIR || r[W_KERNEL] != KERNEL_MFMA) continue;
         MfmaHints& h = e->hints[s];
+        if (p->dtype == CTG_C128) {
+            // FP64 kernel: only needs to know which group holds each operand's
+            // fastest-varying memory index (kept in h.vecA: bit0 A, bit1 B)
+            auto stride1 = [&](int w, int64_t len) -> int64_t {
+                if (len < 2 || r[w] < 0) return INT64_MAX;
+                const int64_t v = p->tables[r[w] + 1] - p->tables[r[w]];
+                return v < 0 ? -v : (v == 0 ? INT64_MAX : v);
+            };
+            const int64_t ak = stride1(W_KA, r[W_K_LO]), am = stride1(W_ROWA_LO, r[W_ROW_LO]);
+            const int64_t bk = stride1(W_KB, r[W_K_LO]), bnn = stride1(W_NB, r[W_N]);
+            h.vecA = (ak < am ? 1 : 0) | (bk < bnn ? 2 : 0);
+            continue;
+        }
         h.bn = mfma_pick_bn(r[W_N]);
         h.stream = mfma_use_stream(r[W_R], r[W_BT], r[W_K], r[W_N]) ? 1 : 0;
         // big square-ish GEMMs: 128x128 tiles (fast path only) halve the LDS
@@ -485,7 +499,9 @@ int launch_step(ctg_exec* e, int64_t s, hipStream_t stream) {
             }
             break;
         case KIND_PAIR:
-            if (r[W_KERNEL] == KERNEL_MFMA)
+            if (r[W_KERNEL] == KERNEL_MFMA && p->dtype == CTG_C128)
+                err = launch_pair_mfma_c128(e->args[s], e->hints[s].vecA /* = stride flags */, stream);
+            else if (r[W_KERNEL] == KERNEL_MFMA)
                 err = launch_pair_mfma(p->dtype, e->args[s], e->hints[s], e->d_scratch, kScratchBytes,
                                        stream);
             else
@@ -916,6 +932,8 @@ int ctg_exec_step_kernel(ctg_exec* e, int64_t step, char* buf, int64_t buflen) {
         snprintf(name, sizeof(name), "single_kernel");
     } else if (r[W_KIND] == KIND_ACCUM) {
         snprintf(name, sizeof(name), "accum_kernel");
+    } else if (r[W_KERNEL] == KERNEL_MFMA && p->dtype == CTG_C128) {
+        snprintf(name, sizeof(name), "pair_mfma_c128_kernel");
     } else if (r[W_KERNEL] == KERNEL_MFMA) {
         const MfmaHints& h = e->hints[step];
         if (h.stream)

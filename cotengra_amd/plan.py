@@ -51,7 +51,7 @@ KIND_PAIR = 1  # gather-GEMM, see module docstring
 KIND_ACCUM = 2  # result[chunk + offR(o)] += src[o]
 
 KERNEL_VALU = 0  # one thread per output element, any dtype / any shape
-KERNEL_MFMA = 1  # LDS-tiled fp32-MFMA kernel (complex64 / float32)
+KERNEL_MFMA = 1  # matrix-core kernels (complex64 on fp32 MFMA, complex128 on fp64 MFMA)
 
 SPACE_INPUTS = 0
 SPACE_ARENA = 1
@@ -381,9 +381,15 @@ def choose_kernel(dtype, Bt, M, K, N):
     """MFMA for complex64/float32 steps big enough to fill tiles; the VALU
     kernel for everything else (tiny leaves, outer products, Hadamards,
     skinny memory-bound steps, and the float64/complex128 parity mode)."""
-    if dtype != "complex64":
+    if dtype not in ("complex64", "complex128"):
         return KERNEL_VALU
     if Bt > MFMA_MAX_BATCH:
+        return KERNEL_VALU
+    if dtype == "complex128":
+        # FP64 matrix cores (csrc/ctg_pair_mfma_f64.hip): tiled kernel without
+        # split-K, so the output must be able to fill the chip on its own
+        if K >= 4 and N >= 8 and M >= 64 and M * N >= (1 << 16):
+            return KERNEL_MFMA
         return KERNEL_VALU
     if K >= 4 and N >= 8 and M >= 32 and (M * N * K) >= (1 << 15):
         return KERNEL_MFMA

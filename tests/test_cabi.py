@@ -76,7 +76,7 @@ def test_plan_rejects_bad_descriptor():
         runtime.DevicePlan(plan)
 
 
-def test_mfma_kernel_only_for_complex64():
+def test_mfma_kernel_only_for_complex_dtypes():
     tree = small_tree(sliced=False)
     plan = compile_tree(tree, "float64", force_kernel=1)
     with pytest.raises(ValueError):

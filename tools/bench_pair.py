@@ -17,11 +17,12 @@ def main():
     eq = sys.argv[1]
     sizes = {kv.split("=")[0]: int(kv.split("=")[1]) for kv in sys.argv[2].split(",")}
     reps = int(sys.argv[3]) if len(sys.argv) > 3 else 5
-    force = int(sys.argv[4]) if len(sys.argv) > 4 else None
+    force = int(sys.argv[4]) if len(sys.argv) > 4 and sys.argv[4] != "-" else None
+    dtype = sys.argv[5] if len(sys.argv) > 5 else "complex64"
     (ta, tb), out = ca.eq_to_inputs_output(eq)
     tree = ca.ContractionTree.from_path([ta, tb], out, sizes, path=[(0, 1)])
     rng = np.random.default_rng(0)
-    arrays = [(rng.normal(size=[sizes[i] for i in t]) + 1j * rng.normal(size=[sizes[i] for i in t])).astype("complex64") for t in (ta, tb)]
+    arrays = [(rng.normal(size=[sizes[i] for i in t]) + 1j * rng.normal(size=[sizes[i] for i in t])).astype(dtype) for t in (ta, tb)]
     fn = HipContractor(tree, force_kernel=force)
     st = fn.setup(*arrays)
     plan, ex = st["plan"], st["exec"]
@@ -32,7 +33,7 @@ def main():
     for r, m in zip(plan.describe_steps(), best):
         if r["kind"] == "pair":
             print(f"{eq} {sizes}: kernel={r['kernel']} R={r['R']} K={r['K']} N={r['N']} "
-                  f"ms={m:.4f} TF={8*r['macs']/m/1e9:.2f} GB/s={r['bytes']/m/1e6:.0f}")
+                  f"ms={m:.4f} TF={(8 if 'complex' in dtype else 2)*r['macs']/m/1e9:.2f} GB/s={r['bytes']/m/1e6:.0f}")
     fn.close()
 
 
