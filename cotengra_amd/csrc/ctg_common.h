@@ -219,6 +219,8 @@ hipError_t launch_pair_mfma(int dtype, const StepArgs& p, const MfmaHints& h, vo
                             int64_t scratch_bytes, hipStream_t stream);
 // complex128 on the FP64 matrix cores (ctg_pair_mfma_f64.hip)
 hipError_t launch_pair_mfma_c128(const StepArgs& p, int flags, hipStream_t stream);
+// float32 / float64 on the 16x16x4 matrix-core instructions
+hipError_t launch_pair_mfma_real(int dtype, const StepArgs& p, int flags, hipStream_t stream);
 hipError_t launch_single(int dtype, const StepArgs& p, hipStream_t stream);
 hipError_t launch_accum(int dtype, const StepArgs& p, const StripState* st, hipStream_t stream);
 

@@ -219,3 +219,222 @@ hipError_t launch_pair_mfma_c128(const StepArgs& p, int flags, hipStream_t strea
 }
 
 }  // namespace ctg
+
+// ------------------------------------------------------------------------- //
+// Real-valued steps (float32 / float64) on the matrix cores: both dtypes have
+// a 16x16x4 MFMA with the same A/B fragment layout (A[i = l & 15][k = l >> 4],
+// B[k = l >> 4][j = l & 15]); only the D layout differs (f32: row = 4*(l>>4)
+// + reg, f64: row = (l>>4) + 4*reg).  Block tile 64 x 64, 16 k per step,
+// 2 x 2 waves with 2 x 2 MFMA tiles each; the reference's `benchmark()`
+// defaults to float64 (core.py:4094).
+// ------------------------------------------------------------------------- //
+
+namespace ctg {
+
+typedef float f32x4r __attribute__((ext_vector_type(4)));
+
+namespace {
+constexpr int RBM = 64, RBN = 64, RBK = 16, RLD = RBK + 1;
+
+__device__ __forceinline__ f32x4r mfma16(float a, float b, f32x4r c) {
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ f64x4 mfma16(double a, double b, f64x4 c) {
+    return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
+}
+template <typename T> struct Vec4;
+template <> struct Vec4<float> { typedef f32x4r type; };
+template <> struct Vec4<double> { typedef f64x4 type; };
+// row of accumulator register t inside a 16x16 tile
+__device__ __forceinline__ int d_row(float, int k4, int t) { return 4 * k4 + t; }
+__device__ __forceinline__ int d_row(double, int k4, int t) { return k4 + 4 * t; }
+}  // namespace
+
+template <typename T>
+__global__ __launch_bounds__(256, 2) void pair_mfma_real_kernel(StepArgs p, int flags, int64_t tiles_m,
+                                                               int64_t tiles_n) {
+    typedef typename Vec4<T>::type V4;
+    __shared__ T lds[2 * (RBM + RBN) * RLD];
+    __shared__ int64_t rowA_s[RBM];
+    __shared__ int64_t rowC_s[RBM];
+    __shared__ int64_t kofs_s[3][2][RBK];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int64_t bid = blockIdx.x;
+    const int64_t xcd = bid & 7, q = bid >> 3;
+    const int64_t tm = (q / tiles_n) * 8 + xcd;
+    const int64_t tn = q % tiles_n;
+    if (tm >= tiles_m) return;
+    const int64_t m0 = tm * RBM, n0 = tn * RBN;
+    const int64_t bz = blockIdx.z;
+
+    const T* __restrict__ A = (const T*)p.A + *p.soffA + p.bA[bz];
+    const T* __restrict__ B = (const T*)p.B + *p.soffB + p.bB[bz];
+    T* __restrict__ C = (T*)p.C + *p.soffC + p.bC[bz];
+    const bool a_kfast = flags & 1, b_kfast = flags & 2;
+    const int64_t nk = (p.K + RBK - 1) / RBK;
+
+    if (tid < RBM) {
+        const int64_t m = m0 + tid;
+        int64_t oa = -1, oc = -1;
+        if (m < p.R) {
+            int64_t hi, lo;
+            split_row(p, m, hi, lo);
+            oa = p.rowA.hi[hi] + p.rowA.lo[lo];
+            oc = p.rowC.hi[hi] + p.rowC.lo[lo];
+        }
+        rowA_s[tid] = oa;
+        rowC_s[tid] = oc;
+    }
+    int64_t kofs_val = -1;
+    auto kofs_fetch = [&](int64_t step) {  // threads tid < 2*RBK
+        const int which = tid / RBK, c = tid % RBK;
+        const int64_t k = step * RBK + c;
+        int64_t off = -1;
+        if (k < p.K) {
+            int64_t kh, kl;
+            split_k(p, k, kh, kl);
+            off = which ? p.kB.hi[kh] + p.kB.lo[kl] : p.kA.hi[kh] + p.kA.lo[kl];
+        }
+        kofs_val = off;
+    };
+    auto kofs_commit = [&](int64_t step) { kofs_s[step % 3][tid / RBK][tid % RBK] = kofs_val; };
+    if (tid < 2 * RBK) {
+        for (int s = 0; s < 3 && s < nk; ++s) {
+            kofs_fetch(s);
+            kofs_commit(s);
+        }
+    }
+
+    int a_r[4], a_c[4], b_k[4], b_n[4];
+    int64_t b_col[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int e = j * 256 + tid;
+        if (a_kfast) {
+            a_r[j] = e / RBK;
+            a_c[j] = e % RBK;
+        } else {
+            a_r[j] = e % RBM;
+            a_c[j] = e / RBM;
+        }
+        if (b_kfast) {
+            b_k[j] = e % RBK;
+            b_n[j] = e / RBK;
+        } else {
+            b_k[j] = e / RBN;
+            b_n[j] = e % RBN;
+        }
+        b_col[j] = (n0 + b_n[j] < p.N) ? p.nB[n0 + b_n[j]] : -1;
+    }
+    __syncthreads();
+    int64_t a_row[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) a_row[j] = rowA_s[a_r[j]];
+
+    T a_reg[4], b_reg[4];
+    auto gather = [&](int64_t step) {
+        const int64_t* ka = kofs_s[step % 3][0];
+        const int64_t* kb = kofs_s[step % 3][1];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int64_t ko = ka[a_c[j]];
+            T v = 0;
+            if (a_row[j] >= 0 && ko >= 0) v = A[a_row[j] + ko];
+            a_reg[j] = v;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int64_t ko = kb[b_k[j]];
+            T v = 0;
+            if (b_col[j] >= 0 && ko >= 0) v = B[b_col[j] + ko];
+            b_reg[j] = v;
+        }
+    };
+    auto stage = [&](int buf) {
+        T* As = lds + buf * (RBM + RBN) * RLD;
+        T* Bs = As + RBM * RLD;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            As[a_r[j] * RLD + a_c[j]] = a_reg[j];
+            Bs[b_n[j] * RLD + b_k[j]] = b_reg[j];
+        }
+    };
+
+    V4 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) acc[i][j][t] = 0;
+
+    const int i16 = lane & 15, k4 = lane >> 4;
+
+    gather(0);
+    stage(0);
+    if (nk > 1) gather(1);
+    __syncthreads();
+
+    for (int64_t kt = 0; kt < nk; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < nk) stage(buf ^ 1);
+        const bool kofs_mine = kt + 3 < nk && tid < 2 * RBK;
+        if (kofs_mine) kofs_fetch(kt + 3);
+        if (kt + 2 < nk) gather(kt + 2);
+
+        const T* As = lds + buf * (RBM + RBN) * RLD;
+        const T* Bs = As + RBM * RLD;
+        const T* a_base = As + (wm * 32 + i16) * RLD + k4;
+        const T* b_base = Bs + (wn * 32 + i16) * RLD + k4;
+#pragma unroll
+        for (int kq = 0; kq < RBK / 4; ++kq) {
+            T af[2], bf[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) af[i] = a_base[i * 16 * RLD + 4 * kq];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) bf[j] = b_base[j * 16 * RLD + 4 * kq];
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = mfma16(af[i], bf[j], acc[i][j]);
+        }
+        if (kofs_mine) kofs_commit(kt + 3);
+        __syncthreads();
+    }
+
+    const T alpha = (T)step_alpha(p);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int64_t n = n0 + wn * 32 + j * 16 + i16;
+        if (n >= p.N) continue;
+        const int64_t ncol = p.nC[n];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int64_t ro = rowC_s[wm * 32 + i * 16 + d_row(T(0), k4, t)];
+                if (ro >= 0) C[ro + ncol] = acc[i][j][t] * alpha;
+            }
+    }
+}
+
+hipError_t launch_pair_mfma_real(int dtype, const StepArgs& p, int flags, hipStream_t stream) {
+    const int64_t tiles_m = (p.R + RBM - 1) / RBM;
+    const int64_t tiles_n = (p.N + RBN - 1) / RBN;
+    const int64_t gx = ((tiles_m + 7) / 8) * 8 * tiles_n;
+    if (gx > 0x7fffffffll || p.Bt > 65535) return hipErrorInvalidValue;
+    const dim3 grid((unsigned)gx, 1, (unsigned)p.Bt);
+    if (dtype == 0)
+        hipLaunchKernelGGL(pair_mfma_real_kernel<float>, grid, dim3(256), 0, stream, p, flags, tiles_m, tiles_n);
+    else if (dtype == 1)
+        hipLaunchKernelGGL(pair_mfma_real_kernel<double>, grid, dim3(256), 0, stream, p, flags, tiles_m, tiles_n);
+    else
+        return hipErrorInvalidValue;
+    return hipGetLastError();
+}
+
+}  // namespace ctg

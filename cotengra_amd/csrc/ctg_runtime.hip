@@ -162,9 +162,8 @@ int validate_plan(ctg_plan* p) {
         if (kind < 0 || kind > 2) return fail(CTG_E_INVALID, "step %lld: bad kind", (long long)s);
         if (r[W_KERNEL] < 0 || r[W_KERNEL] > 1)
             return fail(CTG_E_INVALID, "step %lld: bad kernel", (long long)s);
-        if (r[W_KERNEL] == KERNEL_MFMA &&
-            (kind != KIND_PAIR || (p->dtype != CTG_C64 && p->dtype != CTG_C128)))
-            return fail(CTG_E_INVALID, "step %lld: MFMA kernel needs a complex64/complex128 pair step",
+        if (r[W_KERNEL] == KERNEL_MFMA && kind != KIND_PAIR)
+            return fail(CTG_E_INVALID, "step %lld: the matrix-core kernels execute pair steps only",
                         (long long)s);
         const int64_t R = r[W_R], Bt = r[W_BT], K = r[W_K], N = r[W_N];
         const int64_t row_lo = r[W_ROW_LO], row_hi = r[W_ROW_HI_LEN];
@@ -438,8 +437,8 @@ int build_hints(ctg_exec* e) {
         const int64_t* r = &p->steps[s * STEP_WORDS];
         if (r[W_KIND] != KIND_PAIR || r[W_KERNEL] != KERNEL_MFMA) continue;
         MfmaHints& h = e->hints[s];
-        if (p->dtype == CTG_C128) {
-            // FP64 kernel: only needs to know which group holds each operand's
+        if (p->dtype != CTG_C64) {
+            // FP64 / real kernels: only need to know which group holds each operand's
             // fastest-varying memory index (kept in h.vecA: bit0 A, bit1 B)
             auto stride1 = [&](int w, int64_t len) -> int64_t {
                 if (len < 2 || r[w] < 0) return INT64_MAX;
@@ -501,6 +500,8 @@ int launch_step(ctg_exec* e, int64_t s, hipStream_t stream) {
         case KIND_PAIR:
             if (r[W_KERNEL] == KERNEL_MFMA && p->dtype == CTG_C128)
                 err = launch_pair_mfma_c128(e->args[s], e->hints[s].vecA /* = stride flags */, stream);
+            else if (r[W_KERNEL] == KERNEL_MFMA && p->dtype != CTG_C64)
+                err = launch_pair_mfma_real(p->dtype, e->args[s], e->hints[s].vecA, stream);
             else if (r[W_KERNEL] == KERNEL_MFMA)
                 err = launch_pair_mfma(p->dtype, e->args[s], e->hints[s], e->d_scratch, kScratchBytes,
                                        stream);
@@ -934,6 +935,8 @@ int ctg_exec_step_kernel(ctg_exec* e, int64_t step, char* buf, int64_t buflen) {
         snprintf(name, sizeof(name), "accum_kernel");
     } else if (r[W_KERNEL] == KERNEL_MFMA && p->dtype == CTG_C128) {
         snprintf(name, sizeof(name), "pair_mfma_c128_kernel");
+    } else if (r[W_KERNEL] == KERNEL_MFMA && p->dtype != CTG_C64) {
+        snprintf(name, sizeof(name), "pair_mfma_real_kernel<%s>", p->dtype == CTG_F32 ? "float" : "double");
     } else if (r[W_KERNEL] == KERNEL_MFMA) {
         const MfmaHints& h = e->hints[step];
         if (h.stream)

@@ -381,13 +381,12 @@ def choose_kernel(dtype, Bt, M, K, N):
     """MFMA for complex64/float32 steps big enough to fill tiles; the VALU
     kernel for everything else (tiny leaves, outer products, Hadamards,
     skinny memory-bound steps, and the float64/complex128 parity mode)."""
-    if dtype not in ("complex64", "complex128"):
-        return KERNEL_VALU
     if Bt > MFMA_MAX_BATCH:
         return KERNEL_VALU
-    if dtype == "complex128":
-        # FP64 matrix cores (csrc/ctg_pair_mfma_f64.hip): tiled kernel without
-        # split-K, so the output must be able to fill the chip on its own
+    if dtype != "complex64":
+        # complex128 / float64 / float32 (csrc/ctg_pair_mfma_f64.hip): tiled
+        # 16x16x4-MFMA kernels without split-K, so the output must be able to
+        # fill the chip on its own
         if K >= 4 and N >= 8 and M >= 64 and M * N >= (1 << 16):
             return KERNEL_MFMA
         return KERNEL_VALU

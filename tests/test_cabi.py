@@ -76,9 +76,10 @@ def test_plan_rejects_bad_descriptor():
         runtime.DevicePlan(plan)
 
 
-def test_mfma_kernel_only_for_complex_dtypes():
-    tree = small_tree(sliced=False)
-    plan = compile_tree(tree, "float64", force_kernel=1)
+def test_matrix_core_kernel_only_for_pair_steps():
+    tree = ca.ContractionTree(["aab"], "b", dict(a=3, b=4))
+    plan = compile_tree(tree, "float64")
+    plan.steps[0].kernel = 1  # a SINGLE step cannot run on the MFMA kernels
     with pytest.raises(ValueError):
         runtime.DevicePlan(plan)
 
