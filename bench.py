@@ -145,6 +145,21 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
+    # precision of the complex64 path: one slice of the same tree narrowed to a
+    # CPU-sized width, device complex64 vs the numpy oracle in complex128
+    precision = None
+    if rank == 0 and not args.no_cpu_baseline:
+        from oracle import contract_ref as orc
+
+        small = shrink_for_cpu(tree, 20)
+        got = complex(np.asarray(small.contract_slice(arrays, 3)))
+        ref = complex(orc.contract_slice(small, [a.astype("complex128") for a in arrays], 3))
+        precision = {
+            "check": "slice 3 of the tree narrowed to width 2^20: HIP complex64 vs numpy complex128",
+            "rel_err": abs(got - ref) / abs(ref),
+            "gate": 1e-5,
+        }
+
     flops_slice = plan.flops_per_slice()
     total_slices = args.steps * world
     value = flops_slice * total_slices / dt
@@ -239,6 +254,7 @@ def main():
                 else None,
             },
             "roofline": roofline,
+            "precision": precision,
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(tree, arrays)

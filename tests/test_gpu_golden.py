@@ -172,3 +172,38 @@ def test_full_size_properties_m20():
     parts = sum(np.asarray(fc.contract_slice(arrays, i)) for i in ids)
     fc.close()
     assert abs(parts - full) <= 2e-4 * abs(full)
+
+
+def test_contract_distributed_rccl_single_rank():
+    """The slice-parallel driver on the GPU with the RCCL backend (one rank --
+    the box has one GPU; ranks > 1 are covered by the gloo CPU test)."""
+    import socket
+
+    import torch
+    import torch.distributed as dist
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    case = next(c for c in TREE_CASES if c["name"] == "lattice8x8_sliced")
+    tree = G.tree_of(case)
+    arrays = G.arrays_of(case, "complex128", tree)
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1,
+                            device_id=torch.device("cuda", 0))
+    try:
+        out = tree.contract_distributed([torch.as_tensor(a, device="cuda") for a in arrays])
+        check(out, G.expected("lattice8x8_sliced/complex128"), "complex128")
+        out0 = tree.contract_distributed(arrays, root=0)
+        check(out0, G.expected("lattice8x8_sliced/complex128"), "complex128")
+    finally:
+        dist.destroy_process_group()
+
+
+def test_benchmark_api():
+    case = next(c for c in TREE_CASES if c["name"] == "lattice8x8_sliced")
+    tree = G.tree_of(case)
+    res = tree.benchmark(dtype="complex64", max_time=0.2, min_reps=3, max_reps=20)
+    assert set(res) == {"time_per_slice", "est_time_total", "est_gigaflops"}
+    assert res["time_per_slice"] > 0 and res["est_gigaflops"] > 0
+    assert abs(res["est_time_total"] - res["time_per_slice"] * tree.nslices) < 1e-9
