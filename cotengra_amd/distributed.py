@@ -73,13 +73,19 @@ def contract_distributed(
         )
 
     partial = partial.contiguous()
+    on_host = not partial.is_cuda
+    if on_host and dist.get_backend(group) == "nccl":
+        # RCCL reduces device memory only (numpy inputs were downloaded above)
+        partial = partial.cuda()
     # complex tensors are reduced as pairs of reals (portable across backends)
     buf = torch.view_as_real(partial) if partial.is_complex() else partial
     if root is None:
         dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group)
-        return partial
-    dist.reduce(buf, dst=root, op=dist.ReduceOp.SUM, group=group)
-    return partial if rank == root else None
+    else:
+        dist.reduce(buf, dst=root, op=dist.ReduceOp.SUM, group=group)
+        if rank != root:
+            return None
+    return partial.cpu() if on_host else partial
 
 
 def _to_local_device(x):
