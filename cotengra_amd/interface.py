@@ -126,6 +126,37 @@ def einsum_tree(eq, *shapes, optimize="greedy"):
     return array_contract_tree(inputs, output, size_dict, optimize)
 
 
+class Via:
+    """``fn`` wrapped with input / output conversions -- the reference's
+    host<->device hook (interface.py:476-491), e.g.
+    ``Via(expr, convert_in=torch.as_tensor, convert_out=lambda x: x.cpu().numpy())``."""
+
+    __slots__ = ("fn", "convert_in", "convert_out")
+
+    def __init__(self, fn, convert_in, convert_out):
+        self.fn = fn
+        self.convert_in = convert_in
+        self.convert_out = convert_out
+
+    def __call__(self, *arrays, **kwargs):
+        arrays = map(self.convert_in, arrays)
+        out = self.fn(*arrays, **kwargs)
+        return self.convert_out(out)
+
+
+class Variadic:
+    """``fn(arrays, **kw)`` exposed as ``fn(*arrays, **kw)`` (interface.py:461-473)."""
+
+    __slots__ = ("fn", "kwargs")
+
+    def __init__(self, fn, **kwargs):
+        self.fn = fn
+        self.kwargs = kwargs
+
+    def __call__(self, *arrays, **kwargs):
+        return self.fn(arrays, **self.kwargs, **kwargs)
+
+
 class ContractExpression:
     """Reusable ``expr(*arrays)`` (the object ``_build_expression`` returns,
     interface.py:585-667); sliced trees run all their slices on the device."""
@@ -143,14 +174,18 @@ class ContractExpression:
 
 def array_contract_expression(
     inputs, output, size_dict=None, shapes=None, optimize="greedy",
-    strip_exponent=False, check_zero=False, **_ignored,
+    strip_exponent=False, check_zero=False, via=None, **_ignored,
 ):
-    """interface.py:673."""
+    """interface.py:673.  ``via=(convert_in, convert_out)`` wraps the
+    expression like the reference does (interface.py:664-665)."""
     inputs = [tuple(t) for t in inputs]
     if size_dict is None:
         size_dict = shapes_inputs_to_size_dict(shapes, inputs)
     tree = array_contract_tree(inputs, output, size_dict, optimize)
-    return ContractExpression(tree, strip_exponent, check_zero)
+    expr = ContractExpression(tree, strip_exponent, check_zero)
+    if via is not None:
+        expr = Via(expr, *via)
+    return expr
 
 
 def einsum_expression(eq, *shapes, optimize="greedy", **kwargs):

@@ -907,6 +907,29 @@ class ContractionTree:
             **contract_opts,
         )
 
+    def sort_contraction_indices(self, priority="flops", make_output_contig=True,
+                                 make_contracted_contig=True, reset=True):
+        """Accepted for API compatibility (reference core.py:3421-3506): the
+        reference re-orders every intermediate's indices so that its
+        transposes become cheaper.  The MI355X executor never materialises a
+        permutation -- layouts are chosen by the plan compiler and realised in
+        the kernels' gather addresses -- so there is nothing to sort."""
+        return None
+
+    def print_contractions(self, sort=None, show_brackets=True):
+        """Per-step cost table (cf. reference core.py:3508): step, log10
+        scalar ops, log2 result size, and the pairwise einsum equation."""
+        rows = []
+        for i, (p, l, r) in enumerate(self.traverse()):
+            rows.append((i, math.log10(max(self.get_flops(p), 1)), math.log2(max(self.get_size(p), 1)),
+                         self.get_einsum_eq(p)))
+        if sort == "flops":
+            rows.sort(key=lambda t: -t[1])
+        elif sort == "size":
+            rows.sort(key=lambda t: -t[2])
+        for i, f, s_, eq in rows:
+            print(f"({i}) cost: {f:4.1f} width: {s_:4.1f} {eq if len(eq) < 120 else eq[:117] + '...'}")
+
     # ------------------------------------------------------------------ #
     # description
     # ------------------------------------------------------------------ #

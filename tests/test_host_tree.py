@@ -112,3 +112,17 @@ def test_greedy_path_handles_hyper_and_disconnected():
         t = ca.array_contract_tree(inputs, output, sd)
         xs = [np.random.default_rng(0).normal(size=[sd[i] for i in term]) for term in inputs]
         assert np.allclose(orc.contract(t, xs), np.einsum(eq, *xs))
+
+
+def test_api_compat_helpers(capsys):
+    from cotengra_amd.interface import Variadic, Via
+
+    t = chain_tree()
+    assert t.sort_contraction_indices("flops") is None
+    t.print_contractions()
+    out = capsys.readouterr().out
+    assert out.count("cost:") == 2 and "ab,bc->ac" in out
+    v = Variadic(lambda arrays, scale=1: scale * sum(arrays), scale=2)
+    assert v(1, 2, 3) == 12
+    w = Via(lambda *xs: sum(xs), lambda x: x + 1, lambda y: -y)
+    assert w(1, 2) == -5
