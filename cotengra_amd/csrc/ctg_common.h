@@ -90,6 +90,15 @@ __device__ __forceinline__ int64_t uniform64(int64_t v) {
     return (int64_t)(((unsigned long long)hi << 32) | lo);
 }
 
+// Scalar load of a table entry at a wave-uniform address.  The offset tables
+// are written before the kernel starts and never by it, but the compiler
+// cannot prove that once a persistent kernel has stored to C -- the constant
+// address space tells it, and keeps the lookups on the scalar unit (s_load).
+__device__ __forceinline__ int64_t sload64(const int64_t* p) {
+    typedef const int64_t __attribute__((address_space(4))) * cptr;
+    return *(cptr)(uintptr_t)p;
+}
+
 __device__ __forceinline__ void split_k(const StepArgs& p, int64_t k, int64_t& hi, int64_t& lo) {
     if (p.k_lo_shift >= 0) {
         hi = k >> p.k_lo_shift;

@@ -41,6 +41,8 @@
 // XCD's L2 instead of being re-fetched per tile.
 #include "ctg_common.h"
 
+#include <type_traits>
+
 namespace ctg {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -382,79 +384,93 @@ __global__ __launch_bounds__(256, Cfg::FAST_BLOCKS) void pair_mfma_fast_kernel(S
                                                                 float* __restrict__ partial) {
     constexpr int BM = Cfg::BM, BN = Cfg::BN, BK = Cfg::BK, WN = Cfg::WN;
     constexpr int NA = VEC_A ? Cfg::A_PER_T / 2 : Cfg::A_PER_T;  // A load instructions per thread
-    // Unpadded LDS rows of BK floats with an XOR swizzle of the four 16-byte
-    // columns by (row >> 2) & 3: fragment reads (ds_read_b128 over 16 rows)
-    // stay conflict-free and a block needs 48 KB instead of 60 KB, which lets
-    // three blocks share a CU (12 waves feeding the matrix cores).
+    // Unpadded LDS rows of BK floats.  Fragments are read one k-pair (8 bytes)
+    // at a time; the k-pair slot of a row is XORed with fsw(row), which makes
+    // the 32 rows of a ds_read_b64 lane group (and the 16 rows of each half of
+    // a ds_read2_b64) land on distinct 8-byte slots of the bank row
+    // (conflict-free), and a block needs 48 KB (BN = 64) so three share a CU.
     constexpr int LD = BK;
     constexpr int AF = 2 * BM * LD, BF = 2 * BN * LD;
     __shared__ __attribute__((aligned(16))) float lds[2 * (AF + BF)];
-    auto swz = [](int row, int c) { return row * LD + ((((c >> 2) ^ (row >> 2)) & 3) << 2) + (c & 3); };
+    auto fsw = [](int row) { return ((row >> 1) & 7) ^ ((row >> 4) & 1); };
+    auto swz = [&](int row, int c) { return row * LD + (((c >> 1) ^ fsw(row)) << 1) + (c & 1); };
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WN, wn = wave % WN;
-
     const int64_t S_split = k_chunk;
     const TileMap tmap = map_tile(blockIdx.x, tiles_m * S_split, tiles_n);
     if (!tmap.valid) return;
-    const int64_t tn = tmap.tn;
-    const int64_t tm = tmap.unit % tiles_m;
-    const int64_t ksplit = tmap.unit / tiles_m;
-    const int64_t m0 = tm * BM, n0 = tn * BN;
     const int64_t bz = blockIdx.z;
+    // (64-bit divisions run on the vector ALU: results go back to scalar registers)
+    const int64_t unit = uniform64(tmap.unit), tn = uniform64(tmap.tn);
+    const int64_t ksplit = uniform64(unit / tiles_m);
+    const int64_t tm = unit - ksplit * tiles_m;
+    const int64_t m0 = tm * BM, n0 = tn * BN;
 
-    // ---- uniform bases ---------------------------------------------------------
+    // ---- uniform bases (scalar loads) --------------------------------------------
     int64_t rhi, rlo;
     split_row(p, m0, rhi, rlo);
-    const c64* __restrict__ A = (const c64*)p.A + *p.soffA + p.bA[bz] + p.rowA.hi[rhi] + p.rowA.lo[rlo];
-    const c64* __restrict__ B = (const c64*)p.B + *p.soffB + p.bB[bz] + p.nB[n0];
-    float* __restrict__ C =
-        (float*)((c64*)p.C + *p.soffC + p.bC[bz] + p.rowC.hi[rhi] + p.rowC.lo[rlo] + p.nC[n0]);
+    rhi = uniform64(rhi);
+    rlo = uniform64(rlo);
+    const c64* __restrict__ A = (const c64*)p.A + sload64(p.soffA) + sload64(p.bA + bz) +
+                                sload64(p.rowA.hi + rhi) + sload64(p.rowA.lo + rlo);
+    const c64* __restrict__ B = (const c64*)p.B + sload64(p.soffB) + sload64(p.bB + bz) + sload64(p.nB + n0);
+    float* __restrict__ C = (float*)((c64*)p.C + sload64(p.soffC) + sload64(p.bC + bz) +
+                                     sload64(p.rowC.hi + rhi) + sload64(p.rowC.lo + rlo) + sload64(p.nC + n0));
 
-    // split-K: cyclic distribution of the k-steps over blockIdx.y (see the
-    // general kernel)
+    // split-K: cyclic distribution of the k-steps over the k-split units (see
+    // the general kernel)
     const int64_t nk_total = p.K / BK;
-    const int64_t nk = (nk_total - ksplit + S_split - 1) / S_split;
+    const int64_t nk = uniform64((nk_total - ksplit + S_split - 1) / S_split);
 
     // ---- per-lane constants -----------------------------------------------------
     unsigned a_off[NA];          // element offset of the load relative to the bases
-    int a_lds[Cfg::A_PER_T];     // LDS float offset of each element
+    // LDS float offsets of the elements this lane stages, two 16-bit values per register
+    constexpr int NAL = (Cfg::A_PER_T + 1) / 2, NBL = (Cfg::B_PER_T + 1) / 2;
+    unsigned a_lds[NAL], b_lds[NBL];   // b: Re row 2n of B'; the Im row 2n+1 is LD floats further
     {
         const uint16_t* oa = h.ordA + tid * Cfg::A_PER_T;
 #pragma unroll
         for (int j = 0; j < Cfg::A_PER_T; ++j) {
             const int v = oa[j];
             const int r = v >> 4, c = v & 15;
-            a_lds[j] = swz(r, c);
+            if (j & 1) a_lds[j / 2] |= (unsigned)swz(r, c) << 16;
+            else a_lds[j / 2] = (unsigned)swz(r, c);
             if (!VEC_A || (j & 1) == 0)
                 a_off[VEC_A ? j / 2 : j] = (unsigned)(p.rowA.lo[r] + p.kA.lo[c]);
         }
     }
     unsigned b_off[Cfg::B_PER_T];
-    int b_lds[Cfg::B_PER_T], b_lds2[Cfg::B_PER_T];
     {
         const uint16_t* ob = h.ordB + tid * Cfg::B_PER_T;
 #pragma unroll
         for (int j = 0; j < Cfg::B_PER_T; ++j) {
             const int v = ob[j];
             const int nn = v >> 4, c = v & 15;
-            b_lds[j] = swz(2 * nn, c);
-            b_lds2[j] = swz(2 * nn + 1, c);
+            if (j & 1) b_lds[j / 2] |= (unsigned)swz(2 * nn, c) << 16;
+            else b_lds[j / 2] = (unsigned)swz(2 * nn, c);
             b_off[j] = (unsigned)(p.nB[nn] + p.kB.lo[c]);
         }
     }
+    auto unpack = [](const unsigned* pk, int j) { return (int)((j & 1) ? pk[j / 2] >> 16 : pk[j / 2] & 0xffffu); };
 
     c64 a_reg[Cfg::A_PER_T], b_reg[Cfg::B_PER_T];
-
-    auto gather = [&](int64_t step) {
-        int64_t kh, kl;
-        split_k(p, uniform64((step * S_split + ksplit) * BK), kh, kl);   // scalar loads
-        kh = uniform64(kh);
-        kl = uniform64(kl);
-        const c64* Ak = A + p.kA.hi[kh] + p.kA.lo[kl];
-        const c64* Bk = B + p.kB.hi[kh] + p.kB.lo[kl];
+    // uniform k offsets of the k-step being gathered: the four scalar loads are
+    // issued one phase before their first use (the host only takes this path
+    // when the k tables split at a power of two)
+    int64_t kAh = 0, kAl = 0, kBh = 0, kBl = 0;
+    auto k_bases = [&](int64_t step) {
+        const int64_t k = uniform64((step * S_split + ksplit) * BK);
+        const int64_t kh = k >> p.k_lo_shift, kl = k & (p.k_lo - 1);
+        kAh = sload64(p.kA.hi + kh);
+        kAl = sload64(p.kA.lo + kl);
+        kBh = sload64(p.kB.hi + kh);
+        kBl = sload64(p.kB.lo + kl);
+    };
+    auto gather_a = [&]() {
+        const c64* Ak = A + kAh + kAl;
         if (VEC_A) {
 #pragma unroll
             for (int j = 0; j < NA; ++j) {
@@ -466,80 +482,136 @@ __global__ __launch_bounds__(256, Cfg::FAST_BLOCKS) void pair_mfma_fast_kernel(S
 #pragma unroll
             for (int j = 0; j < NA; ++j) a_reg[j] = Ak[a_off[j]];
         }
+    };
+    auto gather_b = [&]() {
+        const c64* Bk = B + kBh + kBl;
 #pragma unroll
         for (int j = 0; j < Cfg::B_PER_T; ++j)
             if (Cfg::B_PER_T * 256 == BK * BN || j * 256 + tid < BK * BN) b_reg[j] = Bk[b_off[j]];
     };
-    auto stage = [&](int buf) {
+    auto stage_a = [&](int buf) {
         float* As = lds + buf * (AF + BF);
-        float* Bs = As + AF;
 #pragma unroll
         for (int j = 0; j < Cfg::A_PER_T; ++j) {
-            As[a_lds[j]] = a_reg[j].re;
-            As[BM * LD + a_lds[j]] = a_reg[j].im;
+            const int o = unpack(a_lds, j);
+            As[o] = a_reg[j].re;
+            As[BM * LD + o] = a_reg[j].im;
         }
+    };
+    auto stage_b = [&](int buf) {
+        float* Bs = lds + buf * (AF + BF) + AF;
 #pragma unroll
         for (int j = 0; j < Cfg::B_PER_T; ++j) {
             if (Cfg::B_PER_T * 256 == BK * BN || j * 256 + tid < BK * BN) {
-                Bs[b_lds[j]] = b_reg[j].re;
-                Bs[b_lds2[j]] = b_reg[j].im;
+                const int o = unpack(b_lds, j);
+                Bs[o] = b_reg[j].re;
+                Bs[o + LD] = b_reg[j].im;
             }
         }
     };
 
     f32x16 acc[Cfg::FM][Cfg::FN];
+
+    const int kk = lane >> 5;
+    const int l31 = lane & 31;
+    const bool odd = lane & 1;
+    // sign bit to flip on the B fragment: -Im b for lanes (row 1 of B', even column)
+    const unsigned sign = (kk == 1 && !odd) ? 0x80000000u : 0u;
+    const float alpha = (float)step_alpha(p);
+
+    // Fragments: one k-pair (two MFMA k's) per ds_read_b64, double buffered in
+    // registers -- the reads of phase ph+1 are issued before the MFMAs of phase
+    // ph, so a wave never waits on LDS latency.  i*32 / j*32 rows do not change
+    // fsw(row).
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+    f32x2 fa[2][Cfg::FM], fb[2][Cfg::FN];
+    const int a_row = wm * Cfg::WTM + l31;
+    const int b_row = 2 * wn * Cfg::WTN + (l31 ^ kk);
+    const int a_sw = fsw(a_row), b_sw = fsw(b_row);
+    const float* a_frag = lds + kk * BM * LD + a_row * LD;
+    const float* b_frag = lds + AF + b_row * LD;
+    auto load_frag = [&](int buf, int ph, int slot) {
+        const int boff = buf * (AF + BF);
+#pragma unroll
+        for (int i = 0; i < Cfg::FM; ++i)
+            fa[slot][i] = *(const f32x2*)(a_frag + boff + i * 32 * LD + (((ph ^ a_sw) & 7) << 1));
+#pragma unroll
+        for (int j = 0; j < Cfg::FN; ++j)
+            fb[slot][j] = *(const f32x2*)(b_frag + boff + j * 32 * LD + (((ph ^ b_sw) & 7) << 1));
+    };
+
+    // One k-step = 8 phases of FM*FN*2 MFMAs, each phase fenced for the
+    // instruction scheduler.  Everything else a wave has to do for the pipeline
+    // sits between the MFMAs of some phase: fragment reads of the next phase,
+    // LDS writes of the next k-step (phases 0-1), scalar k bases and global
+    // gathers of the k-step after that (phases 2-4).  The single barrier of the
+    // step comes before the last phase: by then this wave has finished reading
+    // `buf` and writing `buf ^ 1`, so after the barrier it prefetches the first
+    // fragments of the next step while its last MFMAs of this step run.
+    // has1 / has2: the tile has a k-step kt+1 / kt+2.
+    auto k_step = [&](int64_t kt, auto has1, auto has2) {
+        constexpr bool H1 = decltype(has1)::value, H2 = decltype(has2)::value;
+        const int buf = (int)(kt & 1);
+#pragma unroll
+        for (int ph = 0; ph < BK / 2; ++ph) {
+            if (ph + 1 < BK / 2) {
+                load_frag(buf, ph + 1, (ph + 1) & 1);
+            } else if (H1) {
+                __syncthreads();
+                load_frag(buf ^ 1, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);   // reads first: a full phase of MFMAs covers them
+            if (H1 && ph == 0) stage_a(buf ^ 1);
+            if (H1 && ph == 1) stage_b(buf ^ 1);
+            if (H2 && ph == 2) k_bases(kt + 2);
+            if (H2 && ph == 3) gather_a();
+            if (H2 && ph == 4) gather_b();
+            // the sign of -Im b is applied here, not at the load, so that the
+            // read stays in flight across the previous phase
+            f32x2 bs[Cfg::FN];
+#pragma unroll
+            for (int j = 0; j < Cfg::FN; ++j)
+                bs[j] = __builtin_bit_cast(f32x2, __builtin_bit_cast(u32x2, fb[ph & 1][j]) ^ sign);
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int i = 0; i < Cfg::FM; ++i)
+#pragma unroll
+                    for (int j = 0; j < Cfg::FN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[ph & 1][i][t], bs[j][t],
+                                                                        acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+
+    k_bases(0);
+    gather_a();
+    gather_b();
+    stage_a(0);
+    stage_b(0);
+    if (nk > 1) {
+        k_bases(1);
+        gather_a();
+        gather_b();
+    }
+    __syncthreads();
+    load_frag(0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int i = 0; i < Cfg::FM; ++i)
 #pragma unroll
         for (int j = 0; j < Cfg::FN; ++j)
 #pragma unroll
             for (int t = 0; t < 16; ++t) acc[i][j][t] = 0.f;
-
-    const int kk = lane >> 5;
-    const int l31 = lane & 31;
-    // sign bit to flip on the B fragment: -Im b for lanes (row 1 of B', even column)
-    const unsigned sign = (kk == 1 && (lane & 1) == 0) ? 0x80000000u : 0u;
-
-    gather(0);
-    stage(0);
-    if (nk > 1) gather(1);
-    __syncthreads();
-
-    for (int64_t kt = 0; kt < nk; ++kt) {
-        const int buf = kt & 1;
-        if (kt + 1 < nk) stage(buf ^ 1);
-        if (kt + 2 < nk) gather(kt + 2);
-
-        const float* As = lds + buf * (AF + BF);
-        const float* Bs = As + AF;
-        // rows of this lane's fragments; i*32 / j*32 do not change (row >> 2) & 3
-        const int a_row = wm * Cfg::WTM + l31;
-        const int b_row = 2 * wn * Cfg::WTN + (l31 ^ kk);
-        const float* a_base = As + kk * BM * LD + a_row * LD;
-        const float* b_base = Bs + b_row * LD;
-        const int a_sw = (a_row >> 2) & 3, b_sw = (b_row >> 2) & 3;
-#pragma unroll
-        for (int kq = 0; kq < BK / 4; ++kq) {
-            f32x4 af[Cfg::FM], bf[Cfg::FN];
-#pragma unroll
-            for (int i = 0; i < Cfg::FM; ++i) af[i] = *(const f32x4*)(a_base + i * 32 * LD + ((kq ^ a_sw) << 2));
-#pragma unroll
-            for (int j = 0; j < Cfg::FN; ++j) {
-                typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-                u32x4 v = *(const u32x4*)(b_base + j * 32 * LD + ((kq ^ b_sw) << 2));
-                v ^= sign;
-                bf[j] = __builtin_bit_cast(f32x4, v);
-            }
-#pragma unroll
-            for (int t = 0; t < 4; ++t)
-#pragma unroll
-                for (int i = 0; i < Cfg::FM; ++i)
-#pragma unroll
-                    for (int j = 0; j < Cfg::FN; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][t], bf[j][t],
-                                                                        acc[i][j], 0, 0, 0);
+    {
+        int64_t kt = 0;
+        for (; kt + 2 < nk; ++kt) k_step(kt, std::true_type{}, std::true_type{});
+        if (kt + 1 < nk) {
+            k_step(kt, std::true_type{}, std::false_type{});
+            ++kt;
         }
-        __syncthreads();
+        k_step(kt, std::false_type{}, std::false_type{});
     }
 
     if (partial != nullptr) {
@@ -558,8 +630,6 @@ __global__ __launch_bounds__(256, Cfg::FAST_BLOCKS) void pair_mfma_fast_kernel(S
         }
         return;
     }
-    const bool odd = lane & 1;
-    const float alpha = (float)step_alpha(p);
     // all store offsets first (one batch of table loads, one wait), then stores
     unsigned ro[Cfg::FM][8], co[Cfg::FN];
 #pragma unroll
@@ -664,13 +734,14 @@ static hipError_t launch_cfg(const StepArgs& p, const MfmaHints& h, void* scratc
     if (gx > 0x7fffffffll) return hipErrorInvalidValue;
     const dim3 grid((unsigned)gx, 1, (unsigned)p.Bt);
     float* part = S > 1 ? (float*)scratch : (float*)nullptr;
-    if (h.fast && h.vecA)
-        hipLaunchKernelGGL((pair_mfma_fast_kernel<Cfg, true>), grid, dim3(256), 0, stream, p, h,
-                           tiles_m, tiles_n, k_chunk, part);
-    else if (h.fast)
-        hipLaunchKernelGGL((pair_mfma_fast_kernel<Cfg, false>), grid, dim3(256), 0, stream, p, h,
-                           tiles_m, tiles_n, k_chunk, part);
-    else if constexpr (Cfg::BN >= 128) {
+    if (h.fast) {
+        if (h.vecA)
+            hipLaunchKernelGGL((pair_mfma_fast_kernel<Cfg, true>), grid, dim3(256), 0, stream, p, h,
+                               tiles_m, tiles_n, k_chunk, part);
+        else
+            hipLaunchKernelGGL((pair_mfma_fast_kernel<Cfg, false>), grid, dim3(256), 0, stream, p, h,
+                               tiles_m, tiles_n, k_chunk, part);
+    } else if constexpr (Cfg::BN >= 128) {
         return hipErrorInvalidValue;  // the 128-wide tile exists for the fast path only
     } else if (h.vecA)
         hipLaunchKernelGGL((pair_mfma_c64_kernel<Cfg, true>), grid, dim3(256), 0, stream, p, h,
@@ -701,8 +772,11 @@ static hipError_t launch_cfg(const StepArgs& p, const MfmaHints& h, void* scratc
 // offsets: one scalar base per group + per-lane constants).
 // ------------------------------------------------------------------------- //
 
+// Occupancy the register allocator is held to: 16 / 12 / 8 waves per CU for
+// 16 / 32 / 64 output columns.  The narrow variants are latency-bound (bytes
+// in flight per CU), so the extra waves are worth more than the registers.
 template <int FN, bool VEC, bool ADD, bool SHORTK>
-__global__ __launch_bounds__(256) void pair_mfma_stream_kernel(StepArgs p, MfmaHints h, int KP,
+__global__ __launch_bounds__(256, (FN == 1 ? 4 : FN == 2 ? 3 : 2)) void pair_mfma_stream_kernel(StepArgs p, MfmaHints h, int KP,
                                                                int64_t n_groups) {
     constexpr int LD = MFMA_BK + 4;
     constexpr int PER_T = 32 * MFMA_BK / 64;  // A elements per lane per chunk (8)

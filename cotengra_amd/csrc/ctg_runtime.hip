@@ -409,6 +409,7 @@ bool mfma_fast_ok(const ctg_plan* p, const int64_t* r, int bn) {
     const int BM = MFMA_BM, BK = MFMA_BK;
     const int64_t R = r[W_R], K = r[W_K], N = r[W_N];
     if (R % BM || K % BK || N % bn) return false;
+    if (r[W_K_LO] & (r[W_K_LO] - 1)) return false;  // the kernel splits k with shift / mask
     if (!tile_additive(p, r[W_ROWA_LO], r[W_ROW_LO], R, BM)) return false;
     if (!tile_additive(p, r[W_ROWC_LO], r[W_ROW_LO], R, BM)) return false;
     if (!tile_additive(p, r[W_KA], r[W_K_LO], K, BK)) return false;
