@@ -90,6 +90,25 @@ __device__ __forceinline__ int64_t uniform64(int64_t v) {
     return (int64_t)(((unsigned long long)hi << 32) | lo);
 }
 
+// Epilogue of the complex-on-real MFMA tiles.  A 32x32 tile leaves Re of complex
+// column n in lane 2n and Im in lane 2n+1, registers t / t+1 holding two
+// adjacent output rows.  Swapping with the neighbour lane (DPP quad_perm
+// [1,0,3,2]: a plain VALU move, no LDS round trip like ds_bpermute) gives the
+// even lane the whole complex number of row t and the odd lane that of row
+// t+1, so every lane stores 8 contiguous bytes.  Written without a select
+// between two elements of the accumulator vector on purpose: the compiler
+// turns that into a per-lane *indexed* extract (a 16-deep v_cndmask chain).
+__device__ __forceinline__ float dpp_swap1(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float2 pair_rows(float a_t, float a_t1, bool odd, float alpha) {
+    const float x = dpp_swap1(a_t), y = dpp_swap1(a_t1);
+    float2 v;
+    v.x = (odd ? y : a_t) * alpha;
+    v.y = (odd ? a_t1 : x) * alpha;
+    return v;
+}
+
 // Scalar load of a table entry at a wave-uniform address.  The offset tables
 // are written before the kernel starts and never by it, but the compiler
 // cannot prove that once a persistent kernel has stored to C -- the constant

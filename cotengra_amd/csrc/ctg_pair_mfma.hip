@@ -349,18 +349,10 @@ __global__ __launch_bounds__(256, 2) void pair_mfma_c64_kernel(StepArgs p, MfmaH
         for (int i = 0; i < Cfg::FM; ++i) {
 #pragma unroll
             for (int t = 0; t < 16; t += 2) {
-                const float send = odd ? acc[i][j][t] : acc[i][j][t + 1];
-                const float recv = __shfl_xor(send, 1, 64);
+                const float2 v = pair_rows(acc[i][j][t], acc[i][j][t + 1], odd, alpha);
                 const int row = wm * Cfg::WTM + i * 32 + (t & 3) + 8 * (t >> 2) + 4 * kk + (odd ? 1 : 0);
                 const int64_t ro = rowC_s[row];
-                if (n_ok && ro >= 0) {
-                    float2 v;
-                    v.x = odd ? recv : acc[i][j][t];
-                    v.y = odd ? acc[i][j][t + 1] : recv;
-                    v.x *= alpha;
-                    v.y *= alpha;
-                    *(float2*)(C + 2 * (ro + ncol)) = v;
-                }
+                if (n_ok && ro >= 0) *(float2*)(C + 2 * (ro + ncol)) = v;
             }
         }
     }
@@ -649,14 +641,8 @@ __global__ __launch_bounds__(256, Cfg::FAST_BLOCKS) void pair_mfma_fast_kernel(S
             const int t = 2 * u;
 #pragma unroll
             for (int j = 0; j < Cfg::FN; ++j) {
-                const float send = odd ? acc[i][j][t] : acc[i][j][t + 1];
-                const float recv = __shfl_xor(send, 1, 64);
-                float2 v;
-                v.x = odd ? recv : acc[i][j][t];
-                v.y = odd ? acc[i][j][t + 1] : recv;
-                v.x *= alpha;
-                v.y *= alpha;
-                *(float2*)(C + 2 * (size_t)(ro[i][u] + co[j])) = v;
+                *(float2*)(C + 2 * (size_t)(ro[i][u] + co[j])) =
+                    pair_rows(acc[i][j][t], acc[i][j][t + 1], odd, alpha);
             }
         }
     }
@@ -1010,16 +996,8 @@ __global__ __launch_bounds__(256, (FN == 1 ? 4 : FN == 2 ? 3 : 2)) void pair_mfm
                 }
 #pragma unroll
                 for (int j = 0; j < FN; ++j) {
-                    const float send = odd ? acc[j][t] : acc[j][t + 1];
-                    const float recv = __shfl_xor(send, 1, 64);
-                    if (n_ok[j] && ro >= 0) {
-                        float2 v;
-                        v.x = odd ? recv : acc[j][t];
-                        v.y = odd ? acc[j][t + 1] : recv;
-                        v.x *= alpha;
-                        v.y *= alpha;
-                        *(float2*)(C + 2 * (ro + ncol[j])) = v;
-                    }
+                    const float2 v = pair_rows(acc[j][t], acc[j][t + 1], odd, alpha);
+                    if (n_ok[j] && ro >= 0) *(float2*)(C + 2 * (ro + ncol[j])) = v;
                 }
             }
             cc = 0;

@@ -455,7 +455,8 @@ int build_hints(ctg_exec* e) {
         h.stream = mfma_use_stream(r[W_R], r[W_BT], r[W_K], r[W_N]) ? 1 : 0;
         // big square-ish GEMMs: 128x128 tiles (fast path only) halve the LDS
         // traffic and barriers per flop
-        if (!h.stream && r[W_N] % 128 == 0 && r[W_R] * r[W_N] >= (1ll << 22) && r[W_K] >= 256 &&
+        static const int64_t bn128_min_k = getenv("CTG_BN128_MINK") ? atoll(getenv("CTG_BN128_MINK")) : 256;  // EXPERIMENT
+        if (!h.stream && r[W_N] % 128 == 0 && r[W_R] * r[W_N] >= (1ll << 22) && r[W_K] >= bn128_min_k &&
             mfma_fast_ok(p, r, 128))
             h.bn = 128;
         h.additive32 = (h.stream && tile_additive(p, r[W_ROWA_LO], r[W_ROW_LO], r[W_R], 32) &&
