@@ -334,7 +334,7 @@ void build_mfma_order(const ctg_plan* p, const int64_t* r, int bn, int BM,
         const bool short_k = BM == 32 && K < BK;
         int n_valid = 0;
         for (int i = 0; i < n_el; ++i) n_valid += off[i] < BIG ? 1 : 0;
-        bool vec = (R % BM == 0) && (short_k ? (K % 4 == 0) : (K % BK == 0));
+        bool vec = (R % BM == 0) && (short_k ? (K % 2 == 0) : (K % BK == 0));
         for (int q = 0; vec && q < n_valid / 2; ++q) {
             const int64_t o0 = off[idx[2 * q]], o1 = off[idx[2 * q + 1]];
             if (o1 != o0 + 1 || (o0 & 1)) vec = false;
@@ -455,8 +455,7 @@ int build_hints(ctg_exec* e) {
         h.stream = mfma_use_stream(r[W_R], r[W_BT], r[W_K], r[W_N]) ? 1 : 0;
         // big square-ish GEMMs: 128x128 tiles (fast path only) halve the LDS
         // traffic and barriers per flop
-        static const int64_t bn128_min_k = getenv("CTG_BN128_MINK") ? atoll(getenv("CTG_BN128_MINK")) : 256;  // EXPERIMENT
-        if (!h.stream && r[W_N] % 128 == 0 && r[W_R] * r[W_N] >= (1ll << 22) && r[W_K] >= bn128_min_k &&
+        if (!h.stream && r[W_N] % 128 == 0 && r[W_R] * r[W_N] >= (1ll << 22) && r[W_K] >= 256 &&
             mfma_fast_ok(p, r, 128))
             h.bn = 128;
         h.additive32 = (h.stream && tile_additive(p, r[W_ROWA_LO], r[W_ROW_LO], r[W_R], 32) &&

@@ -394,7 +394,7 @@ def choose_kernel(dtype, Bt, M, K, N):
         return KERNEL_MFMA
     # tall-skinny streaming kernel: HBM-bound, so padding N up to an MFMA tile
     # costs nothing (csrc/ctg_common.h: mfma_use_stream)
-    if Bt == 1 and 4 <= K <= 128 and N <= 64 and M >= 8192:  # (stream or tiled, runtime picks)
+    if Bt == 1 and 2 <= K <= 128 and N <= 64 and M >= 8192:  # (stream or tiled, runtime picks)
         return KERNEL_MFMA
     return KERNEL_VALU
 

@@ -38,6 +38,9 @@ CASES = [
     ("akbc,kn->abcn", dict(a=32, b=32, c=16, k=4, n=64)),             # 22: K=4, N=64
     ("abcdefghijklmnop,dhpxy->abcefgijklmnoxy", {ix: 2 for ix in "abcdefghijklmnopxy"}),  # 23: K=8 bits
     ("abkc,kn->abcn", dict(a=32, b=32, c=16, k=12, n=16)),            # 24: K=12
+    ("abck,kn->abcn", dict(a=32, b=32, c=16, k=2, n=8)),              # 25: K=2 streaming (pairs along k)
+    ("akbc,kn->abcn", dict(a=32, b=3, c=16, k=3, n=8)),               # 26: K=3 streaming, ragged rows
+    ("kabc,kn->abcn", dict(a=32, b=32, c=16, k=2, n=2)),              # 27: K=2, k slowest, N=2
 ]
 
 

@@ -1,16 +1,17 @@
 #!/bin/bash
 mkdir -p gpurun_out
-timeout 600 python -m pytest tests -x -q -m gpu > gpurun_out/exp_tests.log 2>&1
+timeout 600 python -m pytest tests/test_gpu_pairwise.py tests/test_gpu_golden.py -x -q -m gpu > gpurun_out/exp_tests.log 2>&1
 grep -E "passed|failed|error" gpurun_out/exp_tests.log | tail -3
-for t in main c256 c1024; do
-  if [ $t = main ]; then T=tests/golden/trees/sycamore_m20_w30.json; else T=gpurun_in/t_$t.json; fi
-  timeout 300 python bench.py --steps 3 --warmup 1 --no-cpu-baseline --tree $T --dump-steps gpurun_out/steps_$t.json > gpurun_out/exp_$t.log 2>&1
-  tail -1 gpurun_out/exp_$t.log | python -c "
+CTG_PERSIST_NK=100000 timeout 600 python -m pytest tests/test_gpu_pairwise.py tests/test_gpu_golden.py -x -q -m gpu > gpurun_out/exp_tests_p.log 2>&1
+grep -E "passed|failed|error" gpurun_out/exp_tests_p.log | tail -3
+for nk in 0 4 8 32 100000; do
+  CTG_PERSIST_NK=$nk timeout 600 python bench.py --steps 2 --warmup 1 --no-cpu-baseline --tree gpurun_in/t_rs32.json --dump-steps gpurun_out/steps_rs32_p$nk.json > gpurun_out/exp_p$nk.log 2>&1
+  tail -1 gpurun_out/exp_p$nk.log | python -c "
 import sys, json
 try:
     d = json.loads(sys.stdin.read())
-    print('$t', 'ms/slice %.2f TF %.1f' % (d['ms_per_step'], d['tflops']), 'flops/slice %.3g' % d['config']['flops_per_slice'], 'dominant', d['roofline']['kernel'], '%.1f' % d['roofline']['achieved'])
+    print('persist nk<=$nk', 'ms/slice %.2f TF %.1f' % (d['ms_per_step'], d['tflops']))
 except Exception as e:
-    print('$t', 'FAILED', e)
+    print('$nk', 'FAILED', e)
 "
 done
