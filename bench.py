@@ -27,7 +27,7 @@ sys.path.insert(0, ROOT)
 
 PEAK_MFMA_F32_TFLOPS = 157.3  # MI355X_MICROARCH.md: dense fp32 matrix peak
 PEAK_HBM_GBS = 8000.0
-TREE = os.path.join(ROOT, "tests", "golden", "trees", "sycamore_m20_w30.json")
+TREE = os.path.join(ROOT, "tests", "golden", "trees", "sycamore_m20_w32.json")
 
 
 def shrink_for_cpu(tree, log2_width):
@@ -145,20 +145,29 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
-    # precision of the complex64 path: one slice of the same tree narrowed to a
-    # CPU-sized width, device complex64 vs the numpy oracle in complex128
+    # precision: one slice of the same tree narrowed to a CPU-sized width.  The
+    # complex128 HIP path must reproduce the numpy complex128 oracle (same
+    # schedule, 1e-10); the complex64 production path is held to an fp32 bound
+    # and reported next to the error numpy itself makes in complex64.
     precision = None
     if rank == 0 and not args.no_cpu_baseline:
         from oracle import contract_ref as orc
 
         small = shrink_for_cpu(tree, 20)
-        got = complex(np.asarray(small.contract_slice(arrays, 3)))
         ref = complex(orc.contract_slice(small, [a.astype("complex128") for a in arrays], 3))
+        np64 = complex(orc.contract_slice(small, arrays, 3))
+        got = complex(np.asarray(small.contract_slice(arrays, 3)))
+        got128 = complex(np.asarray(small.contract_slice([a.astype("complex128") for a in arrays], 3)))
         precision = {
-            "check": "slice 3 of the tree narrowed to width 2^20: HIP complex64 vs numpy complex128",
+            "check": "slice 3 of the tree narrowed to width 2^20, vs numpy complex128",
             "rel_err": abs(got - ref) / abs(ref),
-            "gate": 1e-5,
+            "gate": 1e-4,
+            "rel_err_complex128_path": abs(got128 - ref) / abs(ref),
+            "gate_complex128_path": 1e-10,
+            "numpy_complex64_rel_err": abs(np64 - ref) / abs(ref),
         }
+        if precision["rel_err"] > precision["gate"] or precision["rel_err_complex128_path"] > 1e-10:
+            raise SystemExit(f"precision check failed: {precision}")
 
     flops_slice = plan.flops_per_slice()
     total_slices = args.steps * world

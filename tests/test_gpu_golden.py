@@ -139,14 +139,16 @@ def test_check_zero():
     assert np.all(np.asarray(out) == 0)
 
 
-def test_full_size_properties_m20():
-    """Size-independent checks at the benchmark's full slice width (2^30):
-    (1) slicing identity -- a slice of the tree equals the sum of the two
-    slices obtained by slicing one more index; (2) linearity in one input."""
+@pytest.mark.parametrize("fixture", ["sycamore_m20_w30.json", "sycamore_m20_w32.json"])
+def test_full_size_properties_m20(fixture):
+    """Size-independent checks at full slice width (2^30 first-search tree;
+    2^32 refined tree = the benchmark's): (1) slicing identity -- a slice of the
+    tree equals the sum of the two slices obtained by slicing one more index;
+    (2) linearity in one input."""
     import cotengra_amd as ca
     import os
 
-    rec = ca.load_network(os.path.join(os.path.dirname(__file__), "golden", "trees", "sycamore_m20_w30.json"))
+    rec = ca.load_network(os.path.join(os.path.dirname(__file__), "golden", "trees", fixture))
     tree = ca.tree_from_record(rec)
     arrays = ca.make_arrays_from_inputs(tree.inputs, tree.size_dict, seed=42, dtype="complex64", rescale=True)
     coarse = HipContractor(tree)
