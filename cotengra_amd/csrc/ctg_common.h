@@ -208,13 +208,15 @@ constexpr int MFMA_BK = 16;   // complex k per step
 // ordA: [256][BM*BK/256] packed (r << 4 | c): the tile elements a thread
 // gathers, in ascending memory order across the lanes of each load
 // instruction; with vecA entries (2j, 2j+1) are adjacent in memory (one
-// 16-byte load).  ordB: [256][ceil(BK*BN/256)] packed (n << 4 | k).
+// 16-byte load).  ordB: [256][ceil(BK*BN/256)] packed (n << 4 | k)
+// ([64][BK*BN/64] for the k-streaming kernel).
 struct MfmaHints {
     const uint16_t* ordA;
     const uint16_t* ordB;
     int bn;    // column tile: 16, 32 or 64
     int vecA;  // 1: pairs of A elements are contiguous + aligned, tiles are full
-    int stream;      // 1: tall-skinny streaming kernel (row tile 32, B resident in LDS)
+    int stream;      // 1: tall-skinny streaming kernel (row tile 32, B resident in LDS);
+                     // 2: k-streaming kernel (R, N <= 32, both operands stream along K)
     int additive32;  // 1: row offsets are tile-additive for 32-row groups
     int fast;        // 1: full tiles + tile-additive 32-bit offsets (tiled fast path)
 };

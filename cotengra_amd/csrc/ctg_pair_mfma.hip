@@ -596,12 +596,27 @@ __global__ __launch_bounds__(256, Cfg::FAST_BLOCKS) void pair_mfma_fast_kernel(S
         for (int j = 0; j < Cfg::FN; ++j)
 #pragma unroll
             for (int t = 0; t < 16; ++t) acc[i][j][t] = 0.f;
+    unsigned ro[Cfg::FM][8] = {}, co[Cfg::FN] = {};   // epilogue store offsets
     {
         int64_t kt = 0;
         for (; kt + 2 < nk; ++kt) k_step(kt, std::true_type{}, std::true_type{});
         if (kt + 1 < nk) {
             k_step(kt, std::true_type{}, std::false_type{});
             ++kt;
+        }
+        // store offsets of the epilogue: loaded under the last k-step (the gather
+        // registers are dead by now), not after it
+        if (partial == nullptr) {
+#pragma unroll
+            for (int i = 0; i < Cfg::FM; ++i)
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int t = 2 * u;
+                    ro[i][u] = (unsigned)p.rowC.lo[wm * Cfg::WTM + i * 32 + (t & 3) + 8 * (t >> 2) + 4 * kk +
+                                                   (odd ? 1 : 0)];
+                }
+#pragma unroll
+            for (int j = 0; j < Cfg::FN; ++j) co[j] = (unsigned)p.nC[wn * Cfg::WTN + j * 16 + (l31 >> 1)];
         }
         k_step(kt, std::false_type{}, std::false_type{});
     }
@@ -622,18 +637,6 @@ __global__ __launch_bounds__(256, Cfg::FAST_BLOCKS) void pair_mfma_fast_kernel(S
         }
         return;
     }
-    // all store offsets first (one batch of table loads, one wait), then stores
-    unsigned ro[Cfg::FM][8], co[Cfg::FN];
-#pragma unroll
-    for (int i = 0; i < Cfg::FM; ++i)
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int t = 2 * u;
-            ro[i][u] = (unsigned)p.rowC.lo[wm * Cfg::WTM + i * 32 + (t & 3) + 8 * (t >> 2) + 4 * kk +
-                                           (odd ? 1 : 0)];
-        }
-#pragma unroll
-    for (int j = 0; j < Cfg::FN; ++j) co[j] = (unsigned)p.nC[wn * Cfg::WTN + j * 16 + (l31 >> 1)];
 #pragma unroll
     for (int i = 0; i < Cfg::FM; ++i) {
 #pragma unroll
@@ -1059,9 +1062,188 @@ static hipError_t launch_stream(const StepArgs& p, const MfmaHints& h, hipStream
     return launch_stream_t<FN, false, false, false>(p, h, KP, smem, stream);
 }
 
+// ------------------------------------------------------------------------- //
+// k-streaming variant: two big tensors contracted into a tiny result (R <= 32,
+// N <= 32, K in the millions) -- the last step of every amplitude tree.  Here
+// BOTH operands stream.  A wave owns every n_waves-th 16-deep k-chunk: it
+// gathers the 32 x 16 tile of A and the 16 x 16*FN tile of B in address order
+// (two chunks ahead, in registers), transposes both through wave-private LDS
+// into MFMA fragment layout and accumulates one 32 x 16*FN tile for its whole
+// share of K.  The per-wave tiles go to the split-K scratch and are summed in
+// a fixed order by splitk_reduce_kernel.  Host-checked (MfmaHints::stream ==
+// 2): K % 16 == 0, k tables tile-additive per chunk with a power-of-two split,
+// 32-bit lane offsets.
+// ------------------------------------------------------------------------- //
+
+template <int FN, bool VEC_A>
+__global__ __launch_bounds__(256, 3) void pair_mfma_kstream_kernel(StepArgs p, MfmaHints h,
+                                                                   float* __restrict__ partial) {
+    constexpr int LD = MFMA_BK + 4;
+    constexpr int PA = 8;            // A elements per lane per chunk (32 x 16 / 64)
+    constexpr int PB = 4 * FN;       // B elements per lane per chunk (16 x 16 FN / 64)
+    constexpr int A_FL = 2 * 32 * LD, B_FL = 2 * 16 * FN * LD;
+    __shared__ __attribute__((aligned(16))) float lds[4 * (A_FL + B_FL)];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int kk = lane >> 5;
+    const int l31 = lane & 31;
+    const bool negate = kk == 1 && !(lane & 1);
+    float* As = lds + wave * (A_FL + B_FL);
+    float* Bs = As + A_FL;
+
+    const c64* __restrict__ A = (const c64*)p.A + sload64(p.soffA) + sload64(p.rowA.hi);
+    const c64* __restrict__ B = (const c64*)p.B + sload64(p.soffB);
+
+    // per-lane constants: LDS slot and 32-bit offset of every element this lane moves
+    int a_lds[PA], b_lds[PB];
+    int a_off[PA], b_off[PB];        // -1: padding (row >= R / column >= N), never gathered
+    {
+        const int64_t ka0 = p.kA.lo[0], kb0 = p.kB.lo[0];
+        const uint16_t* oa = h.ordA + lane * PA;
+#pragma unroll
+        for (int j = 0; j < PA; ++j) {
+            const int v = oa[j] & 0x7fff;
+            const int r = v >> 4, c = v & 15;
+            a_lds[j] = r * LD + c;
+            a_off[j] = r < p.R ? (int)(p.rowA.lo[r] + p.kA.lo[c] - ka0) : -1;
+        }
+        const uint16_t* ob = h.ordB + lane * PB;
+#pragma unroll
+        for (int j = 0; j < PB; ++j) {
+            const int v = ob[j];
+            const int n = v >> 4, c = v & 15;
+            b_lds[j] = (2 * n) * LD + c;
+            b_off[j] = n < p.N ? (int)(p.nB[n] + p.kB.lo[c] - kb0) : -1;
+        }
+    }
+    for (int i = lane; i < A_FL + B_FL; i += 64) As[i] = 0.f;   // padding reads as zero
+
+    const int64_t n_chunks = p.K / MFMA_BK;
+    const int64_t wave_g = (int64_t)blockIdx.x * 4 + wave;
+    const int64_t n_waves = (int64_t)gridDim.x * 4;
+
+    auto gather = [&](c64 (&ar)[PA], c64 (&br)[PB], int64_t chunk) {
+        const int64_t k = uniform64(chunk * MFMA_BK);
+        const int64_t kh = k >> p.k_lo_shift, kl = k & (p.k_lo - 1);
+        const c64* Ak = A + sload64(p.kA.hi + kh) + sload64(p.kA.lo + kl);
+        const c64* Bk = B + sload64(p.kB.hi + kh) + sload64(p.kB.lo + kl);
+        if (VEC_A) {
+#pragma unroll
+            for (int j = 0; j < PA; j += 2) {
+                const f32x4 v = *(const f32x4*)(Ak + a_off[j]);
+                ar[j] = c64{v[0], v[1]};
+                ar[j + 1] = c64{v[2], v[3]};
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < PA; ++j)
+                if (a_off[j] >= 0) ar[j] = Ak[a_off[j]];
+        }
+#pragma unroll
+        for (int j = 0; j < PB; ++j)
+            if (b_off[j] >= 0) br[j] = Bk[b_off[j]];
+    };
+
+    f32x16 acc[FN];
+#pragma unroll
+    for (int j = 0; j < FN; ++j)
+#pragma unroll
+        for (int t = 0; t < 16; ++t) acc[j][t] = 0.f;
+
+    auto consume = [&](c64 (&ar)[PA], c64 (&br)[PB], int64_t next_chunk) {
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int j = 0; j < PA; ++j)
+            if (VEC_A || a_off[j] >= 0) {
+                As[a_lds[j]] = ar[j].re;
+                As[32 * LD + a_lds[j]] = ar[j].im;
+            }
+#pragma unroll
+        for (int j = 0; j < PB; ++j)
+            if (b_off[j] >= 0) {
+                Bs[b_lds[j]] = br[j].re;
+                Bs[b_lds[j] + LD] = br[j].im;
+            }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (next_chunk < n_chunks) gather(ar, br, next_chunk);   // refill two chunks ahead
+        const float* a_base = As + kk * 32 * LD + l31 * LD;
+        const float* b_base = Bs + (l31 ^ kk) * LD;
+#pragma unroll
+        for (int kq = 0; kq < MFMA_BK / 4; ++kq) {
+            const f32x4 af = *(const f32x4*)(a_base + kq * 4);
+            f32x4 bf[FN];
+#pragma unroll
+            for (int j = 0; j < FN; ++j) {
+                const f32x4 v = *(const f32x4*)(b_base + j * 32 * LD + kq * 4);
+                bf[j] = negate ? -v : v;
+            }
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int j = 0; j < FN; ++j)
+                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[t], bf[j][t], acc[j], 0, 0, 0);
+        }
+    };
+
+    c64 a0[PA], b0[PB], a1[PA], b1[PB];
+#pragma unroll
+    for (int j = 0; j < PA; ++j) a0[j] = a1[j] = c64{0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < PB; ++j) b0[j] = b1[j] = c64{0.f, 0.f};
+    int64_t c = wave_g;
+    if (c < n_chunks) gather(a0, b0, c);
+    if (c + n_waves < n_chunks) gather(a1, b1, c + n_waves);
+    for (; c < n_chunks; c += 2 * n_waves) {
+        consume(a0, b0, c + 2 * n_waves);
+        if (c + n_waves < n_chunks) consume(a1, b1, c + 3 * n_waves);
+    }
+
+    // this wave's tile -> slab wave_g of the split-K scratch ([S][32][2*16*FN] floats)
+    float* slab = partial + wave_g * (32 * 2 * 16 * FN);
+#pragma unroll
+    for (int j = 0; j < FN; ++j)
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+            const int row = (t & 3) + 8 * (t >> 2) + 4 * kk;
+            slab[row * (2 * 16 * FN) + j * 32 + l31] = acc[j][t];
+        }
+}
+
+template <int FN>
+static hipError_t launch_kstream(const StepArgs& p, const MfmaHints& h, void* scratch,
+                                 int64_t scratch_bytes, hipStream_t stream) {
+    const int64_t n_chunks = p.K / MFMA_BK;
+    int64_t blocks = 256 * 3;                       // resident: 3 blocks per CU
+    if (blocks * 4 > n_chunks) blocks = (n_chunks + 3) / 4;
+    const int64_t slab_bytes = 32 * 2 * 16 * FN * 4;
+    if (blocks * 4 * slab_bytes > scratch_bytes) blocks = scratch_bytes / slab_bytes / 4;
+    if (blocks < 1) return hipErrorInvalidValue;
+    if (h.vecA)
+        hipLaunchKernelGGL((pair_mfma_kstream_kernel<FN, true>), dim3((unsigned)blocks), dim3(256), 0, stream,
+                           p, h, (float*)scratch);
+    else
+        hipLaunchKernelGGL((pair_mfma_kstream_kernel<FN, false>), dim3((unsigned)blocks), dim3(256), 0, stream,
+                           p, h, (float*)scratch);
+    int64_t rblocks = (p.R * p.N + 31) / 32;
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)rblocks), dim3(256), 0, stream, p, blocks * 4,
+                       (int64_t)32, (int64_t)(2 * 16 * FN), (const float*)scratch);
+    return hipGetLastError();
+}
+
 hipError_t launch_pair_mfma(int dtype, const StepArgs& p, const MfmaHints& h, void* scratch,
                             int64_t scratch_bytes, hipStream_t stream) {
     if (dtype != 2) return hipErrorInvalidValue;
+    if (h.stream == 2) {
+        switch (h.bn) {
+            case 16: return launch_kstream<1>(p, h, scratch, scratch_bytes, stream);
+            case 32: return launch_kstream<2>(p, h, scratch, scratch_bytes, stream);
+        }
+        return hipErrorInvalidValue;
+    }
     if (h.stream) {
         switch (h.bn) {
             case 16: return launch_stream<1>(p, h, stream);

@@ -309,7 +309,8 @@ bool all_even(const ctg_plan* p, int64_t w, int64_t len, int64_t stride = 1) {
 
 // Build the order tables of one MFMA step; appends to `blob`, returns offsets.
 void build_mfma_order(const ctg_plan* p, const int64_t* r, int bn, int BM,
-                      std::vector<uint16_t>& blob, size_t* offA, size_t* offB, int* vecA) {
+                      std::vector<uint16_t>& blob, size_t* offA, size_t* offB, int* vecA,
+                      int TB = 256) {
     const int BK = MFMA_BK;
     const int T = BM == 32 ? 64 : 256;  // threads sharing one tile gather
     const int64_t R = r[W_R], K = r[W_K], N = r[W_N];
@@ -370,7 +371,7 @@ void build_mfma_order(const ctg_plan* p, const int64_t* r, int bn, int BM,
     }
     // ---- B tile ----
     {
-        const int n_el = BK * bn, per_t = (n_el + 255) / 256;
+        const int n_el = BK * bn, per_t = (n_el + TB - 1) / TB;   // TB threads share the B tile
         std::vector<int64_t> off(n_el);
         std::vector<int> idx(n_el);
         for (int n = 0; n < bn; ++n)
@@ -383,11 +384,11 @@ void build_mfma_order(const ctg_plan* p, const int64_t* r, int bn, int BM,
             }
         std::stable_sort(idx.begin(), idx.end(), [&](int x, int y) { return off[x] < off[y]; });
         *offB = blob.size();
-        blob.resize(blob.size() + 256 * per_t, 0);
+        blob.resize(blob.size() + TB * per_t, 0);
         uint16_t* out = blob.data() + *offB;
-        for (int tid = 0; tid < 256; ++tid)
+        for (int tid = 0; tid < TB; ++tid)
             for (int j = 0; j < per_t; ++j) {
-                const int e = j * 256 + tid;
+                const int e = j * TB + tid;
                 out[tid * per_t + j] =
                     e < n_el ? (uint16_t)(((idx[e] / BK) << 4) | (idx[e] % BK)) : (uint16_t)0;
             }
@@ -430,6 +431,33 @@ bool mfma_fast_ok(const ctg_plan* p, const int64_t* r, int bn) {
     return true;
 }
 
+// conditions of pair_mfma_kstream_kernel: a tiny result reduced over a huge K
+bool kstream_ok(const ctg_plan* p, const int64_t* r) {
+    const int BK = MFMA_BK;
+    const int64_t R = r[W_R], K = r[W_K], N = r[W_N];
+    if (r[W_BT] != 1 || R > 32 || N > 32 || N < 1 || K < (1 << 16) || K % BK) return false;
+    if (R > r[W_ROW_LO]) return false;                       // rows = one low-table lookup
+    if (r[W_K_LO] % BK || (r[W_K_LO] & (r[W_K_LO] - 1))) return false;
+    if (!tile_additive(p, r[W_KA], r[W_K_LO], K, BK)) return false;
+    if (!tile_additive(p, r[W_KB], r[W_K_LO], K, BK)) return false;
+    const int64_t lim = (int64_t)1 << 31;
+    int64_t ma = 0, mk = 0, mn = 0, mkb = 0;
+    for (int64_t i = 0; i < R; ++i) ma = std::max(ma, p->tables[r[W_ROWA_LO] + i]);
+    for (int i = 0; i < BK; ++i) {
+        const int64_t da = p->tables[r[W_KA] + i] - p->tables[r[W_KA]];
+        const int64_t db = p->tables[r[W_KB] + i] - p->tables[r[W_KB]];
+        if (da < 0 || db < 0) return false;
+        mk = std::max(mk, da);
+        mkb = std::max(mkb, db);
+    }
+    for (int64_t i = 0; i < N; ++i) mn = std::max(mn, p->tables[r[W_NB] + i]);
+    for (int64_t i = 0; i < R; ++i)
+        if (p->tables[r[W_ROWA_LO] + i] < 0) return false;
+    for (int64_t i = 0; i < N; ++i)
+        if (p->tables[r[W_NB] + i] < 0) return false;
+    return ma + mk < lim && mn + mkb < lim;
+}
+
 int build_hints(ctg_exec* e) {
     const ctg_plan* p = e->plan;
     std::vector<uint16_t> blob;
@@ -452,6 +480,12 @@ int build_hints(ctg_exec* e) {
             continue;
         }
         h.bn = mfma_pick_bn(r[W_N]);
+        if (kstream_ok(p, r)) {
+            h.stream = 2;
+            h.bn = r[W_N] <= 16 ? 16 : 32;
+            build_mfma_order(p, r, h.bn, 32, blob, &offA[s], &offB[s], &h.vecA, 64);
+            continue;
+        }
         h.stream = mfma_use_stream(r[W_R], r[W_BT], r[W_K], r[W_N]) ? 1 : 0;
         // big square-ish GEMMs: 128x128 tiles (fast path only) halve the LDS
         // traffic and barriers per flop
@@ -940,7 +974,9 @@ int ctg_exec_step_kernel(ctg_exec* e, int64_t step, char* buf, int64_t buflen) {
         snprintf(name, sizeof(name), "pair_mfma_real_kernel<%s>", p->dtype == CTG_F32 ? "float" : "double");
     } else if (r[W_KERNEL] == KERNEL_MFMA) {
         const MfmaHints& h = e->hints[step];
-        if (h.stream)
+        if (h.stream == 2)
+            snprintf(name, sizeof(name), "pair_mfma_kstream_kernel<%d,%s>", h.bn / 16, h.vecA ? "true" : "false");
+        else if (h.stream)
             snprintf(name, sizeof(name), "pair_mfma_stream_kernel<%d,%s,%s,%s>", h.bn / 16,
                      (h.vecA && h.additive32) ? "true" : "false", h.additive32 ? "true" : "false",
                      r[W_K] < MFMA_BK ? "true" : "false");

@@ -41,6 +41,9 @@ CASES = [
     ("abck,kn->abcn", dict(a=32, b=32, c=16, k=2, n=8)),              # 25: K=2 streaming (pairs along k)
     ("akbc,kn->abcn", dict(a=32, b=3, c=16, k=3, n=8)),               # 26: K=3 streaming, ragged rows
     ("kabc,kn->abcn", dict(a=32, b=32, c=16, k=2, n=2)),              # 27: K=2, k slowest, N=2
+    ("ak,kb->ab", dict(a=20, k=1 << 17, b=9)),                        # 28: k-streaming, ragged R / N
+    ("ka,bk->ab", dict(a=32, k=1 << 16, b=16)),                       # 29: k-streaming, k slowest in A
+    ("aklm,mlkb->ba", dict(a=8, k=64, l=64, m=32, b=32)),             # 30: k-streaming, 3 contracted indices
 ]
 
 
