@@ -30,19 +30,20 @@ def contract_distributed(
     """Contract all slices of ``tree`` across the ranks of ``group``.
 
     Returns the full output on every rank (``root=None``, all-reduce) or only
-    on ``root`` (others get ``None``), like ``contract_mpi``.
+    on ``root`` (others get ``None``), like ``contract_mpi``.  Unlike
+    ``contract_mpi``, trees whose sliced indices appear in the output are
+    accepted.
     """
     import torch
     import torch.distributed as dist
 
     if not dist.is_initialized():
         raise RuntimeError("torch.distributed is not initialised.")
-    if not set(tree.sliced_inds).isdisjoint(set(tree.output)):
-        # same restriction as the reference (core.py:4051-4055)
-        raise NotImplementedError(
-            "Sliced and output indices overlap - only a simple sum of result "
-            "slices is supported."
-        )
+    # Sliced *output* indices: the reference refuses them here (core.py:4051-4055,
+    # it would need a gather + stack).  On the device every slice is scatter-added
+    # into its chunk of the full result tensor (``accum_kernel``), so a rank's
+    # partial is the full tensor with its own chunks filled and zeros elsewhere --
+    # the same single sum-reduce completes it.
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
     if tree.multiplicity < world:
@@ -71,6 +72,12 @@ def contract_distributed(
         partial = torch.as_tensor(
             np.ascontiguousarray(executor_factory(tree, arrays, mine))
         )
+        full_shape = tuple(tree.size_dict[ix] for ix in tree.output)
+        if tuple(partial.shape) != full_shape:
+            raise ValueError(
+                f"executor returned shape {tuple(partial.shape)}, expected the full output {full_shape} "
+                "(use scatter_slices for outer-sliced trees)."
+            )
 
     partial = partial.contiguous()
     on_host = not partial.is_cuda
@@ -86,6 +93,26 @@ def contract_distributed(
         if rank != root:
             return None
     return partial.cpu() if on_host else partial
+
+
+def scatter_slices(tree, slice_ids, slices):
+    """Sum per-slice results into the full output tensor (numpy): inner sliced
+    indices add up, outer (output) sliced indices select the chunk -- what
+    ``gather_slices`` (core.py:3825-3882) does, for an arbitrary subset of the
+    slices.  Host-side helper for executors injected into
+    ``contract_distributed``; the HIP executor does this on the device."""
+    shape = tuple(tree.size_dict[ix] for ix in tree.output)
+    out = None
+    for i, x in zip(slice_ids, slices):
+        x = np.asarray(x)
+        if out is None:
+            out = np.zeros(shape, dtype=x.dtype)
+        key = tree.slice_key(i)
+        idx = tuple(key[ix] if ix in key else slice(None) for ix in tree.output)
+        out[idx] += x
+    if out is None:
+        raise ValueError("no slices given")
+    return out
 
 
 def _to_local_device(x):

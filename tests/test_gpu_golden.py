@@ -198,6 +198,12 @@ def test_contract_distributed_rccl_single_rank():
         check(out, G.expected("lattice8x8_sliced/complex128"), "complex128")
         out0 = tree.contract_distributed(arrays, root=0)
         check(out0, G.expected("lattice8x8_sliced/complex128"), "complex128")
+        # output-sliced tree: chunks scatter-added on the device, same single reduce
+        case2 = next(c for c in TREE_CASES if c["name"] == "rand_s42_r2_o2_hi1_ho2_outsliced")
+        tree2 = G.tree_of(case2)
+        arrays2 = G.arrays_of(case2, "complex128", tree2)
+        out2 = tree2.contract_distributed(arrays2)
+        check(out2, G.expected("rand_s42_r2_o2_hi1_ho2_outsliced/complex128"), "complex128")
     finally:
         dist.destroy_process_group()
 
