@@ -764,11 +764,16 @@ static hipError_t launch_cfg(const StepArgs& p, const MfmaHints& h, void* scratc
 // Occupancy the register allocator is held to: 16 / 12 / 8 waves per CU for
 // 16 / 32 / 64 output columns.  The narrow variants are latency-bound (bytes
 // in flight per CU), so the extra waves are worth more than the registers.
-template <int FN, bool VEC, bool ADD, bool SHORTK>
+template <int FN, bool VEC, bool ADD, bool SHORTK, int NV>
 __global__ __launch_bounds__(256, (FN == 1 ? 4 : FN == 2 ? 3 : 2)) void pair_mfma_stream_kernel(StepArgs p, MfmaHints h, int KP,
                                                                int64_t n_groups) {
     constexpr int LD = MFMA_BK + 4;
     constexpr int PER_T = 32 * MFMA_BK / 64;  // A elements per lane per chunk (8)
+    // A short contraction (K <= 8 / K <= 4) fills only the first NV = 4 / 2 slots of a
+    // lane's gather list; the register budget of two full tasks then holds DEPTH =
+    // 4 / 8 tasks in flight, which is what keeps HBM busy when a task is 1-2 KB.
+    constexpr int DEPTH = 2 * (PER_T / NV);
+    static_assert(NV == PER_T || SHORTK, "partial gather lists only for short contractions");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int LDB = KP + 4;
     float* Bs = (float*)smem;                                   // [2*16*FN][LDB]
@@ -812,12 +817,12 @@ __global__ __launch_bounds__(256, (FN == 1 ? 4 : FN == 2 ? 3 : 2)) void pair_mfm
 
     // ---- per-lane constants ---------------------------------------------------
     // a_pk[j] = (row << 16) | lds offset of element j; column = lds offset % LD
-    int a_pk[PER_T];
-    int a_delta[PER_T];  // ADD: row offset relative to the group base (host-checked < 2^31)
+    int a_pk[NV];
+    int a_delta[NV];  // ADD: row offset relative to the group base (host-checked < 2^31)
     {
         const uint16_t* oa = h.ordA + lane * PER_T;
 #pragma unroll
-        for (int j = 0; j < PER_T; ++j) {
+        for (int j = 0; j < NV; ++j) {
             const int v = oa[j];
             if (SHORTK && (v & 0x8000)) {  // short-K padding: nothing to gather for this slot
                 a_pk[j] = -1;
@@ -870,12 +875,12 @@ __global__ __launch_bounds__(256, (FN == 1 ? 4 : FN == 2 ? 3 : 2)) void pair_mfm
             a_base_off = p.rowA.hi[uniform64(hi)] + p.rowA.lo[uniform64(lo)];
         }
     };
-    auto gather = [&](c64 (&a_reg)[PER_T], int64_t g, int chunk) {
+    auto gather = [&](c64 (&a_reg)[NV], int64_t g, int chunk) {
         const int64_t* ka = kofs_s + chunk * MFMA_BK;
         const int64_t m0 = g * 32;
         if (VEC) {
 #pragma unroll
-            for (int j = 0; j < PER_T; j += 2) {
+            for (int j = 0; j < NV; j += 2) {
                 if (SHORTK && a_pk[j] < 0) continue;  // wave-uniform (depends on j only)
                 const int r = a_pk[j] >> 16, c = (a_pk[j] & 0xffff) - r * LD;
                 int64_t ro;
@@ -892,7 +897,7 @@ __global__ __launch_bounds__(256, (FN == 1 ? 4 : FN == 2 ? 3 : 2)) void pair_mfm
             }
         } else {
 #pragma unroll
-            for (int j = 0; j < PER_T; ++j) {
+            for (int j = 0; j < NV; ++j) {
                 if (SHORTK && a_pk[j] < 0) continue;
                 const int r = a_pk[j] >> 16, c = (a_pk[j] & 0xffff) - r * LD;
                 int64_t ro = -1;
@@ -919,7 +924,7 @@ __global__ __launch_bounds__(256, (FN == 1 ? 4 : FN == 2 ? 3 : 2)) void pair_mfm
     int64_t ig = wave_g;
     int ic = 0;
     int64_t issued = 0;
-    auto issue = [&](c64 (&a_reg)[PER_T]) {
+    auto issue = [&](c64 (&a_reg)[NV]) {
         if (issued < n_tasks) {
             if (ic == 0) resolve_rows_a(ig);
             gather(a_reg, ig, ic);
@@ -933,7 +938,7 @@ __global__ __launch_bounds__(256, (FN == 1 ? 4 : FN == 2 ? 3 : 2)) void pair_mfm
     // cursor of the task being CONSUMED
     int64_t cg = wave_g;
     int cc = 0;
-    auto consume = [&](c64 (&a_reg)[PER_T]) {
+    auto consume = [&](c64 (&a_reg)[NV]) {
         if (cc == 0) {
 #pragma unroll
             for (int j = 0; j < FN; ++j)
@@ -943,7 +948,7 @@ __global__ __launch_bounds__(256, (FN == 1 ? 4 : FN == 2 ? 3 : 2)) void pair_mfm
         // registers -> wave-private LDS (transpose to fragment layout)
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
-        for (int j = 0; j < PER_T; ++j) {
+        for (int j = 0; j < NV; ++j) {
             if (SHORTK && a_pk[j] < 0) continue;
             const int o = a_pk[j] & 0xffff;
             As[o] = a_reg[j].re;
@@ -952,7 +957,7 @@ __global__ __launch_bounds__(256, (FN == 1 ? 4 : FN == 2 ? 3 : 2)) void pair_mfm
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        // refill this register set two tasks ahead
+        // refill this register set DEPTH tasks ahead
         issue(a_reg);
         const bool last = cc == n_chunks - 1;
         // C row base of this group: scalar loads hidden behind the MFMAs below
@@ -1010,20 +1015,21 @@ __global__ __launch_bounds__(256, (FN == 1 ? 4 : FN == 2 ? 3 : 2)) void pair_mfm
         }
     };
 
-    c64 r0[PER_T], r1[PER_T];
-    issue(r0);
-    issue(r1);
-    for (int64_t t = 0; t < n_tasks; t += 2) {
-        consume(r0);
-        if (t + 1 < n_tasks) consume(r1);
+    c64 regs[DEPTH][NV];
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d) issue(regs[d]);
+    for (int64_t t = 0; t < n_tasks; t += DEPTH) {
+#pragma unroll
+        for (int d = 0; d < DEPTH; ++d)
+            if (t + d < n_tasks) consume(regs[d]);
     }
     (void)rows_all;
 }
 
-template <int FN, bool VEC, bool ADD, bool SHORTK>
+template <int FN, bool VEC, bool ADD, bool SHORTK, int NV>
 static hipError_t launch_stream_t(const StepArgs& p, const MfmaHints& h, int KP, size_t smem,
                                   hipStream_t stream) {
-    auto kern = pair_mfma_stream_kernel<FN, VEC, ADD, SHORTK>;
+    auto kern = pair_mfma_stream_kernel<FN, VEC, ADD, SHORTK, NV>;
     static int blocks_per_cu[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};  // by KP / 16
     int& bpc = blocks_per_cu[KP / 16];
     if (bpc == 0) {
@@ -1046,20 +1052,26 @@ static hipError_t launch_stream_t(const StepArgs& p, const MfmaHints& h, int KP,
     return hipGetLastError();
 }
 
+template <int FN, bool SHORTK, int NV>
+static hipError_t launch_stream_v(const StepArgs& p, const MfmaHints& h, int KP, size_t smem,
+                                  hipStream_t stream) {
+    if (h.vecA && h.additive32) return launch_stream_t<FN, true, true, SHORTK, NV>(p, h, KP, smem, stream);
+    if (h.additive32) return launch_stream_t<FN, false, true, SHORTK, NV>(p, h, KP, smem, stream);
+    return launch_stream_t<FN, false, false, SHORTK, NV>(p, h, KP, smem, stream);
+}
+
 template <int FN>
 static hipError_t launch_stream(const StepArgs& p, const MfmaHints& h, hipStream_t stream) {
     const int KP = (int)((p.K + MFMA_BK - 1) / MFMA_BK) * MFMA_BK;
     const int LDB = KP + 4;
     const size_t smem = (size_t)2 * 16 * FN * LDB * 4 + (size_t)KP * 8 +
                         (size_t)4 * 2 * 32 * (MFMA_BK + 4) * 4 + (size_t)4 * 64 * 8;
-    if (p.K < MFMA_BK) {  // short contraction: order table holds only the real columns
-        if (h.vecA && h.additive32) return launch_stream_t<FN, true, true, true>(p, h, KP, smem, stream);
-        if (h.additive32) return launch_stream_t<FN, false, true, true>(p, h, KP, smem, stream);
-        return launch_stream_t<FN, false, false, true>(p, h, KP, smem, stream);
-    }
-    if (h.vecA && h.additive32) return launch_stream_t<FN, true, true, false>(p, h, KP, smem, stream);
-    if (h.additive32) return launch_stream_t<FN, false, true, false>(p, h, KP, smem, stream);
-    return launch_stream_t<FN, false, false, false>(p, h, KP, smem, stream);
+    // short contraction: the order table holds only the real columns, 32 K of
+    // them per task = the first K / 2 slots of every lane
+    if (p.K <= 4) return launch_stream_v<FN, true, 2>(p, h, KP, smem, stream);
+    if (p.K <= 8) return launch_stream_v<FN, true, 4>(p, h, KP, smem, stream);
+    if (p.K < MFMA_BK) return launch_stream_v<FN, true, 8>(p, h, KP, smem, stream);
+    return launch_stream_v<FN, false, 8>(p, h, KP, smem, stream);
 }
 
 // ------------------------------------------------------------------------- //

@@ -977,9 +977,9 @@ int ctg_exec_step_kernel(ctg_exec* e, int64_t step, char* buf, int64_t buflen) {
         if (h.stream == 2)
             snprintf(name, sizeof(name), "pair_mfma_kstream_kernel<%d,%s>", h.bn / 16, h.vecA ? "true" : "false");
         else if (h.stream)
-            snprintf(name, sizeof(name), "pair_mfma_stream_kernel<%d,%s,%s,%s>", h.bn / 16,
+            snprintf(name, sizeof(name), "pair_mfma_stream_kernel<%d,%s,%s,%s,%d>", h.bn / 16,
                      (h.vecA && h.additive32) ? "true" : "false", h.additive32 ? "true" : "false",
-                     r[W_K] < MFMA_BK ? "true" : "false");
+                     r[W_K] < MFMA_BK ? "true" : "false", r[W_K] <= 4 ? 2 : (r[W_K] <= 8 ? 4 : 8));
         else
             snprintf(name, sizeof(name), "%s<128,%d,16>,%s",
                      h.fast ? "pair_mfma_fast_kernel" : "pair_mfma_c64_kernel", h.bn,

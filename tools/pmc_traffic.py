@@ -22,9 +22,12 @@ def step_kernel_name(rocprof_name):
     m = re.match(r"(pair_mfma_(?:fast|c64)_kernel)<ctg::MfmaCfg<(\d+), (\d+), (\d+), \d+, \d+>, (true|false)>", rocprof_name)
     if m:
         return f"{m.group(1)}<{m.group(2)},{m.group(3)},{m.group(4)}>,{m.group(5)}"
-    m = re.match(r"pair_mfma_stream_kernel<(\d+), (true|false), (true|false), (true|false)>", rocprof_name)
+    m = re.match(r"pair_mfma_stream_kernel<(\d+), (true|false), (true|false), (true|false), (\d+)>", rocprof_name)
     if m:
-        return f"pair_mfma_stream_kernel<{m.group(1)},{m.group(2)},{m.group(3)},{m.group(4)}>"
+        return f"pair_mfma_stream_kernel<{m.group(1)},{m.group(2)},{m.group(3)},{m.group(4)},{m.group(5)}>"
+    m = re.match(r"pair_mfma_kstream_kernel<(\d+), (true|false)>", rocprof_name)
+    if m:
+        return f"pair_mfma_kstream_kernel<{m.group(1)},{m.group(2)}>"
     return rocprof_name.split("<")[0]
 
 
