@@ -23,3 +23,6 @@ python tools/rocprof_summary.py $F $O/pmc_fetch_k > /dev/null 2>&1
 python tools/rocprof_summary.py $W $O/pmc_write_k > /dev/null 2>&1
 python tools/pmc_traffic.py $F $W 4 $O/pmc_summary.json | tail -8
 find $O -name "*.db" -size +30M -delete
+# per-step roofline table of one slice (HIP events on the exec's stream)
+timeout 600 python bench.py --steps 1 --warmup 1 --no-cpu-baseline --dump-steps $O/steps.json > /dev/null 2>&1
+python tools/steps_report.py $O/steps.json 40 > $O/steps.txt 2>&1
