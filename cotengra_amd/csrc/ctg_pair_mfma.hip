@@ -1230,7 +1230,8 @@ static hipError_t launch_kstream(const StepArgs& p, const MfmaHints& h, void* sc
                                  int64_t scratch_bytes, hipStream_t stream) {
     const int64_t n_chunks = p.K / MFMA_BK;
     int64_t blocks = 256 * 3;                       // resident: 3 blocks per CU
-    if (blocks * 4 > n_chunks) blocks = (n_chunks + 3) / 4;
+    // at least 8 chunks per wave: every wave costs a slab in the final reduction
+    if (blocks * 32 > n_chunks) blocks = (n_chunks + 31) / 32;
     const int64_t slab_bytes = 32 * 2 * 16 * FN * 4;
     if (blocks * 4 * slab_bytes > scratch_bytes) blocks = scratch_bytes / slab_bytes / 4;
     if (blocks < 1) return hipErrorInvalidValue;

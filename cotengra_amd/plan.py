@@ -392,6 +392,11 @@ def choose_kernel(dtype, Bt, M, K, N):
         return KERNEL_VALU
     if K >= 4 and N >= 8 and M >= 32 and (M * N * K) >= (1 << 15):
         return KERNEL_MFMA
+    # small result reduced over a very long contraction: the k-streaming kernel
+    # (csrc: kstream_ok) splits K over the chip.  (Plain dot products stay on the
+    # wavefront-reduction kernel: a 32 x 16 MFMA tile would be 1/32 full.)
+    if Bt == 1 and K >= (1 << 16) and M <= 32 and N <= 32 and M * N >= 256:
+        return KERNEL_MFMA
     # tall-skinny streaming kernel: HBM-bound, so padding N up to an MFMA tile
     # costs nothing (csrc/ctg_common.h: mfma_use_stream)
     if Bt == 1 and 2 <= K <= 128 and N <= 64 and M >= 8192:  # (stream or tiled, runtime picks)
