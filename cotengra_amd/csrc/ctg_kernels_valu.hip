@@ -119,7 +119,12 @@ static hipError_t launch_pair_valu_t(const StepArgs& p, void* scratch, int64_t s
     const int64_t outs = p.R * p.N;
     // few outputs, long contraction -> lanes along k
     if (p.K >= 256 && outs <= (1 << 15)) {
-        int64_t G = (p.K + 2047) / 2048;             // >= 2048 k per item keeps partial traffic low
+        // k per work item: long enough to keep the partial-sum traffic low, short
+        // enough that a handful of outputs still spreads over the whole chip
+        // (at most 256 partials per output: the finish pass adds them serially)
+        int64_t per_item = outs <= 64 ? 512 : 2048;
+        if (per_item * 256 < p.K) per_item = (p.K + 255) / 256;
+        int64_t G = (p.K + per_item - 1) / per_item;
         const int64_t want = (1 << 14) / (outs > 0 ? outs : 1);  // ~16k waves fill the chip
         if (G > want) G = want;
         if (G < 1) G = 1;
