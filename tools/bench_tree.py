@@ -27,4 +27,4 @@ for _ in range(reps):
 ex.sync()
 dt = (time.perf_counter() - t0) / reps
 print(f"{name}: {len(plan.steps)} steps, {dt*1e6:.1f} us per contraction, "
-      f"{plan.flops_per_slice()/dt/1e12:.2f} TFLOP/s, graph={'off' if os.environ.get('CTG_NO_GRAPH') else 'on'}")
+      f"{plan.flops_per_slice()/dt/1e12:.2f} TFLOP/s, hipGraph replay={'on' if os.environ.get('CTG_GRAPH') else 'off'}")
