@@ -709,7 +709,7 @@ static hipError_t launch_cfg(const StepArgs& p, const MfmaHints& h, void* scratc
     const int64_t tiles = tiles_m * tiles_n * p.Bt;
     const int64_t nk_total = (p.K + BK - 1) / BK;
     int64_t S = 1;
-    if (tiles < 512 && nk_total >= 16) {
+    if ((tiles < 256 && nk_total >= 16) || (tiles < 512 && nk_total >= 64)) {
         S = (1024 + tiles - 1) / tiles;
         if (S > nk_total / 4) S = nk_total / 4;
         const int64_t slab_bytes = tiles_m * BM * tiles_n * BN * 8 * p.Bt;

@@ -492,6 +492,12 @@ int build_hints(ctg_exec* e) {
         if (!h.stream && r[W_N] % 128 == 0 && r[W_R] * r[W_N] >= (1ll << 22) && r[W_K] >= 256 &&
             mfma_fast_ok(p, r, 128))
             h.bn = 128;
+        // small problems: narrower column tiles until the output alone gives every
+        // CU a block -- cheaper than split-K (no slabs to write and reduce)
+        if (!h.stream) {
+            const int64_t tiles_m = (r[W_R] + MFMA_BM - 1) / MFMA_BM;
+            while (h.bn > 16 && tiles_m * ((r[W_N] + h.bn - 1) / h.bn) * r[W_BT] < 256) h.bn /= 2;
+        }
         h.additive32 = (h.stream && tile_additive(p, r[W_ROWA_LO], r[W_ROW_LO], r[W_R], 32) &&
                         tile_additive(p, r[W_ROWC_LO], r[W_ROW_LO], r[W_R], 32))
                            ? 1
