@@ -61,8 +61,14 @@ def gate_matrix(name, params=()):
 def circuit_to_network(n, gates, bitstring=None, simplify=True, dtype="complex128"):
     """Amplitude network ``<bitstring| circuit |0...0>``.
 
+    ``bitstring`` holds one character per qubit: ``'0'`` / ``'1'`` project the
+    qubit, any other character (e.g. ``'?'``) leaves it *open* -- the network
+    then has one output index per open qubit (in qubit order) and contracts to
+    the batch of ``2**n_open`` amplitudes, which gives the pairwise steps a real
+    N dimension.
+
     Returns ``(inputs, output, size_dict, arrays)`` with single-character index
-    labels (``utils.get_symbol``), all of size 2, no output indices.
+    labels (``utils.get_symbol``), all of size 2.
     """
     if bitstring is None:
         bitstring = "0" * n
@@ -92,11 +98,15 @@ def circuit_to_network(n, gates, bitstring=None, simplify=True, dtype="complex12
             o0, o1 = new_ix(), new_ix()
             tensors.append([[o0, o1, cur[q0], cur[q1]], U.reshape(2, 2, 2, 2).astype(complex)])
             cur[q0], cur[q1] = o0, o1
+    open_inds = []
     for q in range(n):
-        tensors.append([[cur[q]], (one if bitstring[q] == "1" else zero).copy()])
+        if bitstring[q] in "01":
+            tensors.append([[cur[q]], (one if bitstring[q] == "1" else zero).copy()])
+        else:
+            open_inds.append(cur[q])
 
     if simplify:
-        tensors = absorb_low_rank(tensors)
+        tensors = absorb_low_rank(tensors, keep=set(open_inds))
 
     # relabel compactly in order of appearance
     relabel = {}
@@ -110,12 +120,14 @@ def circuit_to_network(n, gates, bitstring=None, simplify=True, dtype="complex12
         inputs.append(tuple(term))
         arrays.append(np.ascontiguousarray(arr.astype(dtype)))
     size_dict = {ix: 2 for ix in relabel.values()}
-    return inputs, (), size_dict, arrays
+    return inputs, tuple(relabel[ix] for ix in open_inds), size_dict, arrays
 
 
-def absorb_low_rank(tensors):
+def absorb_low_rank(tensors, keep=()):
     """Contract every tensor of rank <= 2 into a neighbour (never raising the
-    neighbour's rank), until none is left."""
+    neighbour's rank), until none is left.  Indices in ``keep`` (open outputs)
+    are never summed."""
+    keep = set(keep)
     tensors = [[list(i), a] for i, a in tensors]
     where = {}
     for t, (inds, _) in enumerate(tensors):
@@ -132,13 +144,15 @@ def absorb_low_rank(tensors):
             if len(inds) > 2 or len(alive) == 1:
                 continue
             # neighbour sharing an index, highest rank first
-            nbrs = {u for ix in inds for u in where[ix] if u != t and u in alive}
+            nbrs = {u for ix in inds if ix not in keep for u in where[ix] if u != t and u in alive}
             if not nbrs:
                 continue
             u = max(nbrs, key=lambda v: (len(tensors[v][0]), -v))
             uinds, uarr = tensors[u]
-            shared = [ix for ix in inds if ix in uinds]
-            keep_t = [ix for ix in inds if ix not in uinds]
+            shared = [ix for ix in inds if ix in uinds and ix not in keep]
+            keep_t = [ix for ix in inds if ix not in shared]
+            if len(keep_t) > 1:
+                continue   # (open index + dangling index: leave the tensor alone)
             # result keeps u's index order with shared slots replaced by t's free index
             letters = {ix: chr(ord("a") + k) for k, ix in enumerate(dict.fromkeys(uinds + inds))}
             out = []

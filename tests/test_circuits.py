@@ -77,6 +77,59 @@ def test_network_amplitudes_match_statevector(simplify):
         assert abs(amp - psi[tuple(int(b) for b in bits)]) < 1e-13
 
 
+def random_circuit(n, depth, seed):
+    """Sycamore-style layers: a random single-qubit gate on every qubit, then
+    fSim gates on a brick pattern of neighbouring pairs."""
+    rng = np.random.default_rng(seed)
+    gates = []
+    for d in range(depth):
+        for q in range(n):
+            name = ("x_1_2", "y_1_2", "hz_1_2", "rz")[int(rng.integers(0, 4))]
+            gates.append((name, (q,), (float(rng.normal()),) if name == "rz" else ()))
+        for q in range(d % 2, n - 1, 2):
+            gates.append(("fs", (q, q + 1), (float(rng.normal()), float(rng.normal()))))
+    return gates
+
+
+@pytest.mark.parametrize("bits", ["0??1", "????", "1?0?"])
+@pytest.mark.parametrize("simplify", [False, True])
+def test_open_qubits_give_amplitude_batches(bits, simplify):
+    n, gates = parse_qsim(QSIM)
+    psi = statevector(n, gates)
+    inputs, output, sd, arrays = circuit_to_network(n, gates, bits, simplify=simplify)
+    assert len(output) == bits.count("?")
+    tree = ca.array_contract_tree(inputs, output, sd)
+    amps = orc.contract(tree, arrays)
+    sel = tuple(slice(None) if b == "?" else int(b) for b in bits)
+    assert np.allclose(amps, psi[sel], atol=1e-13)
+
+
+@pytest.mark.gpu
+def test_batched_amplitudes_on_gpu_sliced():
+    """12 qubits, 6 layers, 5 open qubits: a 32-amplitude batch.  The tree is
+    sliced on one output (outer) and two inner indices, so the HIP path goes
+    through chunk scatter + inner accumulation; checked against the dense
+    state vector."""
+    n = 12
+    gates = random_circuit(n, 6, seed=7)
+    psi = statevector(n, gates)
+    bits = "0?1?0??10?01"
+    inputs, output, sd, arrays = circuit_to_network(n, gates, bits, simplify=True, dtype="complex128")
+    tree = ca.array_contract_tree(inputs, output, sd)
+    sel = tuple(slice(None) if b == "?" else int(b) for b in bits)
+    ref = psi[sel]
+    assert np.allclose(orc.contract(tree, arrays), ref, atol=1e-12)
+    big = max((p for p, _, _ in tree.traverse()), key=tree.get_size)
+    inner = [ix for ix in tree.get_legs(big) if ix not in tree.output][:2]
+    for ix in [tree.output[1]] + inner:
+        tree.remove_ind_(ix)
+    assert tree.nslices == 8
+    for dtype, tol in (("complex128", 1e-11), ("complex64", 2e-5)):
+        got = np.asarray(tree.contract([a.astype(dtype) for a in arrays]))
+        assert got.shape == ref.shape
+        assert np.abs(got - ref).max() <= tol * np.abs(ref).max()
+
+
 def m10():
     rec = ca.load_network(M10_TREE)
     tree = ca.tree_from_record(rec)
