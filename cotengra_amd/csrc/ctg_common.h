@@ -223,11 +223,11 @@ struct MfmaHints {
 
 // steps the streaming kernel takes: short contraction, few columns, many rows
 inline bool mfma_use_stream(int64_t R, int64_t Bt, int64_t K, int64_t N) {
-    // N = 64 only when the contraction is so short that the step is a pure
-    // streaming write (the wide tile costs registers, i.e. occupancy)
+    // thresholds measured on the m20 steps (wider column tiles cost registers, i.e.
+    // waves in flight; longer K costs the resident B panel's LDS)
     // (measured: with 32 columns the tiled kernel wins from K = 128 on -- the resident
     // B panel then costs the streaming kernel a third of its waves)
-    return Bt == 1 && (N <= 16 ? K <= 128 : (N <= 32 ? K <= 64 : (N <= 64 && K <= 8))) && R >= 8192;
+    return Bt == 1 && (N <= 16 ? K <= 128 : (N <= 32 ? K <= 64 : (N <= 64 && K <= 32))) && R >= 8192;
 }
 
 inline int mfma_pick_bn(int64_t N) { return N <= 16 ? 16 : (N <= 32 ? 32 : 64); }
