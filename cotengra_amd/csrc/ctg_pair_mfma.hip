@@ -772,7 +772,9 @@ __global__ __launch_bounds__(256, (FN == 1 ? 4 : FN == 2 ? 3 : 2)) void pair_mfm
     // A short contraction (K <= 8 / K <= 4) fills only the first NV = 4 / 2 slots of a
     // lane's gather list; the register budget of two full tasks then holds DEPTH =
     // 4 / 8 tasks in flight, which is what keeps HBM busy when a task is 1-2 KB.
-    constexpr int DEPTH = 2 * (PER_T / NV);
+    // (32 columns: 12 waves per CU, three tasks each -- measured -8 %; a deeper
+    // ring does nothing for 64 columns, which is not latency-bound)
+    constexpr int DEPTH = (FN == 2 ? 3 : 2) * (PER_T / NV);
     static_assert(NV == PER_T || SHORTK, "partial gather lists only for short contractions");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int LDB = KP + 4;
