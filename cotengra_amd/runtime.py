@@ -83,6 +83,14 @@ def load():
             "(python -c 'import __graft_entry__ as g; g.build()'). "
             "cotengra_amd has no CPU fallback."
         )
+    # PyTorch bundles its own libamdhip64.  The host layer uses torch for device
+    # tensors, streams and RCCL, so torch's runtime must be the one this library
+    # binds to: loading ours first would bring a second HIP runtime into the
+    # process ("no ROCm-capable device" on the later one).
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     lib = C.CDLL(_LIB_PATH)
     i64p = C.POINTER(C.c_int64)
     vp = C.c_void_p
