@@ -45,6 +45,16 @@
 
 namespace ctg {
 
+#ifdef CTG_TIMING
+// experiment build only (tools/exp_timing.py): wall-clock phases of the fast
+// kernel, summed over blocks -- [0] constants, [1] first gather + stage, [2] k
+// loop, [3] epilogue issue, [4] store drain, [5] number of blocks
+__device__ unsigned long long ctg_timing[8];
+#define CTG_STAMP(name) const unsigned long long name = wall_clock64()
+#else
+#define CTG_STAMP(name)
+#endif
+
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
@@ -387,6 +397,7 @@ __global__ __launch_bounds__(256, Cfg::FAST_BLOCKS) void pair_mfma_fast_kernel(S
     auto fsw = [](int row) { return ((row >> 1) & 7) ^ ((row >> 4) & 1); };
     auto swz = [&](int row, int c) { return row * LD + (((c >> 1) ^ fsw(row)) << 1) + (c & 1); };
 
+    CTG_STAMP(T0);
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -448,6 +459,7 @@ __global__ __launch_bounds__(256, Cfg::FAST_BLOCKS) void pair_mfma_fast_kernel(S
     }
     auto unpack = [](const unsigned* pk, int j) { return (int)((j & 1) ? pk[j / 2] >> 16 : pk[j / 2] & 0xffffu); };
 
+    CTG_STAMP(T1);
     c64 a_reg[Cfg::A_PER_T], b_reg[Cfg::B_PER_T];
     // uniform k offsets of the k-step being gathered: the four scalar loads are
     // issued one phase before their first use (the host only takes this path
@@ -588,6 +600,7 @@ __global__ __launch_bounds__(256, Cfg::FAST_BLOCKS) void pair_mfma_fast_kernel(S
         gather_b();
     }
     __syncthreads();
+    CTG_STAMP(T2);
     load_frag(0, 0, 0);
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -621,6 +634,7 @@ __global__ __launch_bounds__(256, Cfg::FAST_BLOCKS) void pair_mfma_fast_kernel(S
         k_step(kt, std::false_type{}, std::false_type{});
     }
 
+    CTG_STAMP(T3);
     if (partial != nullptr) {
         const int64_t ldp = 2 * tiles_n * BN;
         float* slab = partial + ((bz * S_split + ksplit) * (tiles_m * BM)) * ldp;
@@ -649,6 +663,19 @@ __global__ __launch_bounds__(256, Cfg::FAST_BLOCKS) void pair_mfma_fast_kernel(S
             }
         }
     }
+#ifdef CTG_TIMING
+    CTG_STAMP(T4);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // all stores acknowledged
+    CTG_STAMP(T5);
+    if (tid == 0) {
+        atomicAdd(&ctg_timing[0], T1 - T0);
+        atomicAdd(&ctg_timing[1], T2 - T1);
+        atomicAdd(&ctg_timing[2], T3 - T2);
+        atomicAdd(&ctg_timing[3], T4 - T3);
+        atomicAdd(&ctg_timing[4], T5 - T4);
+        atomicAdd(&ctg_timing[5], 1ull);
+    }
+#endif
 }
 
 // sum the split-K slabs in a fixed order and scatter into C.  A block reduces
@@ -1277,3 +1304,15 @@ hipError_t launch_pair_mfma(int dtype, const StepArgs& p, const MfmaHints& h, vo
 }
 
 }  // namespace ctg
+
+#ifdef CTG_TIMING
+extern "C" void ctg_debug_timing(unsigned long long* out, int reset) {
+    (void)hipDeviceSynchronize();
+    (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(ctg::ctg_timing), 64);
+    if (reset) {
+        unsigned long long z[8] = {};
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(ctg::ctg_timing), z, 64);
+    }
+}
+#endif
+

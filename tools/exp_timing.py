@@ -1,3 +1,12 @@
+#!/usr/bin/env python
+"""Where a tile of the fast MFMA kernel spends its time.
+
+Needs an experiment build of the library with the in-kernel wall-clock stamps:
+
+  cd cotengra_amd/csrc && hipcc --offload-arch=gfx950 -O3 -std=c++17 -shared -fPIC -DCTG_TIMING \
+      -o ../lib/libctg_hip_timing.so ctg_runtime.hip ctg_kernels_valu.hip ctg_pair_mfma.hip ctg_pair_mfma_f64.hip
+  CTG_LIB=$PWD/cotengra_amd/lib/libctg_hip_timing.so python tools/exp_timing.py
+"""
 import ctypes as C, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
