@@ -24,7 +24,7 @@ this file              reference (cotengra v0.8.2)
 =====================  =======================================================
 ``SliceInfo``          ``core.py:99-111``
 ``get_slice_strides``  ``core.py:114-122``
-``from_path``          ``core.py:537-636`` (pairwise paths only)
+``from_path``          ``core.py:537-636`` (n-ary steps expanded greedily)
 ``get_legs`` ...       ``core.py:861-1095``
 ``traverse``           ``core.py:1781-1864``
 ``remove_ind``         ``core.py:1966-2042``
@@ -191,9 +191,11 @@ class ContractionTree:
     ):
         """Build a complete tree from a pairwise contraction path, either
         with recycled linear ids (``path``) or single-static-assignment ids
-        (``ssa_path``) -- reference core.py:537-636.  Steps that merge three
-        or more tensors need a sub-optimizer in the reference (core.py:1690)
-        and are rejected here: the pathfinder is out of scope.
+        (``ssa_path``) -- reference core.py:537-636.  A step that merges three
+        or more tensors is expanded into pairwise merges by a small greedy rule
+        (smallest intermediate first); the reference runs a sub-optimizer there
+        (core.py:1690), so for such steps the pairwise order -- not the result --
+        may differ from the reference's.
         """
         if (path is None) == (ssa_path is None):
             raise ValueError(
@@ -203,14 +205,25 @@ class ContractionTree:
         if tree.N == 1:
             return tree
 
+        def merged_size(x, y):
+            lx, ly = tree.get_legs(x), tree.get_legs(y)
+            size = 1
+            for ix in {**lx, **ly}:
+                if lx.get(ix, 0) + ly.get(ix, 0) < tree.appearances[ix]:
+                    size *= tree.size_dict[ix]
+            return size
+
         def merge(group):
+            group = list(group)
             if len(group) == 1:
                 return group[0]
-            if len(group) != 2:
-                raise NotImplementedError(
-                    "Only pairwise paths are supported by the MI355X "
-                    f"executor, got a step contracting {len(group)} tensors."
+            while len(group) > 2:
+                _, i, j = min(
+                    (merged_size(group[i], group[j]), i, j)
+                    for i in range(len(group)) for j in range(i + 1, len(group))
                 )
+                y, x = group.pop(j), group.pop(i)
+                group.append(tree._merge(x, y))
             return tree._merge(*group)
 
         if ssa_path is not None:

@@ -56,8 +56,9 @@ def test_projection_and_errors():
         p.remove_ind("b")
     with pytest.raises(ValueError):
         ca.ContractionTree.from_path(["ab", "bc"], "ac", dict(a=2, b=2, c=2))
-    with pytest.raises(NotImplementedError):
-        ca.ContractionTree.from_path(["ab", "bc", "cd"], "ad", dict(a=2, b=2, c=2, d=2), path=[(0, 1, 2)])
+    # a three-tensor step is expanded into pairwise merges
+    t3 = ca.ContractionTree.from_path(["ab", "bc", "cd"], "ad", dict(a=2, b=2, c=2, d=2), path=[(0, 1, 2)])
+    assert t3.is_complete() and len(list(t3.traverse())) == 2
 
 
 def test_cost_model_and_paths():
@@ -126,3 +127,21 @@ def test_api_compat_helpers(capsys):
     assert v(1, 2, 3) == 12
     w = Via(lambda *xs: sum(xs), lambda x: x + 1, lambda y: -y)
     assert w(1, 2) == -5
+
+
+def test_from_path_expands_multi_tensor_steps():
+    """A path step naming three or more tensors (opt_einsum allows it) becomes
+    pairwise merges; the contraction value is unchanged."""
+    import numpy as np
+    from oracle import contract_ref as orc
+
+    inputs = [("a", "b"), ("b", "c"), ("c", "d"), ("d", "e"), ("e", "a")]
+    size_dict = {"a": 3, "b": 4, "c": 2, "d": 5, "e": 3}
+    tree = ca.ContractionTree.from_path(inputs, (), size_dict, path=[(0, 1, 2), (0, 1, 2)])
+    assert tree.is_complete() and len(list(tree.traverse())) == 4
+    arrays = ca.make_arrays_from_inputs(inputs, size_dict, seed=3, dtype="float64")
+    ref = np.einsum("ab,bc,cd,de,ea->", *arrays)
+    assert abs(orc.contract(tree, arrays) - ref) < 1e-12 * abs(ref)
+    # ssa form as well
+    tree2 = ca.ContractionTree.from_path(inputs, (), size_dict, ssa_path=[(0, 1, 2, 3), (4, 5)])
+    assert abs(orc.contract(tree2, arrays) - ref) < 1e-12 * abs(ref)
