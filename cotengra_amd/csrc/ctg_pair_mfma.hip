@@ -808,7 +808,6 @@ __global__ __launch_bounds__(256, (FN == 1 ? 4 : FN == 2 ? 3 : 2)) void pair_mfm
     float* Bs = (float*)smem;                                   // [2*16*FN][LDB]
     int64_t* kofs_s = (int64_t*)(Bs + 2 * 16 * FN * LDB);       // [KP]
     float* As_all = (float*)(kofs_s + KP);                      // [4 waves][2][32][LD]
-    int64_t* rows_all = (int64_t*)(As_all + 4 * 2 * 32 * LD);   // [4 waves][2][32] (general path)
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -1052,7 +1051,6 @@ __global__ __launch_bounds__(256, (FN == 1 ? 4 : FN == 2 ? 3 : 2)) void pair_mfm
         for (int d = 0; d < DEPTH; ++d)
             if (t + d < n_tasks) consume(regs[d]);
     }
-    (void)rows_all;
 }
 
 template <int FN, bool VEC, bool ADD, bool SHORTK, int NV>
@@ -1094,7 +1092,7 @@ static hipError_t launch_stream(const StepArgs& p, const MfmaHints& h, hipStream
     const int KP = (int)((p.K + MFMA_BK - 1) / MFMA_BK) * MFMA_BK;
     const int LDB = KP + 4;
     const size_t smem = (size_t)2 * 16 * FN * LDB * 4 + (size_t)KP * 8 +
-                        (size_t)4 * 2 * 32 * (MFMA_BK + 4) * 4 + (size_t)4 * 64 * 8;
+                        (size_t)4 * 2 * 32 * (MFMA_BK + 4) * 4;
     // short contraction: the order table holds only the real columns, 32 K of
     // them per task = the first K / 2 slots of every lane
     if (p.K <= 4) return launch_stream_v<FN, true, 2>(p, h, KP, smem, stream);
