@@ -1,0 +1,325 @@
+// ctg_pathfind.cpp -- host-side tree tools behind the C ABI (no GPU involved):
+// a greedy pairwise path finder and a greedy slicer.
+//
+// This is the slot the reference fills with its optional Rust accelerator
+// (`cotengrust`: cotengra/pathfinders/path_basic.py:1351-1383 picks it up for
+// `optimize_greedy`) and, for slicing, with the pure-Python `SliceFinder`
+// (cotengra/slicer.py:204-430 over the incremental cost model of
+// `ContractionCosts`, slicer.py:17-201).  The hyper-optimizers that drive
+// these building blocks stay in the reference, on the host, unchanged; what is
+// native here is the inner loop they call thousands of times -- and what the
+// stand-alone front ends (`cotengra_amd.einsum`, `ContractionTree.slice_`) use
+// when no tree is supplied.
+//
+// Semantics restated from the reference (not its code):
+//  * greedy: every pair of tensors sharing an index is a candidate with
+//      score = size(ab) / costmod - (size(a) + size(b)) * costmod
+//    (path_basic.py:624-639); with a temperature the score becomes
+//    sign(s) log|s| - T * gumbel() (Boltzmann sampling); the best candidate is
+//    contracted, candidates of the new tensor with its neighbours are added;
+//    indices shared by more than `max_neighbors` tensors (batch-like) do not
+//    generate candidates; what is left disconnected is combined smallest first
+//    (path_basic.py:1098-1106).  An index survives on an intermediate while it
+//    still appears elsewhere (inputs + output), which is what makes hyper
+//    indices work (core.py:246-258).
+//  * slicing: removing an index of extent d divides the flops of every
+//    contraction it is involved in and the size of every intermediate it is a
+//    leg of by d, and multiplies the number of slices by d (slicer.py:60-70,
+//    136-192).  Greedy rule: an index is worth the bits it takes off the
+//    intermediates that are still too large; among the most useful indices
+//    the one that leaves the smallest total flops is removed; repeat until
+//    every intermediate fits the target.
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <map>
+#include <queue>
+#include <random>
+#include <set>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "../../include/ctg_hip.h"
+
+namespace {
+
+struct Network {
+    int64_t n_inputs = 0, n_inds = 0;
+    std::vector<std::map<int64_t, int>> legs;  // per tensor: index -> appearances absorbed
+    std::vector<int> appearances;              // per index: total over inputs + output
+    std::vector<double> log2size;              // per index
+    std::vector<double> size;                  // per index
+};
+
+bool build_network(int64_t n_inputs, const int64_t* offsets, const int64_t* inds, int64_t n_out,
+                   const int64_t* out_inds, int64_t n_inds, const double* sizes, Network& net) {
+    if (n_inputs < 1 || n_inds < 0 || !offsets || (!inds && offsets[n_inputs] > 0) || !sizes) return false;
+    net.n_inputs = n_inputs;
+    net.n_inds = n_inds;
+    net.legs.assign(n_inputs, {});
+    net.appearances.assign(n_inds, 0);
+    net.log2size.resize(n_inds);
+    for (int64_t i = 0; i < n_inds; ++i) {
+        if (!(sizes[i] >= 1.0)) return false;
+        net.log2size[i] = std::log2(sizes[i]);
+    }
+    net.size.assign(sizes, sizes + n_inds);
+    for (int64_t t = 0; t < n_inputs; ++t) {
+        if (offsets[t + 1] < offsets[t]) return false;
+        for (int64_t q = offsets[t]; q < offsets[t + 1]; ++q) {
+            const int64_t ix = inds[q];
+            if (ix < 0 || ix >= n_inds) return false;
+            net.legs[t][ix] += 1;
+            net.appearances[ix] += 1;
+        }
+    }
+    for (int64_t q = 0; q < n_out; ++q) {
+        if (out_inds[q] < 0 || out_inds[q] >= n_inds) return false;
+        net.appearances[out_inds[q]] += 1;
+    }
+    return true;
+}
+
+// legs of the contraction of a and b: an index stays while it appears elsewhere
+std::map<int64_t, int> contract_legs(const std::map<int64_t, int>& a, const std::map<int64_t, int>& b,
+                                     const std::vector<int>& appearances) {
+    std::map<int64_t, int> out = a;
+    for (const auto& kv : b) out[kv.first] += kv.second;
+    for (auto it = out.begin(); it != out.end();) {
+        if (it->second >= appearances[it->first]) it = out.erase(it);
+        else ++it;
+    }
+    return out;
+}
+
+double legs_log2size(const std::map<int64_t, int>& legs, const std::vector<double>& l2) {
+    double s = 0;
+    for (const auto& kv : legs) s += l2[kv.first];
+    return s;
+}
+
+// element count as a product (exact below 2^53, like the reference's integers)
+double legs_size(const std::map<int64_t, int>& legs, const std::vector<double>& sz) {
+    double s = 1;
+    for (const auto& kv : legs) s *= sz[kv.first];
+    return s;
+}
+
+int fail(const char* msg);
+
+}  // namespace
+
+// error reporting shares the runtime's thread-local message (ctg_runtime.hip)
+extern "C" __attribute__((visibility("hidden"))) void ctg_set_error_(const char* msg);
+namespace {
+int fail(const char* msg) {
+    ctg_set_error_(msg);
+    return CTG_E_INVALID;
+}
+}  // namespace
+
+extern "C" {
+
+int ctg_path_greedy(int64_t n_inputs, const int64_t* offsets, const int64_t* inds, int64_t n_out,
+                    const int64_t* out_inds, int64_t n_inds, const double* sizes, double costmod,
+                    double temperature, int64_t max_neighbors, uint64_t seed, int64_t* ssa_path) {
+    Network net;
+    if (!ssa_path && n_inputs > 1) return fail("ctg_path_greedy: null output");
+    if (!build_network(n_inputs, offsets, inds, n_out, out_inds, n_inds, sizes, net))
+        return fail("ctg_path_greedy: malformed network");
+    if (!(costmod > 0)) return fail("ctg_path_greedy: costmod must be positive");
+    if (n_inputs == 1) return CTG_OK;
+
+    std::mt19937_64 rng(seed);
+    std::uniform_real_distribution<double> uni(1e-300, 1.0);
+    auto gumbel = [&]() { return -std::log(-std::log(uni(rng))); };
+    // sizes as doubles: 2^1000 is representable, far above any real tensor
+    auto score_of = [&](double sa, double sb, double sab) {
+        const double s = sab / costmod - (sa + sb) * costmod;
+        if (temperature == 0.0) return s;
+        if (s > 0) return std::log(s) - temperature * gumbel();
+        if (s < 0) return -std::log(-s) - temperature * gumbel();
+        return -temperature * gumbel();
+    };
+
+    std::unordered_map<int64_t, std::map<int64_t, int>> nodes;  // alive tensors by ssa id
+    std::unordered_map<int64_t, double> node_l2;   // element count of every alive tensor
+    std::vector<std::set<int64_t>> edges(n_inds);                // index -> alive tensors
+    for (int64_t t = 0; t < n_inputs; ++t) {
+        nodes[t] = net.legs[t];
+        node_l2[t] = legs_size(net.legs[t], net.size);
+        for (const auto& kv : net.legs[t]) edges[kv.first].insert(t);
+    }
+
+    struct Cand {
+        double score;
+        int64_t c, i, j;
+        bool operator<(const Cand& o) const {  // min-heap on (score, c)
+            return score != o.score ? score > o.score : c > o.c;
+        }
+    };
+    std::priority_queue<Cand> queue;
+    int64_t counter = 0;
+    auto push = [&](int64_t i, int64_t j) {
+        const auto k = contract_legs(nodes[i], nodes[j], net.appearances);
+        queue.push(Cand{score_of(node_l2[i], node_l2[j], legs_size(k, net.size)), counter++, i, j});
+    };
+    for (int64_t ix = 0; ix < n_inds; ++ix) {
+        const auto& ts = edges[ix];
+        if (max_neighbors > 0 && (int64_t)ts.size() > max_neighbors) continue;  // batch-like index
+        for (auto a = ts.begin(); a != ts.end(); ++a)
+            for (auto b = std::next(a); b != ts.end(); ++b) push(*a, *b);
+    }
+
+    int64_t next_ssa = n_inputs, n_steps = 0;
+    auto contract = [&](int64_t i, int64_t j) {
+        auto k = contract_legs(nodes[i], nodes[j], net.appearances);
+        for (const auto& kv : nodes[i]) edges[kv.first].erase(i);
+        for (const auto& kv : nodes[j]) edges[kv.first].erase(j);
+        nodes.erase(i);
+        nodes.erase(j);
+        const int64_t id = next_ssa++;
+        for (const auto& kv : k) edges[kv.first].insert(id);
+        node_l2[id] = legs_size(k, net.size);
+        nodes[id] = std::move(k);
+        ssa_path[2 * n_steps] = i;
+        ssa_path[2 * n_steps + 1] = j;
+        ++n_steps;
+        return id;
+    };
+
+    while (!queue.empty()) {
+        const Cand c = queue.top();
+        queue.pop();
+        if (!nodes.count(c.i) || !nodes.count(c.j)) continue;  // stale
+        const int64_t k = contract(c.i, c.j);
+        // neighbours in the order the reference meets them (by leg, then by id),
+        // each once: the push order breaks score ties
+        std::vector<int64_t> nbrs;
+        std::set<int64_t> seen;
+        for (const auto& kv : nodes[k]) {
+            const auto& ts = edges[kv.first];
+            if (max_neighbors > 0 && (int64_t)ts.size() > max_neighbors) continue;
+            for (int64_t t : ts)
+                if (t != k && seen.insert(t).second) nbrs.push_back(t);
+        }
+        for (int64_t l : nbrs) push(k, l);
+    }
+
+    // disconnected remainder: smallest two first
+    while (nodes.size() > 1) {
+        std::vector<std::pair<double, int64_t>> by_size;
+        for (const auto& kv : nodes) by_size.push_back({node_l2[kv.first], kv.first});
+        std::sort(by_size.begin(), by_size.end());
+        contract(by_size[0].second, by_size[1].second);
+    }
+    return n_steps == n_inputs - 1 ? CTG_OK : fail("ctg_path_greedy: internal error");
+}
+
+int ctg_slice_greedy(int64_t n_inputs, const int64_t* offsets, const int64_t* inds, int64_t n_out,
+                     const int64_t* out_inds, int64_t n_inds, const double* sizes,
+                     const int64_t* ssa_path, double target_log2_size, int allow_outer,
+                     int64_t max_sliced, int64_t* sliced, int64_t* n_sliced) {
+    Network net;
+    if (!sliced || !n_sliced || (!ssa_path && n_inputs > 1)) return fail("ctg_slice_greedy: null argument");
+    if (!build_network(n_inputs, offsets, inds, n_out, out_inds, n_inds, sizes, net))
+        return fail("ctg_slice_greedy: malformed network");
+    *n_sliced = 0;
+    if (n_inputs == 1) return CTG_OK;
+
+    // contractions of the tree: involved indices, surviving legs, log2 flops, log2 size
+    struct Con {
+        std::vector<int64_t> involved, legs;
+        double l2flops, l2size;
+    };
+    std::vector<Con> cons;
+    {
+        std::unordered_map<int64_t, std::map<int64_t, int>> nodes;
+        for (int64_t t = 0; t < n_inputs; ++t) nodes[t] = net.legs[t];
+        for (int64_t s = 0; s < n_inputs - 1; ++s) {
+            const int64_t i = ssa_path[2 * s], j = ssa_path[2 * s + 1];
+            if (!nodes.count(i) || !nodes.count(j) || i == j) return fail("ctg_slice_greedy: bad ssa path");
+            Con c;
+            std::map<int64_t, int> inv = nodes[i];
+            for (const auto& kv : nodes[j]) inv[kv.first] += kv.second;
+            auto k = contract_legs(nodes[i], nodes[j], net.appearances);
+            c.l2flops = 0;
+            for (const auto& kv : inv) {
+                c.involved.push_back(kv.first);
+                c.l2flops += net.log2size[kv.first];
+            }
+            c.l2size = 0;
+            for (const auto& kv : k) {
+                c.legs.push_back(kv.first);
+                c.l2size += net.log2size[kv.first];
+            }
+            cons.push_back(std::move(c));
+            nodes.erase(i);
+            nodes.erase(j);
+            nodes[n_inputs + s] = std::move(k);
+        }
+    }
+    std::vector<char> is_out(n_inds, 0), gone(n_inds, 0);
+    for (int64_t q = 0; q < n_out; ++q) is_out[out_inds[q]] = 1;
+
+    auto total_flops_without = [&](int64_t ix) {  // relative units: sum of 2^l2flops, times d
+        double f = 0;
+        const double d = net.log2size[ix];
+        for (const Con& c : cons) {
+            const bool has = std::find(c.involved.begin(), c.involved.end(), ix) != c.involved.end();
+            f += std::exp2(c.l2flops - (has ? d : 0.0));
+        }
+        return f * std::exp2(d);
+    };
+
+    for (;;) {
+        double mx = -1;
+        for (const Con& c : cons) mx = std::max(mx, c.l2size);
+        if (mx <= target_log2_size + 1e-9) break;
+        if (*n_sliced >= max_sliced) return fail("ctg_slice_greedy: more sliced indices than the caller allows");
+        // candidates: legs of the intermediates that are still too large.  An index
+        // is worth the excess (in bits, capped by its own extent) it takes off each
+        // of them; among the most useful ones the cheapest in total flops wins.
+        std::map<int64_t, double> gain;
+        for (const Con& c : cons) {
+            const double excess = c.l2size - target_log2_size;
+            if (excess <= 1e-9) continue;
+            for (int64_t ix : c.legs)
+                if (!gone[ix] && (allow_outer || !is_out[ix]) && net.log2size[ix] > 0)
+                    gain[ix] += std::min(excess, net.log2size[ix]);
+        }
+        if (gain.empty()) return fail("ctg_slice_greedy: target size unreachable (only output indices left)");
+        double best_gain = 0;
+        for (const auto& kv : gain) best_gain = std::max(best_gain, kv.second);
+        int64_t best = -1;
+        double best_flops = 0;
+        for (const auto& kv : gain) {
+            if (kv.second < 0.9 * best_gain) continue;
+            const double f = total_flops_without(kv.first);
+            if (best < 0 || f < best_flops) {
+                best = kv.first;
+                best_flops = f;
+            }
+        }
+        const double d = net.log2size[best];
+        for (Con& c : cons) {
+            auto it = std::find(c.involved.begin(), c.involved.end(), best);
+            if (it != c.involved.end()) {
+                c.involved.erase(it);
+                c.l2flops -= d;
+            }
+            auto jt = std::find(c.legs.begin(), c.legs.end(), best);
+            if (jt != c.legs.end()) {
+                c.legs.erase(jt);
+                c.l2size -= d;
+            }
+        }
+        gone[best] = 1;
+        sliced[(*n_sliced)++] = best;
+    }
+    return CTG_OK;
+}
+
+}  // extern "C"

@@ -592,6 +592,9 @@ int ctg_abi_version(void) { return CTG_ABI_VERSION; }
 
 const char* ctg_last_error(void) { return g_err.c_str(); }
 
+// (shared with the host-only sources of the library; not part of the ABI)
+__attribute__((visibility("hidden"))) void ctg_set_error_(const char* msg) { g_err = msg ? msg : ""; }
+
 int ctg_plan_create(const ctg_plan_desc* d, ctg_plan** out) {
     if (!d || !out) return fail(CTG_E_INVALID, "null argument");
     if (d->n_inputs < 1 || d->n_steps < 0 || d->n_table_words < 1 || d->n_sliced < 0)

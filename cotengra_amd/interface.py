@@ -95,9 +95,11 @@ def _as_tree(inputs, output, size_dict, optimize):
             )
         if len(inputs) == 1:
             return ContractionTree(inputs, output, size_dict)
-        return ContractionTree.from_path(
-            inputs, output, size_dict, path=greedy_path(inputs, output, size_dict)
-        )
+        # the native greedy finder (csrc/ctg_pathfind.cpp); the small Python
+        # heuristic above remains for callers that must not load the library
+        from .pathfind import greedy_tree
+
+        return greedy_tree(inputs, output, size_dict)
     if hasattr(optimize, "get_path") and hasattr(optimize, "sliced_inds"):
         # a foreign (e.g. reference cotengra) tree: adopt its path and slicing
         tree = ContractionTree.from_path(

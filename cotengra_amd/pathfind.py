@@ -1,0 +1,141 @@
+"""Host-side tree tools backed by the native library (no GPU needed):
+
+* ``greedy_ssa_path`` / ``greedy_path`` -- the reference's ``optimize_greedy``
+  (``cotengra/pathfinders/path_basic.py:1038-1106``; its inner loop is what the
+  optional ``cotengrust`` accelerator replaces, ``:1351-1383``);
+* ``random_greedy_tree`` -- repeated Boltzmann-sampled greedy runs, best tree
+  kept (the idea of ``optimize_random_greedy_track_flops``, ``:1113-1240``);
+* ``slice_tree`` -- greedy choice of sliced indices until the largest
+  intermediate fits ``target_size`` (``SliceFinder``, ``cotengra/slicer.py``).
+
+The hyper-optimizers built on top of these stay in the reference; this module
+is what the stand-alone front ends use when they are not handed a tree.
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import runtime
+from .tree import ContractionTree
+
+
+def _csr(inputs, output, size_dict):
+    ids = {}
+    for term in list(inputs) + [output]:
+        for ix in term:
+            if ix not in ids:
+                ids[ix] = len(ids)
+    offsets = np.zeros(len(inputs) + 1, dtype=np.int64)
+    flat = []
+    for t, term in enumerate(inputs):
+        flat.extend(ids[ix] for ix in term)
+        offsets[t + 1] = len(flat)
+    flat = np.asarray(flat, dtype=np.int64) if flat else np.zeros(1, dtype=np.int64)
+    out = np.asarray([ids[ix] for ix in output], dtype=np.int64) if len(output) else np.zeros(1, dtype=np.int64)
+    sizes = np.empty(max(len(ids), 1), dtype=np.float64)
+    for ix, i in ids.items():
+        sizes[i] = float(size_dict[ix])
+    return ids, offsets, flat, out, sizes
+
+
+def _p(a, typ):
+    return a.ctypes.data_as(C.POINTER(typ))
+
+
+def greedy_ssa_path(inputs, output, size_dict, costmod=1.0, temperature=0.0, max_neighbors=16, seed=0):
+    """SSA path ``[(i, j), ...]`` found by the native greedy algorithm."""
+    n = len(inputs)
+    if n < 2:
+        return ()
+    ids, offsets, flat, out, sizes = _csr(inputs, output, size_dict)
+    path = np.empty(2 * (n - 1), dtype=np.int64)
+    runtime._check(
+        runtime.load().ctg_path_greedy(
+            n, _p(offsets, C.c_int64), _p(flat, C.c_int64), len(output), _p(out, C.c_int64), len(ids),
+            _p(sizes, C.c_double), float(costmod), float(temperature), int(max_neighbors or 0),
+            int(seed) & (2**64 - 1), _p(path, C.c_int64),
+        )
+    )
+    return tuple((int(path[2 * s]), int(path[2 * s + 1])) for s in range(n - 1))
+
+
+def greedy_tree(inputs, output, size_dict, **kwargs):
+    """``ContractionTree`` of the native greedy path."""
+    inputs = [tuple(t) for t in inputs]
+    if len(inputs) == 1:
+        return ContractionTree(inputs, tuple(output), size_dict)
+    return ContractionTree.from_path(
+        inputs, tuple(output), size_dict, ssa_path=greedy_ssa_path(inputs, output, size_dict, **kwargs)
+    )
+
+
+def greedy_path(inputs, output, size_dict, **kwargs):
+    """Linear (recycled-id) path, the ``opt_einsum`` convention."""
+    return greedy_tree(inputs, output, size_dict, **kwargs).get_path()
+
+
+def random_greedy_tree(inputs, output, size_dict, repeats=32, costmod=(0.1, 4.0), temperature=(0.001, 1.0),
+                       minimize="flops", seed=0, max_neighbors=16):
+    """Best of ``repeats`` sampled greedy trees.  ``minimize``: ``"flops"``,
+    ``"size"`` or ``"combo-<f>"`` (flops + f * write, the reference's memory
+    aware objective)."""
+    rng = np.random.default_rng(seed)
+
+    def cost(tree):
+        if minimize == "flops":
+            return tree.contraction_cost()
+        if minimize == "size":
+            return tree.max_size()
+        if minimize.startswith("combo"):
+            f = float(minimize.split("-")[1]) if "-" in minimize else 64.0
+            return tree.contraction_cost() + f * tree.total_write()
+        raise ValueError(f"unknown objective {minimize!r}")
+
+    best = greedy_tree(inputs, output, size_dict, max_neighbors=max_neighbors)
+    best_cost = cost(best)
+    lo_t, hi_t = np.log(temperature[0]), np.log(temperature[1])
+    for _ in range(repeats):
+        tree = greedy_tree(
+            inputs, output, size_dict, costmod=float(rng.uniform(*costmod)),
+            temperature=float(np.exp(rng.uniform(lo_t, hi_t))), seed=int(rng.integers(0, 2**63)),
+            max_neighbors=max_neighbors,
+        )
+        c = cost(tree)
+        if c < best_cost:
+            best, best_cost = tree, c
+    return best
+
+
+def find_sliced_inds(tree, target_size, allow_outer=True):
+    """Indices to remove so that no intermediate of ``tree`` exceeds
+    ``target_size`` elements (already sliced indices are taken into account)."""
+    inputs = tree.get_inputs_sliced() if tree.sliced_inds else tree.inputs
+    output = tree.get_output_sliced() if tree.sliced_inds else tree.output
+    n = len(inputs)
+    if n < 2:
+        return ()
+    ids, offsets, flat, out, sizes = _csr(inputs, output, tree.size_dict)
+    ssa = np.asarray([x for pair in tree.get_ssa_path() for x in pair], dtype=np.int64)
+    sliced = np.empty(max(len(ids), 1), dtype=np.int64)
+    n_sliced = C.c_int64(0)
+    runtime._check(
+        runtime.load().ctg_slice_greedy(
+            n, _p(offsets, C.c_int64), _p(flat, C.c_int64), len(output), _p(out, C.c_int64), len(ids),
+            _p(sizes, C.c_double), _p(ssa, C.c_int64), float(np.log2(target_size)), int(bool(allow_outer)),
+            len(ids), _p(sliced, C.c_int64), C.byref(n_sliced),
+        )
+    )
+    names = {i: ix for ix, i in ids.items()}
+    return tuple(names[int(sliced[q])] for q in range(n_sliced.value))
+
+
+def slice_tree(tree, target_size, allow_outer=True, inplace=False):
+    """``tree`` with indices removed until it fits ``target_size`` (reference
+    ``ContractionTree.slice``, core.py:2632-2719, with a greedy finder)."""
+    tree = tree if inplace else tree.copy()
+    for ix in find_sliced_inds(tree, target_size, allow_outer=allow_outer):
+        tree.remove_ind_(ix)
+    return tree

@@ -36,6 +36,8 @@ SYMBOLS = (
     "ctg_exec_result_ptr",
     "ctg_exec_download_result",
     "ctg_exec_download_arena",
+    "ctg_path_greedy",
+    "ctg_slice_greedy",
 )
 
 
@@ -115,6 +117,10 @@ def load():
         "ctg_exec_result_ptr": [vp, C.POINTER(vp)],
         "ctg_exec_download_result": [vp, vp],
         "ctg_exec_download_arena": [vp, C.c_int64, C.c_int64, vp],
+        "ctg_path_greedy": [C.c_int64, i64p, i64p, C.c_int64, i64p, C.c_int64, C.POINTER(C.c_double),
+                            C.c_double, C.c_double, C.c_int64, C.c_uint64, i64p],
+        "ctg_slice_greedy": [C.c_int64, i64p, i64p, C.c_int64, i64p, C.c_int64, C.POINTER(C.c_double),
+                             i64p, C.c_double, C.c_int, C.c_int64, i64p, i64p],
     }
     for name, argtypes in protos.items():
         fn = getattr(lib, name)

@@ -149,6 +149,36 @@ int ctg_exec_download_result(ctg_exec* exec, void* host_out);
  * to the host (synchronous) */
 int ctg_exec_download_arena(ctg_exec* exec, int64_t offset, int64_t n, void* host_out);
 
+/* Host-side tree tools (no GPU): the inner loops of path search and slicing.
+ * The reference runs them in Python, or in its optional Rust accelerator
+ * `cotengrust` when installed (pathfinders/path_basic.py:1351-1383); the
+ * hyper-optimizers that call them stay in the reference unchanged.
+ *
+ * A network is given in CSR form: tensor t carries the index ids
+ * inds[offsets[t] .. offsets[t+1]) (ids in [0, n_inds), repeats allowed),
+ * `out_inds` are the output indices, `sizes[ix]` the extent of index ix. */
+
+/* Greedy pairwise path (reference `optimize_greedy`, path_basic.py:616-700,
+ * 1038-1106): score = size(ab)/costmod - (size(a)+size(b))*costmod, optional
+ * Boltzmann sampling (temperature, seed), indices shared by more than
+ * `max_neighbors` tensors generate no candidates (0 = no limit), disconnected
+ * remainder combined smallest first.  Writes n_inputs-1 pairs of SSA ids
+ * (inputs 0..n-1, intermediates n, n+1, ...) to ssa_path[2*(n_inputs-1)]. */
+int ctg_path_greedy(int64_t n_inputs, const int64_t* offsets, const int64_t* inds, int64_t n_out,
+                    const int64_t* out_inds, int64_t n_inds, const double* sizes, double costmod,
+                    double temperature, int64_t max_neighbors, uint64_t seed, int64_t* ssa_path);
+
+/* Greedy choice of indices to slice until the largest intermediate of the tree
+ * `ssa_path` has at most 2^target_log2_size elements (reference `SliceFinder`
+ * over `ContractionCosts`, slicer.py:17-201, 204-430; cost model: removing an
+ * index of extent d divides the flops / sizes it takes part in by d and
+ * multiplies the slice count by d).  Output indices are only used when
+ * `allow_outer` (core.py:2632-2719).  Writes at most `max_sliced` index ids. */
+int ctg_slice_greedy(int64_t n_inputs, const int64_t* offsets, const int64_t* inds, int64_t n_out,
+                     const int64_t* out_inds, int64_t n_inds, const double* sizes,
+                     const int64_t* ssa_path, double target_log2_size, int allow_outer,
+                     int64_t max_sliced, int64_t* sliced, int64_t* n_sliced);
+
 #ifdef __cplusplus
 }
 #endif

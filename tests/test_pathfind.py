@@ -1,0 +1,89 @@
+"""CPU suite: the native greedy path finder and slicer (csrc/ctg_pathfind.cpp)
+against numbers frozen from the reference's ``optimize_greedy`` and
+``ContractionTree.slice`` (tests/golden/gen/make_pathfind.py)."""
+import json
+import math
+import os
+
+import numpy as np
+import pytest
+
+import cotengra_amd as ca
+from cotengra_amd import pathfind
+from oracle import contract_ref as orc
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CASES = json.load(open(os.path.join(HERE, "golden", "pathfind_cases.json"), encoding="utf-8"))["cases"]
+
+
+def net(case):
+    return [tuple(t) for t in case["inputs"]], tuple(case["output"]), case["size_dict"]
+
+
+@pytest.mark.parametrize("case", CASES, ids=[c["name"] for c in CASES])
+def test_greedy_matches_reference_quality(case):
+    inputs, output, size_dict = net(case)
+    tree = pathfind.greedy_tree(inputs, output, size_dict)
+    assert tree.is_complete()
+    # same deterministic algorithm as the reference's (temperature 0, costmod 1);
+    # ties may be broken differently, hence a small allowance
+    assert tree.contraction_cost(log=10) <= case["ref_greedy_log10_flops"] + 0.15
+    assert tree.max_size(log=2) <= case["ref_greedy_log2_width"] + 2.0
+
+
+@pytest.mark.parametrize("case", CASES, ids=[c["name"] for c in CASES])
+def test_slicer_reaches_target_with_reference_like_overhead(case):
+    inputs, output, size_dict = net(case)
+    tree = pathfind.greedy_tree(inputs, output, size_dict)
+    sliced = tree.slice(target_size=case["slice_target"])
+    assert sliced.max_size() <= case["slice_target"]
+    assert tree.sliced_inds == {} and len(sliced.sliced_inds) >= 1
+    # total work within 2x of what the reference's SliceFinder reaches
+    assert sliced.contraction_cost(log=10) <= case["ref_sliced_log10_flops"] + math.log10(2.0)
+    # removing indices never changes the value: checked on the small cases below
+
+
+def test_paths_are_valid_and_values_agree():
+    inputs, output, shapes, size_dict = ca.lattice_equation([3, 4], d_min=2, d_max=3, seed=5)
+    arrays = ca.make_arrays_from_inputs(inputs, size_dict, seed=1, dtype="complex128")
+    eq = ca.inputs_output_to_eq(inputs, output)
+    ref = np.einsum(eq, *arrays, optimize=True)
+    for kwargs in ({}, {"costmod": 0.5}, {"temperature": 0.3, "seed": 7}, {"temperature": 1.0, "seed": 8}):
+        ssa = pathfind.greedy_ssa_path(inputs, output, size_dict, **kwargs)
+        assert len(ssa) == len(inputs) - 1
+        used = [x for pair in ssa for x in pair]
+        assert sorted(used) == list(range(2 * len(inputs) - 2))  # every id consumed exactly once
+        tree = ca.ContractionTree.from_path(inputs, output, size_dict, ssa_path=ssa)
+        assert np.allclose(orc.contract(tree, arrays), ref, rtol=1e-10, atol=1e-12)
+    tree = pathfind.random_greedy_tree(inputs, output, size_dict, repeats=8, minimize="combo-64")
+    sliced = pathfind.slice_tree(tree, target_size=max(tree.max_size() // 8, 2))
+    assert sliced.nslices > 1 and sliced.max_size() <= max(tree.max_size() // 8, 2)
+    assert np.allclose(orc.contract(sliced, arrays), ref, rtol=1e-10, atol=1e-12)
+    # target_slices and the linear-path convention
+    assert tree.slice(target_slices=4).nslices >= 4
+    lin = pathfind.greedy_path(inputs, output, size_dict)
+    t2 = ca.ContractionTree.from_path(inputs, output, size_dict, path=lin)
+    assert np.allclose(orc.contract(t2, arrays), ref, rtol=1e-10, atol=1e-12)
+
+
+def test_hyper_and_disconnected_networks():
+    # hyper index 'h' on three tensors + output, and a disconnected scalar pair
+    inputs = [("a", "h"), ("h", "b"), ("h", "c"), ("x",), ("x",)]
+    output = ("a", "b", "c", "h")
+    size_dict = dict(a=2, b=3, c=2, h=4, x=5)
+    arrays = ca.make_arrays_from_inputs(inputs, size_dict, seed=2, dtype="float64")
+    ref = np.einsum("ah,hb,hc,x,x->abch", *arrays)
+    tree = pathfind.greedy_tree(inputs, output, size_dict)
+    assert np.allclose(orc.contract(tree, arrays), ref)
+    sliced = tree.slice(target_size=8, allow_outer=True)
+    assert sliced.max_size() <= 8
+    assert np.allclose(orc.contract(sliced, arrays), ref)
+    with pytest.raises(ValueError):
+        tree.slice(target_size=1, allow_outer=False)   # only output indices could do that
+
+
+def test_errors():
+    with pytest.raises(ValueError):
+        pathfind.greedy_ssa_path([("a", "b"), ("b", "c")], ("a", "c"), dict(a=2, b=2, c=2), costmod=0.0)
+    with pytest.raises(ValueError):
+        ca.ContractionTree.from_path([("a",), ("a",)], (), dict(a=2), path=[(0, 1)]).slice()
