@@ -33,6 +33,7 @@
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
+#include <functional>
 #include <map>
 #include <queue>
 #include <random>
@@ -320,6 +321,181 @@ int ctg_slice_greedy(int64_t n_inputs, const int64_t* offsets, const int64_t* in
         sliced[(*n_sliced)++] = best;
     }
     return CTG_OK;
+}
+
+
+// Subtree reconfiguration (reference `ContractionTree.subtree_reconfigure`,
+// core.py:2316-2449): repeatedly take an internal node, grow a subtree below it
+// breadth-first until it has `subtree_size` leaves (themselves arbitrary
+// subtrees, treated as fixed tensors), find the *optimal* contraction order of
+// those leaves by dynamic programming over subsets, and splice it in if it is
+// cheaper.  Cost of one contraction = flops + write_factor * size of its result
+// (the reference's `combo-<f>` objective, scoring.py; write_factor = 0 is plain
+// flops).  Nodes are visited by decreasing cost (`select="max"`); a node whose
+// subtree came out unchanged is not revisited until something below it changes.
+int ctg_subtree_reconfigure(int64_t n_inputs, const int64_t* offsets, const int64_t* inds, int64_t n_out,
+                            const int64_t* out_inds, int64_t n_inds, const double* sizes,
+                            const int64_t* ssa_path_in, int64_t subtree_size, int64_t maxiter,
+                            double write_factor, int64_t* ssa_path_out) {
+    Network net;
+    if ((!ssa_path_in || !ssa_path_out) && n_inputs > 1) return fail("ctg_subtree_reconfigure: null argument");
+    if (!build_network(n_inputs, offsets, inds, n_out, out_inds, n_inds, sizes, net))
+        return fail("ctg_subtree_reconfigure: malformed network");
+    if (subtree_size < 2 || subtree_size > 16) return fail("ctg_subtree_reconfigure: subtree_size must be 2..16");
+    const int64_t n = n_inputs;
+    if (n < 2) return CTG_OK;
+    if (n == 2) {
+        ssa_path_out[0] = ssa_path_in[0];
+        ssa_path_out[1] = ssa_path_in[1];
+        return CTG_OK;
+    }
+
+    struct Node {
+        int64_t l = -1, r = -1, parent = -1;
+        std::map<int64_t, int> legs;
+        double cost = 0;   // flops + write_factor * size of this contraction (0 for leaves)
+        bool alive = true, settled = false;
+    };
+    std::vector<Node> nodes(n);
+    for (int64_t t = 0; t < n; ++t) nodes[t].legs = net.legs[t];
+    auto pair_cost = [&](const std::map<int64_t, int>& a, const std::map<int64_t, int>& b,
+                         const std::map<int64_t, int>& k) {
+        double flops = 1;
+        for (const auto& kv : a) flops *= net.size[kv.first];
+        for (const auto& kv : b)
+            if (!a.count(kv.first)) flops *= net.size[kv.first];
+        return flops + write_factor * legs_size(k, net.size);
+    };
+    int64_t root = -1;
+    {
+        std::vector<char> used(2 * n, 0);
+        for (int64_t s = 0; s < n - 1; ++s) {
+            const int64_t i = ssa_path_in[2 * s], j = ssa_path_in[2 * s + 1];
+            if (i < 0 || j < 0 || i >= n + s || j >= n + s || i == j || used[i] || used[j])
+                return fail("ctg_subtree_reconfigure: bad ssa path");
+            used[i] = used[j] = 1;
+            Node p;
+            p.l = i;
+            p.r = j;
+            p.legs = contract_legs(nodes[i].legs, nodes[j].legs, net.appearances);
+            p.cost = pair_cost(nodes[i].legs, nodes[j].legs, p.legs);
+            nodes.push_back(std::move(p));
+            nodes[i].parent = nodes[j].parent = n + s;
+        }
+        root = 2 * n - 2;
+    }
+
+    const int64_t S = subtree_size;
+    std::vector<double> best;
+    std::vector<int32_t> split;
+    std::vector<std::map<int64_t, int>> mlegs;
+    if (maxiter <= 0) maxiter = std::min<int64_t>(n, 1024);
+    for (int64_t iter = 0; iter < maxiter; ++iter) {
+        // the most expensive node not known to be locally optimal
+        int64_t pick = -1;
+        for (int64_t v = n; v < (int64_t)nodes.size(); ++v)
+            if (nodes[v].alive && !nodes[v].settled && (pick < 0 || nodes[v].cost > nodes[pick].cost)) pick = v;
+        if (pick < 0) break;
+        // frontier: breadth-first expansion of internal nodes until S leaves
+        std::vector<int64_t> frontier, inner, fifo{pick};
+        int64_t n_leaves = 1;
+        for (size_t q = 0; q < fifo.size(); ++q) {
+            const int64_t v = fifo[q];
+            if (nodes[v].l < 0 || n_leaves >= S) {
+                frontier.push_back(v);   // stays a (fixed) leaf of the subtree
+                continue;
+            }
+            inner.push_back(v);
+            ++n_leaves;
+            fifo.push_back(nodes[v].l);
+            fifo.push_back(nodes[v].r);
+        }
+        const int m = (int)frontier.size();
+        if (m < 3) {
+            nodes[pick].settled = true;
+            continue;
+        }
+        double cur = 0;
+        for (int64_t v : inner) cur += nodes[v].cost;
+        // dynamic programming over subsets of the frontier
+        const int full = (1 << m) - 1;
+        best.assign(full + 1, 0.0);
+        split.assign(full + 1, 0);
+        mlegs.assign(full + 1, {});
+        // legs of a subset: counts summed over members, kept while the index appears elsewhere
+        for (int mask = 1; mask <= full; ++mask) {
+            const int low = mask & -mask;
+            const int bit = __builtin_ctz(mask);
+            if (mask == low) {
+                mlegs[mask] = nodes[frontier[bit]].legs;
+                continue;
+            }
+            mlegs[mask] = contract_legs(mlegs[mask ^ low], nodes[frontier[bit]].legs, net.appearances);
+            double b = -1;
+            int bs = 0;
+            // splits with the lowest member on the left side (each unordered split once)
+            const int rest = mask ^ low;
+            for (int sub = rest;; sub = (sub - 1) & rest) {
+                const int left = low | (rest ^ sub), right = sub;   // right may not be empty
+                if (right != 0) {
+                    const double c = best[left] + best[right] + pair_cost(mlegs[left], mlegs[right], mlegs[mask]);
+                    if (b < 0 || c < b) {
+                        b = c;
+                        bs = left;
+                    }
+                }
+                if (sub == 0) break;
+            }
+            best[mask] = b;
+            split[mask] = bs;
+        }
+        if (!(best[full] < cur * (1.0 - 1e-12))) {
+            nodes[pick].settled = true;
+            continue;
+        }
+        // splice the optimal order in: the internal nodes are recycled for it
+        size_t reuse = 0;
+        std::vector<int64_t> freed = inner;   // pick is inner[0]: it stays the subtree root
+        std::function<int64_t(int, int64_t)> build = [&](int mask, int64_t as) -> int64_t {
+            if ((mask & (mask - 1)) == 0) return frontier[__builtin_ctz(mask)];
+            const int64_t id = as >= 0 ? as : freed[++reuse];
+            const int left = split[mask], right = mask ^ left;
+            const int64_t a = build(left, -1), b2 = build(right, -1);
+            Node& nd = nodes[id];
+            nd.l = a;
+            nd.r = b2;
+            nd.legs = mlegs[mask];
+            nd.cost = pair_cost(mlegs[left], mlegs[right], mlegs[mask]);
+            nd.settled = false;
+            nodes[a].parent = nodes[b2].parent = id;
+            return id;
+        };
+        build(full, pick);
+        // everything above may now be improvable again
+        for (int64_t v = nodes[pick].parent; v >= 0; v = nodes[v].parent) nodes[v].settled = false;
+    }
+
+    // emit the SSA path (post-order)
+    std::vector<int64_t> ssa_of(nodes.size(), -1);
+    for (int64_t t = 0; t < n; ++t) ssa_of[t] = t;
+    int64_t next_ssa = n, step = 0;
+    std::vector<std::pair<int64_t, int>> stack{{root, 0}};
+    while (!stack.empty()) {
+        auto [v, st] = stack.back();
+        stack.pop_back();
+        if (nodes[v].l < 0) continue;
+        if (st == 0) {
+            stack.push_back({v, 1});
+            stack.push_back({nodes[v].r, 0});
+            stack.push_back({nodes[v].l, 0});
+        } else {
+            ssa_path_out[2 * step] = ssa_of[nodes[v].l];
+            ssa_path_out[2 * step + 1] = ssa_of[nodes[v].r];
+            ssa_of[v] = next_ssa++;
+            ++step;
+        }
+    }
+    return step == n - 1 ? CTG_OK : fail("ctg_subtree_reconfigure: internal error");
 }
 
 }  // extern "C"

@@ -139,3 +139,60 @@ def slice_tree(tree, target_size, allow_outer=True, inplace=False):
     for ix in find_sliced_inds(tree, target_size, allow_outer=allow_outer):
         tree.remove_ind_(ix)
     return tree
+
+
+def _objective(minimize):
+    """write factor of an objective name: ``"flops"`` -> 0, ``"combo"`` -> 64,
+    ``"combo-<f>"`` -> f (reference scoring.py)."""
+    if minimize in (None, "flops"):
+        return 0.0
+    if minimize == "combo":
+        return 64.0
+    if isinstance(minimize, str) and minimize.startswith("combo-"):
+        return float(minimize.split("-", 1)[1])
+    raise ValueError(f"unknown objective {minimize!r} (flops, combo, combo-<f>)")
+
+
+def subtree_reconfigure(tree, subtree_size=8, maxiter="auto", minimize="flops", inplace=False):
+    """Locally optimal re-ordering of the subtrees of ``tree`` (reference
+    ``ContractionTree.subtree_reconfigure``, core.py:2316-2449) by the native
+    dynamic-programming routine.  Sliced indices are kept and count as size 1,
+    so the per-slice cost is what is minimised."""
+    if tree.N < 3:
+        return tree if inplace else tree.copy()
+    sliced = list(tree.sliced_inds)
+    size_dict = dict(tree.size_dict)
+    eff = {ix: (1 if ix in tree.sliced_inds else d) for ix, d in size_dict.items()}
+    ids, offsets, flat, out, sizes = _csr(tree.inputs, tree.output, eff)
+    ssa_in = np.asarray([x for pair in tree.get_ssa_path() for x in pair], dtype=np.int64)
+    ssa_out = np.empty_like(ssa_in)
+    runtime._check(
+        runtime.load().ctg_subtree_reconfigure(
+            tree.N, _p(offsets, C.c_int64), _p(flat, C.c_int64), len(tree.output), _p(out, C.c_int64),
+            len(ids), _p(sizes, C.c_double), _p(ssa_in, C.c_int64), int(subtree_size),
+            0 if maxiter == "auto" else int(maxiter), _objective(minimize), _p(ssa_out, C.c_int64),
+        )
+    )
+    new = ContractionTree.from_path(
+        tree.inputs, tree.output, size_dict,
+        ssa_path=[(int(ssa_out[2 * s]), int(ssa_out[2 * s + 1])) for s in range(tree.N - 1)],
+    )
+    for ix in sliced:
+        new.remove_ind_(ix)
+    if inplace:
+        tree.__dict__.update(new.__dict__)
+        return tree
+    return new
+
+
+def slice_and_reconfigure(tree, target_size, minimize="flops", subtree_size=8, allow_outer=True, step_bits=2.0):
+    """Interleave slicing with subtree reconfiguration (reference
+    ``ContractionTree.slice_and_reconfigure``, core.py:2723-2808): slice towards
+    ``target_size`` ``step_bits`` at a time, re-optimising the subtrees for
+    the sliced network after every step."""
+    tree = subtree_reconfigure(tree, subtree_size=subtree_size, minimize=minimize)
+    while tree.max_size() > target_size:
+        step = max(float(target_size), tree.max_size() / 2.0**step_bits)
+        tree = slice_tree(tree, step, allow_outer=allow_outer)
+        tree = subtree_reconfigure(tree, subtree_size=subtree_size, minimize=minimize)
+    return tree

@@ -38,6 +38,7 @@ SYMBOLS = (
     "ctg_exec_download_arena",
     "ctg_path_greedy",
     "ctg_slice_greedy",
+    "ctg_subtree_reconfigure",
 )
 
 
@@ -121,6 +122,8 @@ def load():
                             C.c_double, C.c_double, C.c_int64, C.c_uint64, i64p],
         "ctg_slice_greedy": [C.c_int64, i64p, i64p, C.c_int64, i64p, C.c_int64, C.POINTER(C.c_double),
                              i64p, C.c_double, C.c_int, C.c_int64, i64p, i64p],
+        "ctg_subtree_reconfigure": [C.c_int64, i64p, i64p, C.c_int64, i64p, C.c_int64, C.POINTER(C.c_double),
+                                    i64p, C.c_int64, C.c_int64, C.c_double, i64p],
     }
     for name, argtypes in protos.items():
         fn = getattr(lib, name)

@@ -179,6 +179,18 @@ int ctg_slice_greedy(int64_t n_inputs, const int64_t* offsets, const int64_t* in
                      const int64_t* ssa_path, double target_log2_size, int allow_outer,
                      int64_t max_sliced, int64_t* sliced, int64_t* n_sliced);
 
+/* Subtree reconfiguration (reference `ContractionTree.subtree_reconfigure`,
+ * core.py:2316-2449, with its dynamic-programming sub-optimizer): optimal
+ * re-ordering of subtrees of `subtree_size` (2..16) leaves, most expensive node
+ * first, at most `maxiter` subtree optimisations (<= 0: min(n_inputs, 1024)).
+ * Cost of a contraction = flops + write_factor * size(result) -- the reference's
+ * `combo-<write_factor>` objective (0: flops).  Give sliced indices size 1.
+ * Reads ssa_path_in, writes ssa_path_out (both 2*(n_inputs-1) ids). */
+int ctg_subtree_reconfigure(int64_t n_inputs, const int64_t* offsets, const int64_t* inds, int64_t n_out,
+                            const int64_t* out_inds, int64_t n_inds, const double* sizes,
+                            const int64_t* ssa_path_in, int64_t subtree_size, int64_t maxiter,
+                            double write_factor, int64_t* ssa_path_out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -40,6 +40,8 @@ def main():
         width = tree.max_size(log=2)
         target = max(2 ** int(width - 6), 2 ** 8)
         sliced = tree.slice(target_size=target, seed=0) if width > math.log2(target) else tree
+        rf = tree.subtree_reconfigure(subtree_size=8, minimize="flops", seed=0)
+        rc = tree.subtree_reconfigure(subtree_size=8, minimize="combo-256", seed=0)
         cases.append({
             "name": name,
             "inputs": [list(t) for t in inputs],
@@ -51,6 +53,8 @@ def main():
             "ref_sliced_log10_flops": sliced.contraction_cost(log=10),
             "ref_sliced_log2_nslices": math.log2(sliced.nslices),
             "ref_sliced_log2_width": sliced.max_size(log=2),
+            "ref_reconf8_flops_log10_flops": rf.contraction_cost(log=10),
+            "ref_reconf8_combo256_log10_cost": math.log10(rc.contraction_cost() + 256 * rc.total_write()),
         })
         print(name, {k: v for k, v in cases[-1].items() if k.startswith("ref") or k == "slice_target"})
     out = os.path.join(ROOT, "tests", "golden", "pathfind_cases.json")

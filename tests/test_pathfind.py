@@ -87,3 +87,40 @@ def test_errors():
         pathfind.greedy_ssa_path([("a", "b"), ("b", "c")], ("a", "c"), dict(a=2, b=2, c=2), costmod=0.0)
     with pytest.raises(ValueError):
         ca.ContractionTree.from_path([("a",), ("a",)], (), dict(a=2), path=[(0, 1)]).slice()
+
+
+@pytest.mark.parametrize("case", CASES, ids=[c["name"] for c in CASES])
+def test_subtree_reconfigure_matches_reference_quality(case):
+    inputs, output, size_dict = net(case)
+    tree = pathfind.greedy_tree(inputs, output, size_dict)
+    rf = pathfind.subtree_reconfigure(tree, subtree_size=8, minimize="flops")
+    assert rf.is_complete() and rf.contraction_cost() <= tree.contraction_cost()
+    assert rf.contraction_cost(log=10) <= case["ref_reconf8_flops_log10_flops"] + 0.3
+    rc = pathfind.subtree_reconfigure(tree, subtree_size=8, minimize="combo-256")
+    ours = math.log10(rc.contraction_cost() + 256 * rc.total_write())
+    base = math.log10(tree.contraction_cost() + 256 * tree.total_write())
+    assert ours <= base + 1e-9 and ours <= case["ref_reconf8_combo256_log10_cost"] + 0.3
+
+
+def test_reconfigure_preserves_value_and_slicing():
+    inputs, output, shapes, size_dict = ca.lattice_equation([4, 4], d_min=2, d_max=3, seed=5)
+    arrays = ca.make_arrays_from_inputs(inputs, size_dict, seed=1, dtype="complex128")
+    ref = np.einsum(ca.inputs_output_to_eq(inputs, output), *arrays, optimize=True)
+    tree = pathfind.greedy_tree(inputs, output, size_dict, temperature=1.0, seed=3)
+    for ss, mm in ((3, "flops"), (8, "flops"), (11, "combo-64"), (9, "combo")):
+        t2 = pathfind.subtree_reconfigure(tree, subtree_size=ss, minimize=mm)
+        assert np.allclose(orc.contract(t2, arrays), ref, rtol=1e-10, atol=1e-12)
+    # a sliced tree keeps its sliced indices; the per-slice cost is what goes down
+    sliced = tree.slice(target_size=max(tree.max_size() // 4, 2))
+    t3 = pathfind.subtree_reconfigure(sliced, subtree_size=8)
+    assert set(t3.sliced_inds) == set(sliced.sliced_inds)
+    assert t3.contraction_cost() <= sliced.contraction_cost()
+    assert np.allclose(orc.contract(t3, arrays), ref, rtol=1e-10, atol=1e-12)
+    # interleaved slicing + reconfiguration reaches the target
+    t4 = pathfind.slice_and_reconfigure(tree, target_size=max(tree.max_size() // 8, 2), minimize="combo-64")
+    assert t4.max_size() <= max(tree.max_size() // 8, 2) and t4.nslices <= 4096
+    assert np.allclose(orc.contract(t4, arrays), ref, rtol=1e-10, atol=1e-12)
+    with pytest.raises(ValueError):
+        pathfind.subtree_reconfigure(tree, subtree_size=17)
+    with pytest.raises(ValueError):
+        pathfind.subtree_reconfigure(tree, minimize="size")
