@@ -1274,9 +1274,103 @@ static hipError_t launch_kstream(const StepArgs& p, const MfmaHints& h, void* sc
     return hipGetLastError();
 }
 
+
+// ------------------------------------------------------------------------- //
+// Skinny steps (K in {2, 4, 8, 16}, N in {1, 2, 4}, K*N <= 16, R huge): pure HBM streams
+// whose output tile would use 1/8 or less of a matrix-core tile.  Plain FMAs:
+// every thread owns two adjacent rows -- K 16-byte gathers in flight, B and
+// the k offsets in scalar registers, 16-byte stores -- so the only thing the
+// kernel waits for is HBM.  Host-checked (skinny_ok, ctg_runtime.hip): row
+// pairs are contiguous and 16-byte aligned in A and C, n is contiguous in C.
+// ------------------------------------------------------------------------- //
+template <int KU, int NN>
+__global__ __launch_bounds__(256) void pair_skinny_kernel(StepArgs p) {
+    const c64* __restrict__ A = (const c64*)p.A + sload64(p.soffA);
+    const c64* __restrict__ B = (const c64*)p.B + sload64(p.soffB);
+    c64* __restrict__ C = (c64*)p.C + sload64(p.soffC);
+    // row offsets: two table lookups per thread (vector loads), issued first
+    const int64_t row = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 2;
+    if (row >= p.R) return;
+    const int64_t hi = row >> p.row_lo_shift, lo = row & (p.row_lo - 1);
+    const int64_t a_hi = p.rowA.hi[hi], a_lo = p.rowA.lo[lo];
+    const int64_t c_hi = p.rowC.hi[hi], c_lo = p.rowC.lo[lo];
+    // k offsets and B: wave-uniform, all on the scalar unit (no LDS, no barrier)
+    const int64_t ka0 = sload64(p.kA.hi), kb0 = sload64(p.kB.hi);
+    int64_t ko[KU];
+    float br[KU][NN], bi[KU][NN];
+#pragma unroll
+    for (int k = 0; k < KU; ++k) {
+        ko[k] = ka0 + sload64(p.kA.lo + k);
+        const int64_t kb = kb0 + sload64(p.kB.lo + k);
+#pragma unroll
+        for (int n = 0; n < NN; ++n) {
+            typedef const float __attribute__((address_space(4))) * cfptr;
+            cfptr bp = (cfptr)(uintptr_t)(B + kb + sload64(p.nB + n));
+            br[k][n] = bp[0];
+            bi[k][n] = bp[1];
+        }
+    }
+    const c64* a = A + a_hi + a_lo;
+    f32x4 v[KU];
+#pragma unroll
+    for (int k = 0; k < KU; ++k) v[k] = __builtin_nontemporal_load((const f32x4*)(a + ko[k]));
+    const float alpha = (float)step_alpha(p);
+    float acc[2][NN][2];
+#pragma unroll
+    for (int n = 0; n < NN; ++n) acc[0][n][0] = acc[0][n][1] = acc[1][n][0] = acc[1][n][1] = 0.f;
+#pragma unroll
+    for (int k = 0; k < KU; ++k)
+#pragma unroll
+        for (int n = 0; n < NN; ++n)
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                const float ar = v[k][2 * r], ai = v[k][2 * r + 1];
+                acc[r][n][0] = fmaf(ar, br[k][n], acc[r][n][0]);
+                acc[r][n][0] = fmaf(-ai, bi[k][n], acc[r][n][0]);
+                acc[r][n][1] = fmaf(ar, bi[k][n], acc[r][n][1]);
+                acc[r][n][1] = fmaf(ai, br[k][n], acc[r][n][1]);
+            }
+    // two rows x NN columns = 2*NN contiguous complex numbers
+    float* out = (float*)(C + c_hi + c_lo);
+    if (NN == 1) {
+        *(f32x4*)out = f32x4{acc[0][0][0] * alpha, acc[0][0][1] * alpha, acc[1][0][0] * alpha, acc[1][0][1] * alpha};
+    } else {
+#pragma unroll
+        for (int r = 0; r < 2; ++r)
+#pragma unroll
+            for (int n = 0; n < NN; n += 2)
+                *(f32x4*)(out + 2 * (r * NN + n)) = f32x4{acc[r][n][0] * alpha, acc[r][n][1] * alpha,
+                                                          acc[r][n + 1][0] * alpha, acc[r][n + 1][1] * alpha};
+    }
+}
+
+template <int KU, int NN>
+static hipError_t launch_skinny_t(const StepArgs& p, hipStream_t stream) {
+    const int64_t blocks = (p.R / 2 + 255) / 256;
+    if (blocks > 0x7fffffffll) return hipErrorInvalidValue;
+    hipLaunchKernelGGL((pair_skinny_kernel<KU, NN>), dim3((unsigned)blocks), dim3(256), 0, stream, p);
+    return hipGetLastError();
+}
+
+static hipError_t launch_skinny(const StepArgs& p, hipStream_t stream) {
+    switch ((int)p.K * 8 + (int)p.N) {
+        case 2 * 8 + 1: return launch_skinny_t<2, 1>(p, stream);
+        case 4 * 8 + 1: return launch_skinny_t<4, 1>(p, stream);
+        case 8 * 8 + 1: return launch_skinny_t<8, 1>(p, stream);
+        case 16 * 8 + 1: return launch_skinny_t<16, 1>(p, stream);
+        case 2 * 8 + 2: return launch_skinny_t<2, 2>(p, stream);
+        case 4 * 8 + 2: return launch_skinny_t<4, 2>(p, stream);
+        case 8 * 8 + 2: return launch_skinny_t<8, 2>(p, stream);
+        case 2 * 8 + 4: return launch_skinny_t<2, 4>(p, stream);
+        case 4 * 8 + 4: return launch_skinny_t<4, 4>(p, stream);
+    }
+    return hipErrorInvalidValue;
+}
+
 hipError_t launch_pair_mfma(int dtype, const StepArgs& p, const MfmaHints& h, void* scratch,
                             int64_t scratch_bytes, hipStream_t stream) {
     if (dtype != 2) return hipErrorInvalidValue;
+    if (h.stream == 3) return launch_skinny(p, stream);
     if (h.stream == 2) {
         switch (h.bn) {
             case 16: return launch_kstream<1>(p, h, scratch, scratch_bytes, stream);

@@ -231,7 +231,10 @@ void resolve_args(ctg_exec* e) {
     const ctg_plan* p = e->plan;
     const int64_t isz = kItemSize[p->dtype];
     e->args.resize(p->n_steps);
-    e->hints.assign(p->n_steps, MfmaHints{nullptr, nullptr, 0, 0, 0, 0, 0});
+    // (hints depend on the plan only: kept when the arguments are re-resolved,
+    // e.g. by ctg_exec_set_strip_exponent on a live executor)
+    if ((int64_t)e->hints.size() != p->n_steps)
+        e->hints.assign(p->n_steps, MfmaHints{nullptr, nullptr, 0, 0, 0, 0, 0});
     const int64_t* T = e->d_tables;
     for (int64_t s = 0; s < p->n_steps; ++s) {
         const int64_t* r = &p->steps[s * STEP_WORDS];
@@ -458,6 +461,33 @@ bool kstream_ok(const ctg_plan* p, const int64_t* r) {
     return ma + mk < lim && mn + mkb < lim;
 }
 
+// conditions of pair_skinny_kernel: a huge number of rows, a handful of
+// multiply-adds per row; row pairs (2i, 2i+1) contiguous and 16-byte aligned in
+// A and in C, the N output columns contiguous in C
+bool skinny_ok(const ctg_plan* p, const int64_t* r) {
+    const int64_t R = r[W_R], K = r[W_K], N = r[W_N], L = r[W_ROW_LO];
+    if (r[W_BT] != 1 || R < (1 << 16) || (R & 1) || (L & 1) || K < 2 || K > 16) return false;
+    if (N != 1 && N != 2 && N != 4) return false;
+    if (L & (L - 1)) return false;   // rows are split with shift / mask
+    if (K > r[W_K_LO]) return false; // single-level k tables
+    if ((K & (K - 1)) || K * N > 16) return false;
+    for (int64_t i = 0; i < N; ++i)
+        if (p->tables[r[W_NC] + i] != i) return false;
+    for (int64_t lo = 0; lo < L; lo += 2) {
+        const int64_t a0 = p->tables[r[W_ROWA_LO] + lo], c0 = p->tables[r[W_ROWC_LO] + lo];
+        if ((a0 & 1) || p->tables[r[W_ROWA_LO] + lo + 1] != a0 + 1) return false;
+        if ((c0 & 1) || p->tables[r[W_ROWC_LO] + lo + 1] != c0 + N) return false;
+    }
+    if (!all_even(p, r[W_ROWA_HI], r[W_ROW_HI_LEN]) || !all_even(p, r[W_ROWC_HI], r[W_ROW_HI_LEN]))
+        return false;
+    if (!all_even(p, r[W_KA_HI], r[W_K_HI_LEN]) || !all_even(p, r[W_KA], r[W_K_LO])) return false;
+    if ((r[W_A_OFF] & 1) || (r[W_C_OFF] & 1)) return false;
+    if (r[W_A_LEAF] >= 0)
+        for (int64_t j = 0; j < p->n_sliced; ++j)
+            if (p->slice_strides[r[W_A_LEAF] * p->n_sliced + j] & 1) return false;
+    return true;
+}
+
 int build_hints(ctg_exec* e) {
     const ctg_plan* p = e->plan;
     std::vector<uint16_t> blob;
@@ -484,6 +514,10 @@ int build_hints(ctg_exec* e) {
             h.stream = 2;
             h.bn = r[W_N] <= 16 ? 16 : 32;
             build_mfma_order(p, r, h.bn, 32, blob, &offA[s], &offB[s], &h.vecA, 64);
+            continue;
+        }
+        if (skinny_ok(p, r)) {
+            h.stream = 3;
             continue;
         }
         h.stream = mfma_use_stream(r[W_R], r[W_BT], r[W_K], r[W_N]) ? 1 : 0;
@@ -983,7 +1017,9 @@ int ctg_exec_step_kernel(ctg_exec* e, int64_t step, char* buf, int64_t buflen) {
         snprintf(name, sizeof(name), "pair_mfma_real_kernel<%s>", p->dtype == CTG_F32 ? "float" : "double");
     } else if (r[W_KERNEL] == KERNEL_MFMA) {
         const MfmaHints& h = e->hints[step];
-        if (h.stream == 2)
+        if (h.stream == 3)
+            snprintf(name, sizeof(name), "pair_skinny_kernel<%d,%d>", (int)r[W_K], (int)r[W_N]);
+        else if (h.stream == 2)
             snprintf(name, sizeof(name), "pair_mfma_kstream_kernel<%d,%s>", h.bn / 16, h.vecA ? "true" : "false");
         else if (h.stream)
             snprintf(name, sizeof(name), "pair_mfma_stream_kernel<%d,%s,%s,%s,%d>", h.bn / 16,

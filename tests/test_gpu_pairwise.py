@@ -74,6 +74,44 @@ def test_pairwise(case, dtype):
     assert np.abs(np.asarray(got) - ref).max() <= tol * scale
 
 
+SKINNY = [
+    # rows paired along the fastest index of A and C, K a power of two, N in {1, 2, 4}
+    ("kabc,kn->abcn", dict(a=64, b=64, c=32, k=8, n=2)),
+    ("akbc,nk->abcn", dict(a=64, b=64, c=32, k=4, n=4)),
+    ("abkc,k->abc", dict(a=64, b=64, c=32, k=16)),
+    ("kabc,kn->abcn", dict(a=128, b=64, c=32, k=2, n=1)),
+    ("ajbklc,ljkn->abcn", dict(a=32, b=64, c=64, j=2, k=2, l=2, n=2)),   # three contracted bits
+]
+
+
+@pytest.mark.parametrize("case", range(len(SKINNY)))
+def test_skinny_kernel(case):
+    """K*N <= 16 with a huge row count: the FMA streaming kernel (no MFMA tile
+    to fill), checked against numpy in complex128."""
+    from cotengra_amd.contractor import HipContractor
+
+    eq, sizes = SKINNY[case]
+    (ta, tb), out = ca.eq_to_inputs_output(eq)
+    rng = np.random.default_rng(100 + case)
+    arrays = [
+        (rng.normal(size=[sizes[i] for i in t]) + 1j * rng.normal(size=[sizes[i] for i in t])).astype("complex64")
+        for t in (ta, tb)
+    ]
+    tree = ca.ContractionTree.from_path([ta, tb], out, sizes, path=[(0, 1)])
+    fn = HipContractor(tree)
+    st = fn.setup(*arrays)
+    names = [n for n in st["exec"].step_kernels() if n.startswith("pair_")]
+    assert names and all(n.startswith("pair_skinny_kernel") for n in names), names
+    got = np.asarray(fn(*arrays))
+    ref = np.einsum(eq, *[x.astype("complex128") for x in arrays], optimize=True)
+    assert got.shape == ref.shape
+    assert np.abs(got - ref).max() <= 3e-5 * np.abs(ref).max()
+    # with strip_exponent the step scales by 1 / (facA * facB)
+    m, e = fn(*arrays, strip_exponent=True)
+    assert np.abs(np.asarray(m) * 10.0**e - ref).max() <= 3e-5 * np.abs(ref).max()
+    fn.close()
+
+
 def test_tensordot_numpy_semantics():
     from cotengra_amd.interface import tensordot
 
@@ -88,3 +126,25 @@ def test_tensordot_numpy_semantics():
     assert np.allclose(np.asarray(tensordot(a.real, c, 1)), np.tensordot(a.real, c, 1))
     with pytest.raises(ValueError):
         tensordot(a, b, ((0,), (0,)))
+
+
+def test_strip_exponent_toggle_on_live_executor():
+    """The same contractor called without and then with strip_exponent (and
+    back): the kernel hints of the MFMA steps must survive the switch."""
+    from cotengra_amd.contractor import HipContractor
+
+    eq, sizes = "abcd,cdef->abef", dict(a=16, b=32, c=8, d=4, e=8, f=8)
+    (ta, tb), out = ca.eq_to_inputs_output(eq)
+    rng = np.random.default_rng(7)
+    arrays = [
+        (rng.normal(size=[sizes[i] for i in t]) + 1j * rng.normal(size=[sizes[i] for i in t])).astype("complex64")
+        for t in (ta, tb)
+    ]
+    ref = np.einsum(eq, *[x.astype("complex128") for x in arrays], optimize=True)
+    fn = HipContractor(ca.ContractionTree.from_path([ta, tb], out, sizes, path=[(0, 1)]))
+    tol = 3e-5 * np.abs(ref).max()
+    assert np.abs(np.asarray(fn(*arrays)) - ref).max() <= tol
+    m, e = fn(*arrays, strip_exponent=True)
+    assert np.abs(np.asarray(m) * 10.0**e - ref).max() <= tol
+    assert np.abs(np.asarray(fn(*arrays)) - ref).max() <= tol
+    fn.close()
