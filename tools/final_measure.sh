@@ -4,7 +4,7 @@
 # Outputs land in gpurun_out/final/; copy what is to be judged into profiles/.
 R=${GRAFT_REPO_ROOT:-$PWD}
 O=$R/gpurun_out/final
-rm -rf $O; mkdir -p $O
+rm -rf $O; mkdir -p $O   # (locally, delete gpurun_out/final before the call: results are merged, not mirrored)
 cd $R
 timeout 900 python -m pytest tests -x -q -m gpu > $O/tests.log 2>&1
 grep -E "passed|failed|error" $O/tests.log | tail -2
