@@ -523,14 +523,20 @@ int build_hints(ctg_exec* e) {
         h.stream = mfma_use_stream(r[W_R], r[W_BT], r[W_K], r[W_N]) ? 1 : 0;
         // big square-ish GEMMs: 128x128 tiles (fast path only) halve the LDS
         // traffic and barriers per flop
-        if (!h.stream && r[W_N] % 128 == 0 && r[W_R] * r[W_N] >= (1ll << 22) && r[W_K] >= 256 &&
-            mfma_fast_ok(p, r, 128))
+        // (a small result under a very long contraction gets its parallelism from
+        // split-K: widest tile there too)
+        const int64_t splits = r[W_K] / MFMA_BK / 4;   // k-splits launch_cfg may use
+        const int64_t tiles128 = ((r[W_R] + 127) / 128) * ((r[W_N] + 127) / 128) * r[W_BT];
+        if (!h.stream && r[W_N] % 128 == 0 && r[W_K] >= 256 &&
+            (r[W_R] * r[W_N] >= (1ll << 22) || tiles128 * splits >= 1024) && mfma_fast_ok(p, r, 128))
             h.bn = 128;
         // small problems: narrower column tiles until the output alone gives every
-        // CU a block -- cheaper than split-K (no slabs to write and reduce)
+        // CU a block -- cheaper than split-K (no slabs to write and reduce); long
+        // contractions (K >= 1024) count the k-splits as blocks
         if (!h.stream) {
             const int64_t tiles_m = (r[W_R] + MFMA_BM - 1) / MFMA_BM;
-            while (h.bn > 16 && tiles_m * ((r[W_N] + h.bn - 1) / h.bn) * r[W_BT] < 256) h.bn /= 2;
+            const int64_t per_tile = r[W_K] >= 1024 ? splits : 1;
+            while (h.bn > 16 && tiles_m * ((r[W_N] + h.bn - 1) / h.bn) * r[W_BT] * per_tile < 256) h.bn /= 2;
         }
         h.additive32 = (h.stream && tile_additive(p, r[W_ROWA_LO], r[W_ROW_LO], r[W_R], 32) &&
                         tile_additive(p, r[W_ROWC_LO], r[W_ROW_LO], r[W_R], 32))

@@ -37,6 +37,8 @@ from __future__ import annotations
 
 from dataclasses import dataclass, field
 
+import math
+
 import numpy as np
 
 from .utils import prod
@@ -60,6 +62,7 @@ SPACE_RESULT = 2
 STEP_WORDS = 48  # int64 words per serialised step record
 LO_MAX = 4096  # target size of the fast ('lo') level of a row table
 ARENA_ALIGN = 64  # elements; keeps every intermediate 256-B aligned
+MAX_TENSOR_ELEMS = 1 << 36  # one complex128 tensor of this size is 1 TiB: beyond any single device
 
 # MFMA kernel limits (see csrc/ctg_pair_mfma.hip)
 MFMA_MAX_BATCH = 65535
@@ -586,6 +589,14 @@ def compile_tree(tree, dtype, order=None, force_kernel=None):
     plan = Plan(dtype)
     size_dict = tree.size_dict
     N = tree.N
+    if N > 1 and tree.max_size() > MAX_TENSOR_ELEMS:
+        # (the offset tables alone would not fit the host; the reference lets such
+        # a contraction start and die in numpy's allocator)
+        raise MemoryError(
+            f"the largest intermediate of one slice has 2^{math.log2(tree.max_size()):.1f} elements; "
+            f"slice the tree (ContractionTree.slice / pathfind.slice_tree) to at most "
+            f"2^{int(math.log2(MAX_TENSOR_ELEMS))} before contracting on one device"
+        )
 
     # -- inputs space: all (unsliced) inputs back to back, 64-element aligned
     cursor = 0

@@ -1,0 +1,112 @@
+#!/usr/bin/env python
+"""Refine a sliced contraction tree with the package's own host tools
+(cotengra_amd.pathfind: native subtree reconfiguration, csrc/ctg_pathfind.cpp)
+and write the result as a tree fixture.  No reference code is involved.
+
+    python tests/golden/gen/refine_native.py SRC.json combo-512 OUT.json
+
+1. ``subtree_reconfigure(subtree_size=10, minimize=OBJ)`` on the sliced tree:
+   fewer MACs per slice at a smaller width;
+2. greedily take indices out of the slicing again while the largest
+   intermediate stays <= 2^32 elements and the arena <= 160 GiB, each time the
+   index that lowers the modelled time to the full result most, then
+   reconfigure again (subtree size 10 / 12 alternating); six rounds.
+
+The time model prices every step at max(flops / 125 TFLOP/s, bytes / 4.8 TB/s)
+-- the rates the kernels reach on an MI355X.  ``OBJ`` =
+``combo-F`` is ``flops + F * size``: the larger F, the higher the arithmetic
+intensity of the steps (and the FLOP/s), the smaller F, the less total work.
+"""
+import json
+import math
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..", ".."))
+import cotengra_amd as ca  # noqa: E402
+from cotengra_amd import pathfind  # noqa: E402
+from cotengra_amd.plan import compile_tree  # noqa: E402
+
+MAX_WIDTH = 2**32
+MAX_ARENA_GIB = 160.0
+P_FLOPS, BW = 125e12, 4.8e12
+
+
+def model(tree):
+    plan = compile_tree(tree, "complex64")
+    t = sum(max(8 * r["macs"] / P_FLOPS, r["bytes"] / BW) for r in plan.describe_steps())
+    return t, plan.flops_per_slice() / t / 1e12, plan.arena_elems * 8 / 2**30
+
+
+def stat(tree, tag):
+    t, tf, arena = model(tree)
+    print(
+        f"{tag}: 2^{math.log2(tree.nslices):.0f} slices, 10^{tree.contraction_cost(log=10):.3f} MACs, "
+        f"width 2^{tree.max_size(log=2):.0f}, model {t * 1e3:.1f} ms/slice {tf:.1f} TFLOP/s "
+        f"{t * tree.nslices / 86400:.2f} days, arena {arena:.0f} GiB",
+        flush=True,
+    )
+    return t * tree.nslices
+
+
+def main():
+    src, obj, dst = sys.argv[1:4]
+    rec = ca.load_network(src)
+
+    def with_sliced(tree, sliced):
+        r = dict(rec)
+        r["path"] = [list(p) for p in tree.get_path()]
+        r["sliced_inds"] = list(sliced)
+        return ca.tree_from_record(r)
+
+    tree = ca.tree_from_record(rec)
+    stat(tree, "start")
+    t0 = time.time()
+    tree = pathfind.subtree_reconfigure(tree, subtree_size=10, minimize=obj)
+    stat(tree, f"reconfigured ({obj})")
+    for rnd in range(6):
+        while True:
+            cur = model(tree)[0] * tree.nslices
+            best = None
+            for ix in list(tree.sliced_inds):
+                cand = with_sliced(tree, [j for j in tree.sliced_inds if j != ix])
+                if cand.max_size() > MAX_WIDTH:
+                    continue
+                t, _, arena = model(cand)
+                if arena > MAX_ARENA_GIB:
+                    continue
+                if best is None or t * cand.nslices < best[0]:
+                    best = (t * cand.nslices, cand)
+            if best is None or best[0] >= cur:
+                break
+            tree = best[1]
+        again = pathfind.subtree_reconfigure(tree, subtree_size=10 + (rnd % 2) * 2, minimize=obj)
+        if stat(again, f"round {rnd}") < model(tree)[0] * tree.nslices:
+            tree = again
+    out = dict(rec)
+    out["path"] = [list(p) for p in tree.get_path()]
+    out["sliced_inds"] = list(tree.sliced_inds)
+    t, tf, arena = model(tree)
+    out["search"] = {
+        "optimizer": f"tests/golden/gen/refine_native.py {os.path.basename(src)} {obj} "
+        "(cotengra_amd.pathfind: native subtree reconfiguration + model-guided unslicing)",
+        "source_search": rec.get("search"),
+        "seconds": round(time.time() - t0),
+    }
+    out["stats"] = {
+        "nslices_log2": math.log2(tree.nslices),
+        "contraction_cost_log10": tree.contraction_cost(log=10),
+        "cost_per_slice": tree.contraction_cost() // tree.nslices,
+        "write_per_slice": tree.total_write() // tree.nslices,
+        "max_size_log2": tree.max_size(log=2),
+        "model_ms_per_slice": t * 1e3,
+        "arena_gib": arena,
+    }
+    with open(dst, "w") as f:
+        json.dump(out, f, ensure_ascii=False)
+    stat(tree, "final")
+
+
+if __name__ == "__main__":
+    main()

@@ -145,3 +145,16 @@ def test_from_path_expands_multi_tensor_steps():
     # ssa form as well
     tree2 = ca.ContractionTree.from_path(inputs, (), size_dict, ssa_path=[(0, 1, 2, 3), (4, 5)])
     assert abs(orc.contract(tree2, arrays) - ref) < 1e-12 * abs(ref)
+
+
+def test_compile_refuses_unsliceably_wide_trees():
+    """A tree whose single-slice intermediates cannot fit any device fails with a
+    clear MemoryError at plan time instead of exhausting the host."""
+    import cotengra_amd as ca
+    from cotengra_amd.plan import compile_tree
+
+    inputs = [tuple(f"i{j}" for j in range(20)), tuple(f"k{j}" for j in range(20))]
+    sd = {ix: 2 for t in inputs for ix in t}
+    tree = ca.ContractionTree.from_path(inputs, inputs[0] + inputs[1], sd, path=[(0, 1)])
+    with pytest.raises(MemoryError, match="slice the tree"):
+        compile_tree(tree, "complex64")

@@ -22,7 +22,15 @@ def main():
     (ta, tb), out = ca.eq_to_inputs_output(eq)
     tree = ca.ContractionTree.from_path([ta, tb], out, sizes, path=[(0, 1)])
     rng = np.random.default_rng(0)
-    arrays = [(rng.normal(size=[sizes[i] for i in t]) + 1j * rng.normal(size=[sizes[i] for i in t])).astype(dtype) for t in (ta, tb)]
+    def make(t):
+        shape = [sizes[i] for i in t]
+        if int(np.prod(shape)) >= (1 << 24) and dtype == "complex64":
+            import torch  # big operands: generated on the device
+
+            return torch.view_as_complex(torch.randn(shape + [2], device="cuda", dtype=torch.float32))
+        return (rng.normal(size=shape) + 1j * rng.normal(size=shape)).astype(dtype)
+
+    arrays = [make(t) for t in (ta, tb)]
     fn = HipContractor(tree, force_kernel=force)
     st = fn.setup(*arrays)
     plan, ex = st["plan"], st["exec"]
@@ -30,9 +38,9 @@ def main():
     for _ in range(reps):
         ms = ex.profile_slice(0)
         best = ms if best is None else np.minimum(best, ms)
-    for r, m in zip(plan.describe_steps(), best):
+    for r, m, nm in zip(plan.describe_steps(), best, ex.step_kernels()):
         if r["kind"] == "pair":
-            print(f"{eq} {sizes}: kernel={r['kernel']} R={r['R']} K={r['K']} N={r['N']} "
+            print(f"{eq} {sizes}: {nm} R={r['R']} K={r['K']} N={r['N']} "
                   f"ms={m:.4f} TF={(8 if 'complex' in dtype else 2)*r['macs']/m/1e9:.2f} GB/s={r['bytes']/m/1e6:.0f}")
     fn.close()
 
