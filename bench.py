@@ -3,7 +3,10 @@
 
 One "step" = one slice of the m20 contraction tree per GPU (SURVEY.md section 8d:
 unit = one slice).  The tree fixture was found offline by the reference's own
-hyper-optimizer + dynamic slicing; inputs are synthetic tensors of the named
+hyper-optimizer + dynamic slicing and then refined with this package's native
+subtree reconfiguration (tests/golden/gen/refine_native.py; ``--tree`` takes
+any other fixture, e.g. sycamore_m20_w32_c128.json = least time to the full
+amplitude); inputs are synthetic tensors of the named
 shapes (reference ``make_arrays_from_inputs`` semantics, seed 42, complex64,
 rescaled by size**0.25 so fp32 does not underflow) and are resident in HBM
 before the timed region.  With N GPUs every rank contracts its own slices
@@ -27,7 +30,7 @@ sys.path.insert(0, ROOT)
 
 PEAK_MFMA_F32_TFLOPS = 157.3  # MI355X_MICROARCH.md: dense fp32 matrix peak
 PEAK_HBM_GBS = 8000.0
-TREE = os.path.join(ROOT, "tests", "golden", "trees", "sycamore_m20_w32.json")
+TREE = os.path.join(ROOT, "tests", "golden", "trees", "sycamore_m20_w32_c512.json")
 
 
 def shrink_for_cpu(tree, log2_width):

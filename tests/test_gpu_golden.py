@@ -139,10 +139,13 @@ def test_check_zero():
     assert np.all(np.asarray(out) == 0)
 
 
-@pytest.mark.parametrize("fixture", ["sycamore_m20_w30.json", "sycamore_m20_w32.json"])
+@pytest.mark.parametrize(
+    "fixture",
+    ["sycamore_m20_w30.json", "sycamore_m20_w32.json", "sycamore_m20_w32_c512.json", "sycamore_m20_w32_c128.json"],
+)
 def test_full_size_properties_m20(fixture):
     """Size-independent checks at full slice width (2^30 first-search tree;
-    2^32 refined tree = the benchmark's): (1) slicing identity -- a slice of the
+    2^32 refined trees, c512 = the benchmark's): (1) slicing identity -- a slice of the
     tree equals the sum of the two slices obtained by slicing one more index;
     (2) linearity in one input."""
     import cotengra_amd as ca
