@@ -121,6 +121,15 @@ int fail(const char* msg) {
 }
 }  // namespace
 
+// cost of one contraction in the reconfiguration: `flops + write_factor * size`
+// (rates == nullptr), or modelled seconds (see ctg_subtree_reconfigure_timed)
+struct CostModel {
+    double write_factor = 0;
+    const double* rates = nullptr;   // complex MACs / s by floor(log2 K)
+    int64_t n_rates = 0;
+    double elem_rate = 1;            // elements / s through memory
+};
+
 extern "C" {
 
 int ctg_path_greedy(int64_t n_inputs, const int64_t* offsets, const int64_t* inds, int64_t n_out,
@@ -333,10 +342,10 @@ int ctg_slice_greedy(int64_t n_inputs, const int64_t* offsets, const int64_t* in
 // (the reference's `combo-<f>` objective, scoring.py; write_factor = 0 is plain
 // flops).  Nodes are visited by decreasing cost (`select="max"`); a node whose
 // subtree came out unchanged is not revisited until something below it changes.
-int ctg_subtree_reconfigure(int64_t n_inputs, const int64_t* offsets, const int64_t* inds, int64_t n_out,
-                            const int64_t* out_inds, int64_t n_inds, const double* sizes,
-                            const int64_t* ssa_path_in, int64_t subtree_size, int64_t maxiter,
-                            double write_factor, int64_t* ssa_path_out) {
+static int subtree_reconfigure_impl(int64_t n_inputs, const int64_t* offsets, const int64_t* inds, int64_t n_out,
+                                   const int64_t* out_inds, int64_t n_inds, const double* sizes,
+                                   const int64_t* ssa_path_in, int64_t subtree_size, int64_t maxiter,
+                                   const CostModel& cm, int64_t* ssa_path_out) {
     Network net;
     if ((!ssa_path_in || !ssa_path_out) && n_inputs > 1) return fail("ctg_subtree_reconfigure: null argument");
     if (!build_network(n_inputs, offsets, inds, n_out, out_inds, n_inds, sizes, net))
@@ -364,7 +373,26 @@ int ctg_subtree_reconfigure(int64_t n_inputs, const int64_t* offsets, const int6
         for (const auto& kv : a) flops *= net.size[kv.first];
         for (const auto& kv : b)
             if (!a.count(kv.first)) flops *= net.size[kv.first];
-        return flops + write_factor * legs_size(k, net.size);
+        if (cm.rates == nullptr) return flops + cm.write_factor * legs_size(k, net.size);
+        // time model: the step runs at the matrix-core rate its contracted extent
+        // K and its narrower kept side N allow, or at the memory rate
+        const double sa = legs_size(a, net.size), sb = legs_size(b, net.size), sc = legs_size(k, net.size);
+        double kk = 1, keep_a = 1, keep_b = 1;
+        for (const auto& kv : a) {
+            if (k.count(kv.first)) {
+                if (!b.count(kv.first)) keep_a *= net.size[kv.first];
+            } else if (b.count(kv.first)) {
+                kk *= net.size[kv.first];
+            }
+        }
+        for (const auto& kv : b)
+            if (k.count(kv.first) && !a.count(kv.first)) keep_b *= net.size[kv.first];
+        int lk = 0;
+        while (lk + 1 < cm.n_rates && std::ldexp(1.0, lk + 1) <= kk) ++lk;
+        double rate = cm.rates[lk];
+        const double nn = std::min(keep_a, keep_b);
+        if (nn < 16) rate *= std::max(nn, 1.0) / 16.0;   // a matrix-core tile has 16 complex columns
+        return std::max(flops / rate, (sa + sb + sc) / cm.elem_rate);
     };
     int64_t root = -1;
     {
@@ -496,6 +524,39 @@ int ctg_subtree_reconfigure(int64_t n_inputs, const int64_t* offsets, const int6
         }
     }
     return step == n - 1 ? CTG_OK : fail("ctg_subtree_reconfigure: internal error");
+}
+
+int ctg_subtree_reconfigure(int64_t n_inputs, const int64_t* offsets, const int64_t* inds, int64_t n_out,
+                            const int64_t* out_inds, int64_t n_inds, const double* sizes,
+                            const int64_t* ssa_path_in, int64_t subtree_size, int64_t maxiter,
+                            double write_factor, int64_t* ssa_path_out) {
+    CostModel cm;
+    cm.write_factor = write_factor;
+    return subtree_reconfigure_impl(n_inputs, offsets, inds, n_out, out_inds, n_inds, sizes, ssa_path_in,
+                                    subtree_size, maxiter, cm, ssa_path_out);
+}
+
+// The same search with a machine model as the objective: a contraction costs
+// max(MACs / mac_rate[floor(log2 K)], (size_a + size_b + size_out) / elem_rate)
+// seconds, where K is its contracted extent (the last table entry serves every
+// larger K) and the MAC rate is scaled by N/16 when the narrower kept side N
+// has fewer than 16 columns.  The tables are the caller's measurements of the
+// executor's kernels (cotengra_amd.pathfind.MI355X_C64).
+int ctg_subtree_reconfigure_timed(int64_t n_inputs, const int64_t* offsets, const int64_t* inds,
+                                  int64_t n_out, const int64_t* out_inds, int64_t n_inds,
+                                  const double* sizes, const int64_t* ssa_path_in, int64_t subtree_size,
+                                  int64_t maxiter, const double* mac_rate_by_log2k, int64_t n_rates,
+                                  double elem_rate, int64_t* ssa_path_out) {
+    if (!mac_rate_by_log2k || n_rates < 1 || !(elem_rate > 0))
+        return fail("ctg_subtree_reconfigure_timed: bad machine model");
+    for (int64_t i = 0; i < n_rates; ++i)
+        if (!(mac_rate_by_log2k[i] > 0)) return fail("ctg_subtree_reconfigure_timed: bad machine model");
+    CostModel cm;
+    cm.rates = mac_rate_by_log2k;
+    cm.n_rates = n_rates;
+    cm.elem_rate = elem_rate;
+    return subtree_reconfigure_impl(n_inputs, offsets, inds, n_out, out_inds, n_inds, sizes, ssa_path_in,
+                                    subtree_size, maxiter, cm, ssa_path_out);
 }
 
 }  // extern "C"

@@ -6,7 +6,10 @@
 * ``random_greedy_tree`` -- repeated Boltzmann-sampled greedy runs, best tree
   kept (the idea of ``optimize_random_greedy_track_flops``, ``:1113-1240``);
 * ``slice_tree`` -- greedy choice of sliced indices until the largest
-  intermediate fits ``target_size`` (``SliceFinder``, ``cotengra/slicer.py``).
+  intermediate fits ``target_size`` (``SliceFinder``, ``cotengra/slicer.py``);
+* ``subtree_reconfigure`` / ``slice_and_reconfigure`` -- exact re-ordering of
+  subtrees by dynamic programming (``core.py:2316-2449, 2723-2808``), under the
+  reference's objectives or under a machine model (``minimize="time"``).
 
 The hyper-optimizers built on top of these stay in the reference; this module
 is what the stand-alone front ends use when they are not handed a tree.
@@ -15,6 +18,7 @@ is what the stand-alone front ends use when they are not handed a tree.
 from __future__ import annotations
 
 import ctypes as C
+import math
 
 import numpy as np
 
@@ -153,11 +157,38 @@ def _objective(minimize):
     raise ValueError(f"unknown objective {minimize!r} (flops, combo, combo-<f>)")
 
 
+class MachineModel:
+    """What a contraction step costs on the device, as the native reconfiguration
+    prices it under ``minimize=<MachineModel>`` / ``minimize="time"``:
+    ``max(MACs / mac_rate[floor(log2 K)], elements moved / elem_rate)`` seconds,
+    ``K`` = contracted extent (csrc/ctg_pathfind.cpp: CostModel)."""
+
+    def __init__(self, mac_rate_by_log2k, elem_rate):
+        self.mac_rate_by_log2k = tuple(float(x) for x in mac_rate_by_log2k)
+        self.elem_rate = float(elem_rate)
+
+    def step_seconds(self, macs, elems, k, n=16):
+        rate = self.mac_rate_by_log2k[min(max(int(math.floor(math.log2(max(k, 1)))), 0), len(self.mac_rate_by_log2k) - 1)]
+        if n < 16:
+            rate *= max(n, 1) / 16.0
+        return max(macs / rate, elems / self.elem_rate)
+
+
+# complex64 on one MI355X, from the per-step tables of this package's kernels
+# (profiles/r1_m20_steps.txt): complex MACs/s (= TFLOP/s / 8) of pairwise steps
+# by contracted extent K = 1, 2, 4, ... 512+, and 4.8 TB/s of 8-byte elements.
+MI355X_C64 = MachineModel(
+    [x * 1e12 / 8 for x in (4, 8, 16, 30, 50, 75, 100, 118, 127, 131)], 4.8e12 / 8
+)
+
+
 def subtree_reconfigure(tree, subtree_size=8, maxiter="auto", minimize="flops", inplace=False):
     """Locally optimal re-ordering of the subtrees of ``tree`` (reference
     ``ContractionTree.subtree_reconfigure``, core.py:2316-2449) by the native
     dynamic-programming routine.  Sliced indices are kept and count as size 1,
-    so the per-slice cost is what is minimised."""
+    so the per-slice cost is what is minimised.  ``minimize``: ``"flops"``,
+    ``"combo"``, ``"combo-<f>"`` as in the reference, or ``"time"`` / a
+    :class:`MachineModel` -- modelled seconds on the device."""
     if tree.N < 3:
         return tree if inplace else tree.copy()
     sliced = list(tree.sliced_inds)
@@ -166,13 +197,22 @@ def subtree_reconfigure(tree, subtree_size=8, maxiter="auto", minimize="flops", 
     ids, offsets, flat, out, sizes = _csr(tree.inputs, tree.output, eff)
     ssa_in = np.asarray([x for pair in tree.get_ssa_path() for x in pair], dtype=np.int64)
     ssa_out = np.empty_like(ssa_in)
-    runtime._check(
-        runtime.load().ctg_subtree_reconfigure(
-            tree.N, _p(offsets, C.c_int64), _p(flat, C.c_int64), len(tree.output), _p(out, C.c_int64),
-            len(ids), _p(sizes, C.c_double), _p(ssa_in, C.c_int64), int(subtree_size),
-            0 if maxiter == "auto" else int(maxiter), _objective(minimize), _p(ssa_out, C.c_int64),
-        )
+    lib = runtime.load()
+    head = (
+        tree.N, _p(offsets, C.c_int64), _p(flat, C.c_int64), len(tree.output), _p(out, C.c_int64),
+        len(ids), _p(sizes, C.c_double), _p(ssa_in, C.c_int64), int(subtree_size),
+        0 if maxiter == "auto" else int(maxiter),
     )
+    model = MI355X_C64 if minimize == "time" else minimize
+    if isinstance(model, MachineModel):
+        rates = np.asarray(model.mac_rate_by_log2k, dtype=np.float64)
+        runtime._check(
+            lib.ctg_subtree_reconfigure_timed(
+                *head, _p(rates, C.c_double), len(rates), model.elem_rate, _p(ssa_out, C.c_int64)
+            )
+        )
+    else:
+        runtime._check(lib.ctg_subtree_reconfigure(*head, _objective(minimize), _p(ssa_out, C.c_int64)))
     new = ContractionTree.from_path(
         tree.inputs, tree.output, size_dict,
         ssa_path=[(int(ssa_out[2 * s]), int(ssa_out[2 * s + 1])) for s in range(tree.N - 1)],

@@ -39,6 +39,7 @@ SYMBOLS = (
     "ctg_path_greedy",
     "ctg_slice_greedy",
     "ctg_subtree_reconfigure",
+    "ctg_subtree_reconfigure_timed",
 )
 
 
@@ -124,6 +125,9 @@ def load():
                              i64p, C.c_double, C.c_int, C.c_int64, i64p, i64p],
         "ctg_subtree_reconfigure": [C.c_int64, i64p, i64p, C.c_int64, i64p, C.c_int64, C.POINTER(C.c_double),
                                     i64p, C.c_int64, C.c_int64, C.c_double, i64p],
+        "ctg_subtree_reconfigure_timed": [C.c_int64, i64p, i64p, C.c_int64, i64p, C.c_int64,
+                                          C.POINTER(C.c_double), i64p, C.c_int64, C.c_int64,
+                                          C.POINTER(C.c_double), C.c_int64, C.c_double, i64p],
     }
     for name, argtypes in protos.items():
         fn = getattr(lib, name)

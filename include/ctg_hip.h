@@ -191,6 +191,19 @@ int ctg_subtree_reconfigure(int64_t n_inputs, const int64_t* offsets, const int6
                             const int64_t* ssa_path_in, int64_t subtree_size, int64_t maxiter,
                             double write_factor, int64_t* ssa_path_out);
 
+/* The same search with a machine model as the objective (no reference
+ * counterpart; the reference's objectives are the `scoring.py` closed forms): a
+ * contraction costs max(MACs / mac_rate_by_log2k[floor(log2 K)], (size_a + size_b
+ * + size_out) / elem_rate) seconds, K = its contracted extent (the last table
+ * entry serves every larger K), the MAC rate scaled by N/16 when the narrower
+ * kept side has N < 16 columns.  The table holds the caller's measurements of
+ * the executor's kernels (cotengra_amd.pathfind.MI355X_C64). */
+int ctg_subtree_reconfigure_timed(int64_t n_inputs, const int64_t* offsets, const int64_t* inds,
+                                  int64_t n_out, const int64_t* out_inds, int64_t n_inds,
+                                  const double* sizes, const int64_t* ssa_path_in, int64_t subtree_size,
+                                  int64_t maxiter, const double* mac_rate_by_log2k, int64_t n_rates,
+                                  double elem_rate, int64_t* ssa_path_out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -3,7 +3,7 @@
 (cotengra_amd.pathfind: native subtree reconfiguration, csrc/ctg_pathfind.cpp)
 and write the result as a tree fixture.  No reference code is involved.
 
-    python tests/golden/gen/refine_native.py SRC.json combo-512 OUT.json
+    python tests/golden/gen/refine_native.py SRC.json combo-512 OUT.json [flat|mi355x]
 
 1. ``subtree_reconfigure(subtree_size=10, minimize=OBJ)`` on the sliced tree:
    fewer MACs per slice at a smaller width;
@@ -13,9 +13,12 @@ and write the result as a tree fixture.  No reference code is involved.
    reconfigure again (subtree size 10 / 12 alternating); six rounds.
 
 The time model prices every step at max(flops / 125 TFLOP/s, bytes / 4.8 TB/s)
--- the rates the kernels reach on an MI355X.  ``OBJ`` =
-``combo-F`` is ``flops + F * size``: the larger F, the higher the arithmetic
-intensity of the steps (and the FLOP/s), the smaller F, the less total work.
+("flat", the default) or with the matrix-core rate measured for its contracted
+extent K ("mi355x" = cotengra_amd.pathfind.MI355X_C64) -- the rates the kernels
+reach on an MI355X.  ``OBJ`` = ``combo-F`` is ``flops + F *
+size``: the larger F, the higher the arithmetic intensity of the steps (and the
+FLOP/s), the smaller F, the less total work; ``OBJ`` = ``time`` makes the
+reconfiguration itself minimise the modelled seconds.
 """
 import json
 import math
@@ -33,9 +36,17 @@ MAX_ARENA_GIB = 160.0
 P_FLOPS, BW = 125e12, 4.8e12
 
 
+MODEL = "flat"
+
+
 def model(tree):
     plan = compile_tree(tree, "complex64")
-    t = sum(max(8 * r["macs"] / P_FLOPS, r["bytes"] / BW) for r in plan.describe_steps())
+    rows = plan.describe_steps()
+    if MODEL == "flat":
+        t = sum(max(8 * r["macs"] / P_FLOPS, r["bytes"] / BW) for r in rows)
+    else:
+        m = pathfind.MI355X_C64
+        t = sum(m.step_seconds(r["macs"], r["bytes"] / 8, r["K"], r["N"]) for r in rows if r["macs"])
     return t, plan.flops_per_slice() / t / 1e12, plan.arena_elems * 8 / 2**30
 
 
@@ -51,7 +62,9 @@ def stat(tree, tag):
 
 
 def main():
+    global MODEL
     src, obj, dst = sys.argv[1:4]
+    MODEL = sys.argv[4] if len(sys.argv) > 4 else "flat"
     rec = ca.load_network(src)
 
     def with_sliced(tree, sliced):
@@ -89,7 +102,7 @@ def main():
     out["sliced_inds"] = list(tree.sliced_inds)
     t, tf, arena = model(tree)
     out["search"] = {
-        "optimizer": f"tests/golden/gen/refine_native.py {os.path.basename(src)} {obj} "
+        "optimizer": f"tests/golden/gen/refine_native.py {os.path.basename(src)} {obj} {MODEL} "
         "(cotengra_amd.pathfind: native subtree reconfiguration + model-guided unslicing)",
         "source_search": rec.get("search"),
         "seconds": round(time.time() - t0),

@@ -124,3 +124,49 @@ def test_reconfigure_preserves_value_and_slicing():
         pathfind.subtree_reconfigure(tree, subtree_size=17)
     with pytest.raises(ValueError):
         pathfind.subtree_reconfigure(tree, minimize="size")
+
+
+def modelled_seconds(tree, model):
+    """Sum over the tree's contractions of the machine model's step price (the
+    Python restatement of CostModel in csrc/ctg_pathfind.cpp)."""
+    total = 0.0
+    for p, l, r in tree.traverse():
+        ll, rl, pl = tree.get_legs(l), tree.get_legs(r), tree.get_legs(p)
+        size = lambda legs: math.prod(tree.size_dict[ix] for ix in legs if ix not in tree.sliced_inds)
+        k = math.prod(tree.size_dict[ix] for ix in ll if ix in rl and ix not in pl and ix not in tree.sliced_inds)
+        keep_l = math.prod(tree.size_dict[ix] for ix in ll if ix in pl and ix not in rl and ix not in tree.sliced_inds)
+        keep_r = math.prod(tree.size_dict[ix] for ix in rl if ix in pl and ix not in ll and ix not in tree.sliced_inds)
+        macs = math.prod(tree.size_dict[ix] for ix in set(ll) | set(rl) if ix not in tree.sliced_inds)
+        total += model.step_seconds(macs, size(ll) + size(rl) + size(pl), k, min(keep_l, keep_r))
+    return total
+
+
+def test_reconfigure_under_a_machine_model():
+    """minimize="time" / a MachineModel: the native search lowers the modelled
+    seconds (never raises them), keeps value and slicing; the model's two regimes
+    pull in different directions."""
+    inputs, output, shapes, size_dict = ca.lattice_equation([4, 5], d_min=2, d_max=4, seed=11)
+    arrays = ca.make_arrays_from_inputs(inputs, size_dict, seed=2, dtype="complex128")
+    ref = np.einsum(ca.inputs_output_to_eq(inputs, output), *arrays, optimize=True)
+    tree = pathfind.greedy_tree(inputs, output, size_dict, temperature=2.0, seed=9)
+    m = pathfind.MI355X_C64
+    t2 = pathfind.subtree_reconfigure(tree, subtree_size=9, minimize="time")
+    assert modelled_seconds(t2, m) <= modelled_seconds(tree, m) * (1 + 1e-12)
+    assert np.allclose(orc.contract(t2, arrays), ref, rtol=1e-10, atol=1e-12)
+    # compute-only and memory-only machines reproduce the flops / write orderings
+    flops_machine = pathfind.MachineModel([1.0], 1e300)
+    t3 = pathfind.subtree_reconfigure(tree, subtree_size=9, minimize=flops_machine)
+    t4 = pathfind.subtree_reconfigure(tree, subtree_size=9, minimize="flops")
+    # (N < 16 columns are priced at N/16 of the rate, so not exactly "flops")
+    assert modelled_seconds(t3, flops_machine) <= modelled_seconds(t4, flops_machine) * (1 + 1e-12)
+    mem_machine = pathfind.MachineModel([1e300], 1.0)
+    t5 = pathfind.subtree_reconfigure(tree, subtree_size=9, minimize=mem_machine)
+    assert modelled_seconds(t5, mem_machine) <= modelled_seconds(tree, mem_machine) * (1 + 1e-12)
+    assert np.allclose(orc.contract(t5, arrays), ref, rtol=1e-10, atol=1e-12)
+    sliced = tree.slice(target_size=max(tree.max_size() // 4, 2))
+    t6 = pathfind.subtree_reconfigure(sliced, subtree_size=8, minimize="time")
+    assert set(t6.sliced_inds) == set(sliced.sliced_inds)
+    assert modelled_seconds(t6, m) <= modelled_seconds(sliced, m) * (1 + 1e-12)
+    assert np.allclose(orc.contract(t6, arrays), ref, rtol=1e-10, atol=1e-12)
+    with pytest.raises(ValueError):
+        pathfind.subtree_reconfigure(tree, minimize=pathfind.MachineModel([0.0], 1.0))
