@@ -731,6 +731,41 @@ class ContractionTree:
 
     slice_ = functools.partialmethod(slice, inplace=True)
 
+    def subtree_reconfigure(self, subtree_size=8, subtree_search="bfs", weight_what="flops",
+                            weight_pwr=2, select="max", maxiter="auto", seed=None, minimize="flops",
+                            optimize=None, inplace=False, progbar=False):
+        """Reference ``ContractionTree.subtree_reconfigure`` (core.py:2316-2449) on
+        the native dynamic-programming routine (``cotengra_amd.pathfind``): subtrees
+        are grown breadth-first and visited most expensive first -- the reference's
+        defaults; its sampling options are accepted and ignored.  ``minimize`` also
+        takes ``"time"`` / a ``pathfind.MachineModel``."""
+        from .pathfind import subtree_reconfigure
+
+        return subtree_reconfigure(self, subtree_size=subtree_size, maxiter=maxiter, minimize=minimize,
+                                   inplace=inplace)
+
+    subtree_reconfigure_ = functools.partialmethod(subtree_reconfigure, inplace=True)
+
+    def slice_and_reconfigure(self, target_size, step_size=2, temperature=0.01, minimize="flops",
+                              allow_outer=True, max_repeats=16, reslice=False, reconf_opts=None,
+                              progbar=False, inplace=False):
+        """Reference ``ContractionTree.slice_and_reconfigure`` (core.py:2723-2808):
+        slice towards ``target_size`` ``step_size`` bits at a time, re-optimising
+        subtrees in between (``reconf_opts``: ``subtree_size``, ``maxiter``)."""
+        from .pathfind import slice_and_reconfigure
+
+        opts = dict(reconf_opts or {})
+        new = slice_and_reconfigure(
+            self.unslice_all() if reslice else self, target_size, minimize=opts.get("minimize", minimize),
+            subtree_size=opts.get("subtree_size", 8), allow_outer=allow_outer, step_bits=float(step_size),
+        )
+        if inplace:
+            self.__dict__.update(new.__dict__)
+            return self
+        return new
+
+    slice_and_reconfigure_ = functools.partialmethod(slice_and_reconfigure, inplace=True)
+
     def restore_ind(self, ind, inplace=False):
         """Undo :meth:`remove_ind` (reference core.py:2046-2089)."""
         tree = self if inplace else self.copy()

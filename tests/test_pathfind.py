@@ -170,3 +170,22 @@ def test_reconfigure_under_a_machine_model():
     assert np.allclose(orc.contract(t6, arrays), ref, rtol=1e-10, atol=1e-12)
     with pytest.raises(ValueError):
         pathfind.subtree_reconfigure(tree, minimize=pathfind.MachineModel([0.0], 1.0))
+
+
+def test_tree_methods_mirror_the_reference_names():
+    """tree.subtree_reconfigure(_) / tree.slice_and_reconfigure(_) with the
+    reference's keyword names (core.py:2316, 2723)."""
+    inputs, output, shapes, size_dict = ca.lattice_equation([3, 5], d_min=2, d_max=3, seed=2)
+    arrays = ca.make_arrays_from_inputs(inputs, size_dict, seed=4, dtype="complex128")
+    ref = np.einsum(ca.inputs_output_to_eq(inputs, output), *arrays, optimize=True)
+    tree = pathfind.greedy_tree(inputs, output, size_dict, temperature=2.0, seed=1)
+    t2 = tree.subtree_reconfigure(subtree_size=6, minimize="combo", select="max", progbar=False)
+    assert t2 is not tree and t2.contraction_cost() <= tree.contraction_cost() * 64
+    target = max(tree.max_size() // 4, 2)
+    t3 = tree.slice_and_reconfigure(target, step_size=1, minimize="flops", reconf_opts=dict(subtree_size=6))
+    assert t3.max_size() <= target and t3.nslices > 1 and tree.nslices == 1
+    assert np.allclose(orc.contract(t3, arrays), ref, rtol=1e-10, atol=1e-12)
+    cp = tree.copy()
+    assert cp.subtree_reconfigure_(subtree_size=6) is cp
+    assert cp.slice_and_reconfigure_(target, reslice=True) is cp and cp.max_size() <= target
+    assert np.allclose(orc.contract(cp, arrays), ref, rtol=1e-10, atol=1e-12)
