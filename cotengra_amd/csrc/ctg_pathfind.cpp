@@ -128,6 +128,7 @@ struct CostModel {
     const double* rates = nullptr;   // complex MACs / s by floor(log2 K)
     int64_t n_rates = 0;
     double elem_rate = 1;            // elements / s through memory
+    double narrow_factor = 0.8;      // MAC rate of steps whose narrower kept side has 16..63 columns
 };
 
 extern "C" {
@@ -392,6 +393,8 @@ static int subtree_reconfigure_impl(int64_t n_inputs, const int64_t* offsets, co
         double rate = cm.rates[lk];
         const double nn = std::min(keep_a, keep_b);
         if (nn < 16) rate *= std::max(nn, 1.0) / 16.0;   // a matrix-core tile has 16 complex columns
+        else if (nn < 64 && kk >= 64) rate *= cm.narrow_factor;   // 128x32 block tiles (the K < 64 rates
+                                                                  // were measured on such steps already)
         return std::max(flops / rate, (sa + sb + sc) / cm.elem_rate);
     };
     int64_t root = -1;
@@ -540,7 +543,7 @@ int ctg_subtree_reconfigure(int64_t n_inputs, const int64_t* offsets, const int6
 // max(MACs / mac_rate[floor(log2 K)], (size_a + size_b + size_out) / elem_rate)
 // seconds, where K is its contracted extent (the last table entry serves every
 // larger K) and the MAC rate is scaled by N/16 when the narrower kept side N
-// has fewer than 16 columns.  The tables are the caller's measurements of the
+// has fewer than 16 columns, by 0.8 when it has 16..63 and K >= 64 (128x32 tiles).  The tables are the caller's measurements of the
 // executor's kernels (cotengra_amd.pathfind.MI355X_C64).
 int ctg_subtree_reconfigure_timed(int64_t n_inputs, const int64_t* offsets, const int64_t* inds,
                                   int64_t n_out, const int64_t* out_inds, int64_t n_inds,

@@ -196,7 +196,7 @@ int ctg_subtree_reconfigure(int64_t n_inputs, const int64_t* offsets, const int6
  * contraction costs max(MACs / mac_rate_by_log2k[floor(log2 K)], (size_a + size_b
  * + size_out) / elem_rate) seconds, K = its contracted extent (the last table
  * entry serves every larger K), the MAC rate scaled by N/16 when the narrower
- * kept side has N < 16 columns.  The table holds the caller's measurements of
+ * kept side has N < 16 columns and by 0.8 when it has 16..63 and K >= 64.  The table holds the caller's measurements of
  * the executor's kernels (cotengra_amd.pathfind.MI355X_C64). */
 int ctg_subtree_reconfigure_timed(int64_t n_inputs, const int64_t* offsets, const int64_t* inds,
                                   int64_t n_out, const int64_t* out_inds, int64_t n_inds,
