@@ -129,6 +129,18 @@ struct CostModel {
     int64_t n_rates = 0;
     double elem_rate = 1;            // elements / s through memory
     double narrow_factor = 0.8;      // MAC rate of steps whose narrower kept side has 16..63 columns
+
+    // time model: the step runs at the matrix-core rate its contracted extent K
+    // and its narrower kept side N allow, or at the memory rate
+    double seconds(double macs, double elems, double kk, double nn) const {
+        int lk = 0;
+        while (lk + 1 < n_rates && std::ldexp(1.0, lk + 1) <= kk) ++lk;
+        double rate = rates[lk];
+        if (nn < 16) rate *= std::max(nn, 1.0) / 16.0;   // a matrix-core tile has 16 complex columns
+        else if (nn < 64 && kk >= 64) rate *= narrow_factor;   // 128x32 block tiles (the K < 64 rates
+                                                                // were measured on such steps already)
+        return std::max(macs / rate, elems / elem_rate);
+    }
 };
 
 extern "C" {
@@ -375,8 +387,6 @@ static int subtree_reconfigure_impl(int64_t n_inputs, const int64_t* offsets, co
         for (const auto& kv : b)
             if (!a.count(kv.first)) flops *= net.size[kv.first];
         if (cm.rates == nullptr) return flops + cm.write_factor * legs_size(k, net.size);
-        // time model: the step runs at the matrix-core rate its contracted extent
-        // K and its narrower kept side N allow, or at the memory rate
         const double sa = legs_size(a, net.size), sb = legs_size(b, net.size), sc = legs_size(k, net.size);
         double kk = 1, keep_a = 1, keep_b = 1;
         for (const auto& kv : a) {
@@ -388,14 +398,7 @@ static int subtree_reconfigure_impl(int64_t n_inputs, const int64_t* offsets, co
         }
         for (const auto& kv : b)
             if (k.count(kv.first) && !a.count(kv.first)) keep_b *= net.size[kv.first];
-        int lk = 0;
-        while (lk + 1 < cm.n_rates && std::ldexp(1.0, lk + 1) <= kk) ++lk;
-        double rate = cm.rates[lk];
-        const double nn = std::min(keep_a, keep_b);
-        if (nn < 16) rate *= std::max(nn, 1.0) / 16.0;   // a matrix-core tile has 16 complex columns
-        else if (nn < 64 && kk >= 64) rate *= cm.narrow_factor;   // 128x32 block tiles (the K < 64 rates
-                                                                  // were measured on such steps already)
-        return std::max(flops / rate, (sa + sb + sc) / cm.elem_rate);
+        return cm.seconds(flops, sa + sb + sc, kk, std::min(keep_a, keep_b));
     };
     int64_t root = -1;
     {
@@ -417,9 +420,9 @@ static int subtree_reconfigure_impl(int64_t n_inputs, const int64_t* offsets, co
     }
 
     const int64_t S = subtree_size;
-    std::vector<double> best;
+    std::vector<double> best, msize;
     std::vector<int32_t> split;
-    std::vector<std::map<int64_t, int>> mlegs;
+    std::vector<uint64_t> bits;
     if (maxiter <= 0) maxiter = std::min<int64_t>(n, 1024);
     for (int64_t iter = 0; iter < maxiter; ++iter) {
         // the most expensive node not known to be locally optimal
@@ -448,20 +451,72 @@ static int subtree_reconfigure_impl(int64_t n_inputs, const int64_t* offsets, co
         }
         double cur = 0;
         for (int64_t v : inner) cur += nodes[v].cost;
-        // dynamic programming over subsets of the frontier
+        // dynamic programming over subsets of the frontier.  Indices are numbered
+        // locally and every subset's legs are a bitset: an index whose appearances
+        // all lie inside the frontier ("internal") survives in a subset until the
+        // subset holds every leaf that carries it; any other index survives always.
         const int full = (1 << m) - 1;
+        std::vector<int64_t> loc_ix;
+        std::vector<uint32_t> holders;     // which frontier leaves carry the index
+        std::vector<int> inside;           // appearances inside the frontier
+        {
+            std::unordered_map<int64_t, int> loc;
+            for (int t = 0; t < m; ++t)
+                for (const auto& kv : nodes[frontier[t]].legs) {
+                    auto it = loc.find(kv.first);
+                    if (it == loc.end()) {
+                        it = loc.emplace(kv.first, (int)loc_ix.size()).first;
+                        loc_ix.push_back(kv.first);
+                        holders.push_back(0);
+                        inside.push_back(0);
+                    }
+                    holders[it->second] |= 1u << t;
+                    inside[it->second] += kv.second;
+                }
+        }
+        const int L = (int)loc_ix.size(), W = (L + 63) / 64;
+        std::vector<double> lsz(L);
+        for (int i = 0; i < L; ++i) lsz[i] = net.size[loc_ix[i]];
+        bits.assign((size_t)(full + 1) * W, 0);
+        msize.assign(full + 1, 1.0);
+        for (int i = 0; i < L; ++i) {
+            const bool internal = inside[i] >= net.appearances[loc_ix[i]];
+            const uint32_t h = holders[i];
+            for (int mask = 1; mask <= full; ++mask) {
+                if (!(mask & h)) continue;
+                if (internal && !(h & ~(uint32_t)mask)) continue;
+                bits[(size_t)mask * W + (i >> 6)] |= 1ull << (i & 63);
+                msize[mask] *= lsz[i];
+            }
+        }
+        // product of the extents of the indices in (x & y & ~z) / (x & y & z)
+        auto prod_bits = [&](const uint64_t* x, const uint64_t* y, const uint64_t* z, bool with_z) {
+            double p = 1;
+            for (int w = 0; w < W; ++w) {
+                uint64_t v = x[w] & y[w] & (with_z ? z[w] : ~z[w]);
+                while (v) {
+                    p *= lsz[(w << 6) + __builtin_ctzll(v)];
+                    v &= v - 1;
+                }
+            }
+            return p;
+        };
+        auto split_cost = [&](int left, int right, int mask) {
+            const uint64_t* bl = &bits[(size_t)left * W];
+            const uint64_t* br = &bits[(size_t)right * W];
+            const uint64_t* bo = &bits[(size_t)mask * W];
+            // every index of either side is involved once: shared ones divide out
+            const double contracted = prod_bits(bl, br, bo, false), batch = prod_bits(bl, br, bo, true);
+            const double flops = msize[left] * msize[right] / (contracted * batch);
+            if (cm.rates == nullptr) return flops + cm.write_factor * msize[mask];
+            const double keep_a = msize[left] / (contracted * batch), keep_b = msize[right] / (contracted * batch);
+            return cm.seconds(flops, msize[left] + msize[right] + msize[mask], contracted, std::min(keep_a, keep_b));
+        };
         best.assign(full + 1, 0.0);
         split.assign(full + 1, 0);
-        mlegs.assign(full + 1, {});
-        // legs of a subset: counts summed over members, kept while the index appears elsewhere
         for (int mask = 1; mask <= full; ++mask) {
             const int low = mask & -mask;
-            const int bit = __builtin_ctz(mask);
-            if (mask == low) {
-                mlegs[mask] = nodes[frontier[bit]].legs;
-                continue;
-            }
-            mlegs[mask] = contract_legs(mlegs[mask ^ low], nodes[frontier[bit]].legs, net.appearances);
+            if (mask == low) continue;
             double b = -1;
             int bs = 0;
             // splits with the lowest member on the left side (each unordered split once)
@@ -469,7 +524,7 @@ static int subtree_reconfigure_impl(int64_t n_inputs, const int64_t* offsets, co
             for (int sub = rest;; sub = (sub - 1) & rest) {
                 const int left = low | (rest ^ sub), right = sub;   // right may not be empty
                 if (right != 0) {
-                    const double c = best[left] + best[right] + pair_cost(mlegs[left], mlegs[right], mlegs[mask]);
+                    const double c = best[left] + best[right] + split_cost(left, right, mask);
                     if (b < 0 || c < b) {
                         b = c;
                         bs = left;
@@ -495,8 +550,8 @@ static int subtree_reconfigure_impl(int64_t n_inputs, const int64_t* offsets, co
             Node& nd = nodes[id];
             nd.l = a;
             nd.r = b2;
-            nd.legs = mlegs[mask];
-            nd.cost = pair_cost(mlegs[left], mlegs[right], mlegs[mask]);
+            nd.legs = contract_legs(nodes[a].legs, nodes[b2].legs, net.appearances);
+            nd.cost = pair_cost(nodes[a].legs, nodes[b2].legs, nd.legs);
             nd.settled = false;
             nodes[a].parent = nodes[b2].parent = id;
             return id;

@@ -4,6 +4,7 @@
 and write the result as a tree fixture.  No reference code is involved.
 
     python tests/golden/gen/refine_native.py SRC.json combo-512 OUT.json [flat|mi355x]
+    python tests/golden/gen/refine_native.py SRC.json time,combo-64,combo-128 OUT.json mi355x 8,10,12,14
 
 1. ``subtree_reconfigure(subtree_size=10, minimize=OBJ)`` on the sliced tree:
    fewer MACs per slice at a smaller width;
@@ -19,6 +20,11 @@ reach on an MI355X.  ``OBJ`` = ``combo-F`` is ``flops + F 
 size``: the larger F, the higher the arithmetic intensity of the steps (and the
 FLOP/s), the smaller F, the less total work; ``OBJ`` = ``time`` makes the
 reconfiguration itself minimise the modelled seconds.
+
+With a fifth argument (subtree sizes) the script sweeps instead: every
+objective of the comma-separated list x every subtree size, each followed by
+the unslicing of step 2; a candidate is kept when the modelled time to the full
+result drops; repeated until a whole sweep brings nothing (sycamore_m20_w32_time.json).
 """
 import json
 import math
@@ -61,42 +67,72 @@ def stat(tree, tag):
     return t * tree.nslices
 
 
+def with_sliced(rec, tree, sliced):
+    r = dict(rec)
+    r["path"] = [list(p) for p in tree.get_path()]
+    r["sliced_inds"] = list(sliced)
+    return ca.tree_from_record(r)
+
+
+def unslice(rec, tree):
+    """Step 2: take indices out of the slicing while the model says it pays."""
+    while True:
+        cur = model(tree)[0] * tree.nslices
+        best = None
+        for ix in list(tree.sliced_inds):
+            cand = with_sliced(rec, tree, [j for j in tree.sliced_inds if j != ix])
+            if cand.max_size() > MAX_WIDTH:
+                continue
+            t, _, arena = model(cand)
+            if arena > MAX_ARENA_GIB:
+                continue
+            if best is None or t * cand.nslices < best[0]:
+                best = (t * cand.nslices, cand)
+        if best is None or best[0] >= cur:
+            return tree
+        tree = best[1]
+
+
+def sweep(rec, tree, objectives, sizes):
+    best = stat(tree, "start")
+    for rnd in range(8):
+        improved = False
+        for obj in objectives:
+            for sz in sizes:
+                cand = unslice(rec, pathfind.subtree_reconfigure(tree, subtree_size=sz, minimize=obj))
+                v = model(cand)[0] * cand.nslices
+                if v < best * (1 - 1e-6):
+                    best, tree, improved = v, cand, True
+                    stat(tree, f"sweep {rnd} {obj} subtree {sz}")
+        if not improved:
+            break
+    return tree
+
+
 def main():
     global MODEL
     src, obj, dst = sys.argv[1:4]
     MODEL = sys.argv[4] if len(sys.argv) > 4 else "flat"
     rec = ca.load_network(src)
 
-    def with_sliced(tree, sliced):
-        r = dict(rec)
-        r["path"] = [list(p) for p in tree.get_path()]
-        r["sliced_inds"] = list(sliced)
-        return ca.tree_from_record(r)
-
     tree = ca.tree_from_record(rec)
-    stat(tree, "start")
     t0 = time.time()
+    if len(sys.argv) > 5:
+        tree = sweep(rec, tree, obj.split(","), [int(x) for x in sys.argv[5].split(",")])
+        write(rec, tree, src, obj + " " + sys.argv[5], dst, t0)
+        return
+    stat(tree, "start")
     tree = pathfind.subtree_reconfigure(tree, subtree_size=10, minimize=obj)
     stat(tree, f"reconfigured ({obj})")
     for rnd in range(6):
-        while True:
-            cur = model(tree)[0] * tree.nslices
-            best = None
-            for ix in list(tree.sliced_inds):
-                cand = with_sliced(tree, [j for j in tree.sliced_inds if j != ix])
-                if cand.max_size() > MAX_WIDTH:
-                    continue
-                t, _, arena = model(cand)
-                if arena > MAX_ARENA_GIB:
-                    continue
-                if best is None or t * cand.nslices < best[0]:
-                    best = (t * cand.nslices, cand)
-            if best is None or best[0] >= cur:
-                break
-            tree = best[1]
+        tree = unslice(rec, tree)
         again = pathfind.subtree_reconfigure(tree, subtree_size=10 + (rnd % 2) * 2, minimize=obj)
         if stat(again, f"round {rnd}") < model(tree)[0] * tree.nslices:
             tree = again
+    write(rec, tree, src, obj, dst, t0)
+
+
+def write(rec, tree, src, obj, dst, t0):
     out = dict(rec)
     out["path"] = [list(p) for p in tree.get_path()]
     out["sliced_inds"] = list(tree.sliced_inds)

@@ -14,7 +14,8 @@ from oracle import contract_ref as orc
 from oracle.plan_interp import run_plan
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-FIXTURES = ["sycamore_m20_w30.json", "sycamore_m20_w32.json", "sycamore_m20_w32_c512.json", "sycamore_m20_w32_c128.json"]
+FIXTURES = ["sycamore_m20_w30.json", "sycamore_m20_w32.json", "sycamore_m20_w32_c512.json", "sycamore_m20_w32_c128.json",
+     "sycamore_m20_w32_time.json"]
 
 
 def narrowed(tree, log2_width):
