@@ -6,6 +6,7 @@
 #pragma once
 
 #include <hip/hip_runtime.h>
+#include <type_traits>
 #include <stdint.h>
 
 namespace ctg {
@@ -79,6 +80,15 @@ __device__ __forceinline__ double step_alpha(const StepArgs& p) {
     const double f = (*p.facA) * (*p.facB);
     if (f == 0.0 && p.check_zero) return 0.0;
     return 1.0 / f;  // inf -> nan downstream, like the reference without check_zero
+}
+
+// compile-time loop: f(std::integral_constant<int, I>{}) for I in [I0, N)
+template <int I, int N, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(f);
+    }
 }
 
 // Tell the compiler a 64-bit value is wave-uniform so that loads indexed by it

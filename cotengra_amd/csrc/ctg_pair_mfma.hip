@@ -799,9 +799,10 @@ __global__ __launch_bounds__(256, (FN == 1 ? 4 : FN == 2 ? 3 : 2)) void pair_mfm
     // A short contraction (K <= 8 / K <= 4) fills only the first NV = 4 / 2 slots of a
     // lane's gather list; the register budget of two full tasks then holds DEPTH =
     // 4 / 8 tasks in flight, which is what keeps HBM busy when a task is 1-2 KB.
-    // (32 columns: 12 waves per CU, three tasks each -- measured -8 %; a deeper
-    // ring does nothing for 64 columns, which is not latency-bound)
-    constexpr int DEPTH = (FN == 2 ? 3 : 2) * (PER_T / NV);
+    // (with the steady-state loop below keeping exactly DEPTH tasks in flight, two
+    // are enough for every width; three or four measured the same)
+    constexpr int DEPTH = 2 * (PER_T / NV);
+    static_assert((DEPTH & (DEPTH - 1)) == 0, "register sets rotate with a power-of-two period");
     static_assert(NV == PER_T || SHORTK, "partial gather lists only for short contractions");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int LDB = KP + 4;
@@ -895,21 +896,26 @@ __global__ __launch_bounds__(256, (FN == 1 ? 4 : FN == 2 ? 3 : 2)) void pair_mfm
     // in flight while the matrix cores work on the task before.
     int64_t a_base_off = 0;  // ADD: scalar row base of the group being gathered
 
-    auto resolve_rows_a = [&](int64_t g) {
+    auto resolve_rows_a = [&](int64_t g) __attribute__((always_inline)) {
         const int64_t m0 = g * 32;
         if (ADD) {
             int64_t hi, lo;
             split_row(p, uniform64(m0), hi, lo);
-            a_base_off = p.rowA.hi[uniform64(hi)] + p.rowA.lo[uniform64(lo)];
+            // (sload64: the tables are never written on the device, but the kernel
+            // stores to C, so only the constant address space gets a scalar load --
+            // a vector load here would wait for every gather in flight, vmcnt(0))
+            a_base_off = sload64(p.rowA.hi + uniform64(hi)) + sload64(p.rowA.lo + uniform64(lo));
         }
     };
-    auto gather = [&](c64 (&a_reg)[NV], int64_t g, int chunk) {
+    auto gather = [&](c64 (&a_reg)[NV], int64_t g, int chunk, auto all_live) __attribute__((always_inline)) {
         const int64_t* ka = kofs_s + chunk * MFMA_BK;
         const int64_t m0 = g * 32;
         if (VEC) {
 #pragma unroll
             for (int j = 0; j < NV; j += 2) {
-                if (SHORTK && a_pk[j] < 0) continue;  // wave-uniform (depends on j only)
+                // wave-uniform (depends on j only); all_live: the host-side order
+                // table fills every slot, so the loads are unconditional
+                if (!decltype(all_live)::value && SHORTK && a_pk[j] < 0) continue;
                 const int r = a_pk[j] >> 16, c = (a_pk[j] & 0xffff) - r * LD;
                 int64_t ro;
                 if (ADD) {
@@ -952,10 +958,11 @@ __global__ __launch_bounds__(256, (FN == 1 ? 4 : FN == 2 ? 3 : 2)) void pair_mfm
     int64_t ig = wave_g;
     int ic = 0;
     int64_t issued = 0;
-    auto issue = [&](c64 (&a_reg)[NV]) {
-        if (issued < n_tasks) {
+    auto issue = [&](c64 (&a_reg)[NV], auto steady) __attribute__((always_inline)) {
+        constexpr bool STEADY = decltype(steady)::value;   // the task is known to exist
+        if (STEADY || issued < n_tasks) {
             if (ic == 0) resolve_rows_a(ig);
-            gather(a_reg, ig, ic);
+            gather(a_reg, ig, ic, steady);
             ++issued;
             if (++ic == n_chunks) {
                 ic = 0;
@@ -966,8 +973,11 @@ __global__ __launch_bounds__(256, (FN == 1 ? 4 : FN == 2 ? 3 : 2)) void pair_mfm
     // cursor of the task being CONSUMED
     int64_t cg = wave_g;
     int cc = 0;
-    auto consume = [&](c64 (&a_reg)[NV]) {
-        if (cc == 0) {
+    // steady / first / last: compile-time knowledge of the steady-state loop
+    // below (std::false_type everywhere = the general, fully dynamic task)
+    auto consume = [&](c64 (&a_reg)[NV], auto steady, auto first_tag, auto last_tag) __attribute__((always_inline)) {
+        constexpr bool STEADY = decltype(steady)::value;
+        if (STEADY ? decltype(first_tag)::value : cc == 0) {
 #pragma unroll
             for (int j = 0; j < FN; ++j)
 #pragma unroll
@@ -986,14 +996,14 @@ __global__ __launch_bounds__(256, (FN == 1 ? 4 : FN == 2 ? 3 : 2)) void pair_mfm
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         // refill this register set DEPTH tasks ahead
-        issue(a_reg);
-        const bool last = cc == n_chunks - 1;
+        issue(a_reg, steady);
+        const bool last = STEADY ? decltype(last_tag)::value : cc == n_chunks - 1;
         // C row base of this group: scalar loads hidden behind the MFMAs below
         int64_t c_base = 0;
         if (ADD && last) {
             int64_t hi, lo;
             split_row(p, uniform64(cg * 32), hi, lo);
-            c_base = p.rowC.hi[uniform64(hi)] + p.rowC.lo[uniform64(lo)];
+            c_base = sload64(p.rowC.hi + uniform64(hi)) + sload64(p.rowC.lo + uniform64(lo));
         }
         const float* a_base = As + kk * 32 * LD + l31 * LD;
         const float* b_base = Bs + (l31 ^ kk) * LDB + cc * MFMA_BK;
@@ -1033,7 +1043,7 @@ __global__ __launch_bounds__(256, (FN == 1 ? 4 : FN == 2 ? 3 : 2)) void pair_mfm
 #pragma unroll
                 for (int j = 0; j < FN; ++j) {
                     const float2 v = pair_rows(acc[j][t], acc[j][t + 1], odd, alpha);
-                    if (n_ok[j] && ro >= 0) *(float2*)(C + 2 * (ro + ncol[j])) = v;
+                    if (STEADY || (n_ok[j] && ro >= 0)) *(float2*)(C + 2 * (ro + ncol[j])) = v;
                 }
             }
             cc = 0;
@@ -1044,12 +1054,52 @@ __global__ __launch_bounds__(256, (FN == 1 ? 4 : FN == 2 ? 3 : 2)) void pair_mfm
     };
 
     c64 regs[DEPTH][NV];
+    int64_t t = 0;
+    // Steady state.  s_waitcnt vmcnt is positional (it counts the loads AND stores
+    // issued after the one waited for), so the compiler can only keep DEPTH tasks
+    // in flight if it knows exactly which memory instructions lie between a gather
+    // and its use: every conditional gather or store on the way makes it fall back
+    // to "wait for everything".  For full tiles (all columns and gather slots live)
+    // the loop is therefore unrolled over max(chunks per group, DEPTH) tasks with
+    // the first / last chunk of a group known at compile time, unconditional
+    // refills and unconditional stores; the general loop below finishes the tail.
+    bool primed = false;
+    if constexpr (VEC && ADD) {
+        // (short contractions, K < 16, stay on the general loop: measured 25 % slower
+        // in this form at K = 8 -- tasks of 2 KB in, 4 KB out)
+        const bool full = p.N == 16 * FN && !SHORTK;
+        auto steady_loop = [&](auto nc_tag) __attribute__((always_inline)) {
+            constexpr int NC = decltype(nc_tag)::value;
+            constexpr int BODY = NC > DEPTH ? NC : DEPTH;
+            if (n_tasks < BODY + DEPTH) return;
 #pragma unroll
-    for (int d = 0; d < DEPTH; ++d) issue(regs[d]);
-    for (int64_t t = 0; t < n_tasks; t += DEPTH) {
+            for (int d = 0; d < DEPTH; ++d) issue(regs[d], std::true_type{});
+            primed = true;
+            for (; t + BODY + DEPTH <= n_tasks; t += BODY) {
+                static_for<0, BODY>([&](auto i) __attribute__((always_inline)) {
+                    constexpr int I = decltype(i)::value;
+                    consume(regs[I % DEPTH], std::true_type{}, std::bool_constant<(I % NC) == 0>{},
+                            std::bool_constant<(I % NC) == NC - 1>{});
+                });
+            }
+        };
+        if (full) {
+            switch (n_chunks) {
+                case 1: steady_loop(std::integral_constant<int, 1>{}); break;
+                case 2: steady_loop(std::integral_constant<int, 2>{}); break;
+                case 4: steady_loop(std::integral_constant<int, 4>{}); break;
+                case 8: steady_loop(std::integral_constant<int, 8>{}); break;
+            }
+        }
+    }
+    if (!primed) {
+#pragma unroll
+        for (int d = 0; d < DEPTH; ++d) issue(regs[d], std::false_type{});
+    }
+    for (; t < n_tasks; t += DEPTH) {
 #pragma unroll
         for (int d = 0; d < DEPTH; ++d)
-            if (t + d < n_tasks) consume(regs[d]);
+            if (t + d < n_tasks) consume(regs[d], std::false_type{}, std::false_type{}, std::false_type{});
     }
 }
 
