@@ -94,19 +94,14 @@ def unslice(rec, tree):
 
 
 def sweep(rec, tree, objectives, sizes):
-    best = stat(tree, "start")
-    for rnd in range(8):
-        improved = False
-        for obj in objectives:
-            for sz in sizes:
-                cand = unslice(rec, pathfind.subtree_reconfigure(tree, subtree_size=sz, minimize=obj))
-                v = model(cand)[0] * cand.nslices
-                if v < best * (1 - 1e-6):
-                    best, tree, improved = v, cand, True
-                    stat(tree, f"sweep {rnd} {obj} subtree {sz}")
-        if not improved:
-            break
-    return tree
+    """The library routine (cotengra_amd.pathfind.refine) with this script's limits."""
+    assert MODEL == "mi355x", "the sweep prices steps with pathfind.MI355X_C64"
+    stat(tree, "start")
+    return pathfind.refine(
+        tree, objectives=objectives, subtree_sizes=sizes, max_width=MAX_WIDTH,
+        max_arena_bytes=MAX_ARENA_GIB * 2**30,
+        progress=lambda rnd, obj, sz, t, v: stat(t, f"sweep {rnd} {obj} subtree {sz}"),
+    )
 
 
 def main():

@@ -189,3 +189,32 @@ def test_tree_methods_mirror_the_reference_names():
     assert cp.subtree_reconfigure_(subtree_size=6) is cp
     assert cp.slice_and_reconfigure_(target, reslice=True) is cp and cp.max_size() <= target
     assert np.allclose(orc.contract(cp, arrays), ref, rtol=1e-10, atol=1e-12)
+
+
+def test_refine_and_unslice_for_the_device():
+    """pathfind.refine / unslice: model-guided polishing of a sliced tree; the
+    modelled time to the full result only goes down, limits are respected and
+    the contraction value does not change."""
+    inputs, output, shapes, size_dict = ca.lattice_equation([4, 4], d_min=2, d_max=4, seed=21)
+    arrays = ca.make_arrays_from_inputs(inputs, size_dict, seed=3, dtype="complex128")
+    ref = np.einsum(ca.inputs_output_to_eq(inputs, output), *arrays, optimize=True)
+    tree = pathfind.greedy_tree(inputs, output, size_dict, temperature=1.5, seed=4)
+    width = tree.max_size()
+    over = tree.slice(target_size=max(width // 16, 2))      # sliced far more than needed
+    total = lambda t: pathfind.modelled_seconds(t)[0] * t.nslices
+    # everything fits: all indices come back
+    back = pathfind.unslice(over, max_width=width)
+    assert back.nslices < over.nslices and back.max_size() <= width and total(back) <= total(over)
+    # a width limit is honoured
+    lim = pathfind.unslice(over, max_width=max(width // 4, 2))
+    assert lim.max_size() <= max(width // 4, 2) and total(lim) <= total(over)
+    # an arena limit too (nothing may be restored under a zero budget)
+    assert pathfind.unslice(over, max_arena_bytes=0).nslices == over.nslices
+    seen = []
+    best = pathfind.refine(over, objectives=("time", "combo-64"), subtree_sizes=(4, 8), max_width=max(width // 4, 2),
+                           progress=lambda rnd, obj, sz, t, v: seen.append(v))
+    assert total(best) <= total(lim) * (1 + 1e-9) and best.max_size() <= max(width // 4, 2)
+    assert seen == sorted(seen, reverse=True)
+    assert np.allclose(orc.contract(best, arrays), ref, rtol=1e-10, atol=1e-12)
+    secs, arena = pathfind.modelled_seconds(best)
+    assert secs > 0 and arena > 0
