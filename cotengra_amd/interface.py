@@ -5,13 +5,13 @@ Mirrors the call shapes of the reference's high level API
 ``einsum_expression`` (:925), ``array_contract`` (:803),
 ``array_contract_tree`` (:394), ``array_contract_expression`` (:673).
 
-Path *search* is out of scope for this package -- the reference's
-hyper-optimizers stay on the host unchanged and hand over a path or a tree
-(SURVEY.md section 2).  ``optimize`` therefore accepts an explicit path (list of
-pairs), a ``ContractionTree`` (ours, or any object exposing
+The reference's hyper-optimizers stay on the host unchanged and hand over a
+path or a tree.  ``optimize`` therefore accepts an explicit
+path (list of pairs), a ``ContractionTree`` (ours, or any object exposing
 ``inputs/output/size_dict/get_path()/sliced_inds`` such as the reference's
-tree), or the string ``"greedy"`` for the small built-in heuristic below that
-makes the front ends usable stand-alone.
+tree), or the string ``"greedy"`` for the native greedy finder that makes the
+front ends usable stand-alone (``cotengra_amd.pathfind`` has the rest: slicing,
+subtree reconfiguration, ``search`` -- their results are trees to pass here).
 """
 
 from __future__ import annotations

@@ -9,10 +9,15 @@
   intermediate fits ``target_size`` (``SliceFinder``, ``cotengra/slicer.py``);
 * ``subtree_reconfigure`` / ``slice_and_reconfigure`` -- exact re-ordering of
   subtrees by dynamic programming (``core.py:2316-2449, 2723-2808``), under the
-  reference's objectives or under a machine model (``minimize="time"``).
+  reference's objectives or under a machine model (``minimize="time"``);
+* ``modelled_seconds`` / ``unslice`` / ``refine`` -- polishing of a sliced tree
+  for the device, guided by the plan's own step list priced by the model;
+* ``sample_sliced_tree`` / ``search`` -- a stand-alone search built from all of
+  the above (many cheap, very unequal draws; the best ones refined).
 
-The hyper-optimizers built on top of these stay in the reference; this module
-is what the stand-alone front ends use when they are not handed a tree.
+The reference's hyper-optimizers (partition-based builders, Bayesian parameter
+tuning) are not restated; this module is what the stand-alone front ends use
+when they are not handed a tree.
 """
 
 from __future__ import annotations
@@ -304,3 +309,59 @@ def refine(tree, objectives=("time", "combo-64", "combo-128"), subtree_sizes=(8,
         if not improved:
             break
     return tree
+
+
+def sample_sliced_tree(inputs, output, size_dict, target_size, seed=0, repeats=64, minimize="combo-64"):
+    """One draw of the native search: the best of ``repeats`` sampled greedy
+    trees, reconfigured (subtree sizes 10 and 12), then sliced to ``target_size``
+    one bit at a time with reconfiguration in between.  About 13 s for the
+    381-tensor Sycamore m20 network; the outcome varies over four decades of
+    total work with the seed, which is what :func:`search` exploits."""
+    tree = random_greedy_tree(inputs, output, size_dict, repeats=repeats, minimize="flops", seed=seed)
+    for sz in (10, 12):
+        tree = subtree_reconfigure(tree, subtree_size=sz, minimize=minimize)
+    return slice_and_reconfigure(tree, target_size, minimize=minimize, subtree_size=10, step_bits=1.0)
+
+
+def _search_worker(args):
+    inputs, output, size_dict, target_size, seed, repeats, minimize = args
+    tree = sample_sliced_tree(inputs, output, size_dict, target_size, seed, repeats, minimize)
+    return seed, [tuple(p) for p in tree.get_path()], list(tree.sliced_inds)
+
+
+def search(inputs, output, size_dict, target_size=2**32, n_samples=64, seed=0, workers=1, refine_top=1,
+           model=None, max_arena_bytes=160 * 2**30, repeats=64, minimize="combo-64", progress=None):
+    """Stand-alone search for a sliced contraction tree (no reference optimizer
+    involved): ``n_samples`` independent draws of :func:`sample_sliced_tree`
+    (seeds ``seed .. seed + n_samples - 1``, on ``workers`` processes), ranked by
+    the modelled time to the full result; the best ``refine_top`` are polished with
+    :func:`refine` and the winner is returned.  Deterministic for given arguments."""
+    inputs = [tuple(t) for t in inputs]
+    output = tuple(output)
+    jobs = [(inputs, output, dict(size_dict), target_size, seed + i, repeats, minimize) for i in range(n_samples)]
+    if workers and workers > 1:
+        import concurrent.futures as cf
+
+        with cf.ProcessPoolExecutor(max_workers=workers) as pool:
+            results = list(pool.map(_search_worker, jobs))
+    else:
+        results = [_search_worker(j) for j in jobs]
+    ranked = []
+    for sd, path, sliced in results:
+        tree = ContractionTree.from_path(inputs, output, size_dict, path=path)
+        for ix in sliced:
+            tree.remove_ind_(ix)
+        secs, arena = modelled_seconds(tree, model)
+        ranked.append((secs * tree.nslices, sd, tree))
+        if progress is not None:
+            progress("sample", sd, tree, secs * tree.nslices)
+    ranked.sort(key=lambda r: (r[0], r[1]))
+    best = None
+    for total, sd, tree in ranked[: max(1, refine_top)]:
+        tree = refine(tree, model=model, max_width=target_size, max_arena_bytes=max_arena_bytes)
+        total = modelled_seconds(tree, model)[0] * tree.nslices
+        if progress is not None:
+            progress("refined", sd, tree, total)
+        if best is None or total < best[0]:
+            best = (total, tree)
+    return best[1]

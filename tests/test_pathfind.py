@@ -218,3 +218,28 @@ def test_refine_and_unslice_for_the_device():
     assert np.allclose(orc.contract(best, arrays), ref, rtol=1e-10, atol=1e-12)
     secs, arena = pathfind.modelled_seconds(best)
     assert secs > 0 and arena > 0
+
+
+def test_native_search_is_deterministic_and_valid():
+    """pathfind.search: sampled greedy + reconfiguration + slicing, best draws
+    refined; same arguments, same tree (also across worker processes); the value
+    of the contraction is preserved and the width target met."""
+    inputs, output, shapes, size_dict = ca.lattice_equation([4, 4], d_min=2, d_max=3, seed=8)
+    arrays = ca.make_arrays_from_inputs(inputs, size_dict, seed=6, dtype="complex128")
+    ref = np.einsum(ca.inputs_output_to_eq(inputs, output), *arrays, optimize=True)
+    width = pathfind.greedy_tree(inputs, output, size_dict).max_size()
+    target = max(width // 8, 2)
+    log = []
+    a = pathfind.search(inputs, output, size_dict, target_size=target, n_samples=6, seed=3, repeats=8,
+                        refine_top=2, progress=lambda *x: log.append(x[0]))
+    b = pathfind.search(inputs, output, size_dict, target_size=target, n_samples=6, seed=3, repeats=8,
+                        refine_top=2, workers=2)
+    assert a.get_path() == b.get_path() and list(a.sliced_inds) == list(b.sliced_inds)
+    assert a.max_size() <= target and a.nslices > 1
+    assert log.count("sample") == 6 and log.count("refined") == 2
+    assert np.allclose(orc.contract(a, arrays), ref, rtol=1e-10, atol=1e-12)
+    # more samples never hurt (the draws of the smaller search are a subset)
+    c = pathfind.search(inputs, output, size_dict, target_size=target, n_samples=12, seed=3, repeats=8, refine_top=12)
+    d = pathfind.search(inputs, output, size_dict, target_size=target, n_samples=6, seed=3, repeats=8, refine_top=6)
+    total = lambda t: pathfind.modelled_seconds(t)[0] * t.nslices
+    assert total(c) <= total(d) * (1 + 1e-9)
