@@ -130,6 +130,7 @@ class HipContractor:
             )
             stream = torch.cuda.current_stream(dev).cuda_stream
             st["result"] = res
+            st["stream"] = stream
             st["exec"] = runtime.Executor(
                 dplan, device=device, stream=stream, result_ptr=res.data_ptr()
             )
@@ -159,6 +160,12 @@ class HipContractor:
 
             device = torch_in[0].device.index or 0
             st = self._get_exec(dtype, device, True)
+            # the executor follows torch's *current* stream: uploads, kernels and the
+            # caller's own tensor ops (input conversion, result clone) stay ordered
+            cur = torch.cuda.current_stream(torch_in[0].device).cuda_stream
+            if cur != st["stream"]:
+                st["exec"].set_stream(cur)
+                st["stream"] = cur
             tdt = getattr(torch, dtype)
             keep = []
             for x in arrays:
@@ -226,8 +233,7 @@ class HipContractor:
         ex.set_strip_exponent(strip_exponent, check_zero)
         ex.zero_result()
         ex.run_slices(int(i), 1, 1)
-        loc = self.tree.slice_key(int(i))
-        index = tuple(loc.get(ix, slice(None)) for ix in self.tree.output)
+        index = _chunk_index(self.tree, self.tree.slice_key(int(i)))
         return self._finish(st, strip_exponent, check_zero, index=index)
 
     def profile(self, arrays, slice_id=0):
@@ -242,6 +248,20 @@ class HipContractor:
         for _, dplan in self._plans.values():
             dplan.close()
         self._plans.clear()
+
+
+def _chunk_index(tree, loc):
+    """Position of a slice's output inside the full result tensor: sliced
+    output indices are fixed (a projected one sits at 0 of its size-1 axis),
+    the others span their axis."""
+    index = []
+    for ix in tree.output:
+        si = tree.sliced_inds.get(ix)
+        if si is None:
+            index.append(slice(None))
+        else:
+            index.append(0 if si.project is not None else loc[ix])
+    return tuple(index)
 
 
 def _sliced_twin(tree):
@@ -408,10 +428,7 @@ def gen_output_chunks(tree, arrays, with_key=False, progbar=False, **contract_op
         ex.zero_result()
         ex.run_slices(o * stepsize, stepsize, 1)
         loc = tree.slice_key(o * stepsize)
-        index = tuple(
-            loc[ix] if (ix in loc and ix in tree.output) else slice(None)
-            for ix in tree.output
-        )
+        index = _chunk_index(tree, loc)
         chunk = fn._finish(st, False, False, index=index)
         if with_key:
             yield chunk, {ix: x for ix, x in loc.items() if ix in tree.output}

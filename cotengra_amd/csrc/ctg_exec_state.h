@@ -1,0 +1,73 @@
+// ctg_exec_state.h -- the opaque handles of include/ctg_hip.h as seen by the
+// host-side translation units of the library (ctg_runtime.hip,
+// ctg_collective.hip).  Not installed; not part of the ABI.
+#pragma once
+
+#include <string>
+#include <vector>
+
+#include "../../include/ctg_hip.h"
+#include "ctg_common.h"
+
+struct ctg_plan {
+    int dtype = 0;
+    int64_t n_inputs = 0;
+    std::vector<int64_t> input_sizes, input_offsets;
+    int64_t inputs_elems = 0, arena_elems = 0, result_elems = 0;
+    int64_t n_steps = 0;
+    std::vector<int64_t> steps;
+    std::vector<int64_t> tables;
+    int64_t n_sliced = 0;
+    std::vector<int64_t> slice_sizes, slice_fixed, slice_strides;
+    int64_t nslices = 1;
+    // per-leaf maximum slice offset (for bounds validation)
+    std::vector<int64_t> max_soff;
+};
+
+struct ctg_exec {
+    const ctg_plan* plan = nullptr;
+    int device = 0;
+    hipStream_t stream = nullptr;
+    char* d_inputs = nullptr;
+    char* d_arena = nullptr;
+    char* d_result = nullptr;
+    bool owns_result = false;
+    int64_t* d_tables = nullptr;
+    int64_t* d_misc = nullptr;  // [state(2) | zero(1) | soff(n_leaves) | sizes | fixed | strides]
+    int64_t* d_state = nullptr;
+    int64_t* d_zero = nullptr;
+    int64_t* d_soff = nullptr;
+    void* d_scratch = nullptr;
+    ctg::SliceMeta meta{};
+    std::vector<ctg::StepArgs> args;  // resolved per step
+    std::vector<ctg::MfmaHints> hints;  // per step kernel hints (MFMA steps)
+    uint16_t* d_ord = nullptr;     // order tables of all MFMA steps
+    std::vector<hipEvent_t> events;
+    // slice graph: the launch sequence of one slice captured once and replayed,
+    // the slice id advancing on the device (prologue kernel)
+    hipStream_t gstream = nullptr;
+    hipGraphExec_t gexec = nullptr;
+    hipEvent_t ev_in = nullptr, ev_out = nullptr;
+    bool warm = false;
+    bool graph_off = false;
+    // strip_exponent state
+    int strip = 0, check_zero = 0;
+    double* d_fac = nullptr;        // [n_steps + 1] max|.| per pair step; last = constant 1.0
+    int32_t* d_counted = nullptr;   // [n_steps] 1 for pair steps
+    int32_t* d_fac_zero = nullptr;  // [n_steps] 1 for per-slice pair steps
+    // slice-invariant steps: executed once per upload / option change
+    std::vector<char> invariant;
+    bool invariants_ready = false;
+    ctg::StripState* d_strip = nullptr;
+    int64_t root_step = -1;
+};
+
+
+// element size in bytes by CTG_* dtype code
+inline int64_t ctg_item_size(int dtype) {
+    static const int64_t k[4] = {4, 8, 8, 16};
+    return k[dtype];
+}
+
+// records `msg` as the calling thread's ctg_last_error() (ctg_runtime.hip)
+extern "C" __attribute__((visibility("hidden"))) void ctg_set_error_(const char* msg);

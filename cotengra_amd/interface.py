@@ -106,9 +106,8 @@ def _as_tree(inputs, output, size_dict, optimize):
             optimize.inputs, optimize.output, optimize.size_dict,
             path=optimize.get_path(),
         )
-        for ix in optimize.sliced_inds:
-            tree.remove_ind_(ix)
-        return tree
+        # (a mapping ind -> SliceInfo in the reference too: projections carry over)
+        return tree.apply_slicing_(optimize.sliced_inds)
     if len(inputs) == 1:
         return ContractionTree(inputs, output, size_dict)
     return ContractionTree.from_path(inputs, output, size_dict, path=optimize)

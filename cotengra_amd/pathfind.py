@@ -198,7 +198,7 @@ def subtree_reconfigure(tree, subtree_size=8, maxiter="auto", minimize="flops", 
     :class:`MachineModel` -- modelled seconds on the device."""
     if tree.N < 3:
         return tree if inplace else tree.copy()
-    sliced = list(tree.sliced_inds)
+    sliced = dict(tree.sliced_inds)
     size_dict = dict(tree.size_dict)
     eff = {ix: (1 if ix in tree.sliced_inds else d) for ix, d in size_dict.items()}
     ids, offsets, flat, out, sizes = _csr(tree.inputs, tree.output, eff)
@@ -224,8 +224,7 @@ def subtree_reconfigure(tree, subtree_size=8, maxiter="auto", minimize="flops", 
         tree.inputs, tree.output, size_dict,
         ssa_path=[(int(ssa_out[2 * s]), int(ssa_out[2 * s + 1])) for s in range(tree.N - 1)],
     )
-    for ix in sliced:
-        new.remove_ind_(ix)
+    new.apply_slicing_(sliced)  # (projections kept)
     if inplace:
         tree.__dict__.update(new.__dict__)
         return tree
@@ -326,7 +325,7 @@ def sample_sliced_tree(inputs, output, size_dict, target_size, seed=0, repeats=6
 def _search_worker(args):
     inputs, output, size_dict, target_size, seed, repeats, minimize = args
     tree = sample_sliced_tree(inputs, output, size_dict, target_size, seed, repeats, minimize)
-    return seed, [tuple(p) for p in tree.get_path()], list(tree.sliced_inds)
+    return seed, [tuple(p) for p in tree.get_path()], tree.slicing_record()
 
 
 def search(inputs, output, size_dict, target_size=2**32, n_samples=64, seed=0, workers=1, refine_top=1,
@@ -348,9 +347,7 @@ def search(inputs, output, size_dict, target_size=2**32, n_samples=64, seed=0, w
         results = [_search_worker(j) for j in jobs]
     ranked = []
     for sd, path, sliced in results:
-        tree = ContractionTree.from_path(inputs, output, size_dict, path=path)
-        for ix in sliced:
-            tree.remove_ind_(ix)
+        tree = ContractionTree.from_path(inputs, output, size_dict, path=path).apply_slicing_(sliced)
         secs, arena = modelled_seconds(tree, model)
         ranked.append((secs * tree.nslices, sd, tree))
         if progress is not None:

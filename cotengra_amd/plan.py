@@ -607,7 +607,9 @@ def compile_tree(tree, dtype, order=None, force_kernel=None):
         cursor += (n + ARENA_ALIGN - 1) // ARENA_ALIGN * ARENA_ALIGN
 
     # -- result: the full output tensor (all slices accumulate into it)
-    plan.result_shape = tuple(size_dict[ix] for ix in tree.output)
+    # (an output index projected onto one value keeps a size-1 axis, as the
+    # reference's gather_slices stacks over sliced_range = [project], core.py:3866-3876)
+    plan.result_shape = tree.gathered_shape()
     plan.result_elems = prod(plan.result_shape)
     full_out_strides = dict(
         zip(tree.output, _row_major_strides(plan.result_shape))
@@ -625,7 +627,7 @@ def compile_tree(tree, dtype, order=None, force_kernel=None):
         for j, si in enumerate(sliced):
             strides[i, j] = sum(s for ix, s in zip(term, st) if ix == si.ind)
     for j, si in enumerate(sliced):
-        strides[N, j] = full_out_strides.get(si.ind, 0)
+        strides[N, j] = 0 if si.project is not None else full_out_strides.get(si.ind, 0)
     plan.slice_strides = strides
 
     arena = Arena()

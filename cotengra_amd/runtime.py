@@ -12,7 +12,7 @@ import os
 import numpy as np
 
 _LIB_PATH = os.environ.get("CTG_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libctg_hip.so")
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 # every symbol include/ctg_hip.h declares
 SYMBOLS = (
@@ -24,6 +24,7 @@ SYMBOLS = (
     "ctg_plan_workspace_bytes",
     "ctg_exec_create",
     "ctg_exec_destroy",
+    "ctg_exec_set_stream",
     "ctg_exec_upload_inputs_host",
     "ctg_exec_upload_inputs_device",
     "ctg_exec_zero_result",
@@ -36,6 +37,13 @@ SYMBOLS = (
     "ctg_exec_result_ptr",
     "ctg_exec_download_result",
     "ctg_exec_download_arena",
+    "ctg_exec_get_state",
+    "ctg_exec_set_state",
+    "ctg_comm_get_unique_id",
+    "ctg_comm_init",
+    "ctg_comm_info",
+    "ctg_comm_destroy",
+    "ctg_exec_reduce",
     "ctg_path_greedy",
     "ctg_slice_greedy",
     "ctg_subtree_reconfigure",
@@ -45,6 +53,10 @@ SYMBOLS = (
 
 class CtgError(RuntimeError):
     """A call into libctg_hip.so failed."""
+
+
+class CommError(CtgError):
+    """RCCL is missing or a collective failed (CTG_E_COMM)."""
 
 
 class PlanDesc(C.Structure):
@@ -107,6 +119,7 @@ def load():
         "ctg_plan_workspace_bytes": [vp, i64p],
         "ctg_exec_create": [vp, C.c_int, vp, vp, C.POINTER(vp)],
         "ctg_exec_destroy": [vp],
+        "ctg_exec_set_stream": [vp, vp],
         "ctg_exec_upload_inputs_host": [vp, C.POINTER(vp)],
         "ctg_exec_upload_inputs_device": [vp, C.POINTER(vp)],
         "ctg_exec_zero_result": [vp],
@@ -119,6 +132,13 @@ def load():
         "ctg_exec_result_ptr": [vp, C.POINTER(vp)],
         "ctg_exec_download_result": [vp, vp],
         "ctg_exec_download_arena": [vp, C.c_int64, C.c_int64, vp],
+        "ctg_exec_get_state": [vp, vp, C.POINTER(C.c_double), C.POINTER(C.c_int)],
+        "ctg_exec_set_state": [vp, vp, C.c_double, C.c_int],
+        "ctg_comm_get_unique_id": [vp],
+        "ctg_comm_init": [vp, C.c_int, C.c_int, C.c_int, C.POINTER(vp)],
+        "ctg_comm_info": [vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)],
+        "ctg_comm_destroy": [vp],
+        "ctg_exec_reduce": [vp, vp, C.c_int],
         "ctg_path_greedy": [C.c_int64, i64p, i64p, C.c_int64, i64p, C.c_int64, C.POINTER(C.c_double),
                             C.c_double, C.c_double, C.c_int64, C.c_uint64, i64p],
         "ctg_slice_greedy": [C.c_int64, i64p, i64p, C.c_int64, i64p, C.c_int64, C.POINTER(C.c_double),
@@ -148,6 +168,8 @@ def _check(rc):
             raise ValueError(msg)
         if rc == -3:
             raise MemoryError(msg)
+        if rc == -5:
+            raise CommError(msg)
         raise CtgError(f"[{rc}] {msg}")
 
 
@@ -226,6 +248,10 @@ class Executor:
         )
         self.handle = handle
 
+    def set_stream(self, stream):
+        """Enqueue all later work on ``stream`` (a raw ``hipStream_t`` value)."""
+        _check(load().ctg_exec_set_stream(self.handle, C.c_void_p(int(stream) if stream else None)))
+
     # -- inputs ---------------------------------------------------------- #
 
     def upload_host(self, arrays):
@@ -295,6 +321,31 @@ class Executor:
         _check(load().ctg_exec_download_result(self.handle, C.c_void_p(out.ctypes.data)))
         return out
 
+    # -- checkpoint state (include/ctg_hip.h: ctg_exec_get_state / set_state) -- #
+
+    def get_state(self):
+        """``(partial_result, exponent, zero)`` after synchronising: everything
+        a sliced run has accumulated so far."""
+        out = np.empty(self.plan.result_shape, dtype=np.dtype(self.plan.dtype))
+        e, z = C.c_double(), C.c_int()
+        _check(load().ctg_exec_get_state(self.handle, C.c_void_p(out.ctypes.data), C.byref(e), C.byref(z)))
+        return out, e.value, bool(z.value)
+
+    def set_state(self, result, exponent=0.0, zero=False):
+        """Restore what ``get_state`` returned (instead of ``zero_result``)."""
+        arr = np.ascontiguousarray(result, dtype=np.dtype(self.plan.dtype))
+        if arr.size != int(np.prod(self.plan.result_shape, dtype=np.int64)):
+            raise ValueError(f"state has {arr.size} elements, the plan's result {self.plan.result_shape}")
+        _check(load().ctg_exec_set_state(self.handle, C.c_void_p(arr.ctypes.data), float(exponent), int(bool(zero))))
+
+    # -- multi-GPU ---------------------------------------------------------- #
+
+    def reduce(self, comm, root=None):
+        """Sum the ranks' result tensors in place with RCCL on this executor's
+        stream (``root=None``: all-reduce).  Reference ``contract_mpi``'s
+        ``Allreduce`` / ``Reduce`` (core.py:4081, 4089)."""
+        _check(load().ctg_exec_reduce(self.handle, comm.handle, -1 if root is None else int(root)))
+
     def download_arena(self, offset, n):
         out = np.empty(n, dtype=np.dtype(self.plan.dtype))
         _check(
@@ -307,6 +358,52 @@ class Executor:
     def close(self):
         if getattr(self, "handle", None):
             load().ctg_exec_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Comm:
+    """An RCCL communicator behind the C ABI (``ctg_comm_*``): one per process
+    and GPU.  ``Comm.unique_id()`` on one rank, the 128 bytes handed to the
+    others by any channel, then ``Comm(id, rank, world, device)`` collectively."""
+
+    @staticmethod
+    def unique_id():
+        buf = C.create_string_buffer(128)
+        _check(load().ctg_comm_get_unique_id(buf))
+        return buf.raw
+
+    def __init__(self, unique_id, rank, world, device=0):
+        if len(unique_id) != 128:
+            raise ValueError("unique id must be 128 bytes")
+        handle = C.c_void_p()
+        buf = C.create_string_buffer(bytes(unique_id), 128)
+        _check(load().ctg_comm_init(buf, int(rank), int(world), int(device), C.byref(handle)))
+        self.handle = handle
+        self.rank, self.world, self.device = int(rank), int(world), int(device)
+
+    @classmethod
+    def from_torch_group(cls, group=None, device=None):
+        """Create the communicator over the ranks of a ``torch.distributed``
+        group, using the group only to hand the unique id around."""
+        import torch
+        import torch.distributed as dist
+
+        rank, world = dist.get_rank(group), dist.get_world_size(group)
+        box = [cls.unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+        if device is None:
+            device = torch.cuda.current_device()
+        return cls(box[0], rank, world, device)
+
+    def close(self):
+        if getattr(self, "handle", None):
+            load().ctg_comm_destroy(self.handle)
             self.handle = None
 
     def __del__(self):

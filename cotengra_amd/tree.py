@@ -709,6 +709,39 @@ class ContractionTree:
 
     remove_ind_ = functools.partialmethod(remove_ind, inplace=True)
 
+    def apply_slicing_(self, sliced):
+        """Re-apply a slicing taken from another tree or from a record, keeping
+        projections: ``sliced`` is a mapping ``ind -> SliceInfo``-like (anything
+        with ``.project``, e.g. ``other.sliced_inds`` of this package or of the
+        reference), or an iterable of index names / ``(name, project)`` pairs
+        (the form :meth:`slicing_record` writes)."""
+        if hasattr(sliced, "items"):
+            items = [(ix, getattr(si, "project", None)) for ix, si in sliced.items()]
+        else:
+            items = [
+                (e, None) if isinstance(e, str) or not isinstance(e, (tuple, list)) else (e[0], e[1])
+                for e in sliced
+            ]
+        for ix, project in items:
+            self.remove_ind_(ix, project=project)
+        return self
+
+    def gathered_shape(self):
+        """Shape of what :meth:`contract` returns: the output indices at full
+        extent, except that an index projected onto one value keeps a size-1
+        axis (reference ``gather_slices``, core.py:3866-3876)."""
+        return tuple(
+            1 if (ix in self.sliced_inds and self.sliced_inds[ix].project is not None) else self.size_dict[ix]
+            for ix in self.output
+        )
+
+    def slicing_record(self):
+        """JSON-able form of the slicing: index names, ``[name, j]`` for an
+        index projected onto value ``j``."""
+        return [
+            ix if si.project is None else [ix, si.project] for ix, si in self.sliced_inds.items()
+        ]
+
     def slice(self, target_size=None, target_slices=None, allow_outer=True, inplace=False, **_ignored):
         """Remove indices until the largest intermediate has at most
         ``target_size`` elements (reference ``ContractionTree.slice``,

@@ -187,6 +187,5 @@ def tree_from_record(rec):
     tree = ContractionTree.from_path(
         rec["inputs"], rec["output"], rec["size_dict"], path=rec["path"]
     )
-    for ix in rec.get("sliced_inds", ()):
-        tree.remove_ind_(ix)
-    return tree
+    # entries are index names, or [name, j] for an index projected onto value j
+    return tree.apply_slicing_(rec.get("sliced_inds", ()))

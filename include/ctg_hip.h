@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define CTG_ABI_VERSION 1
+#define CTG_ABI_VERSION 2
 
 /* element types of the tensors (reference tests cover all four:
  * tests/test_compute.py:102-115) */
@@ -40,7 +40,8 @@ enum {
     CTG_E_INVALID = -1, /* malformed plan / argument (ValueError in the reference) */
     CTG_E_HIP = -2,     /* a HIP runtime call failed */
     CTG_E_NOMEM = -3,   /* device allocation failed */
-    CTG_E_BOUNDS = -4   /* plan addresses outside a declared buffer */
+    CTG_E_BOUNDS = -4,  /* plan addresses outside a declared buffer */
+    CTG_E_COMM = -5     /* RCCL missing, or a collective call failed */
 };
 
 #define CTG_STEP_WORDS 48
@@ -72,6 +73,7 @@ typedef struct ctg_plan_desc {
 
 typedef struct ctg_plan ctg_plan;
 typedef struct ctg_exec ctg_exec;
+typedef struct ctg_comm ctg_comm;
 
 /* Library / error --------------------------------------------------------- */
 int ctg_abi_version(void);
@@ -96,6 +98,11 @@ int ctg_plan_workspace_bytes(const ctg_plan* plan, int64_t bytes[4]);
 int ctg_exec_create(const ctg_plan* plan, int device, void* stream,
                     void* ext_result, ctg_exec** out);
 int ctg_exec_destroy(ctg_exec* exec);
+/* Move the executor to another stream of its device (a caller that works under
+ * changing stream contexts, e.g. `torch.cuda.stream(...)`): waits for the work
+ * already enqueued on the old stream, then every later call enqueues on
+ * `stream`. */
+int ctg_exec_set_stream(ctg_exec* exec, void* stream);
 
 /* Make the (unsliced) input tensors resident: `ptrs[i]` points to
  * input_sizes[i] contiguous row-major elements.  Replaces passing `*arrays`
@@ -148,6 +155,44 @@ int ctg_exec_download_result(ctg_exec* exec, void* host_out);
 /* debugging aid: copy `n` elements of the arena starting at element `offset`
  * to the host (synchronous) */
 int ctg_exec_download_arena(ctg_exec* exec, int64_t offset, int64_t n, void* host_out);
+
+/* Checkpoint of a sliced run.  The reference sums slices into `result` one at
+ * a time (`gather_slices`, core.py:3842-3844; `contract_mpi`, core.py:4073-4076),
+ * so the whole state of an interrupted run is (slices done, partial sum[,
+ * exponent]); which slices are done is the caller's cursor (it chose first /
+ * count / stride).  `get_state` synchronises and copies the partial result
+ * (result_elems elements) to the host together with the strip_exponent
+ * exponent (0 / not-zero when stripping is off); `set_state` on a fresh
+ * executor (same plan, same strip_exponent setting) replaces
+ * ctg_exec_zero_result, after which run_slices continues the sum exactly where
+ * it stopped: resuming is bit-identical to an uninterrupted run. */
+int ctg_exec_get_state(ctg_exec* exec, void* host_result, double* exponent, int* zero);
+int ctg_exec_set_state(ctg_exec* exec, const void* host_result, double exponent, int zero);
+
+/* Multi-GPU: one process (or thread) per GPU, each with its own exec running
+ * ctg_exec_run_slices(first = rank, stride = world) -- the round-robin of
+ * `contract_mpi` (core.py:4068-4076) -- followed by ONE collective over the
+ * result tensor: `comm.Allreduce` / `comm.Reduce` there (core.py:4081, 4089),
+ * RCCL over xGMI here.  The communicator is created from a 128-byte unique id
+ * made on one rank and handed to the others by whatever channel the caller has
+ * (MPI bcast, a file, torch.distributed's store ...) -- the role of mpi4py's
+ * COMM_WORLD in the reference (core.py:4057-4060).  RCCL is bound with dlopen
+ * at the first call (CTG_RCCL_LIB overrides the library name); CTG_E_COMM if
+ * it is absent. */
+#define CTG_UNIQUE_ID_BYTES 128
+int ctg_comm_get_unique_id(void* id_out /* [CTG_UNIQUE_ID_BYTES] */);
+/* collective over all `world` ranks; `device` is this rank's GPU ordinal */
+int ctg_comm_init(const void* id, int rank, int world, int device, ctg_comm** out);
+int ctg_comm_info(const ctg_comm* comm, int* rank, int* world, int* device);
+int ctg_comm_destroy(ctg_comm* comm);
+/* Sum the ranks' result tensors in place, enqueued on the exec's stream behind
+ * its slices: root < 0 -> every rank ends with the total (Allreduce,
+ * core.py:4081); root >= 0 -> only `root` does, the others' result tensors are
+ * left undefined (Reduce, core.py:4089).  With strip_exponent the partials are
+ * (mantissa, exponent) pairs: the ranks first agree on the largest exponent,
+ * rescale their mantissas to it (the adder of core.py:163-172 across ranks) and
+ * then sum; ctg_exec_get_exponent returns the common exponent afterwards. */
+int ctg_exec_reduce(ctg_exec* exec, ctg_comm* comm, int root);
 
 /* Host-side tree tools (no GPU): the inner loops of path search and slicing.
  * The reference runs them in Python, or in its optional Rust accelerator
