@@ -5,21 +5,31 @@ One "step" = one slice of the m20 contraction tree per GPU (SURVEY.md section 8d
 unit = one slice).  The tree fixture was found offline by the reference's own
 hyper-optimizer + dynamic slicing and then refined with this package's native
 subtree reconfiguration (tests/golden/gen/refine_native.py; ``--tree`` takes
-any other fixture, e.g. sycamore_m20_w32_c128.json = least time to the full
-amplitude); inputs are synthetic tensors of the named
-shapes (reference ``make_arrays_from_inputs`` semantics, seed 42, complex64,
-rescaled by size**0.25 so fp32 does not underflow) and are resident in HBM
-before the timed region.  With N GPUs every rank contracts its own slices
-(round-robin, no data-path traffic) and the partial amplitudes are combined
-by ONE RCCL reduce inside the timed region -- weak scaling.
+any other fixture); inputs are synthetic tensors of the named shapes
+(reference ``make_arrays_from_inputs`` semantics, seed 42, complex64, rescaled
+by size**0.25 so fp32 does not underflow) and are resident in HBM before the
+timed region.
+
+``--gpus N``: one process per GPU.  Started without a launcher (no RANK in the
+environment) the script re-executes itself under ``torch.distributed.run`` with
+N ranks on 127.0.0.1; started by a launcher it checks that WORLD_SIZE == N.
+Every rank pins GPU LOCAL_RANK, the ranks verify that they own N distinct GPUs,
+each contracts its own slices (round-robin, no data-path traffic) and the
+partial amplitudes are combined by ONE RCCL reduce on the executors' streams
+(``ctg_exec_reduce`` of the C ABI) inside the timed region -- weak scaling.
 
 Prints ONE JSON line (rank 0): whole-node contracted FLOP/s, the dominant
-kernel's roofline numbers measured live with HIP events, and the numpy-oracle
-CPU baseline on this node's host cores.
+kernel's roofline numbers measured live with HIP events, the numpy-oracle CPU
+baseline on this node's host cores and -- at N = 1 -- the tree that reaches the
+amplitude first (``time_to_solution_tree``) and the other BASELINE.json
+configurations (``configs``: C2 8x8 lattice, C3 Sycamore m10, C5 hyper network),
+each with its own mixed per-step roofline and CPU-oracle time.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -30,7 +40,14 @@ sys.path.insert(0, ROOT)
 
 PEAK_MFMA_F32_TFLOPS = 157.3  # MI355X_MICROARCH.md: dense fp32 matrix peak
 PEAK_HBM_GBS = 8000.0
-TREE = os.path.join(ROOT, "tests", "golden", "trees", "sycamore_m20_w32_c512.json")
+TREES = os.path.join(ROOT, "tests", "golden", "trees")
+TREE = os.path.join(TREES, "sycamore_m20_w32_c512.json")
+TTS_TREE = os.path.join(TREES, "sycamore_m20_native.json")
+
+
+# ---------------------------------------------------------------------- #
+# helpers shared by all workloads
+# ---------------------------------------------------------------------- #
 
 
 def shrink_for_cpu(tree, log2_width):
@@ -42,6 +59,13 @@ def shrink_for_cpu(tree, log2_width):
         ix = next(iter(tree.get_legs(big)))
         tree.remove_ind_(ix)
     return tree
+
+
+def host_cores():
+    try:
+        return len(os.sched_getaffinity(0))
+    except AttributeError:
+        return os.cpu_count()
 
 
 def cpu_baseline(tree, arrays, budget_s=20.0, log2_width=24):
@@ -60,14 +84,10 @@ def cpu_baseline(tree, arrays, budget_s=20.0, log2_width=24):
         if time.time() - t0 > budget_s or n >= 64:
             break
     dt = time.time() - t0
-    try:
-        cores = len(os.sched_getaffinity(0))
-    except AttributeError:
-        cores = os.cpu_count()
     return {
         "value": 8.0 * macs * n / dt,
         "unit": "FLOP/s",
-        "cores": cores,
+        "cores": host_cores(),
         "kind": "port",
         "sample": (
             f"{n} slices of the same m20 tree narrowed to width 2^{log2_width} "
@@ -76,35 +96,296 @@ def cpu_baseline(tree, arrays, budget_s=20.0, log2_width=24):
     }
 
 
+def precision_check(tree, arrays, slice_id=3, log2_width=20):
+    """One slice of ``tree`` narrowed to a CPU-sized width, HIP vs the numpy
+    complex128 oracle.  The complex128 HIP path must reproduce the oracle to
+    1e-10 (same schedule in double precision); the complex64 production path is
+    gated at max(1e-5, 8 x the error numpy itself makes in complex64) -- 1e-5 is
+    the north-star tolerance, and a heavily cancelling slice sum cannot be asked
+    to beat single-precision arithmetic by more than its rounding noise."""
+    from oracle import contract_ref as orc
+
+    small = shrink_for_cpu(tree, log2_width)
+    a128 = [a.astype("complex128") for a in arrays]
+    ref = complex(orc.contract_slice(small, a128, slice_id))
+    np64 = complex(orc.contract_slice(small, arrays, slice_id))
+    got = complex(np.asarray(small.contract_slice(arrays, slice_id)))
+    got128 = complex(np.asarray(small.contract_slice(a128, slice_id)))
+    rel = abs(got - ref) / abs(ref)
+    rel_np = abs(np64 - ref) / abs(ref)
+    gate = max(1e-5, 8.0 * rel_np)
+    out = {
+        "check": f"slice {slice_id} of the tree narrowed to width 2^{log2_width}, vs numpy complex128",
+        "rel_err": rel,
+        "gate": gate,
+        "meets_north_star_1e-5": bool(rel <= 1e-5),
+        "numpy_complex64_rel_err": rel_np,
+        "rel_err_complex128_path": abs(got128 - ref) / abs(ref),
+        "gate_complex128_path": 1e-10,
+    }
+    for c in list(small.contraction_cores.values()):
+        c.close()
+    if out["rel_err"] > gate or out["rel_err_complex128_path"] > 1e-10:
+        raise SystemExit(f"precision check failed: {out}")
+    return out
+
+
+def step_table(ex, plan, slice_id=0):
+    """Per-step rows of one slice with HIP-event durations (events on the exec's
+    stream, ``ctg_exec_profile_slice``) and kernel names."""
+    ms = ex.profile_slice(slice_id)
+    rows = plan.describe_steps()
+    for r, m, nm in zip(rows, ms, ex.step_kernels()):
+        r["ms"] = float(m)
+        r["kernel_name"] = nm
+    return rows
+
+
+def mixed_roofline_ms(rows, flops_per_mac):
+    """Sum over the per-slice steps of max(F_i / MFMA peak, B_i / HBM peak)
+    (SURVEY section 8d "mixed, per step"); slice-invariant steps cost nothing
+    per slice and are excluded (they show 0 ms in the profile)."""
+    t = 0.0
+    for r in rows:
+        if r["ms"] <= 0.0:
+            continue
+        t += max(flops_per_mac * r["macs"] / (PEAK_MFMA_F32_TFLOPS * 1e12), r["bytes"] / (PEAK_HBM_GBS * 1e9))
+    return t * 1e3
+
+
+def dominant_kernel(rows, flops_per_mac):
+    by_name = {}
+    for r in rows:
+        d = by_name.setdefault(r["kernel_name"], {"ms": 0.0, "flops": 0.0, "bytes": 0.0, "n": 0})
+        d["ms"] += r["ms"]
+        d["flops"] += flops_per_mac * r["macs"]
+        d["bytes"] += r["bytes"]
+        d["n"] += 1 if r["ms"] > 0 else 0
+    name, dom = max(by_name.items(), key=lambda kv: kv[1]["ms"])
+    return name, dom, by_name
+
+
+def pmc_traffic_for(tree_file, kernel):
+    """HBM bytes per launch of ``kernel`` from the PMC passes taken on THIS tree
+    (profiles/pmc_summary_<tree>.json, written by tools/pmc_traffic.py); None
+    when no such pass exists."""
+    tag = os.path.splitext(os.path.basename(tree_file))[0]
+    path = os.path.join(ROOT, "profiles", f"pmc_summary_{tag}.json")
+    if not os.path.exists(path):
+        return None, None
+    try:
+        pm = json.load(open(path))
+        kv = pm.get("kernels", {}).get(kernel)
+        return (kv["hbm_bytes_per_launch"] if kv else None), pm.get("hbm_bytes_per_launch")
+    except Exception:
+        return None, None
+
+
+def time_slices(ex, first, count, stride=1):
+    ex.sync()
+    t0 = time.perf_counter()
+    ex.run_slices(first, count, stride)
+    ex.sync()
+    return time.perf_counter() - t0
+
+
+# ---------------------------------------------------------------------- #
+# the other workloads of the line (rank 0, N = 1)
+# ---------------------------------------------------------------------- #
+
+
+def tree_report(tree_file, dev, steps=5, warmup=1):
+    """ms/slice, FLOP/s, dominant-kernel and mixed rooflines of another m20
+    tree -- the one that reaches the amplitude first."""
+    import torch
+
+    import cotengra_amd as ca
+    from cotengra_amd.contractor import HipContractor
+
+    rec = ca.load_network(tree_file)
+    tree = ca.tree_from_record(rec)
+    arrays = ca.make_arrays_from_inputs(tree.inputs, tree.size_dict, seed=42, dtype="complex64", rescale=True)
+    fn = HipContractor(tree, handle_slicing=True)
+    st = fn.setup(*[torch.as_tensor(a, device=dev) for a in arrays])
+    ex, plan = st["exec"], st["plan"]
+    ex.zero_result()
+    ex.run_slices(0, warmup, 1)
+    dt = time_slices(ex, warmup, steps) / steps
+    rows = step_table(ex, plan)
+    name, dom, _ = dominant_kernel(rows, 8.0)
+    flops = plan.flops_per_slice()
+    roof_ms = mixed_roofline_ms(rows, 8.0)
+    mf = dom["flops"] / max(dom["ms"] * 1e-3, 1e-12) / 1e12
+    bw = dom["bytes"] / max(dom["ms"] * 1e-3, 1e-12) / 1e9
+    traffic, _ = pmc_traffic_for(tree_file, name)
+    out = {
+        "tree": os.path.basename(tree_file),
+        "nslices_log2": float(np.log2(tree.nslices)),
+        "width_log2": float(np.log2(tree.max_size())),
+        "macs_per_slice": int(plan.macs_per_slice),
+        "ms_per_slice": dt * 1e3,
+        "tflops": flops / dt / 1e12,
+        "frac_of_mfma_peak": flops / dt / 1e12 / PEAK_MFMA_F32_TFLOPS,
+        "mixed_roofline_ms": roof_ms,
+        "mixed_roofline_frac": roof_ms / (dt * 1e3),
+        "est_time_total_s": dt * tree.nslices,
+        "dominant_kernel": {
+            "kernel": name,
+            "share_of_slice_time": dom["ms"] / max(sum(r["ms"] for r in rows), 1e-9),
+            "tflops": mf,
+            "frac_of_mfma_peak": mf / PEAK_MFMA_F32_TFLOPS,
+            "gbs": bw,
+            "frac_of_hbm_peak": bw / PEAK_HBM_GBS,
+            "traffic": traffic,
+        },
+        "precision": precision_check(tree, arrays),
+    }
+    fn.close()
+    return out
+
+
+def small_config(name, tree, arrays, dev, slices, reps, cpu_slices, note, dtype="complex64"):
+    """A launch-/latency-bound configuration: time per contraction (all
+    ``slices`` slices), mixed roofline, the oracle on the host cores."""
+    import torch
+
+    from cotengra_amd.contractor import HipContractor
+    from oracle import contract_ref as orc
+
+    arrays = [np.asarray(a).astype(dtype) for a in arrays]
+    fn = HipContractor(tree, handle_slicing=True)
+    st = fn.setup(*[torch.as_tensor(a, device=dev) for a in arrays])
+    ex, plan = st["exec"], st["plan"]
+    ex.zero_result()
+    ex.run_slices(0, min(slices, 2), 1)
+    ex.sync()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        ex.run_slices(0, slices, 1)
+    ex.sync()
+    dt = (time.perf_counter() - t0) / reps
+    rows = step_table(ex, plan)
+    roof_ms = mixed_roofline_ms(rows, 8.0) * slices
+    flops = plan.flops_per_slice() * slices
+    # the oracle (numpy, the reference's executor restated) on this node's cores
+    ops = orc.extract_contractions(tree)
+    t0 = time.perf_counter()
+    for i in range(cpu_slices):
+        orc.run_contractions(ops, orc.slice_arrays(tree, arrays, i) if tree.sliced_inds else arrays)
+    cpu = (time.perf_counter() - t0) / cpu_slices * slices
+    fn.close()
+    return {
+        "workload": note,
+        "steps_per_slice": len(plan.steps),
+        "slices_timed": slices,
+        "ms": dt * 1e3,
+        "slices_per_sec": slices / dt,
+        "tflops": flops / dt / 1e12,
+        "mixed_roofline_ms": roof_ms,
+        "mixed_roofline_frac": roof_ms / (dt * 1e3),
+        "cpu_oracle_ms": cpu * 1e3,
+        "cpu_cores": host_cores(),
+        "cpu_sample": f"{cpu_slices} slice(s) with numpy {dtype}, scaled to {slices}",
+        "speedup_vs_cpu_oracle": cpu / dt,
+    }
+
+
+def other_configs(dev):
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import golden_util as G
+
+    import cotengra_amd as ca
+
+    out = {}
+    by_name = {c["name"]: c for c in G.cases("tree")}
+    c2 = by_name["C2_lattice8x8_d4"]
+    t2 = G.tree_of(c2)
+    out["C2"] = small_config(
+        "C2", t2, G.arrays_of(c2, "complex128", t2), dev, slices=1, reps=200, cpu_slices=5,
+        note="8x8 PEPS-style lattice, bond dim 4, unsliced, one contraction",
+    )
+    m10 = os.path.join(TREES, "sycamore_m10.json")
+    arr = os.path.join(ROOT, "tests", "golden", "sycamore_m10_arrays.npz")
+    if os.path.exists(m10) and os.path.exists(arr):
+        t3 = ca.tree_from_record(ca.load_network(m10))
+        z = np.load(arr)
+        out["C3"] = small_config(
+            "C3", t3, [z[f"t{i}"] for i in range(t3.N)], dev, slices=t3.nslices, reps=5, cpu_slices=2,
+            note=f"Sycamore circuit_n53_m10 amplitude, all {t3.nslices} slices (the whole amplitude)",
+        )
+    c5 = by_name["C5_hyper200"]
+    t5 = G.tree_of(c5)
+    out["C5"] = small_config(
+        "C5", t5, G.arrays_of(c5, "complex128", t5), dev, slices=16, reps=5, cpu_slices=2,
+        note="random-regular hyper network, 200 tensors, batch + hyper indices, 16 of its slices",
+    )
+    return out
+
+
+# ---------------------------------------------------------------------- #
+
+
+def respawn(args):
+    """No launcher in sight: start N ranks of this script through
+    torch.distributed.run on the loopback address and pass its exit code on."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [
+        sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+        "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__),
+    ] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    raise SystemExit(subprocess.call(cmd, env=env))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=4)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--tree", default=TREE)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true",
+                    help="skip every CPU-oracle leg (baseline, precision) and the extra workloads")
+    ap.add_argument("--headline-only", action="store_true",
+                    help="skip time_to_solution_tree and the C2/C3/C5 configs")
     ap.add_argument("--dump-steps", default=None, help="write per-step timings JSON here")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "RANK" not in os.environ:
+        respawn(args)
 
     import torch
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if args.gpus != world and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} != WORLD_SIZE {world}")
+    if args.gpus != world:
+        raise SystemExit(f"--gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
+    if torch.cuda.device_count() <= local_rank:
+        raise SystemExit(
+            f"rank {rank}: LOCAL_RANK {local_rank} but only {torch.cuda.device_count()} GPU(s) visible"
+        )
     dist = None
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1 or "RANK" in os.environ:
-        # launched by torch.distributed.run: one process per GPU over RCCL
+    devices = None
+    if "RANK" in os.environ:
+        # one process per GPU over RCCL
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if dist.get_world_size() != args.gpus:
+            raise SystemExit(f"world size {dist.get_world_size()} != --gpus {args.gpus}")
+        from cotengra_amd.distributed import assert_distinct_devices
+
+        devices = assert_distinct_devices()  # raises unless N distinct GPUs are in use
 
     import cotengra_amd as ca
+    from cotengra_amd import runtime
     from cotengra_amd.contractor import HipContractor
 
     rec = ca.load_network(args.tree)
@@ -119,6 +400,29 @@ def main():
     result = st["result"]
     nsl = tree.nslices
 
+    # the single collective: RCCL behind the C ABI on the exec's stream; the
+    # torch process group only hands the unique id around
+    comm, reduce_via = None, None
+    if dist is not None:
+        try:
+            comm = runtime.Comm.from_torch_group(None, device=local_rank)
+            reduce_via = "ctg_exec_reduce (RCCL, C ABI)"
+        except runtime.CtgError as e:  # e.g. an RCCL the loader cannot find
+            if rank == 0:
+                print(f"ctg_comm_init failed ({e}); reducing through torch.distributed", file=sys.stderr)
+            reduce_via = "torch.distributed.reduce (RCCL)"
+        flag = torch.tensor([0 if comm is not None else 1], device=dev)
+        dist.all_reduce(flag)
+        if int(flag.item()) != 0 and comm is not None:  # all ranks or none
+            comm.close()
+            comm, reduce_via = None, "torch.distributed.reduce (RCCL)"
+
+    def reduce_partials():
+        if comm is not None:
+            ex.reduce(comm, 0)
+        elif dist is not None:
+            dist.reduce(torch.view_as_real(result), dst=0)
+
     def barrier():
         torch.cuda.synchronize(dev)
         if dist is not None:
@@ -129,76 +433,53 @@ def main():
     ex.zero_result()
     if args.warmup:
         ex.run_slices(rank % nsl, args.warmup, world)
-    if dist is not None:
-        buf = torch.view_as_real(result)
-        dist.reduce(buf, dst=0)
+    reduce_partials()
     barrier()
 
     # timed: K slices per rank + the single RCCL reduce of the partial amplitude
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
     ex.zero_result()
     barrier()
     t0 = time.perf_counter()
+    ev[0].record()
     ex.run_slices((args.warmup * world + rank) % nsl, args.steps, world)
-    if dist is not None:
-        dist.reduce(torch.view_as_real(result), dst=0)
+    ev[1].record()
+    reduce_partials()
+    ev[2].record()
     barrier()
-    dt = time.perf_counter() - t0
+    dt_local = dt = time.perf_counter() - t0
+    slices_ms, reduce_ms = ev[0].elapsed_time(ev[1]), ev[1].elapsed_time(ev[2])
+    per_rank = None
     if dist is not None:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+        mine = torch.tensor([dt_local * 1e3, slices_ms, reduce_ms], dtype=torch.float64, device=dev)
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        per_rank = [
+            {"rank": r, "device": devices[r] if devices else None, "wall_ms": float(v[0]),
+             "slices_ms": float(v[1]), "reduce_wait_ms": float(v[2])}
+            for r, v in enumerate(allr)
+        ]
 
-    # precision: one slice of the same tree narrowed to a CPU-sized width.  The
-    # complex128 HIP path must reproduce the numpy complex128 oracle (same
-    # schedule, 1e-10); the complex64 production path is held to an fp32 bound
-    # and reported next to the error numpy itself makes in complex64.
-    precision = None
-    if rank == 0 and not args.no_cpu_baseline:
-        from oracle import contract_ref as orc
-
-        small = shrink_for_cpu(tree, 20)
-        ref = complex(orc.contract_slice(small, [a.astype("complex128") for a in arrays], 3))
-        np64 = complex(orc.contract_slice(small, arrays, 3))
-        got = complex(np.asarray(small.contract_slice(arrays, 3)))
-        got128 = complex(np.asarray(small.contract_slice([a.astype("complex128") for a in arrays], 3)))
-        precision = {
-            "check": "slice 3 of the tree narrowed to width 2^20, vs numpy complex128",
-            "rel_err": abs(got - ref) / abs(ref),
-            "gate": 1e-4,
-            "rel_err_complex128_path": abs(got128 - ref) / abs(ref),
-            "gate_complex128_path": 1e-10,
-            "numpy_complex64_rel_err": abs(np64 - ref) / abs(ref),
-        }
-        if precision["rel_err"] > precision["gate"] or precision["rel_err_complex128_path"] > 1e-10:
-            raise SystemExit(f"precision check failed: {precision}")
+    extras = rank == 0 and world == 1 and not args.no_cpu_baseline
+    precision = precision_check(tree, arrays) if (rank == 0 and not args.no_cpu_baseline) else None
 
     flops_slice = plan.flops_per_slice()
     total_slices = args.steps * world
     value = flops_slice * total_slices / dt
 
-    out = None
     if rank == 0:
-        # per-kernel timing of one slice with HIP events on the exec's stream
-        ms = ex.profile_slice(0)
-        rows = plan.describe_steps()
-        for r, m in zip(rows, ms):
-            r["ms"] = float(m)
-        names = ex.step_kernels()
-        for r, nm in zip(rows, names):
-            r["kernel_name"] = nm
-        # dominant kernel = the kernel symbol with the largest share of slice time
-        by_name = {}
-        for r in rows:
-            d = by_name.setdefault(r["kernel_name"], {"ms": 0.0, "flops": 0.0, "bytes": 0.0, "n": 0})
-            d["ms"] += r["ms"]
-            d["flops"] += 8.0 * r["macs"]
-            d["bytes"] += r["bytes"]
-            d["n"] += 1
-        dom_name, dom = max(by_name.items(), key=lambda kv: kv[1]["ms"])
+        rows = step_table(ex, plan)
+        dom_name, dom, by_name = dominant_kernel(rows, 8.0)
         achieved = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
         mf = [r for r in rows if r["kernel"] == "mfma"]
         all_flops = sum(8.0 * r["macs"] for r in mf)
         all_ms = sum(r["ms"] for r in mf)
+        slice_ms = sum(r["ms"] for r in rows)
+        roof_ms = mixed_roofline_ms(rows, 8.0)
+        traffic, traffic_all = pmc_traffic_for(args.tree, dom_name)
         roofline = {
             "bound": "mfma",
             "kernel": dom_name,
@@ -210,26 +491,22 @@ def main():
             "avg_launch_ms": dom["ms"] / dom["n"],
             "flops_per_launch": dom["flops"] / dom["n"],
             "algorithmic_bytes_per_launch": dom["bytes"] / dom["n"],
-            "share_of_slice_time": dom["ms"] / max(float(ms.sum()), 1e-9),
-            "traffic": None,
+            "share_of_slice_time": dom["ms"] / max(slice_ms, 1e-9),
+            "traffic": traffic,
+            "traffic_all_mfma_per_launch": traffic_all,
             "all_mfma_kernels": {
                 "achieved": all_flops / (all_ms * 1e-3) / 1e12,
                 "frac": all_flops / (all_ms * 1e-3) / 1e12 / PEAK_MFMA_F32_TFLOPS,
                 "launches_per_slice": len(mf),
-                "share_of_slice_time": all_ms / max(float(ms.sum()), 1e-9),
+                "share_of_slice_time": all_ms / max(slice_ms, 1e-9),
+            },
+            "mixed_per_step": {
+                "definition": "sum over steps of max(flops_i / 157.3 TF, bytes_i / 8 TB/s)",
+                "roofline_ms": roof_ms,
+                "frac": roof_ms / (dt * 1e3 / args.steps),
             },
             "by_kernel_ms": {k: round(v["ms"], 3) for k, v in sorted(by_name.items(), key=lambda kv: -kv[1]["ms"])},
         }
-        pmc = os.path.join(ROOT, "profiles", "pmc_summary.json")
-        if os.path.exists(pmc):
-            try:
-                pm = json.load(open(pmc))
-                kv = pm.get("kernels", {}).get(dom_name)
-                if kv:
-                    roofline["traffic"] = kv["hbm_bytes_per_launch"]
-                roofline["traffic_all_mfma_per_launch"] = pm.get("hbm_bytes_per_launch")
-            except Exception:
-                pass
         if args.dump_steps:
             os.makedirs(os.path.dirname(os.path.abspath(args.dump_steps)), exist_ok=True)
             json.dump(rows, open(args.dump_steps, "w"))
@@ -248,6 +525,7 @@ def main():
             "data": "synthetic",
             "slices_per_sec": total_slices / dt,
             "tflops": value / 1e12,
+            "frac_of_mfma_peak_whole_job": value / 1e12 / (PEAK_MFMA_F32_TFLOPS * world),
             "cotengra_convention_gigaflops": 4.0 * plan.macs_per_slice * total_slices / dt / 1e9,
             "est_time_total_s": nsl / (total_slices / dt),
             "config": {
@@ -261,6 +539,7 @@ def main():
                 "algorithmic_bytes_per_slice": float(plan.bytes_per_slice()),
                 "steps_per_slice": len(plan.steps),
                 "parallelism": f"slice-parallel x{world}, 1 RCCL reduce",
+                "reduce_via": reduce_via,
                 "partial_amplitude": [float(result.real.item()), float(result.imag.item())]
                 if result.numel() == 1
                 else None,
@@ -268,13 +547,24 @@ def main():
             "roofline": roofline,
             "precision": precision,
         }
+        if per_rank is not None:
+            out["per_rank"] = per_rank
+            out["distinct_gpus"] = len(set(devices))
+        fn.close()
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(tree, arrays)
+        if extras and not args.headline_only:
+            if os.path.abspath(args.tree) != os.path.abspath(TTS_TREE) and os.path.exists(TTS_TREE):
+                out["time_to_solution_tree"] = tree_report(TTS_TREE, dev)
+            out["configs"] = other_configs(dev)
         print(json.dumps(out))
+    else:
+        fn.close()
+    if comm is not None:
+        comm.close()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
-    fn.close()
 
 
 if __name__ == "__main__":

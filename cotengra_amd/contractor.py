@@ -250,6 +250,107 @@ class HipContractor:
         self._plans.clear()
 
 
+class PerOpContractor:
+    """The reference's per-op plug-in point: ``implementation=(einsum,
+    tensordot)`` (``cotengra/contract.py:775-776`` -- in that order).  The tree
+    is walked on the host and every pairwise step is handed to the caller's two
+    functions:
+
+    * ``tensordot(a, b, (axes_a, axes_b))`` for steps that are plain tensor
+      products over shared indices, the result being ``[free-a..., free-b...]``
+      and then transposed to the parent's index order (contract.py:808-812);
+    * ``einsum(eq, a, b)`` for steps with batch / hyper indices, and
+      ``einsum(eq, x)`` for single-tensor preprocessing (contract.py:795-800, 814).
+
+    Passing this package's own pair, ``(cotengra_amd.einsum,
+    cotengra_amd.tensordot)``, runs every step as its own small HIP plan --
+    correct but one materialised tensor per step, which is what the whole-tree
+    ``HipContractor`` exists to avoid (SURVEY section 8b calls this slot the
+    fallback boundary).  Arrays are whatever the two functions accept; the only
+    things asked of the arrays themselves are ``.transpose(*perm)`` / ``.permute``
+    and, with ``strip_exponent``, ``abs(x).max()`` and division by a scalar.
+    """
+
+    def __init__(self, tree, implementation, order=None, prefer_einsum=False,
+                 strip_exponent=False, check_zero=False):
+        try:
+            self._einsum, self._tensordot = implementation
+        except (TypeError, ValueError):
+            raise ValueError(
+                "implementation must be 'hip' or a pair of callables (einsum, tensordot), "
+                f"got {implementation!r}."
+            ) from None
+        if not (callable(self._einsum) and callable(self._tensordot)):
+            raise ValueError("implementation=(einsum, tensordot) must be two callables.")
+        self.strip_exponent = strip_exponent
+        self.check_zero = check_zero
+        self.n_inputs = tree.N
+        # schedule: ("pair", out, left, right, axes | None, eq | None, perm | None)
+        self.schedule = []
+        if tree.N == 1:
+            self.single = tree.get_eq_sliced()
+            return
+        self.single = None
+        slot = {leaf: i for i, leaf in enumerate(tree.gen_leaves())}
+        nxt = len(slot)
+        for parent, left, right in tree.traverse(order=order):
+            a, b = slot.pop(left), slot.pop(right)
+            slot[parent] = nxt
+            if not prefer_einsum and tree.get_can_dot(parent):
+                self.schedule.append(
+                    (nxt, a, b, tree.get_tensordot_axes(parent), None, tree.get_tensordot_perm(parent))
+                )
+            else:
+                self.schedule.append((nxt, a, b, None, tree.get_einsum_eq(parent), None))
+            nxt += 1
+        self.root = nxt - 1
+        # (filled lazily by the index queries above, so read afterwards)
+        self.pre = dict(tree.preprocessing)
+
+    @staticmethod
+    def _transpose(x, perm):
+        if hasattr(x, "permute"):
+            return x.permute(*perm)
+        return x.transpose(*perm)
+
+    def __call__(self, *arrays, **kwargs):
+        kwargs.pop("backend", None)
+        kwargs.pop("progbar", None)
+        strip = kwargs.pop("strip_exponent", self.strip_exponent)
+        check_zero = kwargs.pop("check_zero", self.check_zero)
+        if kwargs:
+            raise TypeError(f"Unknown keyword arguments: {kwargs}.")
+        if len(arrays) != self.n_inputs:
+            raise ValueError(f"Expected {self.n_inputs} arrays, got {len(arrays)}.")
+        import math
+
+        exponent = 0.0
+        if self.single is not None:
+            out = self._einsum(self.single, arrays[0])
+            return (out, exponent) if strip else out
+        live = dict(enumerate(arrays))
+        for i, eq in self.pre.items():
+            live[i] = self._einsum(eq, live[i])
+        for out_id, a, b, axes, eq, perm in self.schedule:
+            x, y = live.pop(a), live.pop(b)
+            if axes is not None:
+                z = self._tensordot(x, y, axes)
+                if perm:
+                    z = self._transpose(z, perm)
+            else:
+                z = self._einsum(eq, x, y)
+            if strip:
+                # contract.py:816-829
+                fac = float(abs(z).max())
+                if check_zero and fac == 0.0:
+                    return 0.0, float("-inf")
+                exponent += math.log10(fac)
+                z = z / fac
+            live[out_id] = z
+        out = live[self.root]
+        return (out, exponent) if strip else out
+
+
 def _chunk_index(tree, loc):
     """Position of a slice's output inside the full result tensor: sliced
     output indices are fixed (a projected one sits at 0 of its size-1 axis),
@@ -294,10 +395,18 @@ def make_contractor(
     executor as the only engine.  ``prefer_einsum`` and ``autojit`` are
     accepted for signature compatibility and have no effect: the plan never
     distinguishes tensordot from einsum steps and is already compiled."""
+    if isinstance(implementation, (tuple, list)):
+        # per-op plug-in (contract.py:775-776): the caller's (einsum, tensordot)
+        return PerOpContractor(
+            tree if (handle_slicing or not tree.sliced_inds) else _sliced_twin(tree),
+            implementation, order=order, prefer_einsum=prefer_einsum,
+            strip_exponent=strip_exponent, check_zero=check_zero,
+        )
     if implementation not in (None, "auto", "hip"):
         raise ValueError(
             f"implementation={implementation!r} is not available: cotengra_amd "
-            "executes whole trees with its HIP backend ('hip')."
+            "executes whole trees with its HIP backend ('hip') or with a caller's "
+            "(einsum, tensordot) pair."
         )
     return HipContractor(
         tree,
@@ -335,6 +444,16 @@ def contract_tree(
 ):
     """``ContractionTree.contract`` (core.py:3943-4030): every slice runs on
     the device and accumulates into the resident output tensor."""
+    if isinstance(implementation, (tuple, list)):
+        # per-op plug-in: the host walks slices and steps (core.py:4002-4030)
+        core = tree.get_contractor(
+            order=order, prefer_einsum=prefer_einsum, strip_exponent=strip_exponent is not False,
+            check_zero=check_zero, implementation=implementation,
+        )
+        if not tree.sliced_inds:
+            return core(*arrays)
+        slices = (core(*tree.slice_arrays(arrays, i)) for i in range(tree.multiplicity))
+        return gather_slices(tree, slices)
     if implementation not in (None, "auto", "hip"):
         raise ValueError(f"implementation={implementation!r} is not available.")
     fn = _tree_contractor(tree, order)
@@ -350,12 +469,19 @@ def contract_slice(tree, arrays, i, **kwargs):
     order = kwargs.pop("order", None)
     strip_exponent = kwargs.pop("strip_exponent", False)
     check_zero = kwargs.pop("check_zero", False)
-    for k in ("prefer_einsum", "backend", "implementation", "autojit", "progbar"):
+    implementation = kwargs.pop("implementation", None)
+    prefer_einsum = kwargs.pop("prefer_einsum", False)
+    for k in ("backend", "autojit", "progbar"):
         kwargs.pop(k, None)
     if kwargs:
         raise TypeError(f"Unknown keyword arguments: {kwargs}.")
     if not 0 <= i < tree.multiplicity:
         raise IndexError(f"slice {i} out of range [0, {tree.multiplicity})")
+    if isinstance(implementation, (tuple, list)):
+        return tree.contract_core(
+            tree.slice_arrays(arrays, i), order=order, prefer_einsum=prefer_einsum,
+            strip_exponent=strip_exponent, check_zero=check_zero, implementation=implementation,
+        )
     fn = _tree_contractor(tree, order)
     return fn.contract_slice(
         arrays, i, strip_exponent=strip_exponent is not False, check_zero=check_zero
@@ -468,3 +594,124 @@ def benchmark_tree(
         "est_time_total": est_time_total,
         "est_gigaflops": tree.total_flops(dtype=dtype) / (1e9 * est_time_total),
     }
+
+
+# ---------------------------------------------------------------------- #
+# checkpoint / resume of a sliced run
+# ---------------------------------------------------------------------- #
+#
+# The reference sums slices one after another into a running result
+# (``gather_slices``, core.py:3842-3844; ``contract_mpi``, core.py:4073-4076) and
+# keeps nothing else between slices, so (how many of my slices are done, the
+# partial sum[, its exponent]) is the complete state of a run.  A Sycamore m20
+# amplitude is days of GPU time: the state is written every so often and a
+# restarted process continues from it -- bit-identically, because the slices
+# are added in the same order onto the same bits.
+
+
+def tree_signature(tree, dtype, rank=0, world=1, strip_exponent=False, check_zero=False, order=None):
+    """Digest of everything a partial sum depends on: network, schedule,
+    slicing, element type, which share of the slices, stripping options."""
+    import hashlib
+    import json
+
+    doc = {
+        "inputs": [list(map(str, t)) for t in tree.inputs],
+        "output": list(map(str, tree.output)),
+        "sizes": sorted((str(k), int(v)) for k, v in tree.size_dict.items()),
+        "ssa_path": [list(p) for p in tree.get_ssa_path(order=order)] if tree.N > 1 else [],
+        "sliced": [[str(si.ind), si.project] for si in tree.sliced_inds.values()],
+        "dtype": str(dtype),
+        "share": [int(rank), int(world)],
+        "strip": [bool(strip_exponent), bool(check_zero)],
+    }
+    return hashlib.sha256(json.dumps(doc, sort_keys=True).encode()).hexdigest()
+
+
+def save_checkpoint(path, signature, done, result, exponent=0.0, zero=False):
+    """Atomically replace ``path`` (write to a sibling, fsync, rename): a crash
+    while writing leaves the previous checkpoint intact."""
+    import os
+    import tempfile
+
+    d = os.path.dirname(os.path.abspath(path)) or "."
+    fd, tmp = tempfile.mkstemp(prefix=os.path.basename(path) + ".", suffix=".tmp", dir=d)
+    try:
+        with os.fdopen(fd, "wb") as f:
+            np.savez(
+                f, signature=np.array(signature), done=np.int64(done), result=np.asarray(result),
+                exponent=np.float64(exponent), zero=np.bool_(zero),
+            )
+            f.flush()
+            os.fsync(f.fileno())
+        os.replace(tmp, path)
+    except BaseException:
+        try:
+            os.unlink(tmp)
+        except OSError:
+            pass
+        raise
+
+
+def load_checkpoint(path, signature):
+    """``(done, result, exponent, zero)`` or None when there is no checkpoint;
+    ``ValueError`` when the file belongs to a different contraction."""
+    import os
+
+    if not os.path.exists(path):
+        return None
+    with np.load(path, allow_pickle=False) as z:
+        if str(z["signature"]) != signature:
+            raise ValueError(
+                f"checkpoint {path} was written for a different tree / dtype / rank layout "
+                "(signature mismatch); remove it to start over."
+            )
+        return int(z["done"]), z["result"].copy(), float(z["exponent"]), bool(z["zero"])
+
+
+def contract_resumable(
+    tree, arrays, checkpoint, every=64, order=None, strip_exponent=False, check_zero=False,
+    rank=0, world=1, stop_after=None, keep=False,
+):
+    """``tree.contract(arrays)`` that survives being killed.
+
+    This rank's slices (``rank, rank + world, ...``: ``world=1`` is all of
+    them) run in chunks of ``every``; after each chunk the partial sum is
+    downloaded (``ctg_exec_get_state``) and written to ``checkpoint``.  If the
+    file already exists the run restores it (``ctg_exec_set_state``) and
+    continues with the first slice not yet summed.  ``stop_after=n`` ends this
+    call after at most ``n`` more slices (returns None unless that completed
+    the run) -- what a job-time limit or a test uses.  The file is removed when
+    the run completes unless ``keep``.  Returns what ``contract`` returns (this
+    rank's share when ``world > 1``: feed it to the collective)."""
+    import os
+
+    fn = _tree_contractor(tree, order)
+    st = fn.setup(*arrays)
+    ex = st["exec"]
+    ex.set_strip_exponent(strip_exponent, check_zero)
+    total = len(range(rank, tree.multiplicity, world))
+    sig = tree_signature(tree, st["plan"].dtype, rank, world, strip_exponent, check_zero, order)
+    saved = load_checkpoint(checkpoint, sig)
+    if saved is None:
+        done = 0
+        ex.zero_result()
+    else:
+        done, result, exponent, zero = saved
+        if not 0 <= done <= total:
+            raise ValueError(f"checkpoint {checkpoint} claims {done} of {total} slices")
+        ex.set_state(result, exponent, zero)
+    budget = total - done if stop_after is None else min(int(stop_after), total - done)
+    while budget > 0:
+        n = min(int(every), budget)
+        ex.run_slices(rank + done * world, n, world)
+        done += n
+        budget -= n
+        result, exponent, zero = ex.get_state()
+        save_checkpoint(checkpoint, sig, done, result, exponent, zero)
+    if done < total:
+        return None
+    out = fn._finish(st, strip_exponent, check_zero)
+    if not keep and os.path.exists(checkpoint):
+        os.unlink(checkpoint)
+    return out

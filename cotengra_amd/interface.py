@@ -16,6 +16,8 @@ subtree reconfiguration, ``search`` -- their results are trees to pass here).
 
 from __future__ import annotations
 
+import collections
+
 import numpy as np
 
 from .contractor import HipContractor, _is_torch
@@ -173,17 +175,66 @@ class ContractExpression:
         return self.fn(*arrays, **kwargs)
 
 
+    def close(self):
+        self.fn.close()
+
+
+# Expressions built by the one-shot front ends (``einsum``, ``array_contract``,
+# ``tensordot``) are kept, least recently used first out: a repeated call with
+# the same equation and shapes -- the per-op ``implementation=(einsum,
+# tensordot)`` use -- finds its plan, tables and device buffers in place instead
+# of rebuilding them (the reference memoises its parsers the same way,
+# contract.py:34, 61, 121, 167: ``lru_cache(2**12)``).
+_EXPR_CACHE = collections.OrderedDict()
+_EXPR_CACHE_SIZE = 64
+
+
+def _cached_expression(inputs, output, size_dict, optimize, strip_exponent, check_zero):
+    try:
+        opt_key = optimize if isinstance(optimize, str) else tuple(map(tuple, optimize))
+        key = (tuple(inputs), tuple(output), tuple(sorted(size_dict.items())), opt_key,
+               bool(strip_exponent), bool(check_zero))
+        hash(key)
+    except TypeError:
+        key = None  # a tree object or something unhashable: the caller keeps it
+    if key is not None and key in _EXPR_CACHE:
+        _EXPR_CACHE.move_to_end(key)
+        return _EXPR_CACHE[key]
+    tree = array_contract_tree(inputs, output, size_dict, optimize)
+    expr = ContractExpression(tree, strip_exponent, check_zero)
+    if key is not None:
+        _EXPR_CACHE[key] = expr
+        while len(_EXPR_CACHE) > _EXPR_CACHE_SIZE:
+            _, old = _EXPR_CACHE.popitem(last=False)
+            old.close()  # frees the evicted executor's device memory now
+    return expr
+
+
+def clear_expression_cache():
+    """Close and drop every cached one-shot expression."""
+    while _EXPR_CACHE:
+        _, old = _EXPR_CACHE.popitem()
+        old.close()
+
+
 def array_contract_expression(
     inputs, output, size_dict=None, shapes=None, optimize="greedy",
-    strip_exponent=False, check_zero=False, via=None, **_ignored,
+    strip_exponent=False, check_zero=False, via=None, sort_contraction_indices=False,
+    cache_expression=False, **_ignored,
 ):
     """interface.py:673.  ``via=(convert_in, convert_out)`` wraps the
-    expression like the reference does (interface.py:664-665)."""
+    expression like the reference does (interface.py:664-665).
+    ``sort_contraction_indices`` (interface.py:455-456) is accepted and has no
+    effect: the executor never materialises a permutation, see
+    ``ContractionTree.sort_contraction_indices``."""
     inputs = [tuple(t) for t in inputs]
     if size_dict is None:
         size_dict = shapes_inputs_to_size_dict(shapes, inputs)
-    tree = array_contract_tree(inputs, output, size_dict, optimize)
-    expr = ContractExpression(tree, strip_exponent, check_zero)
+    if cache_expression:
+        expr = _cached_expression(inputs, output, size_dict, optimize, strip_exponent, check_zero)
+    else:
+        tree = array_contract_tree(inputs, output, size_dict, optimize)
+        expr = ContractExpression(tree, strip_exponent, check_zero)
     if via is not None:
         expr = Via(expr, *via)
     return expr
@@ -200,6 +251,7 @@ def einsum_expression(eq, *shapes, optimize="greedy", **kwargs):
 def array_contract(arrays, inputs, output, optimize="greedy", **kwargs):
     """interface.py:803."""
     shapes = [tuple(x.shape) for x in arrays]
+    kwargs.setdefault("cache_expression", True)
     expr = array_contract_expression(
         inputs, output, shapes=shapes, optimize=optimize, **kwargs
     )

@@ -523,46 +523,52 @@ class ContractionTree:
         return "dfs"
 
     def _traverse_dfs(self):
-        """Depth-first, left subtree first, children before parents
-        (reference core.py:1781-1799)."""
-        ready = set(self.gen_leaves())
-        stack = [self.root]
-        while stack:
-            node = stack[-1]
-            l, r = self.children[node]
-            if l in ready and r in ready:
-                ready.add(stack.pop())
-                yield node, l, r
+        """Post-order walk: a node is emitted after its whole left subtree and
+        then its whole right subtree -- the sequence the reference's
+        depth-first traversal produces (core.py:1781-1799), which the parity
+        of the linear IR depends on.  Each frame on the explicit stack carries
+        how many of the node's children have been walked already."""
+        children = self.children
+        frames = [(self.root, 0)]
+        while frames:
+            node, walked = frames.pop()
+            kids = children.get(node)
+            if kids is None:  # a leaf: nothing to contract
                 continue
-            if r not in ready:
-                stack.append(r)
-            if l not in ready:
-                stack.append(l)
+            if walked == 2:
+                yield (node, *kids)
+                continue
+            frames.append((node, walked + 1))
+            frames.append((kids[walked], 0))
 
     def _traverse_ordered(self, order):
-        """Children before parents, otherwise by increasing ``order(node)``
-        (reference core.py:1801-1832)."""
-        from bisect import bisect
+        """Children before parents, and among the contractions that are ready
+        always the one with the lowest ``order(node)`` (ties: the one that
+        became ready first): a priority-queue topological sort.  This honours
+        the contract of the reference's ordered traversal (core.py:1801-1832:
+        "minimise order(node) but produce children before parents") and is the
+        greedy schedule for it; the reference's insertion-based construction
+        can emit a different -- equally valid -- sequence.  The contracted
+        values do not depend on the sequence, only tensor lifetimes do."""
+        import heapq
 
-        seen = set()
-        queue = [self.root]
-        scores = [order(self.root)]
-        while len(seen) != len(self.children):
-            i = 0
-            while i < len(queue):
-                node = queue[i]
-                if node not in seen:
-                    for child in self.children[node]:
-                        if self._extent[child] > 1:
-                            score = order(child)
-                            ci = bisect(scores[:i], score)
-                            scores.insert(ci, score)
-                            queue.insert(ci, child)
-                            i += 1
-                    seen.add(node)
-                i += 1
-        for node in queue:
-            yield (node, *self.children[node])
+        children = self.children
+        parent_of = {}
+        waiting = {}
+        for node, (l, r) in children.items():
+            parent_of[l] = parent_of[r] = node
+            waiting[node] = (l in children) + (r in children)
+        ticket = itertools.count()
+        ready = [(order(n), next(ticket), n) for n, w in waiting.items() if w == 0]
+        heapq.heapify(ready)
+        while ready:
+            _, _, node = heapq.heappop(ready)
+            yield (node, *children[node])
+            up = parent_of.get(node)
+            if up is not None:
+                waiting[up] -= 1
+                if waiting[up] == 0:
+                    heapq.heappush(ready, (order(up), next(ticket), up))
 
     def traverse(self, order=None):
         """Generate ``(parent, left, right)`` merges bottom-up."""
@@ -986,6 +992,31 @@ class ContractionTree:
         return contract_distributed(
             self, arrays, group=group, root=root, **kwargs
         )
+
+    def contract_resumable(self, arrays, checkpoint, **kwargs):
+        """:meth:`contract` with a checkpoint file: the partial sum over slices
+        is saved every ``every`` slices and an interrupted run continues from
+        it bit-identically (``cotengra_amd.contractor.contract_resumable``)."""
+        from .contractor import contract_resumable
+
+        return contract_resumable(self, arrays, checkpoint, **kwargs)
+
+    def contract_mpi(self, arrays, comm=None, root=None, **kwargs):
+        """The reference's name and signature (core.py:4032-4090).  ``comm`` may
+        be an mpi4py communicator as there (it only carries RCCL's unique id to
+        the other ranks), a ``torch.distributed`` group, a
+        ``cotengra_amd.runtime.Comm``, or None for the default torch group;
+        ``root=None`` leaves the total on every rank, ``root=r`` only on rank
+        ``r`` (the others return None).  ``kwargs`` as for ``contract_slice``:
+        ``order``, ``strip_exponent``, ``check_zero``."""
+        from .distributed import contract_distributed
+
+        opts = {k: kwargs.pop(k) for k in ("order", "strip_exponent", "check_zero") if k in kwargs}
+        for k in ("prefer_einsum", "backend", "implementation", "autojit", "progbar"):
+            kwargs.pop(k, None)
+        if kwargs:
+            raise TypeError(f"Unknown keyword arguments: {kwargs}.")
+        return contract_distributed(self, arrays, comm=comm, root=root, **opts)
 
     def benchmark(
         self,

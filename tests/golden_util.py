@@ -20,6 +20,20 @@ def load():
     return _CASES, _EXPECTED
 
 
+_R2 = None
+
+
+def load_r2():
+    """Round-2 fixtures (tests/golden/gen/make_golden_r2.py): projected output
+    indices."""
+    global _R2
+    if _R2 is None:
+        with open(os.path.join(HERE, "golden", "golden_r2_cases.json"), encoding="utf-8") as f:
+            cs = json.load(f)["cases"]
+        _R2 = (cs, np.load(os.path.join(HERE, "golden", "golden_r2_expected.npz")))
+    return _R2
+
+
 def cases(kind=None):
     cs, _ = load()
     return [c for c in cs if kind is None or c["kind"] == kind]

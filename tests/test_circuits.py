@@ -165,5 +165,9 @@ def test_m10_full_amplitude_on_gpu(dtype):
         if key.startswith("slice"):
             i = int(key[5:])
             got = complex(np.asarray(tree.contract_slice(xs, i)))
-            tol = 1e-10 if dtype == "complex128" else 2e-4
-            assert abs(got - complex(exp[key])) <= tol * abs(exp[key])
+            tol = 1e-10
+            if dtype == "complex64":
+                # north-star 1e-5, or 8x what numpy itself loses in single precision
+                np64 = complex(orc.contract_slice(tree, xs, i))
+                tol = max(1e-5, 8.0 * abs(np64 - complex(exp[key])) / abs(exp[key]))
+            assert abs(got - complex(exp[key])) <= tol * abs(exp[key]), (abs(got - complex(exp[key])) / abs(exp[key]), tol)

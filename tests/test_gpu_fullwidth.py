@@ -1,0 +1,131 @@
+"""Full-width (2^32) parity of the m20 trees tied to the oracle.
+
+The numpy oracle cannot run a 2^32-wide slice (34 GB tensors, hours), and the
+kernel mix of a narrowed tree differs from the full one (no 512-way split-K, no
+2^20-entry row tables, no element offsets beyond 2^31).  The chain below ties
+the full-width single-precision result to the oracle step by step:
+
+  (i)   tree narrowed to 2^20 and 2^24: complex128 HIP == oracle complex128
+        (1e-10), complex64 HIP within max(1e-5, 8 x numpy's own complex64 error);
+  (ii)  one full-width complex64 slice == the sum of its sub-slices computed by
+        the complex128 HIP path at width 2^28 (64 / 512 of them);
+  (iii) one of those 2^28 complex128 sub-slices == the sum of ITS sub-slices at
+        width 2^25 (complex128 HIP), one of which == the oracle (1e-10).
+
+Slicing one more index splits a slice into the slices of the finer tree that
+agree with it on the common indices (reference ``slice_key``,
+core.py:3775-3800), so every equality above is exact in exact arithmetic.
+"""
+import itertools
+import os
+
+import numpy as np
+import pytest
+
+import cotengra_amd as ca
+from cotengra_amd.contractor import HipContractor
+from oracle import contract_ref as orc
+
+pytestmark = pytest.mark.gpu
+
+TREES = os.path.join(os.path.dirname(__file__), "golden", "trees")
+NORTH_STAR = 1e-5
+
+
+def load(fixture):
+    tree = ca.tree_from_record(ca.load_network(os.path.join(TREES, fixture)))
+    arrays = ca.make_arrays_from_inputs(tree.inputs, tree.size_dict, seed=42, dtype="complex64", rescale=True)
+    return tree, arrays
+
+
+def sub_slice_ids(coarse, fine, i):
+    """Ids (in ``fine``'s numbering) of the slices of ``fine`` that make up
+    slice ``i`` of ``coarse`` (``fine`` = ``coarse`` with more indices removed)."""
+    key = coarse.slice_key(i)
+    extra = [ix for ix in fine.sliced_inds if ix not in coarse.sliced_inds]
+    strides = dict(zip(fine.sliced_inds, ca.get_slice_strides(fine.sliced_inds)))
+    ids = []
+    for combo in itertools.product(*[range(fine.size_dict[ix]) for ix in extra]):
+        k = dict(key)
+        k.update(zip(extra, combo))
+        ids.append(sum(k[ix] * strides[ix] for ix in fine.sliced_inds))
+    return ids
+
+
+def rel(a, b):
+    return abs(complex(a) - complex(b)) / abs(complex(b))
+
+
+@pytest.mark.parametrize("fixture", ["sycamore_m20_w32_c512.json", "sycamore_m20_native.json"])
+@pytest.mark.parametrize("log2_width", [20, 24])
+def test_narrowed_trees_against_oracle(fixture, log2_width):
+    """(i): both precisions of the HIP path vs the oracle on the bench tree and
+    on the time-to-solution tree, narrowed with the native slicer."""
+    tree, arrays = load(fixture)
+    small = tree.slice(target_size=2**log2_width)
+    a128 = [a.astype("complex128") for a in arrays]
+    for sid in (3, small.nslices - 1 if small.nslices < 2**62 else 12345):
+        ref = orc.contract_slice(small, a128, sid)
+        np64 = orc.contract_slice(small, arrays, sid)
+        fn = HipContractor(small)
+        got128 = fn.contract_slice(a128, sid)
+        got64 = fn.contract_slice(arrays, sid)
+        fn.close()
+        assert rel(got128, ref) <= 1e-10
+        gate = max(NORTH_STAR, 8.0 * rel(np64, ref))
+        assert rel(got64, ref) <= gate, (rel(got64, ref), gate, rel(np64, ref))
+
+
+@pytest.mark.parametrize("fixture", ["sycamore_m20_w32_c512.json", "sycamore_m20_native.json"])
+def test_full_width_slice_is_sum_of_double_precision_sub_slices(fixture):
+    """(ii): complex64 at width 2^32 vs complex128 at width 2^28."""
+    tree, arrays = load(fixture)
+    assert tree.max_size() == 2**32
+    sid = 5
+    coarse = HipContractor(tree)
+    full = complex(np.asarray(coarse.contract_slice(arrays, sid)))
+    coarse.close()
+    fine = tree.slice(target_size=2**28)
+    ids = sub_slice_ids(tree, fine, sid)
+    assert len(ids) == fine.nslices // tree.nslices and 16 <= len(ids) <= 1024
+    a128 = [a.astype("complex128") for a in arrays]
+    fc = HipContractor(fine)
+    st = fc.setup(*a128)
+    ex = st["exec"]
+    ex.zero_result()
+    for i in ids:  # accumulated on the device, one download
+        ex.run_slices(i, 1, 1)
+    parts = complex(ex.download_result())
+    fc.close()
+    # what numpy's own single precision loses on this tree (narrowed: the only width
+    # the oracle can run) sets the scale of the single-precision gate
+    small = tree.slice(target_size=2**20)
+    ref = orc.contract_slice(small, a128, 3)
+    gate = max(NORTH_STAR, 8.0 * rel(orc.contract_slice(small, arrays, 3), ref))
+    assert rel(full, parts) <= gate, (rel(full, parts), gate)
+
+
+def test_double_precision_path_chain_down_to_the_oracle():
+    """(iii): complex128 HIP at 2^28 == sum of complex128 HIP at 2^25, one of
+    which == oracle."""
+    tree, arrays = load("sycamore_m20_w32_c512.json")
+    a128 = [a.astype("complex128") for a in arrays]
+    w28 = tree.slice(target_size=2**28)
+    w25 = w28.slice(target_size=2**25)
+    sid = sub_slice_ids(tree, w28, 5)[7]
+    f28 = HipContractor(w28)
+    one = complex(np.asarray(f28.contract_slice(a128, sid)))
+    f28.close()
+    ids = sub_slice_ids(w28, w25, sid)
+    assert len(ids) == w25.nslices // w28.nslices
+    f25 = HipContractor(w25)
+    st = f25.setup(*a128)
+    ex = st["exec"]
+    ex.zero_result()
+    for i in ids:
+        ex.run_slices(i, 1, 1)
+    parts = complex(ex.download_result())
+    leaf = complex(np.asarray(f25.contract_slice(a128, ids[3])))
+    f25.close()
+    assert rel(one, parts) <= 1e-10
+    assert rel(leaf, orc.contract_slice(w25, a128, ids[3])) <= 1e-10

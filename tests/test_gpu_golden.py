@@ -4,7 +4,11 @@ the same seeded inputs where no golden exists.
 
 Tolerances: double precision 1e-10 relative to max|ref| (bit-level agreement
 is not defined for floating point; the reference's own gate is 5e-6,
-tests/test_compute.py:113); single precision 2e-4 (reference gate 5e-3).
+tests/test_compute.py:113).  Single precision: max(1e-5, 8 x the error numpy
+itself makes when the oracle runs the same tree in the same single precision)
+-- 1e-5 is the north-star tolerance; a result whose exact value is a
+cancelling sum cannot be asked to beat fp32 rounding noise by more than that
+(the reference's own single-precision gate is 5e-3).
 """
 import numpy as np
 import pytest
@@ -18,18 +22,35 @@ pytestmark = pytest.mark.gpu
 
 TREE_CASES = G.cases("tree")
 EQ_CASES = G.cases("eq")
-TOL = {"float32": 2e-4, "complex64": 2e-4, "float64": 1e-10, "complex128": 1e-10}
+TOL = {"float64": 1e-10, "complex128": 1e-10}
 LOW = {"complex128": "complex64", "float64": "float32"}
+SINGLE = ("float32", "complex64")
+NORTH_STAR = 1e-5
+UNDERFLOW = 1e-30  # max|ref| below this cannot be represented by an fp32 result
 
 
-def check(got, ref, dtype):
+def single_gate(ref, numpy_single):
+    """Tolerance of a single-precision result: see the module docstring.
+    ``numpy_single`` = the oracle's result on the same inputs in the same
+    single precision (None: no such run, the plain north-star gate)."""
+    if numpy_single is None:
+        return NORTH_STAR
+    return max(NORTH_STAR, 8.0 * G.relerr(np.asarray(numpy_single), ref))
+
+
+def check(got, ref, dtype, numpy_single=None):
     got = np.asarray(got.cpu()) if hasattr(got, "cpu") else np.asarray(got)
-    if dtype in ("float32", "complex64") and np.abs(ref).max() < 1e-30:
-        # below the fp32 normal range (e.g. narrow slices of the hyper network):
-        # single precision is only required to underflow gracefully
-        assert np.all(np.isfinite(got)) and np.abs(got).max() < 1e-25
-        return
-    assert G.relerr(got, ref) < TOL[dtype], (G.relerr(got, ref), dtype)
+    tol = single_gate(ref, numpy_single) if dtype in SINGLE else TOL[dtype]
+    assert G.relerr(got, ref) <= tol, (G.relerr(got, ref), tol, dtype)
+
+
+def check_stripped(pair, ref, dtype, numpy_single=None):
+    """(mantissa, exponent) of a strip_exponent run against ``ref``: how a
+    single-precision run reports values below the fp32 range."""
+    m, e = pair
+    m = np.asarray(m.cpu()) if hasattr(m, "cpu") else np.asarray(m)
+    wide = m.astype("complex128" if np.iscomplexobj(m) else "float64") * 10.0**e
+    check(wide, ref, dtype, numpy_single)
 
 
 @pytest.mark.parametrize("case", TREE_CASES, ids=[c["name"] for c in TREE_CASES])
@@ -39,15 +60,29 @@ def test_tree_cases(case):
         arrays = G.arrays_of(case, dt, tree)
         for run_dt in (dt, LOW[dt]):
             xs = [a.astype(run_dt) for a in arrays]
+            single = run_dt in SINGLE
             if case["slice_ids"]:
                 for i in case["slice_ids"]:
                     if i >= 2**62:
                         continue  # beyond the int64 slice ids of the C ABI
-                    got = tree.contract_slice(xs, i)
-                    check(got, G.expected(f"{case['name']}/{dt}/slice{i}"), run_dt)
+                    ref = G.expected(f"{case['name']}/{dt}/slice{i}")
+                    if single and np.abs(ref).max() < UNDERFLOW:
+                        # below the fp32 range: the value is carried by the exponent
+                        np_pair = orc.contract_slice(tree, xs, i, strip_exponent=True)
+                        np_single = np.asarray(np_pair[0]).astype(dt) * 10.0 ** np_pair[1]
+                        check_stripped(tree.contract_slice(xs, i, strip_exponent=True), ref, run_dt, np_single)
+                        continue
+                    np_single = orc.contract_slice(tree, xs, i) if single else None
+                    check(tree.contract_slice(xs, i), ref, run_dt, np_single)
             else:
-                got = tree.contract(xs)
-                check(got, G.expected(f"{case['name']}/{dt}"), run_dt)
+                ref = G.expected(f"{case['name']}/{dt}")
+                if single and np.abs(ref).max() < UNDERFLOW:
+                    np_pair = orc.contract(tree, xs, strip_exponent=True)
+                    np_single = np.asarray(np_pair[0]).astype(dt) * 10.0 ** np_pair[1]
+                    check_stripped(tree.contract(xs, strip_exponent=True), ref, run_dt, np_single)
+                    continue
+                np_single = orc.contract(tree, xs) if single else None
+                check(tree.contract(xs), ref, run_dt, np_single)
 
 
 @pytest.mark.parametrize("case", EQ_CASES, ids=[c["name"] for c in EQ_CASES])
@@ -55,8 +90,9 @@ def test_reference_test_equations(case):
     for dt in ("complex128", "float64"):
         tree, arrays = G.eq_tree_and_arrays(case, dt)
         for run_dt in (dt, LOW[dt]):
-            got = tree.contract([a.astype(run_dt) for a in arrays])
-            check(got, G.expected(f"{case['name']}/{dt}"), run_dt)
+            xs = [a.astype(run_dt) for a in arrays]
+            np_single = orc.contract(tree, xs) if run_dt in SINGLE else None
+            check(tree.contract(xs), G.expected(f"{case['name']}/{dt}"), run_dt, np_single)
 
 
 def test_projected_slices_sum_to_total():
@@ -121,8 +157,11 @@ def test_device_side_exponent_stripping(dtype):
         m = np.asarray(m)
         assert 0.5 < np.abs(m).max() <= 1.0 + 1e-5 or tree.nslices > 1
         got = m.astype("complex128" if "complex" in dtype else "float64") * 10.0**e
-        tol = 1e-10 if dtype != "complex64" else 5e-4
-        assert abs(got - ref) <= tol * abs(ref)
+        tol = 1e-10
+        if dtype == "complex64":
+            nm, ne = orc.contract(tree, arrays, strip_exponent=True)  # numpy in single precision
+            tol = max(NORTH_STAR, 8.0 * abs(complex(nm) * 10.0**ne - ref) / abs(ref))
+        assert abs(got - ref) <= tol * abs(ref), (abs(got - ref) / abs(ref), tol)
         # the oracle's (mantissa, exponent) pair agrees as a number as well
         om, oe = orc.contract(tree, G.arrays_of(c, base, tree), strip_exponent=True)
         assert abs(om * 10.0**oe - ref) <= 1e-10 * abs(ref)
@@ -162,7 +201,7 @@ def test_full_size_properties_m20(fixture):
     arrays2[7] = arrays[7] * np.complex64(0.5 - 2.0j)
     lin = np.asarray(coarse.contract_slice(arrays2, 5))
     coarse.close()
-    assert abs(lin - full * (0.5 - 2.0j)) <= 2e-4 * abs(full) * abs(0.5 - 2.0j)
+    assert abs(lin - full * (0.5 - 2.0j)) <= 2e-5 * abs(full) * abs(0.5 - 2.0j)
     # one more sliced index: fine slices 2*5, 2*5+1 ... in the finer tree's numbering
     big = max((p for p, _, _ in tree.traverse()), key=tree.get_size)
     ix = next(iter(tree.get_legs(big)))
@@ -177,7 +216,7 @@ def test_full_size_properties_m20(fixture):
     fc = HipContractor(fine)
     parts = sum(np.asarray(fc.contract_slice(arrays, i)) for i in ids)
     fc.close()
-    assert abs(parts - full) <= 2e-4 * abs(full)
+    assert abs(parts - full) <= 5e-5 * abs(full)
 
 
 def test_contract_distributed_rccl_single_rank():
@@ -209,6 +248,9 @@ def test_contract_distributed_rccl_single_rank():
         out2 = tree2.contract_distributed(arrays2)
         check(out2, G.expected("rand_s42_r2_o2_hi1_ho2_outsliced/complex128"), "complex128")
     finally:
+        from cotengra_amd.distributed import close_comms
+
+        close_comms()
         dist.destroy_process_group()
 
 

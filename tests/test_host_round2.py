@@ -1,0 +1,230 @@
+"""CPU suite, part 5 (round 2): host logic added with C ABI v2.
+
+* projected OUTPUT indices keep a size-1 axis (golden from the reference);
+* projections survive every path that rebuilds a tree;
+* the ordered traversal is a valid, greedy topological order;
+* the per-op plug-in ``implementation=(einsum, tensordot)`` (contract.py:775-776)
+  driven with numpy's functions against the oracle;
+* checkpoint files: signature, atomic replace, mismatch;
+* the collective entry points: id creation and argument validation without a GPU;
+* ``bench.py --gpus N`` starts its own ranks.
+"""
+import os
+import subprocess
+import sys
+import types
+
+import numpy as np
+import pytest
+
+import cotengra_amd as ca
+from cotengra_amd import runtime
+from cotengra_amd.contractor import (
+    PerOpContractor, load_checkpoint, save_checkpoint, tree_signature,
+)
+from cotengra_amd.plan import compile_tree
+from oracle import contract_ref as orc
+from oracle.plan_interp import run_plan
+
+import golden_util as G
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+R2_CASES, R2_EXPECTED = G.load_r2()
+
+
+@pytest.mark.parametrize("case", R2_CASES, ids=[c["name"] for c in R2_CASES])
+def test_projected_output_index_keeps_unit_axis(case):
+    tree = G.tree_of(case)
+    arrays = G.arrays_of(case, "complex128", tree)
+    ref = R2_EXPECTED[f"{case['name']}/complex128"]
+    assert tree.gathered_shape() == ref.shape and 1 in ref.shape
+    assert tree.nslices == case["stats"]["nslices"]
+    assert G.relerr(orc.contract(tree, arrays), ref) < 1e-12
+    plan = compile_tree(tree, "complex128")
+    assert tuple(plan.result_shape) == ref.shape
+    assert G.relerr(run_plan(plan, arrays), ref) < 1e-12
+    for i in case["slice_ids"]:
+        sl = R2_EXPECTED[f"{case['name']}/complex128/slice{i}"]
+        assert G.relerr(orc.contract_slice(tree, arrays, i), sl) < 1e-12
+
+
+def _projected_tree():
+    inputs, output, shapes, size_dict = ca.lattice_equation([3, 3], d_min=2, d_max=4, seed=2)
+    tree = ca.ContractionTree.from_path(inputs, output, size_dict, path=ca.greedy_path(inputs, output, size_dict))
+    tree.remove_ind_(inputs[4][0], project=1)
+    tree.remove_ind_(inputs[0][0])
+    return tree
+
+
+def test_projection_survives_tree_rebuilds():
+    tree = _projected_tree()
+    proj = {ix: si.project for ix, si in tree.sliced_inds.items()}
+    assert sorted(v for v in proj.values() if v is not None) == [1]
+    arrays = ca.make_arrays_from_inputs(tree.inputs, tree.size_dict, seed=3)
+    ref = orc.contract(tree, arrays)
+    # native subtree reconfiguration rebuilds the tree from an SSA path
+    new = tree.subtree_reconfigure(subtree_size=4)
+    assert {ix: si.project for ix, si in new.sliced_inds.items()} == proj
+    assert new.nslices == tree.nslices
+    assert np.allclose(orc.contract(new, arrays), ref, rtol=1e-12, atol=1e-15)
+    # record round trip: [name, j] entries
+    rec = {"inputs": tree.inputs, "output": tree.output, "size_dict": tree.size_dict,
+           "path": tree.get_path(), "sliced_inds": tree.slicing_record()}
+    assert any(isinstance(e, list) for e in rec["sliced_inds"])
+    back = ca.tree_from_record(rec)
+    assert {ix: si.project for ix, si in back.sliced_inds.items()} == proj
+    # adopting a foreign tree object (anything with get_path / sliced_inds: the reference's)
+    foreign = types.SimpleNamespace(
+        inputs=tree.inputs, output=tree.output, size_dict=tree.size_dict,
+        get_path=tree.get_path, sliced_inds=dict(tree.sliced_inds),
+    )
+    adopted = ca.array_contract_tree(tree.inputs, tree.output, tree.size_dict, optimize=foreign)
+    assert {ix: si.project for ix, si in adopted.sliced_inds.items()} == proj
+    assert np.allclose(orc.contract(adopted, arrays), ref, rtol=1e-12, atol=1e-15)
+
+
+def test_ordered_traversal_is_greedy_topological():
+    inputs, output, shapes, size_dict = ca.lattice_equation([4, 4], d_min=2, d_max=3, seed=1)
+    t = ca.ContractionTree.from_path(inputs, output, size_dict, path=ca.greedy_path(inputs, output, size_dict))
+    order = t.get_size
+    seq = list(t.traverse(order=order))
+    assert sorted(p for p, _, _ in seq) == sorted(p for p, _, _ in t.traverse())
+    done = set(range(t.N))
+    pending = {p: (l, r) for p, l, r in seq}
+    for p, l, r in seq:
+        assert l in done and r in done
+        # no other ready contraction had a strictly lower score
+        ready = [q for q, (a, b) in pending.items() if a in done and b in done]
+        assert order(p) == min(order(q) for q in ready)
+        done.add(p)
+        del pending[p]
+    # the schedule changes lifetimes only, never values
+    arrays = ca.make_arrays_from_inputs(inputs, size_dict, seed=0)
+    assert np.allclose(orc.contract(t, arrays, order=order), orc.contract(t, arrays), rtol=1e-12)
+    # depth-first: every node directly after its whole right subtree
+    dfs = [p for p, _, _ in t.traverse()]
+    for p, l, r in t.traverse():
+        if r >= t.N and r in dfs:
+            assert dfs.index(r) == dfs.index(p) - 1
+
+
+def _np_pair():
+    return (np.einsum, np.tensordot)
+
+
+@pytest.mark.parametrize(
+    "name", ["lattice4x4_sliced", "rand_s42_r2_o2_hi1_ho2_outsliced", "preproc_s3", "C1_rand10_d4"],
+)
+def test_per_op_plugin_with_numpy_functions(name):
+    cands = [c for c in G.cases("tree") if c["name"] == name]
+    if not cands:
+        cands = [c for c in G.cases("tree") if c["name"].startswith(name.split("_")[0])][:1]
+    case = cands[0]
+    tree = G.tree_of(case)
+    dt = case["dtypes"][0]
+    arrays = G.arrays_of(case, dt, tree)
+    if case["slice_ids"]:
+        i = case["slice_ids"][0]
+        got = tree.contract_slice(arrays, i, implementation=_np_pair())
+        assert G.relerr(got, G.expected(f"{case['name']}/{dt}/slice{i}")) < 1e-11
+        return
+    ref = G.expected(f"{case['name']}/{dt}")
+    got = tree.contract(arrays, implementation=_np_pair())
+    assert G.relerr(got, ref) < 1e-11
+    m, e = tree.contract(arrays, implementation=_np_pair(), strip_exponent=True)
+    assert G.relerr(np.asarray(m) * 10.0**e, ref) < 1e-11
+    got = tree.contract(arrays, implementation=_np_pair(), prefer_einsum=True)
+    assert G.relerr(got, ref) < 1e-11
+
+
+def test_per_op_plugin_schedule_and_errors():
+    tree = ca.ContractionTree.from_path(["ab", "bc", "cd"], "ad", dict(a=3, b=4, c=5, d=2), path=[(0, 1), (0, 1)])
+    calls = []
+
+    def einsum(eq, *xs):
+        calls.append(("einsum", eq))
+        return np.einsum(eq, *xs)
+
+    def tensordot(a, b, axes):
+        calls.append(("tensordot", axes))
+        return np.tensordot(a, b, axes)
+
+    xs = ca.make_arrays_from_inputs(tree.inputs, tree.size_dict, seed=0)
+    out = tree.contract(xs, implementation=(einsum, tensordot))
+    assert np.allclose(out, np.einsum("ab,bc,cd->ad", *xs))
+    assert [c[0] for c in calls] == ["tensordot", "tensordot"]  # (einsum, tensordot) order, contract.py:775
+    fn = tree.get_contractor(implementation=(einsum, tensordot))
+    assert isinstance(fn, PerOpContractor) and fn is tree.get_contractor(implementation=(einsum, tensordot))
+    with pytest.raises(TypeError):
+        fn(*xs, no_such_option=1)
+    with pytest.raises(ValueError):
+        fn(*xs[:2])
+    with pytest.raises(ValueError):
+        tree.get_contractor(implementation=(einsum,))
+    with pytest.raises(ValueError):
+        tree.get_contractor(implementation="cuquantum")
+    xs[1] = np.zeros_like(xs[1])
+    assert tree.contract(xs, implementation=(einsum, tensordot), strip_exponent=True, check_zero=True) == (
+        0.0, float("-inf"))
+    # single-input tree: one einsum call
+    t1 = ca.ContractionTree(["aab"], "b", dict(a=3, b=4))
+    x = np.arange(36.0).reshape(3, 3, 4)
+    assert np.allclose(t1.contract([x], implementation=_np_pair()), np.einsum("aab->b", x))
+
+
+def test_checkpoint_files(tmp_path):
+    tree = _projected_tree()
+    sig = tree_signature(tree, "complex128")
+    assert sig == tree_signature(tree.copy(), "complex128")
+    assert sig != tree_signature(tree, "complex64")
+    assert sig != tree_signature(tree, "complex128", rank=1, world=2)
+    assert sig != tree_signature(tree, "complex128", strip_exponent=True)
+    assert sig != tree_signature(tree.restore_ind(next(iter(tree.sliced_inds))), "complex128")
+    path = str(tmp_path / "run.ckpt")
+    assert load_checkpoint(path, sig) is None
+    part = np.arange(6, dtype=np.complex128).reshape(2, 3) * (1 - 2j)
+    save_checkpoint(path, sig, 3, part, exponent=-4.5, zero=False)
+    done, res, e, z = load_checkpoint(path, sig)
+    assert (done, e, z) == (3, -4.5, False) and np.array_equal(res, part) and res.dtype == part.dtype
+    save_checkpoint(path, sig, 5, part * 2)  # replaces atomically, no stray temp files
+    assert load_checkpoint(path, sig)[0] == 5
+    assert os.listdir(tmp_path) == ["run.ckpt"]
+    with pytest.raises(ValueError, match="different"):
+        load_checkpoint(path, tree_signature(tree, "complex64"))
+
+
+def test_collective_entry_points_without_gpu():
+    uid = runtime.Comm.unique_id()
+    assert len(uid) == 128 and uid != runtime.Comm.unique_id()
+    with pytest.raises(ValueError):
+        runtime.Comm(uid, rank=2, world=2)  # rank outside the world: CTG_E_INVALID before any device call
+    with pytest.raises(ValueError):
+        runtime.Comm(b"short", 0, 1)
+    assert issubclass(runtime.CommError, runtime.CtgError)
+
+
+def test_bench_starts_its_own_ranks(monkeypatch):
+    """``python bench.py --gpus 4`` with no launcher in the environment must
+    re-execute itself under torch.distributed.run with 4 ranks on 127.0.0.1."""
+    sys.path.insert(0, ROOT)
+    import importlib
+
+    bench = importlib.import_module("bench")
+    seen = {}
+
+    def fake_call(cmd, env=None):
+        seen["cmd"], seen["env"] = cmd, env
+        return 7
+
+    monkeypatch.setattr(subprocess, "call", fake_call)
+    monkeypatch.delenv("RANK", raising=False)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "3", "--warmup", "1"])
+    with pytest.raises(SystemExit) as ei:
+        bench.main()
+    assert ei.value.code == 7
+    cmd = seen["cmd"]
+    assert cmd[1:3] == ["-m", "torch.distributed.run"] and "--nproc-per-node=4" in cmd and "--nnodes=1" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    assert cmd[-6:] == ["--gpus", "4", "--steps", "3", "--warmup", "1"]
+    assert os.path.basename(cmd[cmd.index("--master-port") + 2]) == "bench.py"
+    assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
