@@ -111,6 +111,13 @@ __device__ __forceinline__ int64_t uniform64(int64_t v) {
 __device__ __forceinline__ float dpp_swap1(float v) {
     return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));
 }
+__device__ __forceinline__ float2 pair_rows(float a_t, float a_t1, bool odd) {
+    const float x = dpp_swap1(a_t), y = dpp_swap1(a_t1);
+    float2 v;
+    v.x = odd ? y : a_t;
+    v.y = odd ? a_t1 : x;
+    return v;
+}
 __device__ __forceinline__ float2 pair_rows(float a_t, float a_t1, bool odd, float alpha) {
     const float x = dpp_swap1(a_t), y = dpp_swap1(a_t1);
     float2 v;
@@ -238,6 +245,9 @@ inline bool mfma_use_stream(int64_t R, int64_t Bt, int64_t K, int64_t N) {
     // waves in flight; longer K costs the resident B panel's LDS)
     // (measured: with 32 columns the tiled kernel wins from K = 128 on -- the resident
     // B panel then costs the streaming kernel a third of its waves)
+#ifdef CTG_STREAM_WIDE   // experiment builds: wider steps on the streaming kernel
+    return Bt == 1 && (N <= 32 ? K <= 128 : (N <= 64 && K <= 64)) && R >= 8192;
+#endif
     return Bt == 1 && (N <= 16 ? K <= 128 : (N <= 32 ? K <= 64 : (N <= 64 && K <= 32))) && R >= 8192;
 }
 

@@ -58,6 +58,25 @@ __device__ unsigned long long ctg_timing[8];
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+// Knock-out switches of experiment builds (tools/exp_knockout.sh; results are
+// wrong by construction): what does a kernel cost without its stores / matrix
+// instructions / LDS transpose / table-driven prologue?  Off in the product.
+#ifdef CTG_KO_STORE
+#define CTG_STORE_GUARD(alpha) if ((alpha) == 12345.678f)
+#else
+#define CTG_STORE_GUARD(alpha)
+#endif
+#ifdef CTG_KO_MFMA
+// keeps the data dependences (fragments are consumed) at one VALU op per MFMA
+__device__ __forceinline__ f32x16 ko_mfma(float a, float b, f32x16 c) {
+    c[0] = fmaf(a, b, c[0]);
+    return c;
+}
+#define CTG_MFMA(a, b, c) ko_mfma(a, b, c)
+#else
+#define CTG_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0)
+#endif
+
 template <int BM_, int BN_, int BK_, int WM_, int WN_>
 struct MfmaCfg {
     static constexpr int BM = BM_, BN = BN_, BK = BK_, WM = WM_, WN = WN_;
@@ -437,12 +456,20 @@ __global__ __launch_bounds__(256, Cfg::FAST_BLOCKS) void pair_mfma_fast_kernel(S
         const uint16_t* oa = h.ordA + tid * Cfg::A_PER_T;
 #pragma unroll
         for (int j = 0; j < Cfg::A_PER_T; ++j) {
+#ifdef CTG_KO_PRO
+            const int v = ((tid * Cfg::A_PER_T + j) * 37) & 0x7ff;   // no table loads at all
+#else
             const int v = oa[j];
+#endif
             const int r = v >> 4, c = v & 15;
             if (j & 1) a_lds[j / 2] |= (unsigned)swz(r, c) << 16;
             else a_lds[j / 2] = (unsigned)swz(r, c);
             if (!VEC_A || (j & 1) == 0)
+#ifdef CTG_KO_PRO
+                a_off[VEC_A ? j / 2 : j] = (unsigned)((tid * NA + (VEC_A ? j / 2 : j)) * 2);
+#else
                 a_off[VEC_A ? j / 2 : j] = (unsigned)(p.rowA.lo[r] + p.kA.lo[c]);
+#endif
         }
     }
     unsigned b_off[Cfg::B_PER_T];
@@ -450,11 +477,19 @@ __global__ __launch_bounds__(256, Cfg::FAST_BLOCKS) void pair_mfma_fast_kernel(S
         const uint16_t* ob = h.ordB + tid * Cfg::B_PER_T;
 #pragma unroll
         for (int j = 0; j < Cfg::B_PER_T; ++j) {
+#ifdef CTG_KO_PRO
+            const int v = ((tid * Cfg::B_PER_T + j) * 29) & (16 * BN - 1);
+#else
             const int v = ob[j];
+#endif
             const int nn = v >> 4, c = v & 15;
             if (j & 1) b_lds[j / 2] |= (unsigned)swz(2 * nn, c) << 16;
             else b_lds[j / 2] = (unsigned)swz(2 * nn, c);
+#ifdef CTG_KO_PRO
+            b_off[j] = (unsigned)(tid * Cfg::B_PER_T + j);
+#else
             b_off[j] = (unsigned)(p.nB[nn] + p.kB.lo[c]);
+#endif
         }
     }
     auto unpack = [](const unsigned* pk, int j) { return (int)((j & 1) ? pk[j / 2] >> 16 : pk[j / 2] & 0xffffu); };
@@ -478,7 +513,11 @@ __global__ __launch_bounds__(256, Cfg::FAST_BLOCKS) void pair_mfma_fast_kernel(S
         if (VEC_A) {
 #pragma unroll
             for (int j = 0; j < NA; ++j) {
+#ifdef CTG_KO_GATHER
+                const f32x4 v = {(float)a_off[j], 1.f, 2.f, (float)(uintptr_t)Ak};
+#else
                 const f32x4 v = *(const f32x4*)(Ak + a_off[j]);
+#endif
                 a_reg[2 * j] = c64{v[0], v[1]};
                 a_reg[2 * j + 1] = c64{v[2], v[3]};
             }
@@ -583,8 +622,7 @@ __global__ __launch_bounds__(256, Cfg::FAST_BLOCKS) void pair_mfma_fast_kernel(S
                 for (int i = 0; i < Cfg::FM; ++i)
 #pragma unroll
                     for (int j = 0; j < Cfg::FN; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[ph & 1][i][t], bs[j][t],
-                                                                        acc[i][j], 0, 0, 0);
+                        acc[i][j] = CTG_MFMA(fa[ph & 1][i][t], bs[j][t], acc[i][j]);
             __builtin_amdgcn_sched_barrier(0);
         }
     };
@@ -625,11 +663,19 @@ __global__ __launch_bounds__(256, Cfg::FAST_BLOCKS) void pair_mfma_fast_kernel(S
 #pragma unroll
                 for (int u = 0; u < 8; ++u) {
                     const int t = 2 * u;
+#ifdef CTG_KO_PRO
+                    ro[i][u] = (unsigned)((wm * Cfg::WTM + i * 32 + (t & 3) + 8 * (t >> 2) + 4 * kk + (odd ? 1 : 0)) * BN);
+#else
                     ro[i][u] = (unsigned)p.rowC.lo[wm * Cfg::WTM + i * 32 + (t & 3) + 8 * (t >> 2) + 4 * kk +
                                                    (odd ? 1 : 0)];
+#endif
                 }
 #pragma unroll
+#ifdef CTG_KO_PRO
+            for (int j = 0; j < Cfg::FN; ++j) co[j] = (unsigned)(wn * Cfg::WTN + j * 16 + (l31 >> 1));
+#else
             for (int j = 0; j < Cfg::FN; ++j) co[j] = (unsigned)p.nC[wn * Cfg::WTN + j * 16 + (l31 >> 1)];
+#endif
         }
         k_step(kt, std::false_type{}, std::false_type{});
     }
@@ -658,6 +704,7 @@ __global__ __launch_bounds__(256, Cfg::FAST_BLOCKS) void pair_mfma_fast_kernel(S
             const int t = 2 * u;
 #pragma unroll
             for (int j = 0; j < Cfg::FN; ++j) {
+                CTG_STORE_GUARD(alpha)
                 *(float2*)(C + 2 * (size_t)(ro[i][u] + co[j])) =
                     pair_rows(acc[i][j][t], acc[i][j][t + 1], odd, alpha);
             }
@@ -792,7 +839,19 @@ static hipError_t launch_cfg(const StepArgs& p, const MfmaHints& h, void* scratc
 // 16 / 32 / 64 output columns.  The narrow variants are latency-bound (bytes
 // in flight per CU), so the extra waves are worth more than the registers.
 template <int FN, bool VEC, bool ADD, bool SHORTK, int NV>
-__global__ __launch_bounds__(256, (FN == 1 ? 4 : FN == 2 ? 3 : 2)) void pair_mfma_stream_kernel(StepArgs p, MfmaHints h, int KP,
+#ifndef CTG_STREAM_OCC2
+#define CTG_STREAM_OCC2 3
+#endif
+#ifndef CTG_STREAM_OCC4
+#define CTG_STREAM_OCC4 2
+#endif
+#ifndef CTG_STREAM_DEPTH
+#define CTG_STREAM_DEPTH 2
+#endif
+#ifndef CTG_STREAM_BREG   // B panels of up to this many (chunks x column tiles) in registers
+#define CTG_STREAM_BREG 0
+#endif
+__global__ __launch_bounds__(256, (FN == 1 ? 4 : FN == 2 ? CTG_STREAM_OCC2 : CTG_STREAM_OCC4)) void pair_mfma_stream_kernel(StepArgs p, MfmaHints h, int KP,
                                                                int64_t n_groups) {
     constexpr int LD = MFMA_BK + 4;
     constexpr int PER_T = 32 * MFMA_BK / 64;  // A elements per lane per chunk (8)
@@ -801,13 +860,17 @@ __global__ __launch_bounds__(256, (FN == 1 ? 4 : FN == 2 ? 3 : 2)) void pair_mfm
     // 4 / 8 tasks in flight, which is what keeps HBM busy when a task is 1-2 KB.
     // (with the steady-state loop below keeping exactly DEPTH tasks in flight, two
     // are enough for every width; three or four measured the same)
-    constexpr int DEPTH = 2 * (PER_T / NV);
+    constexpr int DEPTH = CTG_STREAM_DEPTH * (PER_T / NV);
     static_assert((DEPTH & (DEPTH - 1)) == 0, "register sets rotate with a power-of-two period");
     static_assert(NV == PER_T || SHORTK, "partial gather lists only for short contractions");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int LDB = KP + 4;
-    float* Bs = (float*)smem;                                   // [2*16*FN][LDB]
-    int64_t* kofs_s = (int64_t*)(Bs + 2 * 16 * FN * LDB);       // [KP]
+    // B' as the MFMA wants it, one plane per k-row of B' so that no lane has to
+    // flip a sign or pick its row at run time: plane 0 (lanes 0-31, kk = 0) holds
+    // rows (Re b_n, Im b_n), plane 1 (lanes 32-63) rows (-Im b_n, Re b_n)
+    constexpr int BROWS = 2 * 16 * FN;
+    float* Bs = (float*)smem;                                   // [2][BROWS][LDB]
+    int64_t* kofs_s = (int64_t*)(Bs + 2 * BROWS * LDB);         // [KP]
     float* As_all = (float*)(kofs_s + KP);                      // [4 waves][2][32][LD]
 
     const int tid = threadIdx.x;
@@ -816,7 +879,6 @@ __global__ __launch_bounds__(256, (FN == 1 ? 4 : FN == 2 ? 3 : 2)) void pair_mfm
     const int kk = lane >> 5;
     const int l31 = lane & 31;
     const bool odd = lane & 1;
-    const bool negate = kk == 1 && !odd;
 
     const c64* __restrict__ A = (const c64*)p.A + *p.soffA;
     const c64* __restrict__ B = (const c64*)p.B + *p.soffB;
@@ -833,6 +895,8 @@ __global__ __launch_bounds__(256, (FN == 1 ? 4 : FN == 2 ? 3 : 2)) void pair_mfm
         }
         Bs[(2 * n) * LDB + k] = v.re;
         Bs[(2 * n + 1) * LDB + k] = v.im;
+        Bs[(BROWS + 2 * n) * LDB + k] = -v.im;
+        Bs[(BROWS + 2 * n + 1) * LDB + k] = v.re;
     }
     for (int k = tid; k < KP; k += 256) {
         int64_t off = -1;
@@ -887,6 +951,7 @@ __global__ __launch_bounds__(256, (FN == 1 ? 4 : FN == 2 ? 3 : 2)) void pair_mfm
     if (SHORTK)
         for (int i = lane; i < 2 * 32 * LD; i += 64) As[i] = 0.f;
     const float alpha = (float)step_alpha(p);
+    const bool scaled = alpha != 1.f;   // (strip_exponent runs only; wave-uniform)
     const int n_chunks = KP / MFMA_BK;
     const int64_t wave_g = (int64_t)blockIdx.x * 4 + wave;
     const int64_t n_waves = (int64_t)gridDim.x * 4;
@@ -925,7 +990,11 @@ __global__ __launch_bounds__(256, (FN == 1 ? 4 : FN == 2 ? 3 : 2)) void pair_mfm
                     split_row(p, m0 + r, hi, lo);
                     ro = p.rowA.hi[hi] + p.rowA.lo[lo];
                 }
+#ifdef CTG_KO_GATHER
+                const f32x4 v = {(float)ro, 1.f, 2.f, (float)ka[c]};
+#else
                 const f32x4 v = *(const f32x4*)(A + ro + ka[c]);
+#endif
                 a_reg[j] = c64{v[0], v[1]};
                 a_reg[j + 1] = c64{v[2], v[3]};
             }
@@ -975,8 +1044,11 @@ __global__ __launch_bounds__(256, (FN == 1 ? 4 : FN == 2 ? 3 : 2)) void pair_mfm
     int cc = 0;
     // steady / first / last: compile-time knowledge of the steady-state loop
     // below (std::false_type everywhere = the general, fully dynamic task)
-    auto consume = [&](c64 (&a_reg)[NV], auto steady, auto first_tag, auto last_tag) __attribute__((always_inline)) {
+    // bsrc: nullptr = B fragments come from LDS; else the 4 * FN fragments of this
+    // chunk held in registers (steady state of small B panels, see steady_loop)
+    auto consume = [&](c64 (&a_reg)[NV], auto steady, auto first_tag, auto last_tag, auto bsrc) __attribute__((always_inline)) {
         constexpr bool STEADY = decltype(steady)::value;
+        constexpr bool BREG = !std::is_same<decltype(bsrc), std::nullptr_t>::value;
         if (STEADY ? decltype(first_tag)::value : cc == 0) {
 #pragma unroll
             for (int j = 0; j < FN; ++j)
@@ -989,8 +1061,12 @@ __global__ __launch_bounds__(256, (FN == 1 ? 4 : FN == 2 ? 3 : 2)) void pair_mfm
         for (int j = 0; j < NV; ++j) {
             if (SHORTK && a_pk[j] < 0) continue;
             const int o = a_pk[j] & 0xffff;
+#ifdef CTG_KO_LDS
+            if (a_reg[j].re == 12345.678f) As[o] = a_reg[j].im;   // (keeps the loads alive)
+#else
             As[o] = a_reg[j].re;
             As[32 * LD + o] = a_reg[j].im;
+#endif
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -1006,46 +1082,89 @@ __global__ __launch_bounds__(256, (FN == 1 ? 4 : FN == 2 ? 3 : 2)) void pair_mfm
             c_base = sload64(p.rowC.hi + uniform64(hi)) + sload64(p.rowC.lo + uniform64(lo));
         }
         const float* a_base = As + kk * 32 * LD + l31 * LD;
-        const float* b_base = Bs + (l31 ^ kk) * LDB + cc * MFMA_BK;
+        const float* b_base = Bs + (kk * BROWS + l31) * LDB + cc * MFMA_BK;
         const int k_left = (int)p.K - cc * MFMA_BK;
         const int nq = k_left >= MFMA_BK ? MFMA_BK / 4 : (k_left + 3) / 4;
+        if constexpr (STEADY && !SHORTK) {
+            // full chunk: the four k-quads are unrolled with the fragments of quad
+            // q+1 read (ds_read_b128) before the MFMAs of quad q are issued, so the
+            // matrix pipe never waits for this wave's LDS latency.  B fragments in
+            // registers (BREG) are already signed: one LDS read per quad remains.
+            f32x4 af[2], bfr[2][FN];
+            af[0] = *(const f32x4*)(a_base);
+            if constexpr (!BREG) {
+#pragma unroll
+                for (int j = 0; j < FN; ++j) bfr[0][j] = *(const f32x4*)(b_base + j * 32 * LDB);
+            }
+#pragma unroll
+            for (int kq = 0; kq < MFMA_BK / 4; ++kq) {
+                if (kq + 1 < MFMA_BK / 4) {
+                    af[(kq + 1) & 1] = *(const f32x4*)(a_base + (kq + 1) * 4);
+                    if constexpr (!BREG) {
+#pragma unroll
+                        for (int j = 0; j < FN; ++j)
+                            bfr[(kq + 1) & 1][j] = *(const f32x4*)(b_base + j * 32 * LDB + (kq + 1) * 4);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                f32x4 bs[FN];
+#pragma unroll
+                for (int j = 0; j < FN; ++j) {
+                    if constexpr (BREG) bs[j] = bsrc[kq * FN + j];
+                    else bs[j] = bfr[kq & 1][j];
+                }
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+#pragma unroll
+                    for (int j = 0; j < FN; ++j)
+                        acc[j] = CTG_MFMA(af[kq & 1][t], bs[j][t], acc[j]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        } else
         for (int kq = 0; kq < nq; ++kq) {
             const f32x4 af = *(const f32x4*)(a_base + kq * 4);
             f32x4 bf[FN];
 #pragma unroll
             for (int j = 0; j < FN; ++j) {
-                const f32x4 v = *(const f32x4*)(b_base + j * 32 * LDB + kq * 4);
-                bf[j] = negate ? -v : v;
+                bf[j] = *(const f32x4*)(b_base + j * 32 * LDB + kq * 4);
             }
 #pragma unroll
             for (int t = 0; t < 4; ++t)
 #pragma unroll
                 for (int j = 0; j < FN; ++j)
-                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[t], bf[j][t], acc[j], 0, 0, 0);
+                    acc[j] = CTG_MFMA(af[t], bf[j][t], acc[j]);
         }
         if (last) {
             // epilogue: pair rows (t, t+1) so each lane stores whole complex numbers
+            auto store_group = [&](auto scaled_tag) __attribute__((always_inline)) {
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int t = 2 * u;
-                int64_t ro;
-                if (ADD) {
-                    ro = c_base + c_delta[u];
-                } else {
-                    const int64_t m = cg * 32 + (t & 3) + 8 * (t >> 2) + 4 * kk + (odd ? 1 : 0);
-                    ro = -1;
-                    if (m < p.R) {
-                        int64_t hi, lo;
-                        split_row(p, m, hi, lo);
-                        ro = p.rowC.hi[hi] + p.rowC.lo[lo];
+                for (int u = 0; u < 8; ++u) {
+                    const int t = 2 * u;
+                    int64_t ro;
+                    if (ADD) {
+                        ro = c_base + c_delta[u];
+                    } else {
+                        const int64_t m = cg * 32 + (t & 3) + 8 * (t >> 2) + 4 * kk + (odd ? 1 : 0);
+                        ro = -1;
+                        if (m < p.R) {
+                            int64_t hi, lo;
+                            split_row(p, m, hi, lo);
+                            ro = p.rowC.hi[hi] + p.rowC.lo[lo];
+                        }
+                    }
+#pragma unroll
+                    for (int j = 0; j < FN; ++j) {
+                        float2 v;
+                        if constexpr (decltype(scaled_tag)::value) v = pair_rows(acc[j][t], acc[j][t + 1], odd, alpha);
+                        else v = pair_rows(acc[j][t], acc[j][t + 1], odd);
+                        CTG_STORE_GUARD(alpha)
+                        if (STEADY || (n_ok[j] && ro >= 0)) *(float2*)(C + 2 * (ro + ncol[j])) = v;
                     }
                 }
-#pragma unroll
-                for (int j = 0; j < FN; ++j) {
-                    const float2 v = pair_rows(acc[j][t], acc[j][t + 1], odd, alpha);
-                    if (STEADY || (n_ok[j] && ro >= 0)) *(float2*)(C + 2 * (ro + ncol[j])) = v;
-                }
-            }
+            };
+            // (alpha != 1 only in strip_exponent runs; wave-uniform branch)
+            if (scaled) store_group(std::true_type{});
+            else store_group(std::false_type{});
             cc = 0;
             cg += n_waves;
         } else {
@@ -1075,13 +1194,45 @@ __global__ __launch_bounds__(256, (FN == 1 ? 4 : FN == 2 ? 3 : 2)) void pair_mfm
 #pragma unroll
             for (int d = 0; d < DEPTH; ++d) issue(regs[d], std::true_type{});
             primed = true;
-            for (; t + BODY + DEPTH <= n_tasks; t += BODY) {
+            // A small B panel (K = N = 16) lives in registers for the whole
+            // kernel: NC chunks x 4 quads x FN fragments = 16 VGPRs; larger
+            // panels would spill.  That takes the B reads out of the task loop --
+            // every instruction issued between MFMAs costs matrix-pipe time
+            // (DESIGN section 4).
+            constexpr bool BREG = NC * FN <= CTG_STREAM_BREG;
+            f32x4 breg[BREG ? NC : 1][4 * FN];
+            if constexpr (BREG) {
+#pragma unroll
+                for (int c = 0; c < NC; ++c)
+#pragma unroll
+                    for (int kq = 0; kq < 4; ++kq)
+#pragma unroll
+                        for (int j = 0; j < FN; ++j) {
+                            breg[c][kq * FN + j] =
+                                *(const f32x4*)(Bs + (kk * BROWS + l31 + j * 32) * LDB + c * MFMA_BK + kq * 4);
+                        }
+            }
+            auto body = [&]() __attribute__((always_inline)) {
                 static_for<0, BODY>([&](auto i) __attribute__((always_inline)) {
                     constexpr int I = decltype(i)::value;
-                    consume(regs[I % DEPTH], std::true_type{}, std::bool_constant<(I % NC) == 0>{},
-                            std::bool_constant<(I % NC) == NC - 1>{});
+                    if constexpr (BREG)
+                        consume(regs[I % DEPTH], std::true_type{}, std::bool_constant<(I % NC) == 0>{},
+                                std::bool_constant<(I % NC) == NC - 1>{}, (const f32x4*)breg[I % NC]);
+                    else
+                        consume(regs[I % DEPTH], std::true_type{}, std::bool_constant<(I % NC) == 0>{},
+                                std::bool_constant<(I % NC) == NC - 1>{}, nullptr);
                 });
-            }
+            };
+            // The first pass is peeled.  The compiler's s_waitcnt at the loop header
+            // must hold for the entry path and for the back edge, and it takes the
+            // smaller count of the two: entered straight from the priming gathers
+            // (no stores issued yet) the header wait became vmcnt(7) -- i.e. every
+            // pass began by waiting for the previous group's stores to be
+            // acknowledged (microseconds) although only its own gather was needed.
+            // With one pass in front both paths carry the same memory operations.
+            body();
+            t += BODY;
+            for (; t + BODY + DEPTH <= n_tasks; t += BODY) body();
         };
         if (full) {
             switch (n_chunks) {
@@ -1099,7 +1250,7 @@ __global__ __launch_bounds__(256, (FN == 1 ? 4 : FN == 2 ? 3 : 2)) void pair_mfm
     for (; t < n_tasks; t += DEPTH) {
 #pragma unroll
         for (int d = 0; d < DEPTH; ++d)
-            if (t + d < n_tasks) consume(regs[d], std::false_type{}, std::false_type{}, std::false_type{});
+            if (t + d < n_tasks) consume(regs[d], std::false_type{}, std::false_type{}, std::false_type{}, nullptr);
     }
 }
 
@@ -1141,7 +1292,7 @@ template <int FN>
 static hipError_t launch_stream(const StepArgs& p, const MfmaHints& h, hipStream_t stream) {
     const int KP = (int)((p.K + MFMA_BK - 1) / MFMA_BK) * MFMA_BK;
     const int LDB = KP + 4;
-    const size_t smem = (size_t)2 * 16 * FN * LDB * 4 + (size_t)KP * 8 +
+    const size_t smem = (size_t)2 * 2 * 16 * FN * LDB * 4 + (size_t)KP * 8 +
                         (size_t)4 * 2 * 32 * (MFMA_BK + 4) * 4;
     // short contraction: the order table holds only the real columns, 32 K of
     // them per task = the first K / 2 slots of every lane

@@ -188,7 +188,7 @@ def contract_distributed(
 
 
 def _injected_partial(tree, arrays, mine, executor_factory):
-    partial = np.ascontiguousarray(executor_factory(tree, arrays, mine))
+    partial = np.array(executor_factory(tree, arrays, mine), order="C")  # (keeps 0-d results 0-d)
     full_shape = tree.gathered_shape()
     if tuple(partial.shape) != full_shape:
         raise ValueError(
@@ -205,7 +205,7 @@ def _reduce_host(partial, exponent, group, rank, root):
     import torch
     import torch.distributed as dist
 
-    t = torch.as_tensor(np.ascontiguousarray(partial)).clone()
+    t = torch.as_tensor(np.array(partial, order="C"))  # a copy; 0-d stays 0-d
     if exponent is not None:
         e = torch.tensor([exponent], dtype=torch.float64)
         dist.all_reduce(e, op=dist.ReduceOp.MAX, group=group)

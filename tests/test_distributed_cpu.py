@@ -70,6 +70,12 @@ def _worker(rank, world, port, root, q):
             ok = ok and bool(np.allclose(out2.numpy(), ref, rtol=1e-12, atol=1e-14))
         else:
             ok = ok and out2 is None
+        # scalar output (an amplitude): the partial is a 0-d array all the way
+        t4 = ca.ContractionTree.from_path(inputs, [], size_dict, path=ca.greedy_path(inputs, [], size_dict))
+        t4.remove_ind_(inputs[5][0])
+        out4 = contract_distributed(t4, arrays, root=root, executor_factory=executor)
+        if root is None or rank == root:
+            ok = ok and out4.shape == () and bool(np.allclose(out4.numpy(), orc.contract(t4, arrays), rtol=1e-12))
         # error behaviour mirrored from contract_mpi
         t3 = tree.unslice_all()
         try:
