@@ -47,6 +47,9 @@ def main():
             "inputs": [list(t) for t in inputs],
             "output": list(output),
             "size_dict": size_dict,
+            # the deterministic greedy path itself (temperature 0): integer work, compared
+            # index for index with the native finder
+            "ref_greedy_ssa_path": [sorted(map(int, p)) for p in path],
             "ref_greedy_log10_flops": tree.contraction_cost(log=10),
             "ref_greedy_log2_width": width,
             "slice_target": target,

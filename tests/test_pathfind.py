@@ -21,14 +21,18 @@ def net(case):
 
 
 @pytest.mark.parametrize("case", CASES, ids=[c["name"] for c in CASES])
-def test_greedy_matches_reference_quality(case):
+def test_greedy_path_is_identical_to_the_reference(case):
+    """Integer work is held to exact agreement: at temperature 0 the native
+    finder (scores, candidate generation, tie-breaking) must take the same
+    pair at every one of the N - 1 steps as the reference's ``optimize_greedy``
+    did (path frozen by tests/golden/gen/make_pathfind.py)."""
     inputs, output, size_dict = net(case)
+    ssa = pathfind.greedy_ssa_path(inputs, output, size_dict)
+    assert [sorted(p) for p in ssa] == case["ref_greedy_ssa_path"]
     tree = pathfind.greedy_tree(inputs, output, size_dict)
     assert tree.is_complete()
-    # same deterministic algorithm as the reference's (temperature 0, costmod 1);
-    # ties may be broken differently, hence a small allowance
-    assert tree.contraction_cost(log=10) <= case["ref_greedy_log10_flops"] + 0.15
-    assert tree.max_size(log=2) <= case["ref_greedy_log2_width"] + 2.0
+    assert abs(tree.contraction_cost(log=10) - case["ref_greedy_log10_flops"]) < 1e-9
+    assert tree.max_size(log=2) == case["ref_greedy_log2_width"]
 
 
 @pytest.mark.parametrize("case", CASES, ids=[c["name"] for c in CASES])
