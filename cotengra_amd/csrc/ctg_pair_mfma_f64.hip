@@ -19,12 +19,19 @@ namespace ctg {
 typedef double f64x4 __attribute__((ext_vector_type(4)));
 
 namespace {
-constexpr int BM = 64, BN = 32, BK = 8, LD = BK + 1;
-constexpr int A_DBL = 2 * BM * LD, B_DBL = 2 * BN * LD;
+constexpr int BK = 8, LD = BK + 1;
 }  // namespace
 
+// TM x TN MFMA tiles (16 rows x 8 complex columns each) per wave, 2 x 2 waves per
+// block: 64 x 32 (TM = TN = 2) for small steps, 128 x 32 (TM = 4) when there are
+// enough rows -- twice the matrix work per k-step, barrier and gathered element.
+template <int TM, int TN>
 __global__ __launch_bounds__(256, 2) void pair_mfma_c128_kernel(StepArgs p, int flags,
                                                                int64_t tiles_m, int64_t tiles_n) {
+    constexpr int BM = 2 * TM * 16, BN = 2 * TN * 8;
+    constexpr int A_DBL = 2 * BM * LD, B_DBL = 2 * BN * LD;
+    constexpr int NA = BM * BK / 256, NB = (BN * BK + 255) / 256;
+    static_assert(BN * BK % 256 == 0, "B tile must divide over the block");
     __shared__ double lds[2 * (A_DBL + B_DBL)];
     __shared__ int64_t rowA_s[BM];
     __shared__ int64_t rowC_s[BM];
@@ -83,10 +90,10 @@ __global__ __launch_bounds__(256, 2) void pair_mfma_c128_kernel(StepArgs p, int 
         }
     }
 
-    // ---- gather coordinates: 2 A elements + 1 B element per thread per step ----
-    int a_r[2], a_c[2];
+    // ---- gather coordinates: NA A elements + NB B elements per thread per step ----
+    int a_r[NA], a_c[NA];
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
+    for (int j = 0; j < NA; ++j) {
         const int e = j * 256 + tid;
         if (a_kfast) {
             a_r[j] = e / BK;
@@ -96,53 +103,64 @@ __global__ __launch_bounds__(256, 2) void pair_mfma_c128_kernel(StepArgs p, int 
             a_c[j] = e / BM;
         }
     }
-    int b_k, b_n;
-    if (b_kfast) {
-        b_k = tid % BK;
-        b_n = tid / BK;
-    } else {
-        b_k = tid / BN;
-        b_n = tid % BN;
-    }
-    const int64_t b_col = (n0 + b_n < p.N) ? p.nB[n0 + b_n] : -1;
-    __syncthreads();
-    int64_t a_row[2];
+    int b_k[NB], b_n[NB];
+    int64_t b_col[NB];
 #pragma unroll
-    for (int j = 0; j < 2; ++j) a_row[j] = rowA_s[a_r[j]];
+    for (int j = 0; j < NB; ++j) {
+        const int e = j * 256 + tid;
+        if (b_kfast) {
+            b_k[j] = e % BK;
+            b_n[j] = e / BK;
+        } else {
+            b_k[j] = e / BN;
+            b_n[j] = e % BN;
+        }
+        b_col[j] = (n0 + b_n[j] < p.N) ? p.nB[n0 + b_n[j]] : -1;
+    }
+    __syncthreads();
+    int64_t a_row[NA];
+#pragma unroll
+    for (int j = 0; j < NA; ++j) a_row[j] = rowA_s[a_r[j]];
 
-    c128 a_reg[2], b_reg;
+    c128 a_reg[NA], b_reg[NB];
     auto gather = [&](int64_t step) {
         const int64_t* ka = kofs_s[step % 3][0];
         const int64_t* kb = kofs_s[step % 3][1];
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
+        for (int j = 0; j < NA; ++j) {
             const int64_t ko = ka[a_c[j]];
             c128 v{0.0, 0.0};
             if (a_row[j] >= 0 && ko >= 0) v = A[a_row[j] + ko];
             a_reg[j] = v;
         }
-        const int64_t ko = kb[b_k];
-        c128 v{0.0, 0.0};
-        if (b_col >= 0 && ko >= 0) v = B[b_col + ko];
-        b_reg = v;
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            const int64_t ko = kb[b_k[j]];
+            c128 v{0.0, 0.0};
+            if (b_col[j] >= 0 && ko >= 0) v = B[b_col[j] + ko];
+            b_reg[j] = v;
+        }
     };
     auto stage = [&](int buf) {
         double* As = lds + buf * (A_DBL + B_DBL);
         double* Bs = As + A_DBL;
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
+        for (int j = 0; j < NA; ++j) {
             As[a_r[j] * LD + a_c[j]] = a_reg[j].re;
             As[BM * LD + a_r[j] * LD + a_c[j]] = a_reg[j].im;
         }
-        Bs[(2 * b_n) * LD + b_k] = b_reg.re;
-        Bs[(2 * b_n + 1) * LD + b_k] = b_reg.im;
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            Bs[(2 * b_n[j]) * LD + b_k[j]] = b_reg[j].re;
+            Bs[(2 * b_n[j] + 1) * LD + b_k[j]] = b_reg[j].im;
+        }
     };
 
-    f64x4 acc[2][2];
+    f64x4 acc[TM][TN];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < TN; ++j)
 #pragma unroll
             for (int t = 0; t < 4; ++t) acc[i][j][t] = 0.0;
 
@@ -167,22 +185,22 @@ __global__ __launch_bounds__(256, 2) void pair_mfma_c128_kernel(StepArgs p, int 
 
         const double* As = lds + buf * (A_DBL + B_DBL);
         const double* Bs = As + A_DBL;
-        const double* a_base = As + part * BM * LD + (wm * 32 + i16) * LD + kc_in;
-        const double* b_base = Bs + (2 * (wn * 16 + (i16 >> 1)) + (cc ^ part)) * LD + kc_in;
+        const double* a_base = As + part * BM * LD + (wm * TM * 16 + i16) * LD + kc_in;
+        const double* b_base = Bs + (2 * (wn * TN * 8 + (i16 >> 1)) + (cc ^ part)) * LD + kc_in;
 #pragma unroll
         for (int kq = 0; kq < BK / 2; ++kq) {
-            double af[2], bf[2];
+            double af[TM], bf[TN];
 #pragma unroll
-            for (int i = 0; i < 2; ++i) af[i] = a_base[i * 16 * LD + 2 * kq];
+            for (int i = 0; i < TM; ++i) af[i] = a_base[i * 16 * LD + 2 * kq];
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
+            for (int j = 0; j < TN; ++j) {
                 const double v = b_base[j * 16 * LD + 2 * kq];
                 bf[j] = negate ? -v : v;
             }
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int j = 0; j < 2; ++j)
+                for (int j = 0; j < TN; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[i], bf[j], acc[i][j], 0, 0, 0);
         }
         if (kofs_mine) kofs_commit(kt + 3);
@@ -192,30 +210,39 @@ __global__ __launch_bounds__(256, 2) void pair_mfma_c128_kernel(StepArgs p, int 
     // D: col = lane & 15 (complex column = col >> 1, part = col & 1), row = (lane >> 4) + 4 * reg
     const double alpha = step_alpha(p);
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int64_t n = n0 + wn * 16 + j * 8 + (i16 >> 1);
+    for (int j = 0; j < TN; ++j) {
+        const int64_t n = n0 + wn * TN * 8 + j * 8 + (i16 >> 1);
         if (n >= p.N) continue;
         const int64_t ncol = p.nC[n];
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < TM; ++i)
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
-                const int row = wm * 32 + i * 16 + k4 + 4 * t;
+                const int row = wm * TM * 16 + i * 16 + k4 + 4 * t;
                 const int64_t ro = rowC_s[row];
                 if (ro >= 0) C[2 * (ro + ncol) + cc] = acc[i][j][t] * alpha;
             }
     }
 }
 
-// flags: bit0 = A's fastest-varying memory index is a contracted one, bit1 = same for B
-hipError_t launch_pair_mfma_c128(const StepArgs& p, int flags, hipStream_t stream) {
+template <int TM, int TN>
+static hipError_t launch_c128_t(const StepArgs& p, int flags, hipStream_t stream) {
+    constexpr int BM = 2 * TM * 16, BN = 2 * TN * 8;
     const int64_t tiles_m = (p.R + BM - 1) / BM;
     const int64_t tiles_n = (p.N + BN - 1) / BN;
     const int64_t gx = ((tiles_m + 7) / 8) * 8 * tiles_n;
     if (gx > 0x7fffffffll || p.Bt > 65535) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(pair_mfma_c128_kernel, dim3((unsigned)gx, 1, (unsigned)p.Bt), dim3(256), 0, stream,
-                       p, flags, tiles_m, tiles_n);
+    hipLaunchKernelGGL((pair_mfma_c128_kernel<TM, TN>), dim3((unsigned)gx, 1, (unsigned)p.Bt), dim3(256), 0,
+                       stream, p, flags, tiles_m, tiles_n);
     return hipGetLastError();
+}
+
+// flags: bit0 = A's fastest-varying memory index is a contracted one, bit1 = same for B
+hipError_t launch_pair_mfma_c128(const StepArgs& p, int flags, hipStream_t stream) {
+    // the tall tile once its blocks alone fill the chip twice over
+    const int64_t tall = ((p.R + 127) / 128) * ((p.N + 31) / 32) * p.Bt;
+    if (tall >= 1024) return launch_c128_t<4, 2>(p, flags, stream);
+    return launch_c128_t<2, 2>(p, flags, stream);
 }
 
 }  // namespace ctg
@@ -234,7 +261,7 @@ namespace ctg {
 typedef float f32x4r __attribute__((ext_vector_type(4)));
 
 namespace {
-constexpr int RBM = 64, RBN = 64, RBK = 16, RLD = RBK + 1;
+constexpr int RBK = 16, RLD = RBK + 1;
 
 __device__ __forceinline__ f32x4r mfma16(float a, float b, f32x4r c) {
     return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
@@ -250,14 +277,21 @@ __device__ __forceinline__ int d_row(float, int k4, int t) { return 4 * k4 + t; 
 __device__ __forceinline__ int d_row(double, int k4, int t) { return k4 + 4 * t; }
 }  // namespace
 
-template <typename T>
+// TM x TN MFMA tiles (16 x 16) per wave, 2 x 2 waves per block: 64 x 64 (TM = TN =
+// 2) for small steps, 128 x 128 (TM = TN = 4) when the output alone fills the
+// chip -- four times the matrix work per k-step and barrier, twice per gathered
+// element and fragment read.
+template <typename T, int TM, int TN>
 __global__ __launch_bounds__(256, 2) void pair_mfma_real_kernel(StepArgs p, int flags, int64_t tiles_m,
                                                                int64_t tiles_n) {
+    constexpr int RBM = 2 * TM * 16, RBN = 2 * TN * 16;
+    constexpr int NA = RBM * RBK / 256, NB = RBN * RBK / 256;
     typedef typename Vec4<T>::type V4;
     __shared__ T lds[2 * (RBM + RBN) * RLD];
     __shared__ int64_t rowA_s[RBM];
     __shared__ int64_t rowC_s[RBM];
     __shared__ int64_t kofs_s[3][2][RBK];
+    static_assert(RBM <= 256, "row offsets are resolved by one thread per row");
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -309,10 +343,10 @@ __global__ __launch_bounds__(256, 2) void pair_mfma_real_kernel(StepArgs p, int 
         }
     }
 
-    int a_r[4], a_c[4], b_k[4], b_n[4];
-    int64_t b_col[4];
+    int a_r[NA], a_c[NA], b_k[NB], b_n[NB];
+    int64_t b_col[NB];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < NA; ++j) {
         const int e = j * 256 + tid;
         if (a_kfast) {
             a_r[j] = e / RBK;
@@ -321,6 +355,10 @@ __global__ __launch_bounds__(256, 2) void pair_mfma_real_kernel(StepArgs p, int 
             a_r[j] = e % RBM;
             a_c[j] = e / RBM;
         }
+    }
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+        const int e = j * 256 + tid;
         if (b_kfast) {
             b_k[j] = e % RBK;
             b_n[j] = e / RBK;
@@ -331,23 +369,23 @@ __global__ __launch_bounds__(256, 2) void pair_mfma_real_kernel(StepArgs p, int 
         b_col[j] = (n0 + b_n[j] < p.N) ? p.nB[n0 + b_n[j]] : -1;
     }
     __syncthreads();
-    int64_t a_row[4];
+    int64_t a_row[NA];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) a_row[j] = rowA_s[a_r[j]];
+    for (int j = 0; j < NA; ++j) a_row[j] = rowA_s[a_r[j]];
 
-    T a_reg[4], b_reg[4];
+    T a_reg[NA], b_reg[NB];
     auto gather = [&](int64_t step) {
         const int64_t* ka = kofs_s[step % 3][0];
         const int64_t* kb = kofs_s[step % 3][1];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < NA; ++j) {
             const int64_t ko = ka[a_c[j]];
             T v = 0;
             if (a_row[j] >= 0 && ko >= 0) v = A[a_row[j] + ko];
             a_reg[j] = v;
         }
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < NB; ++j) {
             const int64_t ko = kb[b_k[j]];
             T v = 0;
             if (b_col[j] >= 0 && ko >= 0) v = B[b_col[j] + ko];
@@ -358,17 +396,16 @@ __global__ __launch_bounds__(256, 2) void pair_mfma_real_kernel(StepArgs p, int 
         T* As = lds + buf * (RBM + RBN) * RLD;
         T* Bs = As + RBM * RLD;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            As[a_r[j] * RLD + a_c[j]] = a_reg[j];
-            Bs[b_n[j] * RLD + b_k[j]] = b_reg[j];
-        }
+        for (int j = 0; j < NA; ++j) As[a_r[j] * RLD + a_c[j]] = a_reg[j];
+#pragma unroll
+        for (int j = 0; j < NB; ++j) Bs[b_n[j] * RLD + b_k[j]] = b_reg[j];
     };
 
-    V4 acc[2][2];
+    V4 acc[TM][TN];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < TN; ++j)
 #pragma unroll
             for (int t = 0; t < 4; ++t) acc[i][j][t] = 0;
 
@@ -388,19 +425,19 @@ __global__ __launch_bounds__(256, 2) void pair_mfma_real_kernel(StepArgs p, int 
 
         const T* As = lds + buf * (RBM + RBN) * RLD;
         const T* Bs = As + RBM * RLD;
-        const T* a_base = As + (wm * 32 + i16) * RLD + k4;
-        const T* b_base = Bs + (wn * 32 + i16) * RLD + k4;
+        const T* a_base = As + (wm * TM * 16 + i16) * RLD + k4;
+        const T* b_base = Bs + (wn * TN * 16 + i16) * RLD + k4;
 #pragma unroll
         for (int kq = 0; kq < RBK / 4; ++kq) {
-            T af[2], bf[2];
+            T af[TM], bf[TN];
 #pragma unroll
-            for (int i = 0; i < 2; ++i) af[i] = a_base[i * 16 * RLD + 4 * kq];
+            for (int i = 0; i < TM; ++i) af[i] = a_base[i * 16 * RLD + 4 * kq];
 #pragma unroll
-            for (int j = 0; j < 2; ++j) bf[j] = b_base[j * 16 * RLD + 4 * kq];
+            for (int j = 0; j < TN; ++j) bf[j] = b_base[j * 16 * RLD + 4 * kq];
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int j = 0; j < 2; ++j) acc[i][j] = mfma16(af[i], bf[j], acc[i][j]);
+                for (int j = 0; j < TN; ++j) acc[i][j] = mfma16(af[i], bf[j], acc[i][j]);
         }
         if (kofs_mine) kofs_commit(kt + 3);
         __syncthreads();
@@ -408,33 +445,47 @@ __global__ __launch_bounds__(256, 2) void pair_mfma_real_kernel(StepArgs p, int 
 
     const T alpha = (T)step_alpha(p);
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int64_t n = n0 + wn * 32 + j * 16 + i16;
+    for (int j = 0; j < TN; ++j) {
+        const int64_t n = n0 + wn * TN * 16 + j * 16 + i16;
         if (n >= p.N) continue;
         const int64_t ncol = p.nC[n];
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < TM; ++i)
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
-                const int64_t ro = rowC_s[wm * 32 + i * 16 + d_row(T(0), k4, t)];
+                const int64_t ro = rowC_s[wm * TM * 16 + i * 16 + d_row(T(0), k4, t)];
                 if (ro >= 0) C[ro + ncol] = acc[i][j][t] * alpha;
             }
     }
 }
 
-hipError_t launch_pair_mfma_real(int dtype, const StepArgs& p, int flags, hipStream_t stream) {
+template <typename T, int TM, int TN>
+static hipError_t launch_real_t(const StepArgs& p, int flags, hipStream_t stream) {
+    constexpr int RBM = 2 * TM * 16, RBN = 2 * TN * 16;
     const int64_t tiles_m = (p.R + RBM - 1) / RBM;
     const int64_t tiles_n = (p.N + RBN - 1) / RBN;
     const int64_t gx = ((tiles_m + 7) / 8) * 8 * tiles_n;
     if (gx > 0x7fffffffll || p.Bt > 65535) return hipErrorInvalidValue;
     const dim3 grid((unsigned)gx, 1, (unsigned)p.Bt);
-    if (dtype == 0)
-        hipLaunchKernelGGL(pair_mfma_real_kernel<float>, grid, dim3(256), 0, stream, p, flags, tiles_m, tiles_n);
-    else if (dtype == 1)
-        hipLaunchKernelGGL(pair_mfma_real_kernel<double>, grid, dim3(256), 0, stream, p, flags, tiles_m, tiles_n);
-    else
-        return hipErrorInvalidValue;
+    hipLaunchKernelGGL((pair_mfma_real_kernel<T, TM, TN>), grid, dim3(256), 0, stream, p, flags, tiles_m,
+                       tiles_n);
     return hipGetLastError();
+}
+
+hipError_t launch_pair_mfma_real(int dtype, const StepArgs& p, int flags, hipStream_t stream) {
+    if (dtype != 0 && dtype != 1) return hipErrorInvalidValue;
+    // the large tile once its blocks alone fill the chip twice over
+    const int64_t big = ((p.R + 127) / 128) * ((p.N + 127) / 128) * p.Bt;
+    const bool wide = big >= 1024 && p.N >= 96;
+    const int64_t tall = ((p.R + 127) / 128) * ((p.N + 63) / 64) * p.Bt;
+    if (dtype == 0) {
+        if (wide) return launch_real_t<float, 4, 4>(p, flags, stream);
+        if (tall >= 1024) return launch_real_t<float, 4, 2>(p, flags, stream);
+        return launch_real_t<float, 2, 2>(p, flags, stream);
+    }
+    // (128 x 128 in double precision would need more than 256 registers per lane)
+    if (tall >= 1024) return launch_real_t<double, 4, 2>(p, flags, stream);
+    return launch_real_t<double, 2, 2>(p, flags, stream);
 }
 
 }  // namespace ctg

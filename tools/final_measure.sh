@@ -1,28 +1,36 @@
 #!/bin/bash
-# End-of-round measurement on the GPU box: tests, the bench line, a kernel
-# trace and the two HBM-traffic counter passes (each bounded by its own timeout).
-# Outputs land in gpurun_out/final/; copy what is to be judged into profiles/.
+# End-of-round measurement on the GPU box: tests, the bench line, a kernel trace of
+# the same command and the HBM-traffic counter passes (separate --pmc runs, each
+# bounded by its own timeout) for the benchmark tree AND the time-to-solution tree.
+# Outputs land in gpurun_out/final/; tools/publish_profiles.py copies what is to be
+# judged into profiles/.
 R=${GRAFT_REPO_ROOT:-$PWD}
 O=$R/gpurun_out/final
 rm -rf $O; mkdir -p $O   # (locally, delete gpurun_out/final before the call: results are merged, not mirrored)
 cd $R
-timeout 900 python -m pytest tests -x -q -m gpu > $O/tests.log 2>&1
-grep -E "passed|failed|error" $O/tests.log | tail -2
-timeout 600 python bench.py > $O/bench.log 2>&1
+if [ "$1" != "notests" ]; then
+  timeout 1500 python -m pytest tests -x -q -m gpu --durations=8 > $O/tests.log 2>&1
+  grep -E "passed|failed|error" $O/tests.log | tail -2
+fi
+timeout 900 python bench.py > $O/bench.log 2>&1
 tail -1 $O/bench.log > $O/bench_line.json
-cut -c1-400 $O/bench_line.json
+cut -c1-400 $O/bench_line.json; echo
 cd /tmp && export TMPDIR=/tmp
-CMD="python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline"
-timeout 600 rocprofv3 --kernel-trace --stats -d $O/trace -- $CMD > $O/trace.log 2>&1
-timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/pmc_fetch -- $CMD > $O/pmc_fetch.log 2>&1
-timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $O/pmc_write -- $CMD > $O/pmc_write.log 2>&1
+timeout 900 rocprofv3 --kernel-trace --stats -d $O/trace -- python $R/bench.py > $O/trace.log 2>&1
 cd $R
-T=$(find $O/trace -name "*.db" | head -1); F=$(find $O/pmc_fetch -name "*.db" | head -1); W=$(find $O/pmc_write -name "*.db" | head -1)
-python tools/rocprof_summary.py $T $O/kernels > /dev/null 2>&1; head -12 $O/kernels_kernels.txt | cut -c1-190
-python tools/rocprof_summary.py $F $O/pmc_fetch_k > /dev/null 2>&1
-python tools/rocprof_summary.py $W $O/pmc_write_k > /dev/null 2>&1
-python tools/pmc_traffic.py $F $W 4 $O/pmc_summary.json | tail -8
-find $O -name "*.db" -size +30M -delete
-# per-step roofline table of one slice (HIP events on the exec's stream)
-timeout 600 python bench.py --steps 1 --warmup 1 --no-cpu-baseline --dump-steps $O/steps.json > /dev/null 2>&1
-python tools/steps_report.py $O/steps.json 40 > $O/steps.txt 2>&1
+T=$(find $O/trace -name "*.db" | head -1)
+python tools/rocprof_summary.py $T $O/kernels > /dev/null 2>&1; head -14 $O/kernels_kernels.txt | cut -c1-190
+for tree in sycamore_m20_w32_c512 sycamore_m20_native; do
+  CMD="python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --tree $R/tests/golden/trees/$tree.json"
+  cd /tmp
+  timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/pmc_fetch_$tree -- $CMD > $O/pmc_fetch_$tree.log 2>&1
+  timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $O/pmc_write_$tree -- $CMD > $O/pmc_write_$tree.log 2>&1
+  cd $R
+  F=$(find $O/pmc_fetch_$tree -name "*.db" | head -1); W=$(find $O/pmc_write_$tree -name "*.db" | head -1)
+  # (2 timed + 1 warm-up + 1 profiled slice = 4 slices in the run)
+  python tools/pmc_traffic.py $F $W 4 $O/pmc_summary_$tree.json $tree.json | tail -8
+  timeout 600 python bench.py --steps 1 --warmup 1 --no-cpu-baseline --tree tests/golden/trees/$tree.json --dump-steps $O/steps_$tree.json > /dev/null 2>&1
+  python tools/steps_report.py $O/steps_$tree.json 40 > $O/steps_$tree.txt 2>&1
+done
+find $O -name "*.db" -delete
+find $O -type d -empty -delete
