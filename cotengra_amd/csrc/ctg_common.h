@@ -237,6 +237,8 @@ struct MfmaHints {
                      // 3: skinny FMA kernel (K <= 16, N <= 4: far below one MFMA tile)
     int additive32;  // 1: row offsets are tile-additive for 32-row groups
     int fast;        // 1: full tiles + tile-additive 32-bit offsets (tiled fast path)
+    const void* lane;  // fast path: per-thread gather / staging constants, built once per
+                       // executor (launch_fast_lane_consts); null: computed by every block
 };
 
 // steps the streaming kernel takes: short contraction, few columns, many rows
@@ -270,6 +272,8 @@ hipError_t launch_pair_valu(int dtype, const StepArgs& p, void* scratch, int64_t
                             hipStream_t stream);
 hipError_t launch_pair_mfma(int dtype, const StepArgs& p, const MfmaHints& h, void* scratch,
                             int64_t scratch_bytes, hipStream_t stream);
+int64_t fast_lane_table_bytes();
+hipError_t launch_fast_lane_consts(const StepArgs& p, const MfmaHints& h, void* out, hipStream_t stream);
 // complex128 on the FP64 matrix cores (ctg_pair_mfma_f64.hip)
 hipError_t launch_pair_mfma_c128(const StepArgs& p, int flags, hipStream_t stream);
 // float32 / float64 on the 16x16x4 matrix-core instructions

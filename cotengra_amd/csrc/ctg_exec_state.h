@@ -42,6 +42,7 @@ struct ctg_exec {
     std::vector<ctg::StepArgs> args;  // resolved per step
     std::vector<ctg::MfmaHints> hints;  // per step kernel hints (MFMA steps)
     uint16_t* d_ord = nullptr;     // order tables of all MFMA steps
+    char* d_lane = nullptr;        // lane-constant tables of the fast tiled steps
     std::vector<hipEvent_t> events;
     // slice graph: the launch sequence of one slice captured once and replayed,
     // the slice id advancing on the device (prologue kernel)

@@ -398,6 +398,106 @@ __global__ __launch_bounds__(256, 2) void pair_mfma_c64_kernel(StepArgs p, MfmaH
 // 4 x 16-byte A loads + B loads + LDS traffic + 64 MFMAs per wave per k-step.
 // ------------------------------------------------------------------------- //
 
+// Per-lane constants of the fast kernel (see its prologue): which tile elements a
+// thread gathers (offsets relative to the tile bases) and where it stages them
+// in LDS.  `compute` derives them from the order and offset tables; the builder
+// kernel below runs it once per step and executor, the tiled kernel then reads
+// the packed words back.
+template <typename Cfg, bool VEC_A>
+struct FastLane {
+    static constexpr int LD = Cfg::BK;
+    static constexpr int NA = VEC_A ? Cfg::A_PER_T / 2 : Cfg::A_PER_T;
+    static constexpr int NAL = (Cfg::A_PER_T + 1) / 2, NBL = (Cfg::B_PER_T + 1) / 2;
+    static constexpr int NW = NA + NAL + Cfg::B_PER_T + NBL;   // 32-bit words per thread
+    static constexpr int NQ = (NW + 3) / 4;                    // 16-byte loads per thread
+    __device__ static __forceinline__ int fsw(int row) { return ((row >> 1) & 7) ^ ((row >> 4) & 1); }
+    __device__ static __forceinline__ int swz(int row, int c) {
+        return row * LD + (((c >> 1) ^ fsw(row)) << 1) + (c & 1);
+    }
+    __device__ static __forceinline__ void compute(const StepArgs& p, const MfmaHints& h, int tid,
+                                                   unsigned (&a_off)[NA], unsigned (&a_lds)[NAL],
+                                                   unsigned (&b_off)[Cfg::B_PER_T], unsigned (&b_lds)[NBL]) {
+        const uint16_t* oa = h.ordA + tid * Cfg::A_PER_T;
+#pragma unroll
+        for (int j = 0; j < Cfg::A_PER_T; ++j) {
+#ifdef CTG_KO_PRO
+            const int v = ((tid * Cfg::A_PER_T + j) * 37) & 0x7ff;   // no table loads at all
+#else
+            const int v = oa[j];
+#endif
+            const int r = v >> 4, c = v & 15;
+            if (j & 1) a_lds[j / 2] |= (unsigned)swz(r, c) << 16;
+            else a_lds[j / 2] = (unsigned)swz(r, c);
+            if (!VEC_A || (j & 1) == 0)
+#ifdef CTG_KO_PRO
+                a_off[VEC_A ? j / 2 : j] = (unsigned)((tid * NA + (VEC_A ? j / 2 : j)) * 2);
+#else
+                a_off[VEC_A ? j / 2 : j] = (unsigned)(p.rowA.lo[r] + p.kA.lo[c]);
+#endif
+        }
+        const uint16_t* ob = h.ordB + tid * Cfg::B_PER_T;
+#pragma unroll
+        for (int j = 0; j < Cfg::B_PER_T; ++j) {
+#ifdef CTG_KO_PRO
+            const int v = ((tid * Cfg::B_PER_T + j) * 29) & (16 * Cfg::BN - 1);
+#else
+            const int v = ob[j];
+#endif
+            const int nn = v >> 4, c = v & 15;
+            if (j & 1) b_lds[j / 2] |= (unsigned)swz(2 * nn, c) << 16;
+            else b_lds[j / 2] = (unsigned)swz(2 * nn, c);
+#ifdef CTG_KO_PRO
+            b_off[j] = (unsigned)(tid * Cfg::B_PER_T + j);
+#else
+            b_off[j] = (unsigned)(p.nB[nn] + p.kB.lo[c]);
+#endif
+        }
+    }
+    __device__ static __forceinline__ void pack_words(unsigned (&w)[NQ * 4], const unsigned (&a_off)[NA],
+                                                      const unsigned (&a_lds)[NAL],
+                                                      const unsigned (&b_off)[Cfg::B_PER_T],
+                                                      const unsigned (&b_lds)[NBL]) {
+        int i = 0;
+#pragma unroll
+        for (int j = 0; j < NA; ++j) w[i++] = a_off[j];
+#pragma unroll
+        for (int j = 0; j < NAL; ++j) w[i++] = a_lds[j];
+#pragma unroll
+        for (int j = 0; j < Cfg::B_PER_T; ++j) w[i++] = b_off[j];
+#pragma unroll
+        for (int j = 0; j < NBL; ++j) w[i++] = b_lds[j];
+#pragma unroll
+        for (; i < NQ * 4; ++i) w[i] = 0u;
+    }
+    __device__ static __forceinline__ void unpack_words(const unsigned (&w)[NQ * 4], unsigned (&a_off)[NA],
+                                                        unsigned (&a_lds)[NAL],
+                                                        unsigned (&b_off)[Cfg::B_PER_T],
+                                                        unsigned (&b_lds)[NBL]) {
+        int i = 0;
+#pragma unroll
+        for (int j = 0; j < NA; ++j) a_off[j] = w[i++];
+#pragma unroll
+        for (int j = 0; j < NAL; ++j) a_lds[j] = w[i++];
+#pragma unroll
+        for (int j = 0; j < Cfg::B_PER_T; ++j) b_off[j] = w[i++];
+#pragma unroll
+        for (int j = 0; j < NBL; ++j) b_lds[j] = w[i++];
+    }
+};
+
+// one block of 256 threads: out[q * 256 + tid] = the q-th 16 bytes of thread tid
+template <typename Cfg, bool VEC_A>
+__global__ __launch_bounds__(256) void fast_lane_consts_kernel(StepArgs p, MfmaHints h, uint4* out) {
+    typedef FastLane<Cfg, VEC_A> Lane;
+    const int tid = threadIdx.x;
+    unsigned a_off[Lane::NA], a_lds[Lane::NAL], b_off[Cfg::B_PER_T], b_lds[Lane::NBL];
+    Lane::compute(p, h, tid, a_off, a_lds, b_off, b_lds);
+    unsigned w[Lane::NQ * 4];
+    Lane::pack_words(w, a_off, a_lds, b_off, b_lds);
+#pragma unroll
+    for (int q = 0; q < Lane::NQ; ++q) out[q * 256 + tid] = uint4{w[4 * q], w[4 * q + 1], w[4 * q + 2], w[4 * q + 3]};
+}
+
 template <typename Cfg, bool VEC_A>
 __global__ __launch_bounds__(256, Cfg::FAST_BLOCKS) void pair_mfma_fast_kernel(StepArgs p, MfmaHints h,
                                                                 int64_t tiles_m, int64_t tiles_n,
@@ -413,8 +513,7 @@ __global__ __launch_bounds__(256, Cfg::FAST_BLOCKS) void pair_mfma_fast_kernel(S
     constexpr int LD = BK;
     constexpr int AF = 2 * BM * LD, BF = 2 * BN * LD;
     __shared__ __attribute__((aligned(16))) float lds[2 * (AF + BF)];
-    auto fsw = [](int row) { return ((row >> 1) & 7) ^ ((row >> 4) & 1); };
-    auto swz = [&](int row, int c) { return row * LD + (((c >> 1) ^ fsw(row)) << 1) + (c & 1); };
+    auto fsw = [](int row) { return FastLane<Cfg, VEC_A>::fsw(row); };
 
     CTG_STAMP(T0);
     const int tid = threadIdx.x;
@@ -448,49 +547,33 @@ __global__ __launch_bounds__(256, Cfg::FAST_BLOCKS) void pair_mfma_fast_kernel(S
     const int64_t nk = uniform64((nk_total - ksplit + S_split - 1) / S_split);
 
     // ---- per-lane constants -----------------------------------------------------
+    // They depend on the thread and the step only, not on the tile: built once per
+    // executor by fast_lane_consts_kernel into a table (h.lane) that every block
+    // reads with NQ coalesced 16-byte loads -- instead of two levels of dependent
+    // table lookups (order table -> offset tables) at the head of every tile.
+    typedef FastLane<Cfg, VEC_A> Lane;
     unsigned a_off[NA];          // element offset of the load relative to the bases
     // LDS float offsets of the elements this lane stages, two 16-bit values per register
-    constexpr int NAL = (Cfg::A_PER_T + 1) / 2, NBL = (Cfg::B_PER_T + 1) / 2;
+    constexpr int NAL = Lane::NAL, NBL = Lane::NBL;
     unsigned a_lds[NAL], b_lds[NBL];   // b: Re row 2n of B'; the Im row 2n+1 is LD floats further
-    {
-        const uint16_t* oa = h.ordA + tid * Cfg::A_PER_T;
-#pragma unroll
-        for (int j = 0; j < Cfg::A_PER_T; ++j) {
-#ifdef CTG_KO_PRO
-            const int v = ((tid * Cfg::A_PER_T + j) * 37) & 0x7ff;   // no table loads at all
-#else
-            const int v = oa[j];
-#endif
-            const int r = v >> 4, c = v & 15;
-            if (j & 1) a_lds[j / 2] |= (unsigned)swz(r, c) << 16;
-            else a_lds[j / 2] = (unsigned)swz(r, c);
-            if (!VEC_A || (j & 1) == 0)
-#ifdef CTG_KO_PRO
-                a_off[VEC_A ? j / 2 : j] = (unsigned)((tid * NA + (VEC_A ? j / 2 : j)) * 2);
-#else
-                a_off[VEC_A ? j / 2 : j] = (unsigned)(p.rowA.lo[r] + p.kA.lo[c]);
-#endif
-        }
-    }
     unsigned b_off[Cfg::B_PER_T];
-    {
-        const uint16_t* ob = h.ordB + tid * Cfg::B_PER_T;
+#ifndef CTG_KO_PRO
+    if (h.lane != nullptr) {
+        unsigned w[Lane::NQ * 4];
+        const uint4* L = (const uint4*)h.lane;
 #pragma unroll
-        for (int j = 0; j < Cfg::B_PER_T; ++j) {
-#ifdef CTG_KO_PRO
-            const int v = ((tid * Cfg::B_PER_T + j) * 29) & (16 * BN - 1);
-#else
-            const int v = ob[j];
-#endif
-            const int nn = v >> 4, c = v & 15;
-            if (j & 1) b_lds[j / 2] |= (unsigned)swz(2 * nn, c) << 16;
-            else b_lds[j / 2] = (unsigned)swz(2 * nn, c);
-#ifdef CTG_KO_PRO
-            b_off[j] = (unsigned)(tid * Cfg::B_PER_T + j);
-#else
-            b_off[j] = (unsigned)(p.nB[nn] + p.kB.lo[c]);
-#endif
+        for (int q = 0; q < Lane::NQ; ++q) {
+            const uint4 v = L[q * 256 + tid];
+            w[4 * q] = v.x;
+            w[4 * q + 1] = v.y;
+            w[4 * q + 2] = v.z;
+            w[4 * q + 3] = v.w;
         }
+        Lane::unpack_words(w, a_off, a_lds, b_off, b_lds);
+    } else
+#endif
+    {
+        Lane::compute(p, h, tid, a_off, a_lds, b_off, b_lds);
     }
     auto unpack = [](const unsigned* pk, int j) { return (int)((j & 1) ? pk[j / 2] >> 16 : pk[j / 2] & 0xffffu); };
 
@@ -697,19 +780,26 @@ __global__ __launch_bounds__(256, Cfg::FAST_BLOCKS) void pair_mfma_fast_kernel(S
         }
         return;
     }
+    auto store_tile = [&](auto scaled_tag) __attribute__((always_inline)) {
 #pragma unroll
-    for (int i = 0; i < Cfg::FM; ++i) {
+        for (int i = 0; i < Cfg::FM; ++i) {
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int t = 2 * u;
+            for (int u = 0; u < 8; ++u) {
+                const int t = 2 * u;
 #pragma unroll
-            for (int j = 0; j < Cfg::FN; ++j) {
-                CTG_STORE_GUARD(alpha)
-                *(float2*)(C + 2 * (size_t)(ro[i][u] + co[j])) =
-                    pair_rows(acc[i][j][t], acc[i][j][t + 1], odd, alpha);
+                for (int j = 0; j < Cfg::FN; ++j) {
+                    float2 v;
+                    if constexpr (decltype(scaled_tag)::value) v = pair_rows(acc[i][j][t], acc[i][j][t + 1], odd, alpha);
+                    else v = pair_rows(acc[i][j][t], acc[i][j][t + 1], odd);
+                    CTG_STORE_GUARD(alpha)
+                    *(float2*)(C + 2 * (size_t)(ro[i][u] + co[j])) = v;
+                }
             }
         }
-    }
+    };
+    // (alpha != 1 only in strip_exponent runs: two multiplies per store otherwise saved)
+    if (alpha != 1.f) store_tile(std::true_type{});
+    else store_tile(std::false_type{});
 #ifdef CTG_TIMING
     CTG_STAMP(T4);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // all stores acknowledged
@@ -847,6 +937,9 @@ template <int FN, bool VEC, bool ADD, bool SHORTK, int NV>
 #endif
 #ifndef CTG_STREAM_DEPTH
 #define CTG_STREAM_DEPTH 2
+#endif
+#ifndef CTG_STREAM_PIPE4  // 64-column steps: fragment reads double-buffered in registers (costs 20 VGPRs)
+#define CTG_STREAM_PIPE4 1
 #endif
 #ifndef CTG_STREAM_BREG   // B panels of up to this many (chunks x column tiles) in registers
 #define CTG_STREAM_BREG 0
@@ -1085,7 +1178,7 @@ __global__ __launch_bounds__(256, (FN == 1 ? 4 : FN == 2 ? CTG_STREAM_OCC2 : CTG
         const float* b_base = Bs + (kk * BROWS + l31) * LDB + cc * MFMA_BK;
         const int k_left = (int)p.K - cc * MFMA_BK;
         const int nq = k_left >= MFMA_BK ? MFMA_BK / 4 : (k_left + 3) / 4;
-        if constexpr (STEADY && !SHORTK) {
+        if constexpr (STEADY && !SHORTK && (FN < 4 || CTG_STREAM_PIPE4)) {
             // full chunk: the four k-quads are unrolled with the fragments of quad
             // q+1 read (ds_read_b128) before the MFMAs of quad q are issued, so the
             // matrix pipe never waits for this wave's LDS latency.  B fragments in
@@ -1564,6 +1657,28 @@ static hipError_t launch_skinny(const StepArgs& p, hipStream_t stream) {
         case 8 * 8 + 2: return launch_skinny_t<8, 2>(p, stream);
         case 2 * 8 + 4: return launch_skinny_t<2, 4>(p, stream);
         case 4 * 8 + 4: return launch_skinny_t<4, 4>(p, stream);
+    }
+    return hipErrorInvalidValue;
+}
+
+template <typename Cfg>
+static hipError_t build_lane_t(const StepArgs& p, const MfmaHints& h, void* out, hipStream_t stream) {
+    if (h.vecA)
+        hipLaunchKernelGGL((fast_lane_consts_kernel<Cfg, true>), dim3(1), dim3(256), 0, stream, p, h, (uint4*)out);
+    else
+        hipLaunchKernelGGL((fast_lane_consts_kernel<Cfg, false>), dim3(1), dim3(256), 0, stream, p, h, (uint4*)out);
+    return hipGetLastError();
+}
+
+// Fill the lane-constant table of a fast tiled step (h.fast, h.bn); `out` holds
+// fast_lane_table_bytes() bytes.  Called once per step when an executor is built.
+int64_t fast_lane_table_bytes() { return 256 * 16 * 8; }   // up to 8 x 16 bytes per thread (128 x 128 tiles: 6)
+hipError_t launch_fast_lane_consts(const StepArgs& p, const MfmaHints& h, void* out, hipStream_t stream) {
+    switch (h.bn) {
+        case 16: return build_lane_t<MfmaCfg<128, 16, 16, 4, 1>>(p, h, out, stream);
+        case 32: return build_lane_t<MfmaCfg<128, 32, 16, 4, 1>>(p, h, out, stream);
+        case 64: return build_lane_t<MfmaCfg<128, 64, 16, 2, 2>>(p, h, out, stream);
+        case 128: return build_lane_t<MfmaCfg<128, 128, 16, 2, 2>>(p, h, out, stream);
     }
     return hipErrorInvalidValue;
 }

@@ -180,7 +180,7 @@ void resolve_args(ctg_exec* e) {
     // (hints depend on the plan only: kept when the arguments are re-resolved,
     // e.g. by ctg_exec_set_strip_exponent on a live executor)
     if ((int64_t)e->hints.size() != p->n_steps)
-        e->hints.assign(p->n_steps, MfmaHints{nullptr, nullptr, 0, 0, 0, 0, 0});
+        e->hints.assign(p->n_steps, MfmaHints{nullptr, nullptr, 0, 0, 0, 0, 0, nullptr});
     const int64_t* T = e->d_tables;
     for (int64_t s = 0; s < p->n_steps; ++s) {
         const int64_t* r = &p->steps[s * STEP_WORDS];
@@ -499,10 +499,30 @@ int build_hints(ctg_exec* e) {
     if (blob.empty()) return CTG_OK;
     HIP_TRY(hipMalloc((void**)&e->d_ord, blob.size() * sizeof(uint16_t)));
     HIP_TRY(hipMemcpy(e->d_ord, blob.data(), blob.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+    int64_t n_fast = 0;
     for (int64_t s = 0; s < p->n_steps; ++s) {
         if (e->hints[s].bn == 0) continue;
         e->hints[s].ordA = e->d_ord + offA[s];
         e->hints[s].ordB = e->d_ord + offB[s];
+        if (e->hints[s].fast) ++n_fast;
+    }
+    // lane-constant tables of the fast tiled steps: built on the device once, read by
+    // every block of every launch (the tables they derive from never change)
+    if (n_fast > 0 && getenv("CTG_NO_LANE_TABLES") == nullptr) {
+        const int64_t each = fast_lane_table_bytes();
+        HIP_TRY(hipMalloc((void**)&e->d_lane, n_fast * each));
+        int64_t i = 0;
+        for (int64_t s = 0; s < p->n_steps; ++s) {
+            MfmaHints& h = e->hints[s];
+            if (h.bn == 0 || !h.fast) continue;
+            void* out = e->d_lane + i * each;
+            ++i;
+            hipError_t err = launch_fast_lane_consts(e->args[s], h, out, e->stream);
+            if (err != hipSuccess)
+                return fail(CTG_E_HIP, "lane-constant kernel of step %lld failed: %s", (long long)s,
+                            hipGetErrorString(err));
+            h.lane = out;
+        }
     }
     return CTG_OK;
 }
@@ -659,6 +679,7 @@ int ctg_exec_destroy(ctg_exec* e) {
     if (e->d_misc) (void)hipFree(e->d_misc);
     if (e->d_scratch) (void)hipFree(e->d_scratch);
     if (e->d_ord) (void)hipFree(e->d_ord);
+    if (e->d_lane) (void)hipFree(e->d_lane);
     if (e->d_fac) (void)hipFree(e->d_fac);
     if (e->d_counted) (void)hipFree(e->d_counted);
     if (e->d_fac_zero) (void)hipFree(e->d_fac_zero);
