@@ -1,0 +1,87 @@
+// ctg_probe.hip -- memory-path probe (experiment tool, not part of libctg_hip.so):
+// a persistent copy kernel shaped like the streaming kernel's traffic (each wave
+// owns 4 KB tasks, two in flight), with the store width / pattern as a parameter.
+//   hipcc --offload-arch=gfx950 -O3 -shared -fPIC -o libctg_probe.so ctg_probe.hip
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// mode 0: 16-B loads, 16-B stores   1: 16-B loads, 8-B stores (same bytes, twice the store instructions)
+// mode 2: 16-B loads, 8-B stores in the MFMA epilogue pattern (4 rows x 128 B per instruction)
+// mode 3: 16-B loads, no stores     4: no loads, 16-B stores     5: no loads, 8-B stores
+template <int MODE>
+__global__ __launch_bounds__(256, 8) void probe_kernel(const f32x4* __restrict__ src, f32x4* __restrict__ dst,
+                                                       int64_t n_tasks) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int64_t n_waves = (int64_t)gridDim.x * 4;
+    f32x4 r[2][4];
+    auto issue = [&](f32x4 (&x)[4], int64_t t) {
+        if (MODE >= 4) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) x[j] = f32x4{(float)t, 1.f, 2.f, (float)j};
+            return;
+        }
+        const f32x4* p = src + t * 256;   // 4 KB = 256 x 16 B
+#pragma unroll
+        for (int j = 0; j < 4; ++j) x[j] = p[j * 64 + lane];
+    };
+    auto retire = [&](f32x4 (&x)[4], int64_t t) {
+        if (MODE == 3) {
+            if (x[0][0] == 12345.678f && x[1][1] == x[2][2] && x[3][3] == 1.f) dst[t] = x[0];
+            return;
+        }
+        f32x4* q = dst + t * 256;
+        if (MODE == 0 || MODE == 4) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) q[j * 64 + lane] = x[j];
+        } else if (MODE == 1 || MODE == 5) {
+            f32x2* q2 = (f32x2*)q;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                q2[(2 * j) * 64 + lane] = f32x2{x[j][0], x[j][1]};
+                q2[(2 * j + 1) * 64 + lane] = f32x2{x[j][2], x[j][3]};
+            }
+        } else {
+            // 8 store instructions of 4 rows x 128 B: rows 256 B apart (N = 32 complex columns)
+            f32x2* q2 = (f32x2*)q;
+            const int col = lane & 15, rsel = lane >> 4;   // 16 lanes x 8 B = 128 B per row piece
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int row = (j >> 1) * 4 + rsel, half = j & 1;   // 16 rows x 2 halves = 4 KB
+                q2[row * 32 + half * 16 + col] = f32x2{x[j >> 1][2 * (j & 1)], x[j >> 1][2 * (j & 1) + 1]};
+            }
+        }
+    };
+    const int64_t mine = wave < n_tasks ? (n_tasks - wave + n_waves - 1) / n_waves : 0;
+    if (mine == 0) return;
+    issue(r[0], wave);
+    if (mine > 1) issue(r[1], wave + n_waves);
+    // (peeled so that the compiler's waits at the loop header count the stores)
+    int64_t i = 0;
+    for (; i + 2 < mine; i += 2) {
+        retire(r[0], wave + i * n_waves);
+        issue(r[0], wave + (i + 2) * n_waves);
+        retire(r[1], wave + (i + 1) * n_waves);
+        if (i + 3 < mine) issue(r[1], wave + (i + 3) * n_waves);
+    }
+    for (; i < mine; ++i) retire(r[i & 1], wave + i * n_waves);
+}
+
+extern "C" int ctg_probe_copy(const void* src, void* dst, int64_t nbytes, int mode, int blocks, void* stream) {
+    const int64_t n_tasks = nbytes / 4096;
+    hipStream_t s = (hipStream_t)stream;
+    const dim3 g((unsigned)blocks), b(256);
+    switch (mode) {
+        case 0: hipLaunchKernelGGL(probe_kernel<0>, g, b, 0, s, (const f32x4*)src, (f32x4*)dst, n_tasks); break;
+        case 1: hipLaunchKernelGGL(probe_kernel<1>, g, b, 0, s, (const f32x4*)src, (f32x4*)dst, n_tasks); break;
+        case 2: hipLaunchKernelGGL(probe_kernel<2>, g, b, 0, s, (const f32x4*)src, (f32x4*)dst, n_tasks); break;
+        case 3: hipLaunchKernelGGL(probe_kernel<3>, g, b, 0, s, (const f32x4*)src, (f32x4*)dst, n_tasks); break;
+        case 4: hipLaunchKernelGGL(probe_kernel<4>, g, b, 0, s, (const f32x4*)src, (f32x4*)dst, n_tasks); break;
+        case 5: hipLaunchKernelGGL(probe_kernel<5>, g, b, 0, s, (const f32x4*)src, (f32x4*)dst, n_tasks); break;
+        default: return -1;
+    }
+    return (int)hipGetLastError();
+}
