@@ -11,11 +11,37 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 // mode 0: 16-B loads, 16-B stores   1: 16-B loads, 8-B stores (same bytes, twice the store instructions)
 // mode 2: 16-B loads, 8-B stores in the MFMA epilogue pattern (4 rows x 128 B per instruction)
 // mode 3: 16-B loads, no stores     4: no loads, 16-B stores     5: no loads, 8-B stores
+// tpw == 0: persistent, wave w takes tasks w, w + n_waves, ...; tpw > 0: short-lived
+// waves, wave w takes the tpw consecutive tasks [w * tpw, (w + 1) * tpw)
 template <int MODE>
 __global__ __launch_bounds__(256, 8) void probe_kernel(const f32x4* __restrict__ src, f32x4* __restrict__ dst,
-                                                       int64_t n_tasks) {
+                                                       int64_t n_tasks, int tpw) {
     const int lane = threadIdx.x & 63;
     const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (tpw > 0) {
+        // (no prefetch ring: all loads of a task, then its stores, like an elementwise kernel)
+        for (int i = 0; i < tpw; ++i) {
+            const int64_t t = wave * tpw + i;
+            if (t >= n_tasks) return;
+            f32x4 x[4];
+            const f32x4* p = src + t * 256;
+            f32x4* q = dst + t * 256;
+            if (MODE < 4) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) x[j] = p[j * 64 + lane];
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) x[j] = f32x4{(float)t, 1.f, 2.f, (float)j};
+            }
+            if (MODE == 3) {
+                if (x[0][0] == 12345.678f && x[1][1] == x[2][2] && x[3][3] == 1.f) dst[t] = x[0];
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) q[j * 64 + lane] = x[j];
+            }
+        }
+        return;
+    }
     const int64_t n_waves = (int64_t)gridDim.x * 4;
     f32x4 r[2][4];
     auto issue = [&](f32x4 (&x)[4], int64_t t) {
@@ -70,17 +96,17 @@ __global__ __launch_bounds__(256, 8) void probe_kernel(const f32x4* __restrict__
     for (; i < mine; ++i) retire(r[i & 1], wave + i * n_waves);
 }
 
-extern "C" int ctg_probe_copy(const void* src, void* dst, int64_t nbytes, int mode, int blocks, void* stream) {
+extern "C" int ctg_probe_copy(const void* src, void* dst, int64_t nbytes, int mode, int blocks, void* stream, int tpw) {
     const int64_t n_tasks = nbytes / 4096;
     hipStream_t s = (hipStream_t)stream;
     const dim3 g((unsigned)blocks), b(256);
     switch (mode) {
-        case 0: hipLaunchKernelGGL(probe_kernel<0>, g, b, 0, s, (const f32x4*)src, (f32x4*)dst, n_tasks); break;
-        case 1: hipLaunchKernelGGL(probe_kernel<1>, g, b, 0, s, (const f32x4*)src, (f32x4*)dst, n_tasks); break;
-        case 2: hipLaunchKernelGGL(probe_kernel<2>, g, b, 0, s, (const f32x4*)src, (f32x4*)dst, n_tasks); break;
-        case 3: hipLaunchKernelGGL(probe_kernel<3>, g, b, 0, s, (const f32x4*)src, (f32x4*)dst, n_tasks); break;
-        case 4: hipLaunchKernelGGL(probe_kernel<4>, g, b, 0, s, (const f32x4*)src, (f32x4*)dst, n_tasks); break;
-        case 5: hipLaunchKernelGGL(probe_kernel<5>, g, b, 0, s, (const f32x4*)src, (f32x4*)dst, n_tasks); break;
+        case 0: hipLaunchKernelGGL(probe_kernel<0>, g, b, 0, s, (const f32x4*)src, (f32x4*)dst, n_tasks, tpw); break;
+        case 1: hipLaunchKernelGGL(probe_kernel<1>, g, b, 0, s, (const f32x4*)src, (f32x4*)dst, n_tasks, tpw); break;
+        case 2: hipLaunchKernelGGL(probe_kernel<2>, g, b, 0, s, (const f32x4*)src, (f32x4*)dst, n_tasks, tpw); break;
+        case 3: hipLaunchKernelGGL(probe_kernel<3>, g, b, 0, s, (const f32x4*)src, (f32x4*)dst, n_tasks, tpw); break;
+        case 4: hipLaunchKernelGGL(probe_kernel<4>, g, b, 0, s, (const f32x4*)src, (f32x4*)dst, n_tasks, tpw); break;
+        case 5: hipLaunchKernelGGL(probe_kernel<5>, g, b, 0, s, (const f32x4*)src, (f32x4*)dst, n_tasks, tpw); break;
         default: return -1;
     }
     return (int)hipGetLastError();
