@@ -29,7 +29,14 @@ template <int TM, int TN>
 __global__ __launch_bounds__(256, 2) void pair_mfma_c128_kernel(StepArgs p, int flags,
                                                                int64_t tiles_m, int64_t tiles_n) {
     constexpr int BM = 2 * TM * 16, BN = 2 * TN * 8;
-    constexpr int A_DBL = 2 * BM * LD, B_DBL = 2 * BN * LD;
+    // a ds_read_b64 is served 32 lanes at a time: 16 rows of the Re plane and the same
+    // 16 rows of the Im plane.  Rows are 18 banks apart (LD = 9 doubles) and BM * LD is a
+    // multiple of the 64-bank period, so un-shifted the two planes collide bank for
+    // bank; 16 doubles (32 banks) of shift put the Im rows exactly on the 16 bank pairs
+    // the Re rows leave free
+    constexpr int A_PLANE = BM * LD + 16;
+    static_assert((BM * LD * 2) % 64 == 0, "plane shift assumes BM * LD is a multiple of the bank period");
+    constexpr int A_DBL = 2 * A_PLANE, B_DBL = 2 * BN * LD;
     constexpr int NA = BM * BK / 256, NB = (BN * BK + 255) / 256;
     static_assert(BN * BK % 256 == 0, "B tile must divide over the block");
     __shared__ double lds[2 * (A_DBL + B_DBL)];
@@ -147,7 +154,7 @@ __global__ __launch_bounds__(256, 2) void pair_mfma_c128_kernel(StepArgs p, int 
 #pragma unroll
         for (int j = 0; j < NA; ++j) {
             As[a_r[j] * LD + a_c[j]] = a_reg[j].re;
-            As[BM * LD + a_r[j] * LD + a_c[j]] = a_reg[j].im;
+            As[A_PLANE + a_r[j] * LD + a_c[j]] = a_reg[j].im;
         }
 #pragma unroll
         for (int j = 0; j < NB; ++j) {
@@ -185,23 +192,31 @@ __global__ __launch_bounds__(256, 2) void pair_mfma_c128_kernel(StepArgs p, int 
 
         const double* As = lds + buf * (A_DBL + B_DBL);
         const double* Bs = As + A_DBL;
-        const double* a_base = As + part * BM * LD + (wm * TM * 16 + i16) * LD + kc_in;
+        const double* a_base = As + part * A_PLANE + (wm * TM * 16 + i16) * LD + kc_in;
         const double* b_base = Bs + (2 * (wn * TN * 8 + (i16 >> 1)) + (cc ^ part)) * LD + kc_in;
+        // fragments double-buffered in registers: the reads of quad q+1 are issued
+        // before the MFMAs of quad q, so the matrix pipe does not wait for LDS
+        double af[2][TM], bf[2][TN];
+        auto load_frag = [&](int kq, int slot) __attribute__((always_inline)) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i) af[slot][i] = a_base[i * 16 * LD + 2 * kq];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) bf[slot][j] = b_base[j * 16 * LD + 2 * kq];
+        };
+        load_frag(0, 0);
 #pragma unroll
         for (int kq = 0; kq < BK / 2; ++kq) {
-            double af[TM], bf[TN];
+            if (kq + 1 < BK / 2) load_frag(kq + 1, (kq + 1) & 1);
+            __builtin_amdgcn_sched_barrier(0);
+            double bs[TN];
 #pragma unroll
-            for (int i = 0; i < TM; ++i) af[i] = a_base[i * 16 * LD + 2 * kq];
-#pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                const double v = b_base[j * 16 * LD + 2 * kq];
-                bf[j] = negate ? -v : v;
-            }
+            for (int j = 0; j < TN; ++j) bs[j] = negate ? -bf[kq & 1][j] : bf[kq & 1][j];
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[i], bf[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[kq & 1][i], bs[j], acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
         }
         if (kofs_mine) kofs_commit(kt + 3);
         __syncthreads();
@@ -427,17 +442,23 @@ __global__ __launch_bounds__(256, 2) void pair_mfma_real_kernel(StepArgs p, int 
         const T* Bs = As + RBM * RLD;
         const T* a_base = As + (wm * TM * 16 + i16) * RLD + k4;
         const T* b_base = Bs + (wn * TN * 16 + i16) * RLD + k4;
+        T af[2][TM], bf[2][TN];
+        auto load_frag = [&](int kq, int slot) __attribute__((always_inline)) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i) af[slot][i] = a_base[i * 16 * RLD + 4 * kq];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) bf[slot][j] = b_base[j * 16 * RLD + 4 * kq];
+        };
+        load_frag(0, 0);
 #pragma unroll
         for (int kq = 0; kq < RBK / 4; ++kq) {
-            T af[TM], bf[TN];
-#pragma unroll
-            for (int i = 0; i < TM; ++i) af[i] = a_base[i * 16 * RLD + 4 * kq];
-#pragma unroll
-            for (int j = 0; j < TN; ++j) bf[j] = b_base[j * 16 * RLD + 4 * kq];
+            if (kq + 1 < RBK / 4) load_frag(kq + 1, (kq + 1) & 1);
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int j = 0; j < TN; ++j) acc[i][j] = mfma16(af[i], bf[j], acc[i][j]);
+                for (int j = 0; j < TN; ++j) acc[i][j] = mfma16(af[kq & 1][i], bf[kq & 1][j], acc[i][j]);
+            __builtin_amdgcn_sched_barrier(0);
         }
         if (kofs_mine) kofs_commit(kt + 3);
         __syncthreads();

@@ -111,3 +111,61 @@ extern "C" int ctg_probe_copy(const void* src, void* dst, int64_t nbytes, int mo
     }
     return (int)hipGetLastError();
 }
+
+// ---- matrix-core issue rate: independent MFMA chains, no memory traffic ---- //
+typedef double f64x4p __attribute__((ext_vector_type(4)));
+typedef float f32x4p __attribute__((ext_vector_type(4)));
+typedef float f32x16p __attribute__((ext_vector_type(16)));
+
+template <int WHICH, int CHAINS>
+__global__ __launch_bounds__(256) void mfma_rate_kernel(float* out, int iters) {
+    const int lane = threadIdx.x & 63;
+    if (WHICH == 0) {          // v_mfma_f64_16x16x4_f64
+        f64x4p acc[CHAINS];
+        for (int c = 0; c < CHAINS; ++c) acc[c] = f64x4p{0, 0, 0, 0};
+        const double a = 1.0 + lane * 1e-3, b = 0.5 - lane * 1e-3;
+        for (int i = 0; i < iters; ++i)
+#pragma unroll
+            for (int c = 0; c < CHAINS; ++c) acc[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[c], 0, 0, 0);
+        double s = 0;
+        for (int c = 0; c < CHAINS; ++c) s += acc[c][0] + acc[c][3];
+        if (s == 12345.678) out[threadIdx.x] = (float)s;
+    } else if (WHICH == 1) {   // v_mfma_f32_16x16x4_f32
+        f32x4p acc[CHAINS];
+        for (int c = 0; c < CHAINS; ++c) acc[c] = f32x4p{0, 0, 0, 0};
+        const float a = 1.0f + lane * 1e-3f, b = 0.5f - lane * 1e-3f;
+        for (int i = 0; i < iters; ++i)
+#pragma unroll
+            for (int c = 0; c < CHAINS; ++c) acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[c], 0, 0, 0);
+        float s = 0;
+        for (int c = 0; c < CHAINS; ++c) s += acc[c][0] + acc[c][3];
+        if (s == 12345.678f) out[threadIdx.x] = s;
+    } else {                   // v_mfma_f32_32x32x2_f32
+        f32x16p acc[CHAINS];
+        for (int c = 0; c < CHAINS; ++c)
+            for (int t = 0; t < 16; ++t) acc[c][t] = 0.f;
+        const float a = 1.0f + lane * 1e-3f, b = 0.5f - lane * 1e-3f;
+        for (int i = 0; i < iters; ++i)
+#pragma unroll
+            for (int c = 0; c < CHAINS; ++c) acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[c], 0, 0, 0);
+        float s = 0;
+        for (int c = 0; c < CHAINS; ++c) s += acc[c][0] + acc[c][15];
+        if (s == 12345.678f) out[threadIdx.x] = s;
+    }
+}
+
+// returns flops issued by the launch (per MFMA: 2048 / 2048 / 4096)
+extern "C" double ctg_probe_mfma(int which, int chains, int blocks, int iters, float* out, void* stream) {
+    hipStream_t s = (hipStream_t)stream;
+    const dim3 g((unsigned)blocks), b(256);
+#define LAUNCH(W, C) hipLaunchKernelGGL((mfma_rate_kernel<W, C>), g, b, 0, s, out, iters)
+    if (which == 0 && chains == 4) LAUNCH(0, 4);
+    else if (which == 0 && chains == 8) LAUNCH(0, 8);
+    else if (which == 1 && chains == 4) LAUNCH(1, 4);
+    else if (which == 1 && chains == 8) LAUNCH(1, 8);
+    else if (which == 2 && chains == 4) LAUNCH(2, 4);
+    else return -1.0;
+#undef LAUNCH
+    const double per = which == 2 ? 4096.0 : 2048.0;
+    return per * chains * (double)iters * 4.0 * blocks;
+}
