@@ -39,6 +39,10 @@ def _current_device():
     return 0
 
 
+def _is_out_of_memory(exc):
+    return isinstance(exc, MemoryError) or "out of memory" in str(exc).lower()
+
+
 def _is_torch(x):
     return type(x).__module__.split(".")[0] == "torch"
 
@@ -88,6 +92,7 @@ class HipContractor:
         device=None,
         force_kernel=None,
     ):
+        self._origin = tree  # whose ``contraction_cores`` hold this contractor's siblings
         if handle_slicing or not tree.sliced_inds:
             self.tree = tree
         else:
@@ -120,6 +125,44 @@ class HipContractor:
         except KeyError:
             pass
         plan, dplan = self.get_plan(dtype)
+        try:
+            st = self._new_exec(plan, dplan, dtype, device, use_torch)
+        except (MemoryError, RuntimeError) as exc:
+            # Every cached contractor of a tree (``contract`` and ``contract_core``,
+            # each dtype) keeps its own arena resident -- tens of GiB for a wide tree.
+            # When the device is full, give up the siblings' executors (they are
+            # rebuilt on demand) and try once more.
+            if not _is_out_of_memory(exc) or not self._evict_siblings():
+                raise
+            st = self._new_exec(plan, dplan, dtype, device, use_torch)
+        self._execs[key] = st
+        return st
+
+    def _evict_siblings(self):
+        """Close the executors of the other contractors cached on the same tree
+        (and this contractor's own executors for other dtypes / devices).
+        Returns True if anything was freed."""
+        freed = False
+        cores = getattr(self._origin, "contraction_cores", {})
+        for other in list(cores.values()) + [self]:
+            execs = getattr(other, "_execs", None)
+            if not execs:
+                continue
+            for st in execs.values():
+                st["exec"].close()
+                st.pop("result", None)
+                freed = True
+            execs.clear()
+        if freed:
+            try:
+                import torch
+
+                torch.cuda.empty_cache()  # result tensors went through torch's allocator
+            except ImportError:
+                pass
+        return freed
+
+    def _new_exec(self, plan, dplan, dtype, device, use_torch):
         st = {"plan": plan}
         if use_torch:
             import torch
@@ -136,7 +179,6 @@ class HipContractor:
             )
         else:
             st["exec"] = runtime.Executor(dplan, device=device)
-        self._execs[key] = st
         return st
 
     def setup(self, *arrays):

@@ -228,3 +228,43 @@ def test_bench_starts_its_own_ranks(monkeypatch):
     assert cmd[-6:] == ["--gpus", "4", "--steps", "3", "--warmup", "1"]
     assert os.path.basename(cmd[cmd.index("--master-port") + 2]) == "bench.py"
     assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+
+
+def test_full_device_evicts_sibling_executors(monkeypatch):
+    """A tree's cached contractors each keep an arena resident; when a new
+    executor does not fit, the siblings' executors are closed and the
+    allocation retried (they are rebuilt on demand)."""
+    from cotengra_amd import contractor as ctr
+
+    tree = _projected_tree()
+    closed = []
+
+    class FakeExec:
+        def __init__(self, tag):
+            self.tag = tag
+
+        def close(self):
+            closed.append(self.tag)
+
+    attempts = []
+
+    def fake_executor(dplan, device=0, stream=0, result_ptr=None):
+        attempts.append(device)
+        if len(attempts) == 1:
+            raise MemoryError("hipMalloc failed: out of memory")
+        return FakeExec("new")
+
+    monkeypatch.setattr(ctr.runtime, "Executor", fake_executor)
+    monkeypatch.setattr(ctr.runtime, "DevicePlan", lambda plan: object())
+    sibling = ctr.HipContractor(tree, handle_slicing=False)
+    sibling._execs[("complex128", 0, False)] = {"exec": FakeExec("sibling"), "plan": None}
+    tree.contraction_cores["some-key"] = sibling
+    fn = ctr.HipContractor(tree, handle_slicing=True)
+    st = fn._get_exec("complex128", 0, False)
+    assert st["exec"].tag == "new" and closed == ["sibling"] and len(attempts) == 2
+    assert sibling._execs == {}
+    # nothing to evict: the error surfaces
+    attempts.clear()
+    fn2 = ctr.HipContractor(_projected_tree(), handle_slicing=True)
+    with pytest.raises(MemoryError):
+        fn2._get_exec("complex64", 0, False)
