@@ -257,7 +257,7 @@ def small_config(name, tree, arrays, dev, slices, reps, cpu_slices, note, dtype=
     st = fn.setup(*[torch.as_tensor(a, device=dev) for a in arrays])
     ex, plan = st["exec"], st["plan"]
     ex.zero_result()
-    ex.run_slices(0, min(slices, 2), 1)
+    ex.run_slices(0, slices, 1)   # warm-up touches every arena replica of the slice batch
     ex.sync()
     t0 = time.perf_counter()
     for _ in range(reps):
@@ -265,6 +265,7 @@ def small_config(name, tree, arrays, dev, slices, reps, cpu_slices, note, dtype=
     ex.sync()
     dt = (time.perf_counter() - t0) / reps
     rows = step_table(ex, plan)
+    batch = ex.batch
     roof_ms = mixed_roofline_ms(rows, 8.0) * slices
     flops = plan.flops_per_slice() * slices
     # the oracle (numpy, the reference's executor restated) on this node's cores
@@ -286,6 +287,7 @@ def small_config(name, tree, arrays, dev, slices, reps, cpu_slices, note, dtype=
         "cpu_oracle_ms": cpu * 1e3,
         "cpu_cores": host_cores(),
         "cpu_sample": f"{cpu_slices} slice(s) with numpy {dtype}, scaled to {slices}",
+        "slices_per_launch": int(min(slices, batch)),
         "speedup_vs_cpu_oracle": cpu / dt,
     }
 

@@ -73,7 +73,22 @@ struct StepArgs {
     const double* facA;
     const double* facB;
     int32_t check_zero;
+    // Slice batching: a launch may carry `nz` consecutive slices of a run in
+    // gridDim.y (kernels whose launcher cannot, loop over z0 instead).  Slice-in-
+    // batch z = z0 + blockIdx.y reads its per-leaf base offsets at soffX[z * zsX]
+    // and its replica of the per-slice arena at z * zX elements (both 0 for
+    // operands that are the same in every slice: inputs without a sliced index,
+    // slice-invariant intermediates, the result tensor).
+    int32_t nz, z0;
+    int64_t zA, zB, zC;     // arena replica strides (elements)
+    int64_t zsA, zsB, zsC;  // strides of the soff arrays (entries)
 };
+
+// element offset of an operand for the slice-in-batch this block works on
+__device__ __forceinline__ int64_t zid(const StepArgs& p) { return (int64_t)p.z0 + blockIdx.y; }
+__device__ __forceinline__ int64_t zoffA(const StepArgs& p) { const int64_t z = zid(p); return p.soffA[z * p.zsA] + z * p.zA; }
+__device__ __forceinline__ int64_t zoffB(const StepArgs& p) { const int64_t z = zid(p); return p.soffB[z * p.zsB] + z * p.zB; }
+__device__ __forceinline__ int64_t zoffC(const StepArgs& p) { const int64_t z = zid(p); return p.soffC[z * p.zsC] + z * p.zC; }
 
 __device__ __forceinline__ double step_alpha(const StepArgs& p) {
     if (p.facA == nullptr) return 1.0;
@@ -134,6 +149,11 @@ __device__ __forceinline__ int64_t sload64(const int64_t* p) {
     typedef const int64_t __attribute__((address_space(4))) * cptr;
     return *(cptr)(uintptr_t)p;
 }
+
+// the same through scalar loads (z is uniform over the block)
+__device__ __forceinline__ int64_t zoffA_s(const StepArgs& p) { const int64_t z = zid(p); return sload64(p.soffA + z * p.zsA) + z * p.zA; }
+__device__ __forceinline__ int64_t zoffB_s(const StepArgs& p) { const int64_t z = zid(p); return sload64(p.soffB + z * p.zsB) + z * p.zB; }
+__device__ __forceinline__ int64_t zoffC_s(const StepArgs& p) { const int64_t z = zid(p); return sload64(p.soffC + z * p.zsC) + z * p.zC; }
 
 __device__ __forceinline__ void split_k(const StepArgs& p, int64_t k, int64_t& hi, int64_t& lo) {
     if (p.k_lo_shift >= 0) {
@@ -239,7 +259,29 @@ struct MfmaHints {
     int fast;        // 1: full tiles + tile-additive 32-bit offsets (tiled fast path)
     const void* lane;  // fast path: per-thread gather / staging constants, built once per
                        // executor (launch_fast_lane_consts); null: computed by every block
+    int splitk;        // tiled kernels: number of k-splits (>= 1), fixed when the executor is
+                       // built -- a function of the step alone, so that a result does not
+                       // depend on how many slices share a launch or on the tile width
 };
+
+// k-splits of a tiled step: when the output alone cannot fill the chip but K is long
+// (slabs of the partial tiles go through `scratch_bytes` of scratch memory)
+inline int64_t mfma_split_count(int64_t R, int64_t N, int64_t K, int64_t Bt, int bn, int64_t scratch_bytes) {
+    const int64_t tiles_m = (R + MFMA_BM - 1) / MFMA_BM, tiles_n = (N + bn - 1) / bn;
+    const int64_t tiles = tiles_m * tiles_n * Bt;
+    const int64_t nk_total = (K + MFMA_BK - 1) / MFMA_BK;
+    int64_t S = 1;
+    if ((tiles < 256 && nk_total >= 16) || (tiles < 512 && nk_total >= 64)) {
+        S = (1024 + tiles - 1) / tiles;
+        if (S > nk_total / 4) S = nk_total / 4;
+        const int64_t slab_bytes = tiles_m * MFMA_BM * tiles_n * bn * 8 * Bt;
+        if (S * slab_bytes > scratch_bytes) S = scratch_bytes / slab_bytes;
+        if (S > 65535) S = 65535;
+        if (S < 1) S = 1;
+    }
+    if (S > nk_total) S = nk_total;
+    return S;
+}
 
 // steps the streaming kernel takes: short contraction, few columns, many rows
 inline bool mfma_use_stream(int64_t R, int64_t Bt, int64_t K, int64_t N) {
@@ -264,6 +306,21 @@ struct StripState {
     int32_t zero;   // a zero intermediate was met (check_zero)
     int32_t pad;
 };
+
+// A launcher whose kernel cannot carry the slices of a batch in gridDim.y (it
+// owns scratch memory, or its grid is persistent) runs them one after another.
+template <typename F>
+inline hipError_t for_each_z(const StepArgs& p, F launch_one) {
+    if (p.nz <= 1) return launch_one(p);
+    for (int z = 0; z < p.nz; ++z) {
+        StepArgs q = p;
+        q.z0 = p.z0 + z;
+        q.nz = 1;
+        const hipError_t e = launch_one(q);
+        if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
+}
 
 // ---- launchers implemented in the kernel translation units ---------------- //
 
@@ -300,8 +357,9 @@ struct SliceMeta {
 // soff[n_leaves] receives the per-leaf base offsets of slice `sid`; with sid < 0
 // the id is taken from the device counter state[0], which is then advanced by
 // state[1] (lets a captured graph walk over slices without host involvement)
+// (nz > 1: the offsets of slices sid, sid + stride, ... in soff[z * n_leaves + leaf])
 hipError_t launch_prologue(const SliceMeta& m, int64_t* state, int64_t* soff, int64_t sid,
-                           hipStream_t stream);
+                           hipStream_t stream, int nz = 1, int64_t stride = 1);
 // state[0] = next, state[1] = stride (device-side slice counter of a graph replay)
 hipError_t launch_set_state(int64_t* state, int64_t next, int64_t stride, hipStream_t stream);
 

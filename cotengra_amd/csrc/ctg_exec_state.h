@@ -41,8 +41,16 @@ struct ctg_exec {
     ctg::SliceMeta meta{};
     std::vector<ctg::StepArgs> args;  // resolved per step
     std::vector<ctg::MfmaHints> hints;  // per step kernel hints (MFMA steps)
+    // the same for launches that carry several slices (batch > 1): wider column tiles
+    // where one slice alone would not fill the chip; same k-splits, same kernels otherwise
+    std::vector<ctg::MfmaHints> hints_b;
+    uint16_t* d_ord_b = nullptr;
+    char* d_lane_b = nullptr;
     uint16_t* d_ord = nullptr;     // order tables of all MFMA steps
     char* d_lane = nullptr;        // lane-constant tables of the fast tiled steps
+    // slice batching: up to `batch` slices of a run share every launch (gridDim.y);
+    // the arena holds `batch` replicas of itself, d_soff `batch` rows of leaf offsets
+    int batch = 1;
     std::vector<hipEvent_t> events;
     // slice graph: the launch sequence of one slice captured once and replayed,
     // the slice id advancing on the device (prologue kernel)

@@ -27,9 +27,9 @@ namespace ctg {
 template <typename T>
 __global__ __launch_bounds__(256) void pair_valu_kernel(StepArgs p, int tn_shift,
                                                         int64_t col_tiles, int64_t n_tiles) {
-    const T* __restrict__ A = (const T*)p.A + *p.soffA;
-    const T* __restrict__ B = (const T*)p.B + *p.soffB;
-    T* __restrict__ C = (T*)p.C + *p.soffC;
+    const T* __restrict__ A = (const T*)p.A + zoffA(p);
+    const T* __restrict__ B = (const T*)p.B + zoffB(p);
+    T* __restrict__ C = (T*)p.C + zoffC(p);
     const double alpha = step_alpha(p);
     const int TN = 1 << tn_shift;
     const int TR = 256 >> tn_shift;
@@ -66,8 +66,8 @@ __global__ __launch_bounds__(256) void pair_valu_kernel(StepArgs p, int tn_shift
 template <typename T>
 __global__ __launch_bounds__(256) void pair_kred_kernel(StepArgs p, int64_t G, int64_t chunk,
                                                         T* __restrict__ partial) {
-    const T* __restrict__ A = (const T*)p.A + *p.soffA;
-    const T* __restrict__ B = (const T*)p.B + *p.soffB;
+    const T* __restrict__ A = (const T*)p.A + zoffA(p);
+    const T* __restrict__ B = (const T*)p.B + zoffB(p);
     const int lane = threadIdx.x & 63;
     const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     const int64_t n_waves = (int64_t)gridDim.x * 4;
@@ -91,14 +91,14 @@ __global__ __launch_bounds__(256) void pair_kred_kernel(StepArgs p, int64_t G, i
             fma_acc(acc, a[p.kA.hi[kh] + p.kA.lo[kl]], b[p.kB.hi[kh] + p.kB.lo[kl]]);
         }
         acc = wave_sum(acc);
-        if (lane == 0) partial[w] = acc;
+        if (lane == 0) partial[(int64_t)blockIdx.y * items + w] = acc;   // (scratch per slice of this launch)
     }
 }
 
 template <typename T>
 __global__ __launch_bounds__(256) void pair_kred_finish_kernel(StepArgs p, int64_t G,
                                                                const T* __restrict__ partial) {
-    T* __restrict__ C = (T*)p.C + *p.soffC;
+    T* __restrict__ C = (T*)p.C + zoffC(p);
     const double alpha = step_alpha(p);
     const int64_t outs = p.R * p.N;
     for (int64_t o = (int64_t)blockIdx.x * 256 + threadIdx.x; o < outs;
@@ -106,7 +106,7 @@ __global__ __launch_bounds__(256) void pair_kred_finish_kernel(StepArgs p, int64
         const int64_t row = o / p.N;
         const int64_t n = o - row * p.N;
         T acc = zero_of(T{});
-        for (int64_t g = 0; g < G; ++g) acc = add_of(acc, partial[o * G + g]);
+        for (int64_t g = 0; g < G; ++g) acc = add_of(acc, partial[((int64_t)blockIdx.y * outs + o) * G + g]);
         int64_t hi, lo;
         split_row(p, row, hi, lo);
         C[p.rowC.hi[hi] + p.rowC.lo[lo] + p.nC[n]] = scale_of(acc, alpha);
@@ -119,6 +119,7 @@ static hipError_t launch_pair_valu_t(const StepArgs& p, void* scratch, int64_t s
     const int64_t outs = p.R * p.N;
     // few outputs, long contraction -> lanes along k
     if (p.K >= 256 && outs <= (1 << 15)) {
+
         // k per work item: long enough to keep the partial-sum traffic low, short
         // enough that a handful of outputs still spreads over the whole chip
         // (at most 256 partials per output: the finish pass adds them serially)
@@ -135,13 +136,17 @@ static hipError_t launch_pair_valu_t(const StepArgs& p, void* scratch, int64_t s
             chunk = (chunk + 63) / 64 * 64;
             G = (p.K + chunk - 1) / chunk;
             const int64_t items = outs * G;
+            // (G is a function of the step alone; the partial sums of every slice of a
+            // batch must fit the scratch buffer, else the slices go one by one)
+            if (p.nz > 1 && items * (int64_t)sizeof(T) * p.nz > scratch_bytes)
+                return for_each_z(p, [&](const StepArgs& q) { return launch_pair_valu_t<T>(q, scratch, scratch_bytes, stream); });
             int64_t blocks = (items + 3) / 4;
             if (blocks > 8192) blocks = 8192;
-            hipLaunchKernelGGL(pair_kred_kernel<T>, dim3((unsigned)blocks), dim3(256), 0, stream, p,
+            hipLaunchKernelGGL(pair_kred_kernel<T>, dim3((unsigned)blocks, (unsigned)p.nz), dim3(256), 0, stream, p,
                                G, chunk, (T*)scratch);
             int64_t fblocks = (outs + 255) / 256;
             if (fblocks > 4096) fblocks = 4096;
-            hipLaunchKernelGGL(pair_kred_finish_kernel<T>, dim3((unsigned)fblocks), dim3(256), 0,
+            hipLaunchKernelGGL(pair_kred_finish_kernel<T>, dim3((unsigned)fblocks, (unsigned)p.nz), dim3(256), 0,
                                stream, p, G, (const T*)scratch);
             return hipGetLastError();
         }
@@ -155,8 +160,9 @@ static hipError_t launch_pair_valu_t(const StepArgs& p, void* scratch, int64_t s
     int64_t blocks = n_tiles;
     if (blocks > (1 << 20)) blocks = 1 << 20;
     if (blocks < 1) blocks = 1;
-    hipLaunchKernelGGL(pair_valu_kernel<T>, dim3((unsigned)blocks), dim3(256), 0, stream, p, tn_shift,
-                       col_tiles, n_tiles);
+    if (blocks * p.nz > (1 << 20)) blocks = (1 << 20) / p.nz;
+    hipLaunchKernelGGL(pair_valu_kernel<T>, dim3((unsigned)blocks, (unsigned)p.nz), dim3(256), 0, stream, p,
+                       tn_shift, col_tiles, n_tiles);
     return hipGetLastError();
 }
 
@@ -177,8 +183,8 @@ hipError_t launch_pair_valu(int dtype, const StepArgs& p, void* scratch, int64_t
 
 template <typename T>
 __global__ __launch_bounds__(256) void single_kernel(StepArgs p) {
-    const T* __restrict__ A = (const T*)p.A + *p.soffA;
-    T* __restrict__ C = (T*)p.C + *p.soffC;
+    const T* __restrict__ A = (const T*)p.A + zoffA(p);
+    T* __restrict__ C = (T*)p.C + zoffC(p);
     for (int64_t row = (int64_t)blockIdx.x * 256 + threadIdx.x; row < p.R;
          row += (int64_t)gridDim.x * 256) {
         int64_t hi, lo;
@@ -197,8 +203,8 @@ __global__ __launch_bounds__(256) void single_kernel(StepArgs p) {
 // traces): lanes along the summed group + wavefront reduction
 template <typename T>
 __global__ __launch_bounds__(256) void single_wave_kernel(StepArgs p) {
-    const T* __restrict__ A = (const T*)p.A + *p.soffA;
-    T* __restrict__ C = (T*)p.C + *p.soffC;
+    const T* __restrict__ A = (const T*)p.A + zoffA(p);
+    T* __restrict__ C = (T*)p.C + zoffC(p);
     const int lane = threadIdx.x & 63;
     const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     for (int64_t row = wave; row < p.R; row += (int64_t)gridDim.x * 4) {
@@ -221,13 +227,13 @@ static hipError_t launch_single_t(const StepArgs& p, hipStream_t stream) {
     if (p.K >= 256 && p.R <= (1 << 14)) {
         int64_t blocks = (p.R + 3) / 4;
         if (blocks < 1) blocks = 1;
-        hipLaunchKernelGGL(single_wave_kernel<T>, dim3((unsigned)blocks), dim3(256), 0, stream, p);
+        hipLaunchKernelGGL(single_wave_kernel<T>, dim3((unsigned)blocks, (unsigned)p.nz), dim3(256), 0, stream, p);
         return hipGetLastError();
     }
     int64_t blocks = (p.R + 255) / 256;
-    if (blocks > (1 << 20)) blocks = 1 << 20;
+    if (blocks * p.nz > (1 << 20)) blocks = (1 << 20) / p.nz;
     if (blocks < 1) blocks = 1;
-    hipLaunchKernelGGL(single_kernel<T>, dim3((unsigned)blocks), dim3(256), 0, stream, p);
+    hipLaunchKernelGGL(single_kernel<T>, dim3((unsigned)blocks, (unsigned)p.nz), dim3(256), 0, stream, p);
     return hipGetLastError();
 }
 
@@ -245,18 +251,22 @@ hipError_t launch_single(int dtype, const StepArgs& p, hipStream_t stream) {
 // accumulate a slice into the result tensor
 // ------------------------------------------------------------------------- //
 
+// The slices of a batch are added one after another by the same thread, in slice
+// order: the sum is formed exactly as by one launch per slice (the left fold of
+// gather_slices, core.py:3842-3844), whichever way the slices were batched.
 template <typename T>
 __global__ __launch_bounds__(256) void accum_kernel(StepArgs p, const StripState* st) {
-    const T* __restrict__ A = (const T*)p.A + *p.soffA;
-    T* __restrict__ C = (T*)p.C + *p.soffC;
     const double coef = st ? st->coefm : 1.0;
     for (int64_t row = (int64_t)blockIdx.x * 256 + threadIdx.x; row < p.R;
          row += (int64_t)gridDim.x * 256) {
         int64_t hi, lo;
         split_row(p, row, hi, lo);
-        T* c = C + p.rowC.hi[hi] + p.rowC.lo[lo];
-        const T a = A[p.rowA.hi[hi] + p.rowA.lo[lo]];
-        *c = add_of(*c, st ? scale_of(a, coef) : a);
+        const int64_t ra = p.rowA.hi[hi] + p.rowA.lo[lo], rc = p.rowC.hi[hi] + p.rowC.lo[lo];
+        for (int64_t z = p.z0; z < p.z0 + p.nz; ++z) {
+            const T a = ((const T*)p.A + p.soffA[z * p.zsA] + z * p.zA)[ra];
+            T* c = (T*)p.C + p.soffC[z * p.zsC] + z * p.zC + rc;
+            *c = add_of(*c, st ? scale_of(a, coef) : a);
+        }
     }
 }
 
@@ -374,10 +384,12 @@ hipError_t launch_rescale(int dtype, void* result, int64_t n, const StripState* 
 // ------------------------------------------------------------------------- //
 
 __global__ __launch_bounds__(256) void prologue_kernel(SliceMeta m, int64_t* state, int64_t* soff,
-                                                       int64_t sid_arg) {
-    const int64_t sid = sid_arg >= 0 ? sid_arg : state[0];
-    for (int64_t leaf = threadIdx.x; leaf < m.n_leaves; leaf += blockDim.x) {
-        int64_t rem = sid;
+                                                       int64_t sid_arg, int nz, int64_t stride) {
+    // slices sid, sid + stride, ... (nz of them): soff[z * n_leaves + leaf]
+    const int64_t sid0 = sid_arg >= 0 ? sid_arg : state[0];
+    for (int64_t w = threadIdx.x; w < m.n_leaves * nz; w += blockDim.x) {
+        const int64_t z = w / m.n_leaves, leaf = w - z * m.n_leaves;
+        int64_t rem = sid0 + z * stride;
         int64_t off = 0;
         const int64_t* st = m.strides + leaf * m.n_sliced;
         for (int64_t j = m.n_sliced - 1; j >= 0; --j) {
@@ -392,13 +404,13 @@ __global__ __launch_bounds__(256) void prologue_kernel(SliceMeta m, int64_t* sta
             }
             off += digit * st[j];
         }
-        soff[leaf] = off;
+        soff[w] = off;
     }
     if (m.fac)
         for (int64_t i = threadIdx.x; i < m.n_fac; i += blockDim.x)
             if (m.fac_zero[i]) m.fac[i] = 0.0;
     __syncthreads();
-    if (threadIdx.x == 0 && sid_arg < 0) state[0] = sid + state[1];
+    if (threadIdx.x == 0 && sid_arg < 0) state[0] = sid0 + state[1];
 }
 
 __global__ void set_state_kernel(int64_t* state, int64_t next, int64_t stride) {
@@ -412,8 +424,8 @@ hipError_t launch_set_state(int64_t* state, int64_t next, int64_t stride, hipStr
 }
 
 hipError_t launch_prologue(const SliceMeta& m, int64_t* state, int64_t* soff, int64_t sid,
-                           hipStream_t stream) {
-    hipLaunchKernelGGL(prologue_kernel, dim3(1), dim3(256), 0, stream, m, state, soff, sid);
+                           hipStream_t stream, int nz, int64_t stride) {
+    hipLaunchKernelGGL(prologue_kernel, dim3(1), dim3(256), 0, stream, m, state, soff, sid, nz, stride);
     return hipGetLastError();
 }
 

@@ -154,7 +154,9 @@ __global__ __launch_bounds__(256, 2) void pair_mfma_c64_kernel(StepArgs p, MfmaH
     const int wm = wave / WN, wn = wave % WN;
 
     const int64_t S_split = k_chunk;  // number of k-splits (1 = none)
-    const TileMap tmap = map_tile(blockIdx.x, tiles_m * S_split, tiles_n);
+    // (slices of a batch rotate the XCD their patches go to: a small step whose tiles
+    // make up a single patch would otherwise put every slice on XCD 0)
+    const TileMap tmap = map_tile((blockIdx.x & ~7u) | ((blockIdx.x + blockIdx.y) & 7u), tiles_m * S_split, tiles_n);
     if (!tmap.valid) return;
     const int64_t tn = tmap.tn;
     const int64_t tm = tmap.unit % tiles_m;
@@ -162,9 +164,9 @@ __global__ __launch_bounds__(256, 2) void pair_mfma_c64_kernel(StepArgs p, MfmaH
     const int64_t m0 = tm * BM, n0 = tn * BN;
     const int64_t bz = blockIdx.z;
 
-    const c64* __restrict__ A = (const c64*)p.A + *p.soffA + p.bA[bz];
-    const c64* __restrict__ B = (const c64*)p.B + *p.soffB + p.bB[bz];
-    float* __restrict__ C = (float*)((c64*)p.C + *p.soffC + p.bC[bz]);
+    const c64* __restrict__ A = (const c64*)p.A + zoffA(p) + p.bA[bz];
+    const c64* __restrict__ B = (const c64*)p.B + zoffB(p) + p.bB[bz];
+    float* __restrict__ C = (float*)((c64*)p.C + zoffC(p) + p.bC[bz]);
 
     // split-K: the k-steps are dealt out cyclically -- block y of S takes steps
     // y, y+S, y+2S, ... -- so that the blocks running at the same time sweep
@@ -351,7 +353,9 @@ __global__ __launch_bounds__(256, 2) void pair_mfma_c64_kernel(StepArgs p, MfmaH
     if (partial != nullptr) {
         // dense fp32 slab [batch][split][tiles_m*BM][2*tiles_n*BN]
         const int64_t ldp = 2 * tiles_n * BN;
-        float* slab = partial + ((bz * S_split + ksplit) * (tiles_m * BM)) * ldp;
+        // (slice-in-batch z owns its own set of slabs: gridDim.z * S_split of them)
+        // (scratch is divided among the slices of THIS launch: blockIdx.y, not z0 + blockIdx.y)
+        float* slab = partial + ((((int64_t)blockIdx.y * gridDim.z + bz) * S_split + ksplit) * (tiles_m * BM)) * ldp;
 #pragma unroll
         for (int j = 0; j < Cfg::FN; ++j) {
             const int64_t col = 2 * (n0 + wn * Cfg::WTN + j * 16) + l31;
@@ -521,7 +525,9 @@ __global__ __launch_bounds__(256, Cfg::FAST_BLOCKS) void pair_mfma_fast_kernel(S
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WN, wn = wave % WN;
     const int64_t S_split = k_chunk;
-    const TileMap tmap = map_tile(blockIdx.x, tiles_m * S_split, tiles_n);
+    // (slices of a batch rotate the XCD their patches go to: a small step whose tiles
+    // make up a single patch would otherwise put every slice on XCD 0)
+    const TileMap tmap = map_tile((blockIdx.x & ~7u) | ((blockIdx.x + blockIdx.y) & 7u), tiles_m * S_split, tiles_n);
     if (!tmap.valid) return;
     const int64_t bz = blockIdx.z;
     // (64-bit divisions run on the vector ALU: results go back to scalar registers)
@@ -535,10 +541,10 @@ __global__ __launch_bounds__(256, Cfg::FAST_BLOCKS) void pair_mfma_fast_kernel(S
     split_row(p, m0, rhi, rlo);
     rhi = uniform64(rhi);
     rlo = uniform64(rlo);
-    const c64* __restrict__ A = (const c64*)p.A + sload64(p.soffA) + sload64(p.bA + bz) +
+    const c64* __restrict__ A = (const c64*)p.A + zoffA_s(p) + sload64(p.bA + bz) +
                                 sload64(p.rowA.hi + rhi) + sload64(p.rowA.lo + rlo);
-    const c64* __restrict__ B = (const c64*)p.B + sload64(p.soffB) + sload64(p.bB + bz) + sload64(p.nB + n0);
-    float* __restrict__ C = (float*)((c64*)p.C + sload64(p.soffC) + sload64(p.bC + bz) +
+    const c64* __restrict__ B = (const c64*)p.B + zoffB_s(p) + sload64(p.bB + bz) + sload64(p.nB + n0);
+    float* __restrict__ C = (float*)((c64*)p.C + zoffC_s(p) + sload64(p.bC + bz) +
                                      sload64(p.rowC.hi + rhi) + sload64(p.rowC.lo + rlo) + sload64(p.nC + n0));
 
     // split-K: cyclic distribution of the k-steps over the k-split units (see
@@ -766,7 +772,9 @@ __global__ __launch_bounds__(256, Cfg::FAST_BLOCKS) void pair_mfma_fast_kernel(S
     CTG_STAMP(T3);
     if (partial != nullptr) {
         const int64_t ldp = 2 * tiles_n * BN;
-        float* slab = partial + ((bz * S_split + ksplit) * (tiles_m * BM)) * ldp;
+        // (slice-in-batch z owns its own set of slabs: gridDim.z * S_split of them)
+        // (scratch is divided among the slices of THIS launch: blockIdx.y, not z0 + blockIdx.y)
+        float* slab = partial + ((((int64_t)blockIdx.y * gridDim.z + bz) * S_split + ksplit) * (tiles_m * BM)) * ldp;
 #pragma unroll
         for (int j = 0; j < Cfg::FN; ++j) {
             const int64_t col = 2 * (n0 + wn * Cfg::WTN + j * 16) + l31;
@@ -836,7 +844,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(StepArgs p, int64_t 
             const int64_t rem = o - b * per_b;
             m = rem / p.N;
             n = rem - m * p.N;
-            const float* src = partial + (b * S * Mpad + m) * ldp + 2 * n;
+            const float* src = partial + (((int64_t)blockIdx.y * p.Bt + b) * S * Mpad + m) * ldp + 2 * n;
             const int64_t slab = Mpad * ldp;
 #pragma unroll 8
             for (int64_t s = sy; s < S; s += 8) {
@@ -856,7 +864,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(StepArgs p, int64_t 
             }
             int64_t hi, lo;
             split_row(p, m, hi, lo);
-            c64* C = (c64*)p.C + *p.soffC + p.bC[b];
+            c64* C = (c64*)p.C + zoffC(p) + p.bC[b];
             C[p.rowC.hi[hi] + p.rowC.lo[lo] + p.nC[n]] = c64{r2 * alpha, i2 * alpha};
         }
         __syncthreads();
@@ -869,23 +877,21 @@ static hipError_t launch_cfg(const StepArgs& p, const MfmaHints& h, void* scratc
     constexpr int BM = Cfg::BM, BN = Cfg::BN, BK = Cfg::BK;
     const int64_t tiles_m = (p.R + BM - 1) / BM;
     const int64_t tiles_n = (p.N + BN - 1) / BN;
-    // split-K when the output alone cannot fill the chip but K is long
-    const int64_t tiles = tiles_m * tiles_n * p.Bt;
+    // split-K when the output alone cannot fill the chip but K is long: decided once per
+    // step when the executor is built (MfmaHints::splitk)
     const int64_t nk_total = (p.K + BK - 1) / BK;
-    int64_t S = 1;
-    if ((tiles < 256 && nk_total >= 16) || (tiles < 512 && nk_total >= 64)) {
-        S = (1024 + tiles - 1) / tiles;
-        if (S > nk_total / 4) S = nk_total / 4;
-        const int64_t slab_bytes = tiles_m * BM * tiles_n * BN * 8 * p.Bt;
-        if (S * slab_bytes > scratch_bytes) S = scratch_bytes / slab_bytes;
-        if (S > 65535) S = 65535;
-        if (S < 1) S = 1;
-    }
+    int64_t S = h.splitk > 0 ? h.splitk : mfma_split_count(p.R, p.N, p.K, p.Bt, BN, scratch_bytes);
     if (S > nk_total) S = nk_total;
+    if (S > 1 && S * (tiles_m * BM * tiles_n * BN * 8 * p.Bt) > scratch_bytes) return hipErrorInvalidValue;
+    // (the split depends on the step alone, never on how many slices a launch
+    // carries: a result must not depend on the batching of a run)
+    if (S > 1 && p.nz > 1 &&   // the slabs of every slice of the batch must fit the scratch buffer
+        S * (tiles_m * BM * tiles_n * BN * 8 * p.Bt) * p.nz > scratch_bytes)
+        return for_each_z(p, [&](const StepArgs& q) { return launch_cfg<Cfg>(q, h, scratch, scratch_bytes, stream); });
     const int64_t k_chunk = S;  // the kernels' k_chunk argument carries the split count
     const int64_t gx = tile_grid_blocks(tiles_m * S, tiles_n);
-    if (gx > 0x7fffffffll) return hipErrorInvalidValue;
-    const dim3 grid((unsigned)gx, 1, (unsigned)p.Bt);
+    if (gx > 0x7fffffffll || p.nz > 65535) return hipErrorInvalidValue;
+    const dim3 grid((unsigned)gx, (unsigned)p.nz, (unsigned)p.Bt);
     float* part = S > 1 ? (float*)scratch : (float*)nullptr;
     if (h.fast) {
         if (h.vecA)
@@ -905,7 +911,7 @@ static hipError_t launch_cfg(const StepArgs& p, const MfmaHints& h, void* scratc
     if (S > 1) {
         int64_t blocks = (p.R * p.N * p.Bt + 31) / 32;
         if (blocks > 8192) blocks = 8192;
-        hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, p, S,
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)blocks, (unsigned)p.nz), dim3(256), 0, stream, p, S,
                            tiles_m * BM, 2 * tiles_n * BN, (const float*)scratch);
     }
     return hipGetLastError();
@@ -973,9 +979,9 @@ __global__ __launch_bounds__(256, (FN == 1 ? 4 : FN == 2 ? CTG_STREAM_OCC2 : CTG
     const int l31 = lane & 31;
     const bool odd = lane & 1;
 
-    const c64* __restrict__ A = (const c64*)p.A + *p.soffA;
-    const c64* __restrict__ B = (const c64*)p.B + *p.soffB;
-    float* __restrict__ C = (float*)((c64*)p.C + *p.soffC);
+    const c64* __restrict__ A = (const c64*)p.A + zoffA(p);
+    const c64* __restrict__ B = (const c64*)p.B + zoffB(p);
+    float* __restrict__ C = (float*)((c64*)p.C + zoffC(p));
 
     // ---- B and the k offsets of A into LDS (once per block) -----------------
     for (int e = tid; e < KP * 16 * FN; e += 256) {
@@ -1369,7 +1375,10 @@ static hipError_t launch_stream_t(const StepArgs& p, const MfmaHints& h, int KP,
     int64_t blocks = (n_groups + 3) / 4;
     const int64_t cap = 256ll * bpc;  // persistent: exactly the resident blocks
     if (blocks > cap) blocks = cap;
-    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), smem, stream, p, h, KP, n_groups);
+    // the slices of a batch divide the resident blocks among themselves (every block
+    // strides over the row groups of its slice, whatever their number)
+    if (p.nz > 1 && blocks * p.nz > cap) blocks = cap / p.nz > 0 ? cap / p.nz : 1;
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks, (unsigned)p.nz), dim3(256), smem, stream, p, h, KP, n_groups);
     return hipGetLastError();
 }
 
@@ -1426,8 +1435,8 @@ __global__ __launch_bounds__(256, 3) void pair_mfma_kstream_kernel(StepArgs p, M
     float* As = lds + wave * (A_FL + B_FL);
     float* Bs = As + A_FL;
 
-    const c64* __restrict__ A = (const c64*)p.A + sload64(p.soffA) + sload64(p.rowA.hi);
-    const c64* __restrict__ B = (const c64*)p.B + sload64(p.soffB);
+    const c64* __restrict__ A = (const c64*)p.A + zoffA_s(p) + sload64(p.rowA.hi);
+    const c64* __restrict__ B = (const c64*)p.B + zoffB_s(p);
 
     // per-lane constants: LDS slot and 32-bit offset of every element this lane moves
     int a_lds[PA], b_lds[PB];
@@ -1549,6 +1558,8 @@ __global__ __launch_bounds__(256, 3) void pair_mfma_kstream_kernel(StepArgs p, M
 template <int FN>
 static hipError_t launch_kstream(const StepArgs& p, const MfmaHints& h, void* scratch,
                                  int64_t scratch_bytes, hipStream_t stream) {
+    if (p.nz > 1)  // (per-wave partial tiles live in the one scratch buffer)
+        return for_each_z(p, [&](const StepArgs& q) { return launch_kstream<FN>(q, h, scratch, scratch_bytes, stream); });
     const int64_t n_chunks = p.K / MFMA_BK;
     int64_t blocks = 256 * 3;                       // resident: 3 blocks per CU
     // at least 8 chunks per wave: every wave costs a slab in the final reduction
@@ -1579,9 +1590,9 @@ static hipError_t launch_kstream(const StepArgs& p, const MfmaHints& h, void* sc
 // ------------------------------------------------------------------------- //
 template <int KU, int NN>
 __global__ __launch_bounds__(256) void pair_skinny_kernel(StepArgs p) {
-    const c64* __restrict__ A = (const c64*)p.A + sload64(p.soffA);
-    const c64* __restrict__ B = (const c64*)p.B + sload64(p.soffB);
-    c64* __restrict__ C = (c64*)p.C + sload64(p.soffC);
+    const c64* __restrict__ A = (const c64*)p.A + zoffA_s(p);
+    const c64* __restrict__ B = (const c64*)p.B + zoffB_s(p);
+    c64* __restrict__ C = (c64*)p.C + zoffC_s(p);
     // row offsets: two table lookups per thread (vector loads), issued first
     const int64_t row = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 2;
     if (row >= p.R) return;
@@ -1641,8 +1652,8 @@ __global__ __launch_bounds__(256) void pair_skinny_kernel(StepArgs p) {
 template <int KU, int NN>
 static hipError_t launch_skinny_t(const StepArgs& p, hipStream_t stream) {
     const int64_t blocks = (p.R / 2 + 255) / 256;
-    if (blocks > 0x7fffffffll) return hipErrorInvalidValue;
-    hipLaunchKernelGGL((pair_skinny_kernel<KU, NN>), dim3((unsigned)blocks), dim3(256), 0, stream, p);
+    if (blocks > 0x7fffffffll || p.nz > 65535) return hipErrorInvalidValue;
+    hipLaunchKernelGGL((pair_skinny_kernel<KU, NN>), dim3((unsigned)blocks, (unsigned)p.nz), dim3(256), 0, stream, p);
     return hipGetLastError();
 }
 

@@ -59,9 +59,9 @@ __global__ __launch_bounds__(256, 2) void pair_mfma_c128_kernel(StepArgs p, int 
     const int64_t m0 = tm * BM, n0 = tn * BN;
     const int64_t bz = blockIdx.z;
 
-    const c128* __restrict__ A = (const c128*)p.A + *p.soffA + p.bA[bz];
-    const c128* __restrict__ B = (const c128*)p.B + *p.soffB + p.bB[bz];
-    double* __restrict__ C = (double*)((c128*)p.C + *p.soffC + p.bC[bz]);
+    const c128* __restrict__ A = (const c128*)p.A + zoffA(p) + p.bA[bz];
+    const c128* __restrict__ B = (const c128*)p.B + zoffB(p) + p.bB[bz];
+    double* __restrict__ C = (double*)((c128*)p.C + zoffC(p) + p.bC[bz]);
     const bool a_kfast = flags & 1, b_kfast = flags & 2;
     const int64_t nk = (p.K + BK - 1) / BK;
 
@@ -246,9 +246,9 @@ static hipError_t launch_c128_t(const StepArgs& p, int flags, hipStream_t stream
     const int64_t tiles_m = (p.R + BM - 1) / BM;
     const int64_t tiles_n = (p.N + BN - 1) / BN;
     const int64_t gx = ((tiles_m + 7) / 8) * 8 * tiles_n;
-    if (gx > 0x7fffffffll || p.Bt > 65535) return hipErrorInvalidValue;
-    hipLaunchKernelGGL((pair_mfma_c128_kernel<TM, TN>), dim3((unsigned)gx, 1, (unsigned)p.Bt), dim3(256), 0,
-                       stream, p, flags, tiles_m, tiles_n);
+    if (gx > 0x7fffffffll || p.Bt > 65535 || p.nz > 65535) return hipErrorInvalidValue;
+    hipLaunchKernelGGL((pair_mfma_c128_kernel<TM, TN>), dim3((unsigned)gx, (unsigned)p.nz, (unsigned)p.Bt),
+                       dim3(256), 0, stream, p, flags, tiles_m, tiles_n);
     return hipGetLastError();
 }
 
@@ -320,9 +320,9 @@ __global__ __launch_bounds__(256, 2) void pair_mfma_real_kernel(StepArgs p, int 
     const int64_t m0 = tm * RBM, n0 = tn * RBN;
     const int64_t bz = blockIdx.z;
 
-    const T* __restrict__ A = (const T*)p.A + *p.soffA + p.bA[bz];
-    const T* __restrict__ B = (const T*)p.B + *p.soffB + p.bB[bz];
-    T* __restrict__ C = (T*)p.C + *p.soffC + p.bC[bz];
+    const T* __restrict__ A = (const T*)p.A + zoffA(p) + p.bA[bz];
+    const T* __restrict__ B = (const T*)p.B + zoffB(p) + p.bB[bz];
+    T* __restrict__ C = (T*)p.C + zoffC(p) + p.bC[bz];
     const bool a_kfast = flags & 1, b_kfast = flags & 2;
     const int64_t nk = (p.K + RBK - 1) / RBK;
 
@@ -486,8 +486,8 @@ static hipError_t launch_real_t(const StepArgs& p, int flags, hipStream_t stream
     const int64_t tiles_m = (p.R + RBM - 1) / RBM;
     const int64_t tiles_n = (p.N + RBN - 1) / RBN;
     const int64_t gx = ((tiles_m + 7) / 8) * 8 * tiles_n;
-    if (gx > 0x7fffffffll || p.Bt > 65535) return hipErrorInvalidValue;
-    const dim3 grid((unsigned)gx, 1, (unsigned)p.Bt);
+    if (gx > 0x7fffffffll || p.Bt > 65535 || p.nz > 65535) return hipErrorInvalidValue;
+    const dim3 grid((unsigned)gx, (unsigned)p.nz, (unsigned)p.Bt);
     hipLaunchKernelGGL((pair_mfma_real_kernel<T, TM, TN>), grid, dim3(256), 0, stream, p, flags, tiles_m,
                        tiles_n);
     return hipGetLastError();

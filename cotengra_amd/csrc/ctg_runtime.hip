@@ -180,8 +180,21 @@ void resolve_args(ctg_exec* e) {
     // (hints depend on the plan only: kept when the arguments are re-resolved,
     // e.g. by ctg_exec_set_strip_exponent on a live executor)
     if ((int64_t)e->hints.size() != p->n_steps)
-        e->hints.assign(p->n_steps, MfmaHints{nullptr, nullptr, 0, 0, 0, 0, 0, nullptr});
+        e->hints.assign(p->n_steps, MfmaHints{nullptr, nullptr, 0, 0, 0, 0, 0, nullptr, 0});
     const int64_t* T = e->d_tables;
+    // arena ranges written by slice-invariant steps: never recycled, the same in every slice
+    std::vector<std::pair<int64_t, int64_t>> persistent;
+    for (int64_t s = 0; s < p->n_steps; ++s) {
+        const int64_t* r = &p->steps[s * STEP_WORDS];
+        if (r[W_INVARIANT] != 0 && r[W_KIND] != KIND_ACCUM && r[W_C_SPACE] == SPACE_ARENA)
+            persistent.emplace_back(r[W_C_OFF], r[W_C_OFF] + r[W_C_SIZE]);
+    }
+    auto per_slice = [&](int64_t space, int64_t off) -> int64_t {
+        if (space != SPACE_ARENA) return 0;
+        for (const auto& iv : persistent)
+            if (off >= iv.first && off < iv.second) return 0;
+        return p->arena_elems;
+    };
     for (int64_t s = 0; s < p->n_steps; ++s) {
         const int64_t* r = &p->steps[s * STEP_WORDS];
         StepArgs& a = e->args[s];
@@ -219,6 +232,16 @@ void resolve_args(ctg_exec* e) {
         a.bA = tab(W_BA);
         a.bB = tab(W_BB);
         a.bC = tab(W_BC);
+        // slice batching: per-slice operands step through the arena replicas and the
+        // rows of d_soff; inputs, slice-invariant intermediates and the result do not
+        a.nz = 1;
+        a.z0 = 0;
+        a.zA = per_slice(r[W_A_SPACE], r[W_A_OFF]);
+        a.zB = per_slice(r[W_B_SPACE], r[W_B_OFF]);
+        a.zC = per_slice(r[W_C_SPACE], r[W_C_OFF]);
+        a.zsA = r[W_A_LEAF] >= 0 ? p->n_inputs + 1 : 0;
+        a.zsB = r[W_B_LEAF] >= 0 ? p->n_inputs + 1 : 0;
+        a.zsC = r[W_C_LEAF] >= 0 ? p->n_inputs + 1 : 0;
         a.facA = a.facB = nullptr;
         a.check_zero = e->check_zero;
         if (e->strip && r[W_KIND] == KIND_PAIR) {
@@ -434,14 +457,18 @@ bool skinny_ok(const ctg_plan* p, const int64_t* r) {
     return true;
 }
 
-int build_hints(ctg_exec* e) {
+// zmult: how many slices a launch with these hints carries at most (1, or the
+// executor's batch size); `like`: hints already built for zmult = 1, whose k-splits
+// are kept
+int build_hints_into(ctg_exec* e, std::vector<MfmaHints>& hints, int64_t zmult,
+                     const std::vector<MfmaHints>* like, uint16_t** d_ord_out, char** d_lane_out) {
     const ctg_plan* p = e->plan;
     std::vector<uint16_t> blob;
     std::vector<size_t> offA(p->n_steps, 0), offB(p->n_steps, 0);
     for (int64_t s = 0; s < p->n_steps; ++s) {
         const int64_t* r = &p->steps[s * STEP_WORDS];
         if (r[W_KIND] != KIND_PAIR || r[W_KERNEL] != KERNEL_MFMA) continue;
-        MfmaHints& h = e->hints[s];
+        MfmaHints& h = hints[s];
         if (p->dtype != CTG_C64) {
             // FP64 / real kernels: only need to know which group holds each operand's
             // fastest-varying memory index (kept in h.vecA: bit0 A, bit1 B)
@@ -474,7 +501,8 @@ int build_hints(ctg_exec* e) {
         const int64_t splits = r[W_K] / MFMA_BK / 4;   // k-splits launch_cfg may use
         const int64_t tiles128 = ((r[W_R] + 127) / 128) * ((r[W_N] + 127) / 128) * r[W_BT];
         if (!h.stream && r[W_N] % 128 == 0 && r[W_K] >= 256 &&
-            (r[W_R] * r[W_N] >= (1ll << 22) || tiles128 * splits >= 1024) && mfma_fast_ok(p, r, 128))
+            (r[W_R] * r[W_N] * zmult >= (1ll << 22) || tiles128 * splits * zmult >= 1024) &&
+            mfma_fast_ok(p, r, 128))
             h.bn = 128;
         // small problems: narrower column tiles until the output alone gives every
         // CU a block -- cheaper than split-K (no slabs to write and reduce); long
@@ -482,7 +510,16 @@ int build_hints(ctg_exec* e) {
         if (!h.stream) {
             const int64_t tiles_m = (r[W_R] + MFMA_BM - 1) / MFMA_BM;
             const int64_t per_tile = r[W_K] >= 1024 ? splits : 1;
-            while (h.bn > 16 && tiles_m * ((r[W_N] + h.bn - 1) / h.bn) * r[W_BT] * per_tile < 256) h.bn /= 2;
+            while (h.bn > 16 && tiles_m * ((r[W_N] + h.bn - 1) / h.bn) * r[W_BT] * per_tile * zmult < 256)
+                h.bn /= 2;
+            // the number of k-splits belongs to the step: taken from the single-slice
+            // hints; a wider tile whose slabs would not fit the scratch is given up
+            h.splitk = (int)(like ? (*like)[s].splitk
+                                  : mfma_split_count(r[W_R], r[W_N], r[W_K], r[W_BT], h.bn, kScratchBytes));
+            if (like) {
+                const int64_t slab = tiles_m * MFMA_BM * ((r[W_N] + h.bn - 1) / h.bn) * h.bn * 8 * r[W_BT];
+                if ((int64_t)h.splitk * slab > kScratchBytes) h.bn = (*like)[s].bn;
+            }
         }
         h.additive32 = (h.stream && tile_additive(p, r[W_ROWA_LO], r[W_ROW_LO], r[W_R], 32) &&
                         tile_additive(p, r[W_ROWC_LO], r[W_ROW_LO], r[W_R], 32))
@@ -497,25 +534,25 @@ int build_hints(ctg_exec* e) {
         h.fast = (!h.stream && mfma_fast_ok(p, r, h.bn)) ? 1 : 0;
     }
     if (blob.empty()) return CTG_OK;
-    HIP_TRY(hipMalloc((void**)&e->d_ord, blob.size() * sizeof(uint16_t)));
-    HIP_TRY(hipMemcpy(e->d_ord, blob.data(), blob.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+    HIP_TRY(hipMalloc((void**)d_ord_out, blob.size() * sizeof(uint16_t)));
+    HIP_TRY(hipMemcpy(*d_ord_out, blob.data(), blob.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
     int64_t n_fast = 0;
     for (int64_t s = 0; s < p->n_steps; ++s) {
-        if (e->hints[s].bn == 0) continue;
-        e->hints[s].ordA = e->d_ord + offA[s];
-        e->hints[s].ordB = e->d_ord + offB[s];
-        if (e->hints[s].fast) ++n_fast;
+        if (hints[s].bn == 0) continue;
+        hints[s].ordA = *d_ord_out + offA[s];
+        hints[s].ordB = *d_ord_out + offB[s];
+        if (hints[s].fast) ++n_fast;
     }
     // lane-constant tables of the fast tiled steps: built on the device once, read by
     // every block of every launch (the tables they derive from never change)
     if (n_fast > 0 && getenv("CTG_NO_LANE_TABLES") == nullptr) {
         const int64_t each = fast_lane_table_bytes();
-        HIP_TRY(hipMalloc((void**)&e->d_lane, n_fast * each));
+        HIP_TRY(hipMalloc((void**)d_lane_out, n_fast * each));
         int64_t i = 0;
         for (int64_t s = 0; s < p->n_steps; ++s) {
-            MfmaHints& h = e->hints[s];
+            MfmaHints& h = hints[s];
             if (h.bn == 0 || !h.fast) continue;
-            void* out = e->d_lane + i * each;
+            void* out = *d_lane_out + i * each;
             ++i;
             hipError_t err = launch_fast_lane_consts(e->args[s], h, out, e->stream);
             if (err != hipSuccess)
@@ -525,6 +562,13 @@ int build_hints(ctg_exec* e) {
         }
     }
     return CTG_OK;
+}
+
+int build_hints(ctg_exec* e) {
+    int rc = build_hints_into(e, e->hints, 1, nullptr, &e->d_ord, &e->d_lane);
+    if (rc != CTG_OK || e->batch <= 1 || e->plan->dtype != CTG_C64) return rc;
+    e->hints_b.assign(e->plan->n_steps, MfmaHints{nullptr, nullptr, 0, 0, 0, 0, 0, nullptr, 0});
+    return build_hints_into(e, e->hints_b, e->batch, &e->hints, &e->d_ord_b, &e->d_lane_b);
 }
 
 int launch_step(ctg_exec* e, int64_t s, hipStream_t stream) {
@@ -550,8 +594,9 @@ int launch_step(ctg_exec* e, int64_t s, hipStream_t stream) {
             else if (r[W_KERNEL] == KERNEL_MFMA && p->dtype != CTG_C64)
                 err = launch_pair_mfma_real(p->dtype, e->args[s], e->hints[s].vecA, stream);
             else if (r[W_KERNEL] == KERNEL_MFMA)
-                err = launch_pair_mfma(p->dtype, e->args[s], e->hints[s], e->d_scratch, kScratchBytes,
-                                       stream);
+                err = launch_pair_mfma(p->dtype, e->args[s],
+                                       (e->args[s].nz > 1 && !e->hints_b.empty()) ? e->hints_b[s] : e->hints[s],
+                                       e->d_scratch, kScratchBytes, stream);
             else
                 err = launch_pair_valu(p->dtype, e->args[s], e->d_scratch, kScratchBytes, stream);
             break;
@@ -680,6 +725,8 @@ int ctg_exec_destroy(ctg_exec* e) {
     if (e->d_scratch) (void)hipFree(e->d_scratch);
     if (e->d_ord) (void)hipFree(e->d_ord);
     if (e->d_lane) (void)hipFree(e->d_lane);
+    if (e->d_ord_b) (void)hipFree(e->d_ord_b);
+    if (e->d_lane_b) (void)hipFree(e->d_lane_b);
     if (e->d_fac) (void)hipFree(e->d_fac);
     if (e->d_counted) (void)hipFree(e->d_counted);
     if (e->d_fac_zero) (void)hipFree(e->d_fac_zero);
@@ -713,8 +760,22 @@ int ctg_exec_create(const ctg_plan* p, int device, void* stream, void* ext_resul
             return bail(fail(_e == hipErrorOutOfMemory ? CTG_E_NOMEM : CTG_E_HIP, "%s failed: %s", \
                              #expr, hipGetErrorString(_e)));                                    \
     } while (0)
+    // Slice batching: small slices are launch-bound (a slice of the Sycamore m10 tree is
+    // 170 launches of a few microseconds), so up to `batch` slices of a run go through
+    // every launch together, each in its own replica of the arena.  Wide trees (one slice
+    // = tens of GiB) keep batch = 1.  CTG_SLICE_BATCH caps the count (1 = off),
+    // CTG_SLICE_BATCH_MIB the memory spent on replicas.
+    {
+        int64_t cap = 64, mib = 4096;
+        if (const char* v = getenv("CTG_SLICE_BATCH")) cap = atoll(v);
+        if (const char* v = getenv("CTG_SLICE_BATCH_MIB")) mib = atoll(v);
+        int64_t b = std::min<int64_t>(cap, p->nslices);
+        const int64_t per = std::max<int64_t>(p->arena_elems * isz, 1);
+        b = std::min<int64_t>(b, (mib << 20) / per);
+        e->batch = (int)std::max<int64_t>(b, 1);
+    }
     HIP_TRY_E(hipMalloc((void**)&e->d_inputs, p->inputs_elems * isz));
-    HIP_TRY_E(hipMalloc((void**)&e->d_arena, p->arena_elems * isz));
+    HIP_TRY_E(hipMalloc((void**)&e->d_arena, p->arena_elems * isz * e->batch));
     if (ext_result) {
         e->d_result = (char*)ext_result;
     } else {
@@ -724,7 +785,7 @@ int ctg_exec_create(const ctg_plan* p, int device, void* stream, void* ext_resul
     HIP_TRY_E(hipMalloc((void**)&e->d_tables, p->tables.size() * 8));
     HIP_TRY_E(hipMalloc(&e->d_scratch, kScratchBytes));
     const int64_t n_leaves = p->n_inputs + 1;
-    const int64_t misc_words = 3 + n_leaves + 2 * p->n_sliced + n_leaves * p->n_sliced;
+    const int64_t misc_words = 3 + n_leaves * e->batch + 2 * p->n_sliced + n_leaves * p->n_sliced;
     HIP_TRY_E(hipMalloc((void**)&e->d_misc, misc_words * 8));
     std::vector<int64_t> misc(misc_words, 0);
     int64_t* cur = e->d_misc;
@@ -733,7 +794,7 @@ int ctg_exec_create(const ctg_plan* p, int device, void* stream, void* ext_resul
     e->d_zero = cur;
     cur += 1;
     e->d_soff = cur;
-    cur += n_leaves;
+    cur += n_leaves * e->batch;
     int64_t* d_sizes = cur;
     cur += p->n_sliced;
     int64_t* d_fixed = cur;
@@ -895,18 +956,31 @@ int ctg_exec_run_slices(ctg_exec* e, int64_t first, int64_t count, int64_t strid
         const int rc = run_invariants(e);
         if (rc != CTG_OK) return rc;
     }
-    auto eager = [&](int64_t sid) -> int {
-        hipError_t err = launch_prologue(e->meta, e->d_state, e->d_soff, sid, e->stream);
+    // slices sid, sid + stride, ... (nb of them) through one launch sequence
+    auto eager = [&](int64_t sid, int nb = 1) -> int {
+        hipError_t err = launch_prologue(e->meta, e->d_state, e->d_soff, sid, e->stream, nb, stride);
         if (err != hipSuccess)
             return fail(CTG_E_HIP, "prologue launch failed: %s", hipGetErrorString(err));
         for (int64_t s = 0; s < p->n_steps; ++s) {
             if (e->invariant[s]) continue;
+            e->args[s].nz = nb;
             const int rc = launch_step(e, s, e->stream);
+            e->args[s].nz = 1;
             if (rc != CTG_OK) return rc;
         }
         return CTG_OK;
     };
     int64_t i = 0;
+    // (strip_exponent keeps one scale per step and slice: no batching there)
+    const int64_t batch = e->strip ? 1 : e->batch;
+    if (batch > 1 && count > 1) {
+        for (; i < count; i += batch) {
+            const int rc = eager(first + i * stride, (int)std::min<int64_t>(batch, count - i));
+            if (rc != CTG_OK) return rc;
+        }
+        e->warm = true;
+        return CTG_OK;
+    }
     if (!e->graph_off && (count >= 2 || e->warm)) {
         if (!e->warm) {  // first slice eagerly: lets the launchers do their one-time setup
             const int rc = eager(first);
@@ -952,6 +1026,12 @@ int ctg_exec_run_slices(ctg_exec* e, int64_t first, int64_t count, int64_t strid
         if (rc != CTG_OK) return rc;
     }
     e->warm = true;
+    return CTG_OK;
+}
+
+int ctg_exec_slice_batch(ctg_exec* e, int64_t* batch) {
+    if (!e || !batch) return fail(CTG_E_INVALID, "null argument");
+    *batch = e->strip ? 1 : e->batch;
     return CTG_OK;
 }
 

@@ -31,6 +31,7 @@ SYMBOLS = (
     "ctg_exec_set_strip_exponent",
     "ctg_exec_get_exponent",
     "ctg_exec_run_slices",
+    "ctg_exec_slice_batch",
     "ctg_exec_profile_slice",
     "ctg_exec_step_kernel",
     "ctg_exec_sync",
@@ -126,6 +127,7 @@ def load():
         "ctg_exec_set_strip_exponent": [vp, C.c_int, C.c_int],
         "ctg_exec_get_exponent": [vp, C.POINTER(C.c_double), C.POINTER(C.c_int)],
         "ctg_exec_run_slices": [vp, C.c_int64, C.c_int64, C.c_int64],
+        "ctg_exec_slice_batch": [vp, i64p],
         "ctg_exec_profile_slice": [vp, C.c_int64, C.POINTER(C.c_float)],
         "ctg_exec_step_kernel": [vp, C.c_int64, C.c_char_p, C.c_int64],
         "ctg_exec_sync": [vp],
@@ -293,6 +295,13 @@ class Executor:
         if count is None:
             count = (self.plan.nslices - first + stride - 1) // stride
         _check(load().ctg_exec_run_slices(self.handle, first, count, stride))
+
+    @property
+    def batch(self):
+        """Slices that share one launch sequence in ``run_slices`` (1 for wide trees)."""
+        n = C.c_int64()
+        _check(load().ctg_exec_slice_batch(self.handle, C.byref(n)))
+        return n.value
 
     def profile_slice(self, slice_id=0):
         ms = (C.c_float * max(len(self.plan.steps), 1))()

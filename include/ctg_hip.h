@@ -135,6 +135,18 @@ int ctg_exec_get_exponent(ctg_exec* exec, double* exponent, int* zero);
  * core.py:3802-3819) happens on the device. */
 int ctg_exec_run_slices(ctg_exec* exec, int64_t first, int64_t count, int64_t stride);
 
+/* How many slices of a run_slices call share one launch sequence.  A slice of a
+ * narrow tree is launch-bound (Sycamore m10: 170 launches of a few microseconds),
+ * so the executor carries up to `batch` consecutive slices of a run through every
+ * launch (gridDim.y), each in its own replica of the arena; the reference's slice
+ * loop (core.py:4015-4028) has no counterpart -- it is one Python iteration per
+ * slice.  Chosen when the executor is built: min(64, nslices), bounded by 4 GiB
+ * of arena replicas (environment: CTG_SLICE_BATCH, CTG_SLICE_BATCH_MIB); wide
+ * trees get 1.  The result does not depend on it bit for bit: the k-split of
+ * every step, the kernels and the order in which slices are added are those of
+ * one launch sequence per slice. */
+int ctg_exec_slice_batch(ctg_exec* exec, int64_t* batch);
+
 /* Same as run_slices(slice_id, 1, 1) but brackets every step with events and
  * returns its duration in milliseconds (`ms[n_steps]`); synchronous.  Serves
  * the role of `tree.print_contractions` + `tree.benchmark`

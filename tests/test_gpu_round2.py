@@ -356,3 +356,53 @@ def test_projected_output_index_on_the_gpu(case):
             assert G.relerr(np.asarray(tree.contract_slice(arrays, i)), sl) <= tol
         chunks = list(tree.gen_output_chunks(arrays))
         assert sum(np.abs(np.asarray(ch)).sum() for ch in chunks) > 0
+
+
+# ---------------------------------------------------------------------- #
+# slice batching
+# ---------------------------------------------------------------------- #
+
+
+@pytest.mark.parametrize("dtype", ["complex64", "complex128"])
+def test_slice_batching_does_not_change_a_bit(monkeypatch, dtype):
+    """Up to 64 slices of a run share every launch (gridDim.y, one arena replica
+    each).  The split of a contraction, the kernels and the order in which
+    slices are added are those of one launch sequence per slice, so the result
+    must be identical bit for bit, for any batch size."""
+    import json
+
+    names = ["lattice8x8_sliced", "rand_s42_r2_o2_hi1_ho2_outsliced", "lattice4x4_sliced"]
+    for name in names:
+        c = case_named(name)
+        outs = []
+        for cap in ("64", "3", "1"):
+            monkeypatch.setenv("CTG_SLICE_BATCH", cap)
+            tree = G.tree_of(c)
+            arrays = [a.astype(dtype) for a in G.arrays_of(c, "complex128", tree)]
+            outs.append(np.asarray(tree.contract(arrays)))
+            for fn in tree.contraction_cores.values():
+                fn.close()
+        assert np.array_equal(outs[0], outs[2]) and np.array_equal(outs[1], outs[2]), name
+        if dtype == "complex128" and c.get("rescale", False):
+            assert G.relerr(outs[0], G.expected(f"{name}/complex128")) < 1e-10
+    # the Sycamore m10 amplitude: 64 slices of 170 steps, streaming kernels included
+    rec = ca.load_network(os.path.join(ROOT, "tests", "golden", "trees", "sycamore_m10.json"))
+    z = np.load(os.path.join(ROOT, "tests", "golden", "sycamore_m10_arrays.npz"))
+    amps = []
+    for cap in ("64", "5", "1"):
+        monkeypatch.setenv("CTG_SLICE_BATCH", cap)
+        tree = ca.tree_from_record(rec)
+        xs = [z[f"t{i}"].astype(dtype) for i in range(tree.N)]
+        amps.append(complex(np.asarray(tree.contract(xs))))
+        # a strided share of the slices, as one rank of a multi-GPU run takes it
+        fn = HipContractor(tree)
+        st = fn.setup(*xs)
+        st["exec"].zero_result()
+        st["exec"].run_slices(1, 21, 3)
+        amps.append(complex(st["exec"].download_result()))
+        fn.close()
+        for f in tree.contraction_cores.values():
+            f.close()
+    assert amps[0] == amps[2] == amps[4] and amps[1] == amps[3] == amps[5]
+    ref = complex(np.load(os.path.join(ROOT, "tests", "golden", "sycamore_m10_expected.npz"))["amplitude"])
+    assert abs(amps[0] - ref) <= (1e-10 if dtype == "complex128" else 1e-5) * abs(ref)
