@@ -322,6 +322,20 @@ inline hipError_t for_each_z(const StepArgs& p, F launch_one) {
     return hipSuccess;
 }
 
+// The same in chunks of at most `fit` slices (scratch memory holds that many at once).
+template <typename F>
+inline hipError_t for_each_z_chunk(const StepArgs& p, int64_t fit, F launch_chunk) {
+    if (fit < 1) fit = 1;
+    for (int64_t z = 0; z < p.nz; z += fit) {
+        StepArgs q = p;
+        q.z0 = p.z0 + (int32_t)z;
+        q.nz = (int32_t)(p.nz - z < fit ? p.nz - z : fit);
+        const hipError_t e = launch_chunk(q);
+        if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
+}
+
 // ---- launchers implemented in the kernel translation units ---------------- //
 
 // dtype: 0 f32, 1 f64, 2 c64, 3 c128

@@ -885,9 +885,13 @@ static hipError_t launch_cfg(const StepArgs& p, const MfmaHints& h, void* scratc
     if (S > 1 && S * (tiles_m * BM * tiles_n * BN * 8 * p.Bt) > scratch_bytes) return hipErrorInvalidValue;
     // (the split depends on the step alone, never on how many slices a launch
     // carries: a result must not depend on the batching of a run)
-    if (S > 1 && p.nz > 1 &&   // the slabs of every slice of the batch must fit the scratch buffer
-        S * (tiles_m * BM * tiles_n * BN * 8 * p.Bt) * p.nz > scratch_bytes)
-        return for_each_z(p, [&](const StepArgs& q) { return launch_cfg<Cfg>(q, h, scratch, scratch_bytes, stream); });
+    if (S > 1 && p.nz > 1) {   // the slabs of the slices in one launch must fit the scratch buffer
+        const int64_t fit = scratch_bytes / (S * (tiles_m * BM * tiles_n * BN * 8 * p.Bt));
+        if (fit < p.nz)
+            return for_each_z_chunk(p, fit, [&](const StepArgs& q) {
+                return launch_cfg<Cfg>(q, h, scratch, scratch_bytes, stream);
+            });
+    }
     const int64_t k_chunk = S;  // the kernels' k_chunk argument carries the split count
     const int64_t gx = tile_grid_blocks(tiles_m * S, tiles_n);
     if (gx > 0x7fffffffll || p.nz > 65535) return hipErrorInvalidValue;
