@@ -169,3 +169,27 @@ extern "C" double ctg_probe_mfma(int which, int chains, int blocks, int iters, f
     const double per = which == 2 ? 4096.0 : 2048.0;
     return per * chains * (double)iters * 4.0 * blocks;
 }
+
+// ---- vector ALU rate: independent FMA chains per lane ---------------------- //
+template <typename T, int CHAINS>
+__global__ __launch_bounds__(256) void valu_rate_kernel(T* out, int iters) {
+    T acc[CHAINS];
+    const T a = (T)1.000001 + (T)threadIdx.x * (T)1e-9, b = (T)0.999999;
+#pragma unroll
+    for (int c = 0; c < CHAINS; ++c) acc[c] = (T)c;
+    for (int i = 0; i < iters; ++i)
+#pragma unroll
+        for (int c = 0; c < CHAINS; ++c) acc[c] = __builtin_fma(acc[c], a, b);
+    T s = 0;
+#pragma unroll
+    for (int c = 0; c < CHAINS; ++c) s += acc[c];
+    if (s == (T)12345.678) out[threadIdx.x] = s;
+}
+
+// which: 0 = f64 FMA, 1 = f32 FMA; returns the flops issued (2 per FMA per lane)
+extern "C" double ctg_probe_valu(int which, int blocks, int iters, void* out, void* stream) {
+    hipStream_t s = (hipStream_t)stream;
+    if (which == 0) hipLaunchKernelGGL((valu_rate_kernel<double, 16>), dim3(blocks), dim3(256), 0, s, (double*)out, iters);
+    else hipLaunchKernelGGL((valu_rate_kernel<float, 16>), dim3(blocks), dim3(256), 0, s, (float*)out, iters);
+    return 2.0 * 16 * (double)iters * 256.0 * blocks;
+}

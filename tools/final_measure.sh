@@ -20,6 +20,11 @@ timeout 900 rocprofv3 --kernel-trace --stats -d $O/trace -- python $R/bench.py >
 cd $R
 T=$(find $O/trace -name "*.db" | head -1)
 python tools/rocprof_summary.py $T $O/kernels > /dev/null 2>&1; head -14 $O/kernels_kernels.txt | cut -c1-190
+# the headline part alone: its per-kernel averages are what roofline.avg_launch_ms must agree with
+cd /tmp
+timeout 600 rocprofv3 --kernel-trace --stats -d $O/trace_headline -- python $R/bench.py --headline-only --no-cpu-baseline --steps 4 --warmup 1 > $O/trace_headline.log 2>&1
+cd $R
+python tools/rocprof_summary.py $(find $O/trace_headline -name "*.db" | head -1) $O/kernels_headline > /dev/null 2>&1; head -4 $O/kernels_headline_kernels.txt | cut -c1-190
 for tree in sycamore_m20_w32_c512 sycamore_m20_native; do
   CMD="python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --tree $R/tests/golden/trees/$tree.json"
   cd /tmp

@@ -15,6 +15,8 @@ pairs = {
     "kernels_kernels.json": f"{tag}_bench_kernels.json",
     "kernels_kernels.txt": f"{tag}_bench_kernels.txt",
     "bench_line.json": f"{tag}_bench_line.json",
+    "kernels_headline_kernels.json": f"{tag}_bench_kernels_headline.json",
+    "kernels_headline_kernels.txt": f"{tag}_bench_kernels_headline.txt",
 }
 for tree in ("sycamore_m20_w32_c512", "sycamore_m20_native"):
     pairs[f"pmc_summary_{tree}.json"] = f"pmc_summary_{tree}.json"   # (read by bench.py: roofline.traffic)
