@@ -80,6 +80,8 @@ struct StepArgs {
     // operands that are the same in every slice: inputs without a sliced index,
     // slice-invariant intermediates, the result tensor).
     int32_t nz, z0;
+    int64_t scratch_total;  // bytes of scratch actually allocated (>= the 64 MiB the split
+                            // heuristics are computed with): how many slices fit one launch
     int64_t zA, zB, zC;     // arena replica strides (elements)
     int64_t zsA, zsB, zsC;  // strides of the soff arrays (entries)
 };

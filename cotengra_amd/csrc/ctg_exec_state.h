@@ -51,6 +51,7 @@ struct ctg_exec {
     // slice batching: up to `batch` slices of a run share every launch (gridDim.y);
     // the arena holds `batch` replicas of itself, d_soff `batch` rows of leaf offsets
     int batch = 1;
+    int64_t scratch_total = 0;     // bytes of d_scratch (64 MiB x up to 8 for batching executors)
     std::vector<hipEvent_t> events;
     // slice graph: the launch sequence of one slice captured once and replayed,
     // the slice id advancing on the device (prologue kernel)

@@ -138,8 +138,9 @@ static hipError_t launch_pair_valu_t(const StepArgs& p, void* scratch, int64_t s
             const int64_t items = outs * G;
             // (G is a function of the step alone; the partial sums of every slice of a
             // batch must fit the scratch buffer, else the slices go one by one)
-            if (p.nz > 1 && items * (int64_t)sizeof(T) * p.nz > scratch_bytes)
-                return for_each_z_chunk(p, scratch_bytes / (items * (int64_t)sizeof(T)), [&](const StepArgs& q) {
+            const int64_t room = p.scratch_total > scratch_bytes ? p.scratch_total : scratch_bytes;
+            if (p.nz > 1 && items * (int64_t)sizeof(T) * p.nz > room)
+                return for_each_z_chunk(p, room / (items * (int64_t)sizeof(T)), [&](const StepArgs& q) {
                     return launch_pair_valu_t<T>(q, scratch, scratch_bytes, stream);
                 });
             int64_t blocks = (items + 3) / 4;

@@ -886,7 +886,8 @@ static hipError_t launch_cfg(const StepArgs& p, const MfmaHints& h, void* scratc
     // (the split depends on the step alone, never on how many slices a launch
     // carries: a result must not depend on the batching of a run)
     if (S > 1 && p.nz > 1) {   // the slabs of the slices in one launch must fit the scratch buffer
-        const int64_t fit = scratch_bytes / (S * (tiles_m * BM * tiles_n * BN * 8 * p.Bt));
+        const int64_t room = p.scratch_total > scratch_bytes ? p.scratch_total : scratch_bytes;
+        const int64_t fit = room / (S * (tiles_m * BM * tiles_n * BN * 8 * p.Bt));
         if (fit < p.nz)
             return for_each_z_chunk(p, fit, [&](const StepArgs& q) {
                 return launch_cfg<Cfg>(q, h, scratch, scratch_bytes, stream);

@@ -236,6 +236,7 @@ void resolve_args(ctg_exec* e) {
         // rows of d_soff; inputs, slice-invariant intermediates and the result do not
         a.nz = 1;
         a.z0 = 0;
+        a.scratch_total = e->scratch_total;
         a.zA = per_slice(r[W_A_SPACE], r[W_A_OFF]);
         a.zB = per_slice(r[W_B_SPACE], r[W_B_OFF]);
         a.zC = per_slice(r[W_C_SPACE], r[W_C_OFF]);
@@ -702,7 +703,7 @@ int ctg_plan_workspace_bytes(const ctg_plan* p, int64_t bytes[4]) {
     bytes[0] = p->inputs_elems * isz;
     bytes[1] = p->arena_elems * isz;
     bytes[2] = p->result_elems * isz;
-    bytes[3] = (int64_t)p->tables.size() * 8 + kScratchBytes +
+    bytes[3] = (int64_t)p->tables.size() * 8 + kScratchBytes +   /* (x up to 8 when slices are batched) */
                8 * (3 + (p->n_inputs + 1) * (1 + p->n_sliced) + 2 * p->n_sliced);
     return CTG_OK;
 }
@@ -783,7 +784,10 @@ int ctg_exec_create(const ctg_plan* p, int device, void* stream, void* ext_resul
         e->owns_result = true;
     }
     HIP_TRY_E(hipMalloc((void**)&e->d_tables, p->tables.size() * 8));
-    HIP_TRY_E(hipMalloc(&e->d_scratch, kScratchBytes));
+    // (split heuristics are always computed with kScratchBytes; a batching executor gets
+    // more room so that more slices of a split-K / k-reduction step fit one launch)
+    e->scratch_total = kScratchBytes * std::min<int64_t>(std::max(e->batch, 1), 8);
+    HIP_TRY_E(hipMalloc(&e->d_scratch, e->scratch_total));
     const int64_t n_leaves = p->n_inputs + 1;
     const int64_t misc_words = 3 + n_leaves * e->batch + 2 * p->n_sliced + n_leaves * p->n_sliced;
     HIP_TRY_E(hipMalloc((void**)&e->d_misc, misc_words * 8));
