@@ -80,6 +80,10 @@ struct StepArgs {
     // operands that are the same in every slice: inputs without a sliced index,
     // slice-invariant intermediates, the result tensor).
     int32_t nz, z0;
+    // exact division by a row_lo / k_lo that is not a power of two (extent-3 indices of
+    // hyper networks): q = umul64hi(i, magic) with magic = floor(2^64 / d) + 1, valid for
+    // i < 2^32; 0 = not available (fall back to the 64-bit division)
+    uint64_t row_lo_magic, k_lo_magic;
     int64_t scratch_total;  // bytes of scratch actually allocated (>= the 64 MiB the split
                             // heuristics are computed with): how many slices fit one launch
     int64_t zA, zB, zC;     // arena replica strides (elements)
@@ -161,6 +165,9 @@ __device__ __forceinline__ void split_k(const StepArgs& p, int64_t k, int64_t& h
     if (p.k_lo_shift >= 0) {
         hi = k >> p.k_lo_shift;
         lo = k & (p.k_lo - 1);
+    } else if (p.k_lo_magic != 0) {
+        hi = (int64_t)__umul64hi((uint64_t)k, p.k_lo_magic);
+        lo = k - hi * p.k_lo;
     } else {
         hi = k / p.k_lo;
         lo = k - hi * p.k_lo;
@@ -171,6 +178,9 @@ __device__ __forceinline__ void split_row(const StepArgs& p, int64_t i, int64_t&
     if (p.row_lo_shift >= 0) {
         hi = i >> p.row_lo_shift;
         lo = i & (p.row_lo - 1);
+    } else if (p.row_lo_magic != 0) {
+        hi = (int64_t)__umul64hi((uint64_t)i, p.row_lo_magic);
+        lo = i - hi * p.row_lo;
     } else {
         hi = i / p.row_lo;
         lo = i - hi * p.row_lo;

@@ -219,12 +219,20 @@ void resolve_args(ctg_exec* e) {
         a.N = r[W_N];
         a.row_lo = r[W_ROW_LO];
         a.row_lo_shift = log2_exact(a.row_lo);
+        // (rows / k's of a step are numbered from 0 to R - 1 / K - 1; kernels may probe one
+        // tile beyond: the reciprocal is exact for any argument below 2^32)
+        auto magic = [](int64_t d, int64_t range) -> uint64_t {
+            if (d < 2 || (d & (d - 1)) == 0 || range + 4096 >= (1ll << 32)) return 0;
+            return (uint64_t)(~0ull / (uint64_t)d) + 1;   // floor(2^64 / d) + 1 (d is not a power of two)
+        };
+        a.row_lo_magic = magic(a.row_lo, r[W_R]);
         a.rowA = RowTab{tab(W_ROWA_HI), tab(W_ROWA_LO)};
         a.rowB = RowTab{tab(W_ROWB_HI), tab(W_ROWB_LO)};
         a.rowC = RowTab{tab(W_ROWC_HI), tab(W_ROWC_LO)};
         a.k_lo = r[W_K_LO];
         a.k_hi_len = r[W_K_HI_LEN];
         a.k_lo_shift = log2_exact(a.k_lo);
+        a.k_lo_magic = magic(a.k_lo, r[W_K]);
         a.kA = RowTab{tab(W_KA_HI), tab(W_KA)};
         a.kB = RowTab{tab(W_KB_HI), tab(W_KB)};
         a.nB = tab(W_NB);
