@@ -268,3 +268,38 @@ def test_full_device_evicts_sibling_executors(monkeypatch):
     fn2 = ctr.HipContractor(_projected_tree(), handle_slicing=True)
     with pytest.raises(MemoryError):
         fn2._get_exec("complex64", 0, False)
+
+
+def test_committed_bench_line_follows_the_contract():
+    """The bench line the round published (profiles/r2_bench_line.json, written by
+    bench.py on the GPU box) carries every field the driver and the judge read."""
+    import json
+
+    path = os.path.join(ROOT, "profiles", "r2_bench_line.json")
+    if not os.path.exists(path):
+        pytest.skip("no published bench line")
+    d = json.load(open(path))
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
+              "scaling", "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["scaling"] == "weak" and d["vs_baseline"] is None and d["data"] == "synthetic"
+    assert "workload" in d["config"] and "model" not in d["config"]
+    r = d["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in r, k
+    assert r["bound"] in ("hbm", "mfma") and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
+    assert r["achieved"] <= r["peak"] and d["value"] / 1e12 <= 157.3 * d["n_gpus"]
+    # the dominant kernel's launches cannot take longer than the step they are part of
+    assert r["avg_launch_ms"] * r["launches_per_slice"] <= d["ms_per_step"] * 1.02
+    c = d["cpu_baseline"]
+    for k in ("value", "unit", "cores", "kind", "sample"):
+        assert k in c, k
+    assert c["kind"] in ("port", "reference") and c["cores"] >= 1
+    # the value is slices x algorithmic flops / time
+    assert abs(d["value"] - d["config"]["flops_per_slice"] * d["steps"] / (d["ms_per_step"] * d["steps"] * 1e-3)) < 1e-6 * d["value"]
+    assert d["precision"]["rel_err"] <= d["precision"]["gate"]
+    t = d["time_to_solution_tree"]
+    assert 0 < t["mixed_roofline_frac"] <= 1 and 0 < t["frac_of_mfma_peak"] <= 1
+    for name in ("C2", "C3", "C5"):
+        cfg = d["configs"][name]
+        assert cfg["ms"] > 0 and 0 < cfg["mixed_roofline_frac"] <= 1 and cfg["cpu_oracle_ms"] > 0
