@@ -14,6 +14,8 @@
 // row offsets and the k offsets of the next steps resolved into LDS.
 #include "ctg_common.h"
 
+#include <type_traits>
+
 namespace ctg {
 
 typedef double f64x4 __attribute__((ext_vector_type(4)));
@@ -416,6 +418,78 @@ __global__ __launch_bounds__(256, 2) void pair_mfma_real_kernel(StepArgs p, int 
         for (int j = 0; j < NB; ++j) Bs[b_n[j] * RLD + b_k[j]] = b_reg[j];
     };
 
+    // float32 with an even number of 16-row / 16-column tiles per wave runs on the 32x32x2
+    // instruction: it issues at 155 TFLOP/s on this hardware, the 16x16x4 form at 139
+    // (profiles/r2_mfma_issue_rates.txt); float64 only has the 16x16x4 form.
+    constexpr bool WIDE = std::is_same<T, float>::value && TM % 2 == 0 && TN % 2 == 0;
+    if constexpr (WIDE) {
+        constexpr int WM = TM / 2, WN = TN / 2;   // 32x32 tiles per wave
+        typedef float f32x16r __attribute__((ext_vector_type(16)));
+        f32x16r acc[WM][WN];
+#pragma unroll
+        for (int i = 0; i < WM; ++i)
+#pragma unroll
+            for (int j = 0; j < WN; ++j)
+#pragma unroll
+                for (int t = 0; t < 16; ++t) acc[i][j][t] = 0.f;
+        const int l31 = lane & 31, kk = lane >> 5;   // A[row = l31][k = kk], B[k = kk][col = l31]
+
+        gather(0);
+        stage(0);
+        if (nk > 1) gather(1);
+        __syncthreads();
+
+        for (int64_t kt = 0; kt < nk; ++kt) {
+            const int buf = kt & 1;
+            if (kt + 1 < nk) stage(buf ^ 1);
+            const bool kofs_mine = kt + 3 < nk && tid < 2 * RBK;
+            if (kofs_mine) kofs_fetch(kt + 3);
+            if (kt + 2 < nk) gather(kt + 2);
+
+            const float* As = (const float*)lds + buf * (RBM + RBN) * RLD;
+            const float* Bs = As + RBM * RLD;
+            const float* a_base = As + (wm * TM * 16 + l31) * RLD + kk;
+            const float* b_base = Bs + (wn * TN * 16 + l31) * RLD + kk;
+            float af[2][WM], bf[2][WN];
+            auto load_frag = [&](int ks, int slot) __attribute__((always_inline)) {
+#pragma unroll
+                for (int i = 0; i < WM; ++i) af[slot][i] = a_base[i * 32 * RLD + 2 * ks];
+#pragma unroll
+                for (int j = 0; j < WN; ++j) bf[slot][j] = b_base[j * 32 * RLD + 2 * ks];
+            };
+            load_frag(0, 0);
+#pragma unroll
+            for (int ks = 0; ks < RBK / 2; ++ks) {
+                if (ks + 1 < RBK / 2) load_frag(ks + 1, (ks + 1) & 1);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int i = 0; i < WM; ++i)
+#pragma unroll
+                    for (int j = 0; j < WN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[ks & 1][i], bf[ks & 1][j], acc[i][j], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (kofs_mine) kofs_commit(kt + 3);
+            __syncthreads();
+        }
+
+        // D of the 32x32 tile: column l31, rows (t & 3) + 8 * (t >> 2) + 4 * kk
+        const float alpha = (float)step_alpha(p);
+#pragma unroll
+        for (int j = 0; j < WN; ++j) {
+            const int64_t n = n0 + wn * TN * 16 + j * 32 + l31;
+            if (n >= p.N) continue;
+            const int64_t ncol = p.nC[n];
+#pragma unroll
+            for (int i = 0; i < WM; ++i)
+#pragma unroll
+                for (int t = 0; t < 16; ++t) {
+                    const int64_t ro = rowC_s[wm * TM * 16 + i * 32 + (t & 3) + 8 * (t >> 2) + 4 * kk];
+                    if (ro >= 0) ((float*)C)[ro + ncol] = acc[i][j][t] * alpha;
+                }
+        }
+        return;
+    } else {
     V4 acc[TM][TN];
 #pragma unroll
     for (int i = 0; i < TM; ++i)
@@ -477,6 +551,7 @@ __global__ __launch_bounds__(256, 2) void pair_mfma_real_kernel(StepArgs p, int 
                 const int64_t ro = rowC_s[wm * TM * 16 + i * 16 + d_row(T(0), k4, t)];
                 if (ro >= 0) C[ro + ncol] = acc[i][j][t] * alpha;
             }
+    }
     }
 }
 
