@@ -617,19 +617,23 @@ def benchmark_tree(
     st = fn.setup(*arrays)
     ex = st["exec"]
     ex.set_strip_exponent(False)
+    # slices are timed the way ``contract`` runs them: as many per launch sequence as
+    # the executor batches (1 for wide trees, up to 64 for narrow ones)
+    nb = max(1, min(int(ex.batch), tree.nslices))
+    nstart = max(tree.nslices - nb + 1, 1)
     for i in range(int(warmup)):
-        ex.run_slices(i % tree.nslices, 1, 1)
+        ex.run_slices((i * nb) % nstart, nb, 1)
     ex.sync()
     t0 = ti = time.time()
     i = 0
     while (ti - t0 < max_time) or (i < min_reps):
-        ex.run_slices(i % tree.nslices, 1, 1)
+        ex.run_slices((i * nb) % nstart, nb, 1)
         ex.sync()
         ti = time.time()
         i += 1
         if i >= max_reps:
             break
-    time_per_slice = (ti - t0) / i
+    time_per_slice = (ti - t0) / (i * nb)
     est_time_total = time_per_slice * tree.nslices
     return {
         "time_per_slice": time_per_slice,
