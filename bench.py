@@ -273,6 +273,7 @@ def small_config(name, tree, arrays, dev, slices, reps, cpu_slices, note, dtype=
     dt = sorted(times)[len(times) // 2]
     rows = step_table(ex, plan)
     batch = ex.batch
+    launches = ex.launch_count()[1]   # independent small steps share launches
     roof_ms = mixed_roofline_ms(rows, 8.0) * slices
     flops = plan.flops_per_slice() * slices
     # the oracle (numpy, the reference's executor restated) on this node's cores
@@ -285,6 +286,7 @@ def small_config(name, tree, arrays, dev, slices, reps, cpu_slices, note, dtype=
     return {
         "workload": note,
         "steps_per_slice": len(plan.steps),
+        "launches_per_slice": launches,
         "slices_timed": slices,
         "ms": dt * 1e3,
         "ms_slowest_group": max(times) * 1e3,

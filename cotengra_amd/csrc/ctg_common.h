@@ -353,8 +353,34 @@ inline hipError_t for_each_z_chunk(const StepArgs& p, int64_t fit, F launch_chun
 // dtype: 0 f32, 1 f64, 2 c64, 3 c128
 hipError_t launch_pair_valu(int dtype, const StepArgs& p, void* scratch, int64_t scratch_bytes,
                             hipStream_t stream);
+// Independent small thread-per-output steps sharing one launch: item i owns the
+// workgroups [block_begin, block_begin + n_blocks) of the grid.
+struct ValuGroupItem {
+    StepArgs p;
+    int64_t col_tiles, n_tiles;
+    int32_t tn_shift;
+    uint32_t block_begin, n_blocks;
+};
+constexpr int64_t kValuGroupMaxTiles = 4096;  // larger steps fill the chip on their own
+bool valu_thread_per_output(const StepArgs& p);  // the route launch_pair_valu takes for this step
+uint32_t valu_group_fill(const StepArgs& p, ValuGroupItem* it, uint32_t block_begin);  // -> n_blocks
+hipError_t launch_pair_valu_group(int dtype, const ValuGroupItem* d_items, int n_items, uint32_t blocks,
+                                  int nz, hipStream_t stream);
 hipError_t launch_pair_mfma(int dtype, const StepArgs& p, const MfmaHints& h, void* scratch,
                             int64_t scratch_bytes, hipStream_t stream);
+// Independent small steps of the tiled fast kernel sharing one launch (same tile
+// shape and gather width: `key`); item i owns workgroups [block_begin, +n_blocks).
+struct FastGroupItem {
+    StepArgs p;
+    MfmaHints h;
+    int64_t tiles_m, tiles_n;
+    uint32_t block_begin, n_blocks;
+};
+constexpr int64_t kFastGroupMaxTiles = 128;  // larger steps fill the chip on their own
+int fast_group_key(const StepArgs& p, const MfmaHints& h);  // -1: the step launches alone
+uint32_t fast_group_fill(const StepArgs& p, const MfmaHints& h, FastGroupItem* it, uint32_t block_begin);
+hipError_t launch_pair_mfma_fast_group(int key, const FastGroupItem* d_items, int n_items, uint32_t blocks,
+                                       int nz, hipStream_t stream);
 int64_t fast_lane_table_bytes();
 hipError_t launch_fast_lane_consts(const StepArgs& p, const MfmaHints& h, void* out, hipStream_t stream);
 // complex128 on the FP64 matrix cores (ctg_pair_mfma_f64.hip)

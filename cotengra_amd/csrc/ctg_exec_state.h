@@ -52,6 +52,18 @@ struct ctg_exec {
     // the arena holds `batch` replicas of itself, d_soff `batch` rows of leaf offsets
     int batch = 1;
     int64_t scratch_total = 0;     // bytes of d_scratch (64 MiB x up to 8 for batching executors)
+    // the launch list of one slice: steps that launch alone (cls < 0) and wave-front
+    // groups -- n independent small steps of one kernel shape sharing a launch (cls 0:
+    // thread-per-output items, 1 + key: tiled fast-kernel items, starting at item0)
+    struct Issue {
+        int64_t step;
+        int cls;
+        int32_t item0, n;
+        uint32_t blocks;
+    };
+    std::vector<Issue> issue;
+    ctg::ValuGroupItem* d_group_items = nullptr;
+    ctg::FastGroupItem* d_fast_items = nullptr;
     std::vector<hipEvent_t> events;
     // slice graph: the launch sequence of one slice captured once and replayed,
     // the slice id advancing on the device (prologue kernel)

@@ -24,9 +24,10 @@ namespace ctg {
 // pair: thread per output
 // ------------------------------------------------------------------------- //
 
+// one workgroup's share (tiles bx, bx + gx, ...) of a thread-per-output step
 template <typename T>
-__global__ __launch_bounds__(256) void pair_valu_kernel(StepArgs p, int tn_shift,
-                                                        int64_t col_tiles, int64_t n_tiles) {
+__device__ __forceinline__ void pair_valu_body(const StepArgs& p, int tn_shift, int64_t col_tiles,
+                                               int64_t n_tiles, int64_t bx, int64_t gx) {
     const T* __restrict__ A = (const T*)p.A + zoffA(p);
     const T* __restrict__ B = (const T*)p.B + zoffB(p);
     T* __restrict__ C = (T*)p.C + zoffC(p);
@@ -36,7 +37,7 @@ __global__ __launch_bounds__(256) void pair_valu_kernel(StepArgs p, int tn_shift
     const int c = threadIdx.x & (TN - 1);
     const int r = threadIdx.x >> tn_shift;
 
-    for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    for (int64_t tile = bx; tile < n_tiles; tile += gx) {
         const int64_t rt = tile / col_tiles;
         const int64_t ct = tile - rt * col_tiles;
         const int64_t row = rt * TR + r;
@@ -56,6 +57,29 @@ __global__ __launch_bounds__(256) void pair_valu_kernel(StepArgs p, int tn_shift
         }
         C[p.rowC.hi[hi] + p.rowC.lo[lo] + p.nC[n]] = scale_of(acc, alpha);
     }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void pair_valu_kernel(StepArgs p, int tn_shift,
+                                                        int64_t col_tiles, int64_t n_tiles) {
+    pair_valu_body<T>(p, tn_shift, col_tiles, n_tiles, blockIdx.x, gridDim.x);
+}
+
+// Several INDEPENDENT small steps in one launch (the leaves-upward wave fronts of
+// a small tree: dozens of steps of a few microseconds each, every one of which
+// would otherwise wait for the previous launch to drain).  Workgroups
+// [block_begin, next block_begin) belong to item i; each item is a complete
+// step description, computed exactly as its own launch would (same threads,
+// same order of operations: the results are bit-identical).
+template <typename T>
+__global__ __launch_bounds__(256) void pair_valu_group_kernel(const ValuGroupItem* __restrict__ items,
+                                                              int n_items) {
+    int i = 0;
+    while (i + 1 < n_items && blockIdx.x >= items[i + 1].block_begin) ++i;
+    i = __builtin_amdgcn_readfirstlane(i);
+    const ValuGroupItem& it = items[i];
+    pair_valu_body<T>(it.p, it.tn_shift, it.col_tiles, it.n_tiles, blockIdx.x - it.block_begin,
+                      it.n_blocks);
 }
 
 // ------------------------------------------------------------------------- //
@@ -95,18 +119,30 @@ __global__ __launch_bounds__(256) void pair_kred_kernel(StepArgs p, int64_t G, i
     }
 }
 
-template <typename T>
+// WAVE: few outputs, many partials -- one wavefront per output adds the partials
+// (lane l takes l, l + 64, ... in order, then a butterfly: a fixed tree), instead
+// of one thread walking up to 256 of them.
+template <typename T, bool WAVE>
 __global__ __launch_bounds__(256) void pair_kred_finish_kernel(StepArgs p, int64_t G,
                                                                const T* __restrict__ partial) {
     T* __restrict__ C = (T*)p.C + zoffC(p);
     const double alpha = step_alpha(p);
     const int64_t outs = p.R * p.N;
-    for (int64_t o = (int64_t)blockIdx.x * 256 + threadIdx.x; o < outs;
-         o += (int64_t)gridDim.x * 256) {
+    const int lane = threadIdx.x & 63;
+    const int64_t first = WAVE ? (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6) : (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t step = WAVE ? (int64_t)gridDim.x * 4 : (int64_t)gridDim.x * 256;
+    for (int64_t o = first; o < outs; o += step) {
         const int64_t row = o / p.N;
         const int64_t n = o - row * p.N;
         T acc = zero_of(T{});
-        for (int64_t g = 0; g < G; ++g) acc = add_of(acc, partial[((int64_t)blockIdx.y * outs + o) * G + g]);
+        const T* src = partial + ((int64_t)blockIdx.y * outs + o) * G;
+        if (WAVE) {
+            for (int64_t g = lane; g < G; g += 64) acc = add_of(acc, src[g]);
+            acc = wave_sum(acc);
+            if (lane != 0) continue;
+        } else {
+            for (int64_t g = 0; g < G; ++g) acc = add_of(acc, src[g]);
+        }
         int64_t hi, lo;
         split_row(p, row, hi, lo);
         C[p.rowC.hi[hi] + p.rowC.lo[lo] + p.nC[n]] = scale_of(acc, alpha);
@@ -147,25 +183,54 @@ static hipError_t launch_pair_valu_t(const StepArgs& p, void* scratch, int64_t s
             if (blocks > 8192) blocks = 8192;
             hipLaunchKernelGGL(pair_kred_kernel<T>, dim3((unsigned)blocks, (unsigned)p.nz), dim3(256), 0, stream, p,
                                G, chunk, (T*)scratch);
-            int64_t fblocks = (outs + 255) / 256;
-            if (fblocks > 4096) fblocks = 4096;
-            hipLaunchKernelGGL(pair_kred_finish_kernel<T>, dim3((unsigned)fblocks, (unsigned)p.nz), dim3(256), 0,
-                               stream, p, G, (const T*)scratch);
+            if (outs <= 4096 && G >= 16) {
+                hipLaunchKernelGGL((pair_kred_finish_kernel<T, true>), dim3((unsigned)((outs + 3) / 4), (unsigned)p.nz),
+                                   dim3(256), 0, stream, p, G, (const T*)scratch);
+            } else {
+                int64_t fblocks = (outs + 255) / 256;
+                if (fblocks > 4096) fblocks = 4096;
+                hipLaunchKernelGGL((pair_kred_finish_kernel<T, false>), dim3((unsigned)fblocks, (unsigned)p.nz),
+                                   dim3(256), 0, stream, p, G, (const T*)scratch);
+            }
             return hipGetLastError();
         }
     }
-    int tn_shift = 0;
-    while ((1 << tn_shift) < p.N && tn_shift < 8) ++tn_shift;
-    const int64_t TN = 1 << tn_shift, TR = 256 >> tn_shift;
-    const int64_t col_tiles = (p.N + TN - 1) / TN;
-    const int64_t row_tiles = (p.R + TR - 1) / TR;
-    const int64_t n_tiles = col_tiles * row_tiles;
-    int64_t blocks = n_tiles;
+    ValuGroupItem it;
+    valu_group_fill(p, &it, 0);
+    int64_t blocks = it.n_tiles;
     if (blocks > (1 << 20)) blocks = 1 << 20;
     if (blocks < 1) blocks = 1;
     if (blocks * p.nz > (1 << 20)) blocks = (1 << 20) / p.nz;
     hipLaunchKernelGGL(pair_valu_kernel<T>, dim3((unsigned)blocks, (unsigned)p.nz), dim3(256), 0, stream, p,
-                       tn_shift, col_tiles, n_tiles);
+                       it.tn_shift, it.col_tiles, it.n_tiles);
+    return hipGetLastError();
+}
+
+bool valu_thread_per_output(const StepArgs& p) { return !(p.K >= 256 && p.R * p.N <= (1 << 15)); }
+
+uint32_t valu_group_fill(const StepArgs& p, ValuGroupItem* it, uint32_t block_begin) {
+    int tn_shift = 0;
+    while ((1 << tn_shift) < p.N && tn_shift < 8) ++tn_shift;
+    const int64_t TN = 1 << tn_shift, TR = 256 >> tn_shift;
+    it->p = p;
+    it->tn_shift = tn_shift;
+    it->col_tiles = (p.N + TN - 1) / TN;
+    it->n_tiles = it->col_tiles * ((p.R + TR - 1) / TR);
+    it->block_begin = block_begin;
+    it->n_blocks = (uint32_t)(it->n_tiles < 1 ? 1 : (it->n_tiles > kValuGroupMaxTiles ? kValuGroupMaxTiles : it->n_tiles));
+    return it->n_blocks;
+}
+
+hipError_t launch_pair_valu_group(int dtype, const ValuGroupItem* d_items, int n_items, uint32_t blocks,
+                                  int nz, hipStream_t stream) {
+    const dim3 grid(blocks, (unsigned)nz);
+    switch (dtype) {
+        case 0: hipLaunchKernelGGL(pair_valu_group_kernel<float>, grid, dim3(256), 0, stream, d_items, n_items); break;
+        case 1: hipLaunchKernelGGL(pair_valu_group_kernel<double>, grid, dim3(256), 0, stream, d_items, n_items); break;
+        case 2: hipLaunchKernelGGL(pair_valu_group_kernel<c64>, grid, dim3(256), 0, stream, d_items, n_items); break;
+        case 3: hipLaunchKernelGGL(pair_valu_group_kernel<c128>, grid, dim3(256), 0, stream, d_items, n_items); break;
+        default: return hipErrorInvalidValue;
+    }
     return hipGetLastError();
 }
 
@@ -389,8 +454,11 @@ hipError_t launch_rescale(int dtype, void* result, int64_t n, const StripState* 
 __global__ __launch_bounds__(256) void prologue_kernel(SliceMeta m, int64_t* state, int64_t* soff,
                                                        int64_t sid_arg, int nz, int64_t stride) {
     // slices sid, sid + stride, ... (nz of them): soff[z * n_leaves + leaf]
+    // (several workgroups when the slice id comes from the host: 64 slices x hundreds of
+    // leaves x dozens of sliced indices is 0.4 ms of dependent divisions for one of them)
     const int64_t sid0 = sid_arg >= 0 ? sid_arg : state[0];
-    for (int64_t w = threadIdx.x; w < m.n_leaves * nz; w += blockDim.x) {
+    for (int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; w < m.n_leaves * nz;
+         w += (int64_t)gridDim.x * blockDim.x) {
         const int64_t z = w / m.n_leaves, leaf = w - z * m.n_leaves;
         int64_t rem = sid0 + z * stride;
         int64_t off = 0;
@@ -409,10 +477,11 @@ __global__ __launch_bounds__(256) void prologue_kernel(SliceMeta m, int64_t* sta
         }
         soff[w] = off;
     }
-    if (m.fac)
+    if (m.fac && blockIdx.x == 0)
         for (int64_t i = threadIdx.x; i < m.n_fac; i += blockDim.x)
             if (m.fac_zero[i]) m.fac[i] = 0.0;
     __syncthreads();
+    // (the device-side slice counter of a graph replay: always a single workgroup)
     if (threadIdx.x == 0 && sid_arg < 0) state[0] = sid0 + state[1];
 }
 
@@ -428,7 +497,10 @@ hipError_t launch_set_state(int64_t* state, int64_t next, int64_t stride, hipStr
 
 hipError_t launch_prologue(const SliceMeta& m, int64_t* state, int64_t* soff, int64_t sid,
                            hipStream_t stream, int nz, int64_t stride) {
-    hipLaunchKernelGGL(prologue_kernel, dim3(1), dim3(256), 0, stream, m, state, soff, sid, nz, stride);
+    int64_t blocks = sid < 0 ? 1 : (m.n_leaves * nz + 255) / 256;
+    if (blocks > 1024) blocks = 1024;
+    hipLaunchKernelGGL(prologue_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, m, state, soff, sid, nz,
+                       stride);
     return hipGetLastError();
 }
 

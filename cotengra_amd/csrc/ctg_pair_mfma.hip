@@ -502,11 +502,38 @@ __global__ __launch_bounds__(256) void fast_lane_consts_kernel(StepArgs p, MfmaH
     for (int q = 0; q < Lane::NQ; ++q) out[q * 256 + tid] = uint4{w[4 * q], w[4 * q + 1], w[4 * q + 2], w[4 * q + 3]};
 }
 
-template <typename Cfg, bool VEC_A>
-__global__ __launch_bounds__(256, Cfg::FAST_BLOCKS) void pair_mfma_fast_kernel(StepArgs p, MfmaHints h,
-                                                                int64_t tiles_m, int64_t tiles_n,
+// GROUPED: one launch carries the tiles of several independent small steps (no
+// k-split, no batch group); workgroups [block_begin, block_begin + n_blocks) of
+// the grid belong to item i, whose step description replaces the kernel
+// arguments.  The arithmetic of a tile is the same instruction sequence either
+// way: grouping does not change a result bit.
+template <typename Cfg, bool VEC_A, bool GROUPED = false>
+__global__ __launch_bounds__(256, Cfg::FAST_BLOCKS) void pair_mfma_fast_kernel(StepArgs p_, MfmaHints h_,
+                                                                int64_t tiles_m_, int64_t tiles_n_,
                                                                 int64_t k_chunk,
-                                                                float* __restrict__ partial) {
+                                                                float* __restrict__ partial,
+                                                                const FastGroupItem* __restrict__ items,
+                                                                int n_items) {
+    StepArgs p;
+    MfmaHints h;
+    int64_t tiles_m, tiles_n;
+    unsigned bx;
+    if constexpr (GROUPED) {
+        int gi = 0;
+        while (gi + 1 < n_items && blockIdx.x >= items[gi + 1].block_begin) ++gi;
+        gi = __builtin_amdgcn_readfirstlane(gi);
+        p = items[gi].p;
+        h = items[gi].h;
+        tiles_m = items[gi].tiles_m;
+        tiles_n = items[gi].tiles_n;
+        bx = blockIdx.x - items[gi].block_begin;
+    } else {
+        p = p_;
+        h = h_;
+        tiles_m = tiles_m_;
+        tiles_n = tiles_n_;
+        bx = blockIdx.x;
+    }
     constexpr int BM = Cfg::BM, BN = Cfg::BN, BK = Cfg::BK, WN = Cfg::WN;
     constexpr int NA = VEC_A ? Cfg::A_PER_T / 2 : Cfg::A_PER_T;  // A load instructions per thread
     // Unpadded LDS rows of BK floats.  Fragments are read one k-pair (8 bytes)
@@ -527,7 +554,15 @@ __global__ __launch_bounds__(256, Cfg::FAST_BLOCKS) void pair_mfma_fast_kernel(S
     const int64_t S_split = k_chunk;
     // (slices of a batch rotate the XCD their patches go to: a small step whose tiles
     // make up a single patch would otherwise put every slice on XCD 0)
-    const TileMap tmap = map_tile((blockIdx.x & ~7u) | ((blockIdx.x + blockIdx.y) & 7u), tiles_m * S_split, tiles_n);
+    TileMap tmap;
+    if constexpr (GROUPED) {
+        // (a few tiles per step: plain row-major, consecutive workgroups go to different XCDs)
+        tmap.unit = bx / (unsigned)tiles_n;
+        tmap.tn = bx - (unsigned)tmap.unit * (unsigned)tiles_n;
+        tmap.valid = true;
+    } else {
+        tmap = map_tile((bx & ~7u) | ((bx + blockIdx.y) & 7u), tiles_m * S_split, tiles_n);
+    }
     if (!tmap.valid) return;
     const int64_t bz = blockIdx.z;
     // (64-bit divisions run on the vector ALU: results go back to scalar registers)
@@ -901,10 +936,10 @@ static hipError_t launch_cfg(const StepArgs& p, const MfmaHints& h, void* scratc
     if (h.fast) {
         if (h.vecA)
             hipLaunchKernelGGL((pair_mfma_fast_kernel<Cfg, true>), grid, dim3(256), 0, stream, p, h,
-                               tiles_m, tiles_n, k_chunk, part);
+                               tiles_m, tiles_n, k_chunk, part, (const FastGroupItem*)nullptr, 0);
         else
             hipLaunchKernelGGL((pair_mfma_fast_kernel<Cfg, false>), grid, dim3(256), 0, stream, p, h,
-                               tiles_m, tiles_n, k_chunk, part);
+                               tiles_m, tiles_n, k_chunk, part, (const FastGroupItem*)nullptr, 0);
     } else if constexpr (Cfg::BN >= 128) {
         return hipErrorInvalidValue;  // the 128-wide tile exists for the fast path only
     } else if (h.vecA)
@@ -1695,6 +1730,52 @@ hipError_t launch_fast_lane_consts(const StepArgs& p, const MfmaHints& h, void* 
         case 32: return build_lane_t<MfmaCfg<128, 32, 16, 4, 1>>(p, h, out, stream);
         case 64: return build_lane_t<MfmaCfg<128, 64, 16, 2, 2>>(p, h, out, stream);
         case 128: return build_lane_t<MfmaCfg<128, 128, 16, 2, 2>>(p, h, out, stream);
+    }
+    return hipErrorInvalidValue;
+}
+
+// ---- several independent small tiled steps in one launch ------------------- //
+
+int fast_group_key(const StepArgs& p, const MfmaHints& h) {
+    if (h.stream != 0 || !h.fast || h.splitk > 1 || p.Bt != 1) return -1;
+    if (h.bn != 16 && h.bn != 32 && h.bn != 64) return -1;
+    const int64_t tiles = ((p.R + MFMA_BM - 1) / MFMA_BM) * ((p.N + h.bn - 1) / h.bn);
+    if (tiles > kFastGroupMaxTiles || p.K < MFMA_BK) return -1;
+    return h.bn * 2 + (h.vecA ? 1 : 0);
+}
+
+uint32_t fast_group_fill(const StepArgs& p, const MfmaHints& h, FastGroupItem* it, uint32_t block_begin) {
+    it->p = p;
+    it->h = h;
+    it->tiles_m = (p.R + MFMA_BM - 1) / MFMA_BM;
+    it->tiles_n = (p.N + h.bn - 1) / h.bn;
+    it->block_begin = block_begin;
+    it->n_blocks = (uint32_t)(it->tiles_m * it->tiles_n);
+    return it->n_blocks;
+}
+
+template <typename Cfg>
+static hipError_t launch_fast_group_t(bool vec, const FastGroupItem* d_items, int n_items, uint32_t blocks,
+                                      int nz, hipStream_t stream) {
+    const dim3 grid(blocks, (unsigned)nz, 1);
+    const StepArgs none{};
+    const MfmaHints noh{};
+    if (vec)
+        hipLaunchKernelGGL((pair_mfma_fast_kernel<Cfg, true, true>), grid, dim3(256), 0, stream, none, noh,
+                           (int64_t)0, (int64_t)0, (int64_t)1, (float*)nullptr, d_items, n_items);
+    else
+        hipLaunchKernelGGL((pair_mfma_fast_kernel<Cfg, false, true>), grid, dim3(256), 0, stream, none, noh,
+                           (int64_t)0, (int64_t)0, (int64_t)1, (float*)nullptr, d_items, n_items);
+    return hipGetLastError();
+}
+
+hipError_t launch_pair_mfma_fast_group(int key, const FastGroupItem* d_items, int n_items, uint32_t blocks,
+                                       int nz, hipStream_t stream) {
+    const bool vec = key & 1;
+    switch (key >> 1) {
+        case 16: return launch_fast_group_t<MfmaCfg<128, 16, 16, 4, 1>>(vec, d_items, n_items, blocks, nz, stream);
+        case 32: return launch_fast_group_t<MfmaCfg<128, 32, 16, 4, 1>>(vec, d_items, n_items, blocks, nz, stream);
+        case 64: return launch_fast_group_t<MfmaCfg<128, 64, 16, 2, 2>>(vec, d_items, n_items, blocks, nz, stream);
     }
     return hipErrorInvalidValue;
 }

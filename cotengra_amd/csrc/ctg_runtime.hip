@@ -519,7 +519,10 @@ int build_hints_into(ctg_exec* e, std::vector<MfmaHints>& hints, int64_t zmult,
         if (!h.stream) {
             const int64_t tiles_m = (r[W_R] + MFMA_BM - 1) / MFMA_BM;
             const int64_t per_tile = r[W_K] >= 1024 ? splits : 1;
-            while (h.bn > 16 && tiles_m * ((r[W_N] + h.bn - 1) / h.bn) * r[W_BT] * per_tile * zmult < 256)
+            // (two blocks per CU: a CU with a single block has nothing to overlap its
+            // gather latency with -- 8x8 lattice, 4096 x 256 x 256 step: 49 -> 20 us)
+            static const int64_t fill = getenv("CTG_TILE_FILL") ? atoll(getenv("CTG_TILE_FILL")) : 512;
+            while (h.bn > 16 && tiles_m * ((r[W_N] + h.bn - 1) / h.bn) * r[W_BT] * per_tile * zmult < fill)
                 h.bn /= 2;
             // the number of k-splits belongs to the step: taken from the single-slice
             // hints; a wider tile whose slabs would not fit the scratch is given up
@@ -617,6 +620,130 @@ int launch_step(ctg_exec* e, int64_t s, hipStream_t stream) {
     }
     if (err != hipSuccess)
         return fail(CTG_E_HIP, "launch of step %lld failed: %s", (long long)s, hipGetErrorString(err));
+    return CTG_OK;
+}
+
+// Wave-front groups.  Small trees (and the early levels of any tree) are chains
+// of launches of a few microseconds each, every one waiting for the previous to
+// drain; the planner emits such trees level by level (plan.py: compile_tree) and
+// runs of consecutive small steps that neither read nor overwrite each other's
+// tensors go out as ONE launch per kernel shape.  The test is on the memory
+// intervals of the plan itself, so any step order is safe: an order that
+// interleaves dependent steps simply forms no groups.  Within a run the steps
+// are mutually independent, so issuing them shape by shape is a legal reorder.
+int build_groups(ctg_exec* e) {
+    const ctg_plan* p = e->plan;
+    const int64_t n = p->n_steps;
+    e->issue.clear();
+    if (e->d_group_items) (void)hipFree(e->d_group_items);
+    if (e->d_fast_items) (void)hipFree(e->d_fast_items);
+    e->d_group_items = nullptr;
+    e->d_fast_items = nullptr;
+    // (strip_exponent measures every intermediate right after its step)
+    const bool off = e->strip || getenv("CTG_NO_GROUPS");
+    const bool fast_off = getenv("CTG_NO_FAST_GROUPS") != nullptr;
+    // class of a step: -1 launches alone, 0 thread-per-output, 1 + key tiled fast kernel
+    auto class_of = [&](int64_t s) -> int {
+        const int64_t* r = &p->steps[s * STEP_WORDS];
+        if (off || r[W_KIND] != KIND_PAIR || e->invariant[s]) return -1;
+        if (r[W_KERNEL] != KERNEL_MFMA) {
+            if (!valu_thread_per_output(e->args[s])) return -1;
+            ValuGroupItem it;
+            valu_group_fill(e->args[s], &it, 0);
+            return it.n_tiles <= kValuGroupMaxTiles ? 0 : -1;
+        }
+        if (p->dtype != CTG_C64 || fast_off) return -1;
+        const int key = fast_group_key(e->args[s], e->hints[s]);
+        // (a launch that carries several slices may prefer a wider tile: such steps stay alone)
+        if (key < 0 || (!e->hints_b.empty() && fast_group_key(e->args[s], e->hints_b[s]) != key)) return -1;
+        return 1 + key;
+    };
+    auto overlap = [&](const int64_t* x, int xs, int xo, int xn, const int64_t* y, int ys, int yo, int yn) {
+        return x[xs] == y[ys] && x[xo] < y[yo] + y[yn] && y[yo] < x[xo] + x[xn];
+    };
+    auto independent = [&](int64_t j, int64_t i) {
+        const int64_t* a = &p->steps[i * STEP_WORDS];
+        const int64_t* b = &p->steps[j * STEP_WORDS];
+        return !overlap(b, W_A_SPACE, W_A_OFF, W_A_SIZE, a, W_C_SPACE, W_C_OFF, W_C_SIZE) &&
+               !overlap(b, W_B_SPACE, W_B_OFF, W_B_SIZE, a, W_C_SPACE, W_C_OFF, W_C_SIZE) &&
+               !overlap(b, W_C_SPACE, W_C_OFF, W_C_SIZE, a, W_A_SPACE, W_A_OFF, W_A_SIZE) &&
+               !overlap(b, W_C_SPACE, W_C_OFF, W_C_SIZE, a, W_B_SPACE, W_B_OFF, W_B_SIZE) &&
+               !overlap(b, W_C_SPACE, W_C_OFF, W_C_SIZE, a, W_C_SPACE, W_C_OFF, W_C_SIZE);
+    };
+    std::vector<ValuGroupItem> vitems;
+    std::vector<FastGroupItem> fitems;
+    for (int64_t s = 0; s < n;) {
+        if (e->invariant[s]) {
+            ++s;
+            continue;
+        }
+        if (class_of(s) < 0) {
+            e->issue.push_back(ctg_exec::Issue{s, -1, 0, 1, 0});
+            ++s;
+            continue;
+        }
+        int64_t j = s + 1;
+        for (; j < n && j - s < 64 && !e->invariant[j] && class_of(j) >= 0; ++j) {
+            bool ok = true;
+            for (int64_t i = s; i < j && ok; ++i) ok = independent(j, i);
+            if (!ok) break;
+        }
+        std::vector<char> done((size_t)(j - s), 0);
+        for (int64_t a = s; a < j; ++a) {
+            if (done[a - s]) continue;
+            const int cls = class_of(a);
+            std::vector<int64_t> members;
+            for (int64_t b = a; b < j; ++b)
+                if (!done[b - s] && class_of(b) == cls) {
+                    members.push_back(b);
+                    done[b - s] = 1;
+                }
+            if (members.size() == 1) {
+                e->issue.push_back(ctg_exec::Issue{a, -1, 0, 1, 0});
+                continue;
+            }
+            uint32_t blocks = 0;
+            const int32_t item0 = (int32_t)(cls == 0 ? vitems.size() : fitems.size());
+            for (int64_t m : members) {
+                if (cls == 0) {
+                    vitems.emplace_back();
+                    blocks += valu_group_fill(e->args[m], &vitems.back(), blocks);
+                } else {
+                    fitems.emplace_back();
+                    blocks += fast_group_fill(e->args[m], e->hints[m], &fitems.back(), blocks);
+                }
+            }
+            e->issue.push_back(ctg_exec::Issue{a, cls, item0, (int32_t)members.size(), blocks});
+        }
+        s = j;
+    }
+    if (!vitems.empty()) {
+        HIP_TRY(hipMalloc((void**)&e->d_group_items, vitems.size() * sizeof(ValuGroupItem)));
+        HIP_TRY(hipMemcpy(e->d_group_items, vitems.data(), vitems.size() * sizeof(ValuGroupItem),
+                          hipMemcpyHostToDevice));
+    }
+    if (!fitems.empty()) {
+        HIP_TRY(hipMalloc((void**)&e->d_fast_items, fitems.size() * sizeof(FastGroupItem)));
+        HIP_TRY(hipMemcpy(e->d_fast_items, fitems.data(), fitems.size() * sizeof(FastGroupItem),
+                          hipMemcpyHostToDevice));
+    }
+    return CTG_OK;
+}
+
+// one entry of the per-slice launch list, for a batch of nb slices
+int launch_issue(ctg_exec* e, const ctg_exec::Issue& q, int nb, hipStream_t stream) {
+    if (q.cls < 0) {
+        e->args[q.step].nz = nb;
+        const int rc = launch_step(e, q.step, stream);
+        e->args[q.step].nz = 1;
+        return rc;
+    }
+    const hipError_t err =
+        q.cls == 0 ? launch_pair_valu_group(e->plan->dtype, e->d_group_items + q.item0, q.n, q.blocks, nb, stream)
+                   : launch_pair_mfma_fast_group(q.cls - 1, e->d_fast_items + q.item0, q.n, q.blocks, nb, stream);
+    if (err != hipSuccess)
+        return fail(CTG_E_HIP, "launch of the %d steps grouped at step %lld failed: %s", (int)q.n,
+                    (long long)q.step, hipGetErrorString(err));
     return CTG_OK;
 }
 
@@ -736,6 +863,8 @@ int ctg_exec_destroy(ctg_exec* e) {
     if (e->d_lane) (void)hipFree(e->d_lane);
     if (e->d_ord_b) (void)hipFree(e->d_ord_b);
     if (e->d_lane_b) (void)hipFree(e->d_lane_b);
+    if (e->d_group_items) (void)hipFree(e->d_group_items);
+    if (e->d_fast_items) (void)hipFree(e->d_fast_items);
     if (e->d_fac) (void)hipFree(e->d_fac);
     if (e->d_counted) (void)hipFree(e->d_counted);
     if (e->d_fac_zero) (void)hipFree(e->d_fac_zero);
@@ -775,7 +904,15 @@ int ctg_exec_create(const ctg_plan* p, int device, void* stream, void* ext_resul
     // = tens of GiB) keep batch = 1.  CTG_SLICE_BATCH caps the count (1 = off),
     // CTG_SLICE_BATCH_MIB the memory spent on replicas.
     {
-        int64_t cap = 64, mib = 4096;
+        int64_t cap = 64, mib = 8192;
+        {
+            // (at most a quarter of what the device has free right now)
+            size_t free_b = 0, total_b = 0;
+            if (hipMemGetInfo(&free_b, &total_b) == hipSuccess)
+                mib = std::min<int64_t>(mib, (int64_t)(free_b >> 22));
+            else
+                (void)hipGetLastError();
+        }
         if (const char* v = getenv("CTG_SLICE_BATCH")) cap = atoll(v);
         if (const char* v = getenv("CTG_SLICE_BATCH_MIB")) mib = atoll(v);
         int64_t b = std::min<int64_t>(cap, p->nslices);
@@ -857,7 +994,8 @@ int ctg_exec_create(const ctg_plan* p, int device, void* stream, void* ext_resul
     e->graph_off = getenv("CTG_GRAPH") == nullptr;
     resolve_args(e);
     {
-        const int rc = build_hints(e);
+        int rc = build_hints(e);
+        if (rc == CTG_OK) rc = build_groups(e);
         if (rc != CTG_OK) return bail(rc);
     }
     *out = e;
@@ -936,6 +1074,10 @@ int ctg_exec_set_strip_exponent(ctg_exec* e, int strip, int check_zero) {
     e->meta.n_fac = strip ? e->plan->n_steps : 0;
     e->invariants_ready = false;  // their stored scale changes with the option
     resolve_args(e);
+    {
+        const int rc = build_groups(e);
+        if (rc != CTG_OK) return rc;
+    }
     // a captured slice graph embeds the old arguments
     if (e->gexec) {
         (void)hipGraphExecDestroy(e->gexec);
@@ -973,11 +1115,8 @@ int ctg_exec_run_slices(ctg_exec* e, int64_t first, int64_t count, int64_t strid
         hipError_t err = launch_prologue(e->meta, e->d_state, e->d_soff, sid, e->stream, nb, stride);
         if (err != hipSuccess)
             return fail(CTG_E_HIP, "prologue launch failed: %s", hipGetErrorString(err));
-        for (int64_t s = 0; s < p->n_steps; ++s) {
-            if (e->invariant[s]) continue;
-            e->args[s].nz = nb;
-            const int rc = launch_step(e, s, e->stream);
-            e->args[s].nz = 1;
+        for (const ctg_exec::Issue& q : e->issue) {
+            const int rc = launch_issue(e, q, nb, e->stream);
             if (rc != CTG_OK) return rc;
         }
         return CTG_OK;
@@ -1009,8 +1148,8 @@ int ctg_exec_run_slices(ctg_exec* e, int64_t first, int64_t count, int64_t strid
             if (ok) ok = hipStreamBeginCapture(e->gstream, hipStreamCaptureModeThreadLocal) == hipSuccess;
             if (ok) {
                 bool launched = launch_prologue(e->meta, e->d_state, e->d_soff, -1, e->gstream) == hipSuccess;
-                for (int64_t s = 0; launched && s < p->n_steps; ++s)
-                    if (!e->invariant[s]) launched = launch_step(e, s, e->gstream) == CTG_OK;
+                for (size_t q = 0; launched && q < e->issue.size(); ++q)
+                    launched = launch_issue(e, e->issue[q], 1, e->gstream) == CTG_OK;
                 ok = hipStreamEndCapture(e->gstream, &graph) == hipSuccess && launched && graph;
             }
             if (ok) ok = hipGraphInstantiate(&e->gexec, graph, nullptr, nullptr, 0) == hipSuccess;
@@ -1038,6 +1177,18 @@ int ctg_exec_run_slices(ctg_exec* e, int64_t first, int64_t count, int64_t strid
         if (rc != CTG_OK) return rc;
     }
     e->warm = true;
+    return CTG_OK;
+}
+
+int ctg_exec_launch_count(ctg_exec* e, int64_t* steps, int64_t* launches) {
+    if (!e || !steps || !launches) return fail(CTG_E_INVALID, "null argument");
+    int64_t ns = 0, nl = 0;
+    for (const ctg_exec::Issue& q : e->issue) {
+        ns += q.n;
+        nl += 1;
+    }
+    *steps = ns;
+    *launches = nl;
     return CTG_OK;
 }
 

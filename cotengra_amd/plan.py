@@ -62,6 +62,8 @@ SPACE_RESULT = 2
 STEP_WORDS = 48  # int64 words per serialised step record
 LO_MAX = 4096  # target size of the fast ('lo') level of a row table
 ARENA_ALIGN = 64  # elements; keeps every intermediate 256-B aligned
+# trees whose largest intermediate is at most this are emitted level by level (compile_tree)
+LEVEL_ORDER_MAX_ELEMS = 1 << 22
 MAX_TENSOR_ELEMS = 1 << 36  # one complex128 tensor of this size is 1 TiB: beyond any single device
 
 # MFMA kernel limits (see csrc/ctg_pair_mfma.hip)
@@ -709,6 +711,21 @@ def compile_tree(tree, dtype, order=None, force_kernel=None):
 
     root_order = tuple(ix for ix in tree.output if ix not in tree.sliced_inds)
 
+    # Small trees are executed wave front by wave front: a slice of such a tree is
+    # a chain of launches of a few microseconds each, so the steps are emitted
+    # level by level (level = 1 + the deeper child; the steps of a level are
+    # independent), cheapest first, and operands are recycled only once their
+    # whole level is done -- the executor then sends consecutive independent
+    # small steps out as one launch (ctg_runtime.hip: build_groups).  The
+    # contracted values do not depend on the order, only lifetimes do; wide
+    # trees keep the reference's depth-first order and its smaller peak memory.
+    level = None
+    if order is None and N > 3 and tree.max_size() <= LEVEL_ORDER_MAX_ELEMS:
+        level = {}
+        for p, l, r in tree.traverse():
+            level[p] = 1 + max(level.get(l, 0), level.get(r, 0))
+        order = lambda node: (level[node], tree.get_flops(node))  # noqa: E731
+
     if N == 1:
         step = build_single_step(
             size_dict, tensors[0], root_order, arena_factory(), node=tree.root
@@ -717,7 +734,12 @@ def compile_tree(tree, dtype, order=None, force_kernel=None):
         final = step.c
     else:
         final = None
+        pending, cur_level = [], 0
         for p, l, r in tree.traverse(order=order):
+            if level is not None and level[p] != cur_level:
+                for ref in pending:
+                    release(ref)
+                pending, cur_level = [], level[p]
             is_root = p == tree.root
             depends[p] = depends[l] or depends[r] or is_root
             inv = not depends[p]
@@ -735,10 +757,15 @@ def compile_tree(tree, dtype, order=None, force_kernel=None):
             )
             step.invariant = inv
             add(step)
-            release(step.a)
-            release(step.b)
+            if level is not None:
+                pending += [step.a, step.b]
+            else:
+                release(step.a)
+                release(step.b)
             tensors[p] = step.c
             final = step.c
+        for ref in pending:
+            release(ref)
 
     # -- accumulate the slice into the full result at its chunk position
     acc = Step(kind=KIND_ACCUM, a=final, node=-1, label="accumulate")

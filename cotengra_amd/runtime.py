@@ -32,6 +32,7 @@ SYMBOLS = (
     "ctg_exec_get_exponent",
     "ctg_exec_run_slices",
     "ctg_exec_slice_batch",
+    "ctg_exec_launch_count",
     "ctg_exec_profile_slice",
     "ctg_exec_step_kernel",
     "ctg_exec_sync",
@@ -128,6 +129,7 @@ def load():
         "ctg_exec_get_exponent": [vp, C.POINTER(C.c_double), C.POINTER(C.c_int)],
         "ctg_exec_run_slices": [vp, C.c_int64, C.c_int64, C.c_int64],
         "ctg_exec_slice_batch": [vp, i64p],
+        "ctg_exec_launch_count": [vp, i64p, i64p],
         "ctg_exec_profile_slice": [vp, C.c_int64, C.POINTER(C.c_float)],
         "ctg_exec_step_kernel": [vp, C.c_int64, C.c_char_p, C.c_int64],
         "ctg_exec_sync": [vp],
@@ -302,6 +304,12 @@ class Executor:
         n = C.c_int64()
         _check(load().ctg_exec_slice_batch(self.handle, C.byref(n)))
         return n.value
+
+    def launch_count(self):
+        """``(steps, launches)`` of one slice: independent small steps share launches."""
+        ns, nl = C.c_int64(), C.c_int64()
+        _check(load().ctg_exec_launch_count(self.handle, C.byref(ns), C.byref(nl)))
+        return ns.value, nl.value
 
     def profile_slice(self, slice_id=0):
         ms = (C.c_float * max(len(self.plan.steps), 1))()

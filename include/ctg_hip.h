@@ -140,12 +140,21 @@ int ctg_exec_run_slices(ctg_exec* exec, int64_t first, int64_t count, int64_t st
  * so the executor carries up to `batch` consecutive slices of a run through every
  * launch (gridDim.y), each in its own replica of the arena; the reference's slice
  * loop (core.py:4015-4028) has no counterpart -- it is one Python iteration per
- * slice.  Chosen when the executor is built: min(64, nslices), bounded by 4 GiB
- * of arena replicas (environment: CTG_SLICE_BATCH, CTG_SLICE_BATCH_MIB); wide
+ * slice.  Chosen when the executor is built: min(64, nslices), bounded by 8 GiB
+ * (and a quarter of the free device memory) of arena replicas (environment: CTG_SLICE_BATCH, CTG_SLICE_BATCH_MIB); wide
  * trees get 1.  The result does not depend on it bit for bit: the k-split of
  * every step, the kernels and the order in which slices are added are those of
  * one launch sequence per slice. */
 int ctg_exec_slice_batch(ctg_exec* exec, int64_t* batch);
+
+/* Steps of one slice and the kernel launches they take.  Independent small steps
+ * (the leaves-upward wave fronts of a tree; the reference contracts them one
+ * einsum call after the other, contract.py:788-829) share launches: `steps` pair /
+ * single / accumulate steps per slice go out as `launches` launches.  Grouping
+ * never changes a result bit (every output element is computed by the same
+ * thread in the same order); it is off under strip_exponent and with the
+ * environment variable CTG_NO_GROUPS. */
+int ctg_exec_launch_count(ctg_exec* exec, int64_t* steps, int64_t* launches);
 
 /* Same as run_slices(slice_id, 1, 1) but brackets every step with events and
  * returns its duration in milliseconds (`ms[n_steps]`); synchronous.  Serves

@@ -406,3 +406,41 @@ def test_slice_batching_does_not_change_a_bit(monkeypatch, dtype):
     assert amps[0] == amps[2] == amps[4] and amps[1] == amps[3] == amps[5]
     ref = complex(np.load(os.path.join(ROOT, "tests", "golden", "sycamore_m10_expected.npz"))["amplitude"])
     assert abs(amps[0] - ref) <= (1e-10 if dtype == "complex128" else 1e-5) * abs(ref)
+
+
+# ---------------------------------------------------------------------- #
+# wave-front groups
+# ---------------------------------------------------------------------- #
+
+
+@pytest.mark.parametrize("dtype", ["float32", "float64", "complex64", "complex128"])
+def test_grouped_launches_do_not_change_a_bit(monkeypatch, dtype):
+    """Small trees are emitted level by level and consecutive independent small
+    steps share one launch.  Every output element is still computed by the same
+    thread in the same order: identical bits with grouping on and off, with the
+    reference's depth-first order, and under slice batching; fewer launches."""
+    for name in ["C2_lattice8x8_d4", "C5_hyper200", "lattice8x8_sliced", "rand_s42_r2_o2_hi1_ho2_outsliced"]:
+        c = case_named(name)
+        outs, counts = [], []
+        for groups, order in ((True, None), (False, None), (True, "dfs")):
+            if groups:
+                monkeypatch.delenv("CTG_NO_GROUPS", raising=False)
+            else:
+                monkeypatch.setenv("CTG_NO_GROUPS", "1")
+            tree = G.tree_of(c)
+            arrays = [np.real(a).astype(dtype) if not dtype.startswith("complex") else a.astype(dtype)
+                      for a in G.arrays_of(c, "complex128", tree)]
+            fn = HipContractor(tree, order=order)
+            st = fn.setup(*arrays)
+            ex = st["exec"]
+            counts.append(ex.launch_count())
+            ex.zero_result()
+            ex.run_slices(0, min(tree.nslices, 70), 1)
+            outs.append(np.array(ex.download_result()))
+            fn.close()
+        assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[0], outs[2]), name
+        assert np.all(np.isfinite(outs[0]))
+        (s0, l0), (s1, l1), _ = counts
+        assert s0 == s1 == l1 and l0 <= s0
+        if name.startswith("C"):
+            assert l0 * 2 <= s0, (name, counts)
