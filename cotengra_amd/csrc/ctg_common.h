@@ -267,6 +267,7 @@ struct MfmaHints {
     int stream;      // 1: tall-skinny streaming kernel (row tile 32, B resident in LDS);
                      // 2: k-streaming kernel (R, N <= 32, both operands stream along K)
                      // 3: skinny FMA kernel (K <= 16, N <= 4: far below one MFMA tile)
+                     // 4: row-wise FMA kernel (K <= 32, N <= 16, any extents and layout)
     int additive32;  // 1: row offsets are tile-additive for 32-row groups
     int fast;        // 1: full tiles + tile-additive 32-bit offsets (tiled fast path)
     const void* lane;  // fast path: per-thread gather / staging constants, built once per
@@ -381,6 +382,7 @@ int fast_group_key(const StepArgs& p, const MfmaHints& h);  // -1: the step laun
 uint32_t fast_group_fill(const StepArgs& p, const MfmaHints& h, FastGroupItem* it, uint32_t block_begin);
 hipError_t launch_pair_mfma_fast_group(int key, const FastGroupItem* d_items, int n_items, uint32_t blocks,
                                        int nz, hipStream_t stream);
+bool rowwise_ok(const StepArgs& p);  // shapes the row-wise kernel takes (MfmaHints::stream == 4)
 int64_t fast_lane_table_bytes();
 hipError_t launch_fast_lane_consts(const StepArgs& p, const MfmaHints& h, void* out, hipStream_t stream);
 // complex128 on the FP64 matrix cores (ctg_pair_mfma_f64.hip)

@@ -109,10 +109,29 @@ __global__ __launch_bounds__(256) void pair_kred_kernel(StepArgs p, int64_t G, i
         const int64_t k0 = g * chunk;
         const int64_t k1 = (k0 + chunk < p.K) ? k0 + chunk : p.K;
         T acc = zero_of(T{});
-        for (int64_t k = k0 + lane; k < k1; k += 64) {
-            int64_t kh, kl;
-            split_k(p, k, kh, kl);
-            fma_acc(acc, a[p.kA.hi[kh] + p.kA.lo[kl]], b[p.kB.hi[kh] + p.kB.lo[kl]]);
+        // four elements per lane and round: the table lookups of all four, then their
+        // loads, then the multiply-adds in the order a lane always took them (k, k + 64,
+        // ...) -- a quarter of the dependent round trips, the same bits
+        constexpr int U = 4;
+        for (int64_t k = k0 + lane; k < k1; k += 64 * U) {
+            int64_t ia[U], ib[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int64_t ku = k + 64 * u < k1 ? k + 64 * u : k;   // (clamped: a valid address)
+                int64_t kh, kl;
+                split_k(p, ku, kh, kl);
+                ia[u] = p.kA.hi[kh] + p.kA.lo[kl];
+                ib[u] = p.kB.hi[kh] + p.kB.lo[kl];
+            }
+            T av[U], bv[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                av[u] = a[ia[u]];
+                bv[u] = b[ib[u]];
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+                if (k + 64 * u < k1) fma_acc(acc, av[u], bv[u]);
         }
         acc = wave_sum(acc);
         if (lane == 0) partial[(int64_t)blockIdx.y * items + w] = acc;   // (scratch per slice of this launch)

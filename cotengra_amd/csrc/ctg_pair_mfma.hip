@@ -1100,6 +1100,28 @@ __global__ __launch_bounds__(256, (FN == 1 ? 4 : FN == 2 ? CTG_STREAM_OCC2 : CTG
     // in flight while the matrix cores work on the task before.
     int64_t a_base_off = 0;  // ADD: scalar row base of the group being gathered
 
+    // !ADD (rows of a group are not base + per-lane constant: extents that are not
+    // powers of two): lane l holds the A offset of row l of the group being
+    // gathered (-1 past the last row) and of the group this wave gathers next --
+    // fetched one group ahead, so the two dependent table loads per row sit behind a
+    // whole task's gathers instead of in front of every single element's load; the
+    // element loads pick their row's offset from its lane (ds_bpermute).  Same for
+    // the C offsets of the group whose tile is stored next.
+    int64_t a_row_cur = -1, a_row_next = -1, c_row_cur = -1, c_row_next = -1;
+    bool a_rows_primed = false, c_rows_primed = false;
+    auto fetch_row = [&](const RowTab& tab, int64_t g) __attribute__((always_inline)) -> int64_t {
+        const int64_t m = g * 32 + l31;
+        if (g >= n_groups || m >= p.R) return -1;
+        int64_t hi, lo;
+        split_row(p, m, hi, lo);
+        return tab.hi[hi] + tab.lo[lo];
+    };
+    auto lane_get = [&](int64_t v, int src) __attribute__((always_inline)) -> int64_t {
+        const int lo = __shfl((int)(v & 0xffffffffll), src, 64);
+        const int hi = __shfl((int)(v >> 32), src, 64);
+        return ((int64_t)hi << 32) | (unsigned)lo;
+    };
+
     auto resolve_rows_a = [&](int64_t g) __attribute__((always_inline)) {
         const int64_t m0 = g * 32;
         if (ADD) {
@@ -1109,6 +1131,10 @@ __global__ __launch_bounds__(256, (FN == 1 ? 4 : FN == 2 ? CTG_STREAM_OCC2 : CTG
             // stores to C, so only the constant address space gets a scalar load --
             // a vector load here would wait for every gather in flight, vmcnt(0))
             a_base_off = sload64(p.rowA.hi + uniform64(hi)) + sload64(p.rowA.lo + uniform64(lo));
+        } else {
+            a_row_cur = a_rows_primed ? a_row_next : fetch_row(p.rowA, g);
+            a_rows_primed = true;
+            a_row_next = fetch_row(p.rowA, g + n_waves);
         }
     };
     auto gather = [&](c64 (&a_reg)[NV], int64_t g, int chunk, auto all_live) __attribute__((always_inline)) {
@@ -1119,16 +1145,14 @@ __global__ __launch_bounds__(256, (FN == 1 ? 4 : FN == 2 ? CTG_STREAM_OCC2 : CTG
             for (int j = 0; j < NV; j += 2) {
                 // wave-uniform (depends on j only); all_live: the host-side order
                 // table fills every slot, so the loads are unconditional
-                if (!decltype(all_live)::value && SHORTK && a_pk[j] < 0) continue;
                 const int r = a_pk[j] >> 16, c = (a_pk[j] & 0xffff) - r * LD;
                 int64_t ro;
                 if (ADD) {
                     ro = a_base_off + a_delta[j];
                 } else {
-                    int64_t hi, lo;
-                    split_row(p, m0 + r, hi, lo);
-                    ro = p.rowA.hi[hi] + p.rowA.lo[lo];
+                    ro = lane_get(a_row_cur, r & 31);   // (cross-lane: before any per-lane skip)
                 }
+                if (!decltype(all_live)::value && SHORTK && a_pk[j] < 0) continue;
 #ifdef CTG_KO_GATHER
                 const f32x4 v = {(float)ro, 1.f, 2.f, (float)ka[c]};
 #else
@@ -1140,16 +1164,14 @@ __global__ __launch_bounds__(256, (FN == 1 ? 4 : FN == 2 ? CTG_STREAM_OCC2 : CTG
         } else {
 #pragma unroll
             for (int j = 0; j < NV; ++j) {
-                if (SHORTK && a_pk[j] < 0) continue;
                 const int r = a_pk[j] >> 16, c = (a_pk[j] & 0xffff) - r * LD;
                 int64_t ro = -1;
                 if (ADD) {
                     ro = a_base_off + a_delta[j];
-                } else if (m0 + r < p.R) {
-                    int64_t hi, lo;
-                    split_row(p, m0 + r, hi, lo);
-                    ro = p.rowA.hi[hi] + p.rowA.lo[lo];
+                } else {
+                    ro = lane_get(a_row_cur, r & 31);   // (cross-lane: before any per-lane skip)
                 }
+                if (SHORTK && a_pk[j] < 0) continue;
                 const int64_t ko = ka[c];
                 c64 v{0.f, 0.f};
                 if (ro >= 0 && ko >= 0) v = A[ro + ko];
@@ -1220,6 +1242,11 @@ __global__ __launch_bounds__(256, (FN == 1 ? 4 : FN == 2 ? CTG_STREAM_OCC2 : CTG
             split_row(p, uniform64(cg * 32), hi, lo);
             c_base = sload64(p.rowC.hi + uniform64(hi)) + sload64(p.rowC.lo + uniform64(lo));
         }
+        if (!ADD && last) {
+            c_row_cur = c_rows_primed ? c_row_next : fetch_row(p.rowC, cg);
+            c_rows_primed = true;
+            c_row_next = fetch_row(p.rowC, cg + n_waves);
+        }
         const float* a_base = As + kk * 32 * LD + l31 * LD;
         const float* b_base = Bs + (kk * BROWS + l31) * LDB + cc * MFMA_BK;
         const int k_left = (int)p.K - cc * MFMA_BK;
@@ -1283,13 +1310,7 @@ __global__ __launch_bounds__(256, (FN == 1 ? 4 : FN == 2 ? CTG_STREAM_OCC2 : CTG
                     if (ADD) {
                         ro = c_base + c_delta[u];
                     } else {
-                        const int64_t m = cg * 32 + (t & 3) + 8 * (t >> 2) + 4 * kk + (odd ? 1 : 0);
-                        ro = -1;
-                        if (m < p.R) {
-                            int64_t hi, lo;
-                            split_row(p, m, hi, lo);
-                            ro = p.rowC.hi[hi] + p.rowC.lo[lo];
-                        }
+                        ro = lane_get(c_row_cur, (t & 3) + 8 * (t >> 2) + 4 * kk + (odd ? 1 : 0));
                     }
 #pragma unroll
                     for (int j = 0; j < FN; ++j) {
@@ -1712,6 +1733,134 @@ static hipError_t launch_skinny(const StepArgs& p, hipStream_t stream) {
     return hipErrorInvalidValue;
 }
 
+// ------------------------------------------------------------------------- //
+// Row-wise kernel for tall steps with a handful of multiply-adds per row and
+// no structure to exploit: K <= 32, N <= 16, any extents (3s of hyper networks),
+// any layout.  One thread per row: its A and C row offsets through the two-level
+// tables (once), K element loads, K * N complex FMAs against B broadcast from
+// LDS, N element stores.  Neighbouring threads are neighbouring rows, so loads
+// and stores coalesce whenever a kept index is the fastest in memory.  The
+// matrix-core kernels pad such a step to 16 x 16 tiles and, when 32-row groups
+// are not base + constant, fall back to per-group table lookups.
+// ------------------------------------------------------------------------- //
+// TS: the N output columns are the fastest index of C -- the 256 x N results of a
+// block go through LDS so that consecutive lanes store consecutive columns
+// (contiguous 8-byte stores) instead of one column of 64 different rows
+// (measured on the 200-tensor hyper network: 2.4 -> 4.6 TB/s at N = 8).  The
+// same for the loads when a contracted index is the fastest one of A measured
+// slower than the plain per-thread loads (L1 serves the k-neighbours) and is
+// not built.  blockIdx.z: batch index of the step.
+template <int NN, bool TS>
+__global__ __launch_bounds__(256) void pair_rowwise_kernel(StepArgs p) {
+    constexpr int KMAX = 32;
+    constexpr int CS = NN + 1;   // padded row of the result tile (float2 units)
+    __shared__ float2 Bs[KMAX * NN];
+    __shared__ int64_t kofs[KMAX];
+    __shared__ int64_t ncol[NN];
+    __shared__ int64_t roff[TS ? 256 : 1];
+    __shared__ float2 tile[TS ? 256 * CS : 1];
+    const int64_t bz = blockIdx.z;
+    const c64* __restrict__ A = (const c64*)p.A + zoffA(p) + p.bA[bz];
+    const c64* __restrict__ B = (const c64*)p.B + zoffB(p) + p.bB[bz];
+    c64* __restrict__ C = (c64*)p.C + zoffC(p) + p.bC[bz];
+    const int tid = threadIdx.x;
+    const int K = (int)p.K, N = (int)p.N;
+    const int64_t row0 = (int64_t)blockIdx.x * 256;
+    const int64_t row = row0 + tid;
+    const bool live = row < p.R;
+    int64_t a_off = 0, c_off = 0;
+    if (live) {   // (issued first: the longest dependent chain of the thread)
+        int64_t hi, lo;
+        split_row(p, row, hi, lo);
+        a_off = p.rowA.hi[hi] + p.rowA.lo[lo];
+        c_off = p.rowC.hi[hi] + p.rowC.lo[lo];
+    }
+    for (int e = tid; e < K * NN; e += 256) {
+        const int k = e / NN, n = e - k * NN;
+        c64 v{0.f, 0.f};
+        if (n < N) {
+            int64_t kh, kl;
+            split_k(p, k, kh, kl);
+            v = B[p.nB[n] + p.kB.hi[kh] + p.kB.lo[kl]];
+        }
+        Bs[e] = float2{v.re, v.im};
+    }
+    if (tid < K) {
+        int64_t kh, kl;
+        split_k(p, tid, kh, kl);
+        kofs[tid] = p.kA.hi[kh] + p.kA.lo[kl];
+    }
+    if (tid >= 64 && tid < 64 + NN) ncol[tid - 64] = tid - 64 < N ? p.nC[tid - 64] : 0;
+    __syncthreads();
+    const float alpha = (float)step_alpha(p);
+    float accr[NN], acci[NN];
+#pragma unroll
+    for (int n = 0; n < NN; ++n) accr[n] = acci[n] = 0.f;
+    if (live) {
+        const c64* a = A + a_off;
+        for (int k0 = 0; k0 < K; k0 += 8) {
+            c64 av[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) av[j] = k0 + j < K ? a[kofs[k0 + j]] : c64{0.f, 0.f};
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                if (k0 + j >= K) break;   // (wave-uniform)
+                const float2* b = Bs + (k0 + j) * NN;
+#pragma unroll
+                for (int n = 0; n < NN; ++n) {
+                    const float2 bv = b[n];
+                    accr[n] = fmaf(av[j].re, bv.x, accr[n]);
+                    accr[n] = fmaf(-av[j].im, bv.y, accr[n]);
+                    acci[n] = fmaf(av[j].re, bv.y, acci[n]);
+                    acci[n] = fmaf(av[j].im, bv.x, acci[n]);
+                }
+            }
+        }
+    }
+    if (TS) {
+        const int rows_here = (int)(p.R - row0 < 256 ? p.R - row0 : 256);
+        roff[tid] = c_off;
+#pragma unroll
+        for (int n = 0; n < NN; ++n) tile[tid * CS + n] = float2{accr[n] * alpha, acci[n] * alpha};
+        __syncthreads();
+        const unsigned inv = 0xffffffffu / (unsigned)N + 1u;   // exact e / N for e < 2^16 (N >= 2)
+        const int total = rows_here * N;
+        for (int e = tid; e < total; e += 256) {
+            const int r = (int)__umulhi((unsigned)e, inv), n = e - r * N;
+            const float2 v = tile[r * CS + n];
+            C[roff[r] + ncol[n]] = c64{v.x, v.y};
+        }
+    } else if (live) {
+        c64* c = C + c_off;
+#pragma unroll
+        for (int n = 0; n < NN; ++n)
+            if (n < N) c[ncol[n]] = c64{accr[n] * alpha, acci[n] * alpha};
+    }
+}
+
+bool rowwise_ok(const StepArgs& p) {
+    return p.Bt >= 1 && p.Bt <= 65535 && p.K >= 1 && p.K <= 32 && p.N >= 1 && p.N <= 16;
+}
+
+template <int NN>
+static void launch_rowwise_t(const StepArgs& p, bool ts, dim3 grid, hipStream_t stream) {
+    if (ts) hipLaunchKernelGGL((pair_rowwise_kernel<NN, true>), grid, dim3(256), 0, stream, p);
+    else hipLaunchKernelGGL((pair_rowwise_kernel<NN, false>), grid, dim3(256), 0, stream, p);
+}
+
+// flags (MfmaHints::vecA of a row-wise step): bit 0 = the output columns are the
+// fastest-varying memory index of C
+static hipError_t launch_rowwise(const StepArgs& p, int flags, hipStream_t stream) {
+    const int64_t blocks = (p.R + 255) / 256;
+    if (blocks > 0x7fffffffll || p.nz > 65535 || !rowwise_ok(p)) return hipErrorInvalidValue;
+    const dim3 grid((unsigned)blocks, (unsigned)p.nz, (unsigned)p.Bt);
+    const bool ts = (flags & 1) && p.N >= 2;
+    if (p.N <= 4) launch_rowwise_t<4>(p, ts, grid, stream);
+    else if (p.N <= 8) launch_rowwise_t<8>(p, ts, grid, stream);
+    else launch_rowwise_t<16>(p, ts, grid, stream);
+    return hipGetLastError();
+}
+
 template <typename Cfg>
 static hipError_t build_lane_t(const StepArgs& p, const MfmaHints& h, void* out, hipStream_t stream) {
     if (h.vecA)
@@ -1784,6 +1933,7 @@ hipError_t launch_pair_mfma(int dtype, const StepArgs& p, const MfmaHints& h, vo
                             int64_t scratch_bytes, hipStream_t stream) {
     if (dtype != 2) return hipErrorInvalidValue;
     if (h.stream == 3) return launch_skinny(p, stream);
+    if (h.stream == 4) return launch_rowwise(p, h.vecA, stream);
     if (h.stream == 2) {
         switch (h.bn) {
             case 16: return launch_kstream<1>(p, h, scratch, scratch_bytes, stream);

@@ -542,6 +542,28 @@ int build_hints_into(ctg_exec* e, std::vector<MfmaHints>& hints, int64_t zmult,
             const int64_t a = p->tables[r[W_ROWA_LO] + rr], c = p->tables[r[W_ROWC_LO] + rr];
             if (a < 0 || a > INT32_MAX || c < 0 || c > INT32_MAX) h.additive32 = 0;
         }
+        {
+            // Tall steps with a handful of multiply-adds per row go to the row-wise FMA
+            // kernel instead of 1/8-full MFMA tiles when (a) K, N <= 8: fewer instructions
+            // per byte than staging 32-row groups through LDS (200-tensor hyper network:
+            // 2.6-3.0 -> 3.2-3.9 TB/s), (b) their 32-row groups are not base + constant
+            // (extents that are not powers of two) and the contraction is shorter than one
+            // MFMA k-step (1.7 -> 3.5-4.6 TB/s), (c) they carry a batch index, which the
+            // streaming kernel does not take.  CTG_ROWWISE=0 turns the kernel off, 2 sends
+            // every step of its shape there (experiments).
+            static const int rw = getenv("CTG_ROWWISE") ? atoi(getenv("CTG_ROWWISE")) : 1;
+            const bool shape = r[W_K] <= 32 && r[W_N] <= 16 && r[W_R] >= 8192;
+            const bool pick = (h.stream == 1 && ((r[W_K] <= 8 && r[W_N] <= 8) ||
+                                                 (!h.additive32 && r[W_K] < MFMA_BK) || rw >= 2)) ||
+                              (h.stream == 0 && r[W_BT] > 1);
+            if (rw > 0 && shape && pick) {
+                h.stream = 4;
+                // h.vecA bit 0: the output columns are the fastest-varying index of C
+                h.vecA = (r[W_N] >= 2 && p->tables[r[W_NC] + 1] - p->tables[r[W_NC]] == 1) ? 1 : 0;
+                if (getenv("CTG_ROWWISE_T")) h.vecA &= atoi(getenv("CTG_ROWWISE_T"));
+                continue;
+            }
+        }
         build_mfma_order(p, r, h.bn, h.stream ? 32 : MFMA_BM, blob, &offA[s], &offB[s], &h.vecA);
         h.fast = (!h.stream && mfma_fast_ok(p, r, h.bn)) ? 1 : 0;
     }
@@ -1212,12 +1234,20 @@ int ctg_exec_profile_slice(ctg_exec* e, int64_t slice_id, float* ms) {
         const int rc = run_invariants(e);
         if (rc != CTG_OK) return rc;
     }
-    hipError_t err = launch_prologue(e->meta, e->d_state, e->d_soff, slice_id, e->stream);
+    // (development: CTG_PROFILE_SLICES=n times every step with n slices in its launch,
+    // as a batched run issues it -- step by step, without the wave-front groups)
+    int nb = 1;
+    if (const char* v = getenv("CTG_PROFILE_SLICES"))
+        nb = (int)std::max<int64_t>(1, std::min<int64_t>({(int64_t)atoll(v), (int64_t)(e->strip ? 1 : e->batch),
+                                                          p->nslices - slice_id}));
+    hipError_t err = launch_prologue(e->meta, e->d_state, e->d_soff, slice_id, e->stream, nb, 1);
     if (err != hipSuccess) return fail(CTG_E_HIP, "prologue launch failed: %s", hipGetErrorString(err));
     HIP_TRY(hipEventRecord(e->events[0], e->stream));
     for (int64_t s = 0; s < p->n_steps; ++s) {
         if (!e->invariant[s]) {  // invariant steps cost nothing per slice: 0 ms
+            e->args[s].nz = nb;
             const int rc = launch_step(e, s, e->stream);
+            e->args[s].nz = 1;
             if (rc != CTG_OK) return rc;
         }
         HIP_TRY(hipEventRecord(e->events[s + 1], e->stream));
@@ -1244,7 +1274,9 @@ int ctg_exec_step_kernel(ctg_exec* e, int64_t step, char* buf, int64_t buflen) {
         snprintf(name, sizeof(name), "pair_mfma_real_kernel<%s>", p->dtype == CTG_F32 ? "float" : "double");
     } else if (r[W_KERNEL] == KERNEL_MFMA) {
         const MfmaHints& h = e->hints[step];
-        if (h.stream == 3)
+        if (h.stream == 4)
+            snprintf(name, sizeof(name), "pair_rowwise_kernel<%d>", r[W_N] <= 4 ? 4 : (r[W_N] <= 8 ? 8 : 16));
+        else if (h.stream == 3)
             snprintf(name, sizeof(name), "pair_skinny_kernel<%d,%d>", (int)r[W_K], (int)r[W_N]);
         else if (h.stream == 2)
             snprintf(name, sizeof(name), "pair_mfma_kstream_kernel<%d,%s>", h.bn / 16, h.vecA ? "true" : "false");

@@ -406,6 +406,9 @@ def choose_kernel(dtype, Bt, M, K, N):
     # costs nothing (csrc/ctg_common.h: mfma_use_stream)
     if Bt == 1 and 2 <= K <= 128 and N <= 64 and M >= 8192:  # (stream or tiled, runtime picks)
         return KERNEL_MFMA
+    # the same with a batch index: row-wise FMA kernel (csrc: pair_rowwise_kernel)
+    if 2 <= K <= 32 and N <= 16 and M >= 8192:
+        return KERNEL_MFMA
     return KERNEL_VALU
 
 
