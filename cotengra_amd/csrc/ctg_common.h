@@ -279,9 +279,11 @@ struct MfmaHints {
 
 // k-splits of a tiled step: when the output alone cannot fill the chip but K is long
 // (slabs of the partial tiles go through `scratch_bytes` of scratch memory)
-inline int64_t mfma_split_count(int64_t R, int64_t N, int64_t K, int64_t Bt, int bn, int64_t scratch_bytes) {
+// (zn: slices a launch of this plan nominally carries -- they fill the chip like tiles do)
+inline int64_t mfma_split_count(int64_t R, int64_t N, int64_t K, int64_t Bt, int bn, int64_t scratch_bytes,
+                                int64_t zn = 1) {
     const int64_t tiles_m = (R + MFMA_BM - 1) / MFMA_BM, tiles_n = (N + bn - 1) / bn;
-    const int64_t tiles = tiles_m * tiles_n * Bt;
+    const int64_t tiles = tiles_m * tiles_n * Bt * (zn > 1 ? zn : 1);
     const int64_t nk_total = (K + MFMA_BK - 1) / MFMA_BK;
     int64_t S = 1;
     if ((tiles < 256 && nk_total >= 16) || (tiles < 512 && nk_total >= 64)) {

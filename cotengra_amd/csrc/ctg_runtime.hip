@@ -527,7 +527,8 @@ int build_hints_into(ctg_exec* e, std::vector<MfmaHints>& hints, int64_t zmult,
             // the number of k-splits belongs to the step: taken from the single-slice
             // hints; a wider tile whose slabs would not fit the scratch is given up
             h.splitk = (int)(like ? (*like)[s].splitk
-                                  : mfma_split_count(r[W_R], r[W_N], r[W_K], r[W_BT], h.bn, kScratchBytes));
+                                  : mfma_split_count(r[W_R], r[W_N], r[W_K], r[W_BT], h.bn, kScratchBytes,
+                                                     e->batch_nominal));
             if (like) {
                 const int64_t slab = tiles_m * MFMA_BM * ((r[W_N] + h.bn - 1) / h.bn) * h.bn * 8 * r[W_BT];
                 if ((int64_t)h.splitk * slab > kScratchBytes) h.bn = (*like)[s].bn;
@@ -941,6 +942,13 @@ int ctg_exec_create(const ctg_plan* p, int device, void* stream, void* ext_resul
         const int64_t per = std::max<int64_t>(p->arena_elems * isz, 1);
         b = std::min<int64_t>(b, (mib << 20) / per);
         e->batch = (int)std::max<int64_t>(b, 1);
+        // what the plan alone says about batching (no environment, no free-memory
+        // query): the k-splits of its steps are chosen for launches of this many
+        // slices, so that they are a function of the plan and a result never depends
+        // on how a run is cut into launches
+        const int64_t nominal = std::min<int64_t>({(int64_t)64, p->nslices, ((int64_t)8192 << 20) / per});
+        e->batch_nominal = (int)std::max<int64_t>(nominal, 1);
+        if (getenv("CTG_SPLITK_PER_SLICE")) e->batch_nominal = 1;   // (experiments: round-2 rule)
     }
     HIP_TRY_E(hipMalloc((void**)&e->d_inputs, p->inputs_elems * isz));
     HIP_TRY_E(hipMalloc((void**)&e->d_arena, p->arena_elems * isz * e->batch));

@@ -141,10 +141,13 @@ int ctg_exec_run_slices(ctg_exec* exec, int64_t first, int64_t count, int64_t st
  * launch (gridDim.y), each in its own replica of the arena; the reference's slice
  * loop (core.py:4015-4028) has no counterpart -- it is one Python iteration per
  * slice.  Chosen when the executor is built: min(64, nslices), bounded by 8 GiB
- * (and a quarter of the free device memory) of arena replicas (environment: CTG_SLICE_BATCH, CTG_SLICE_BATCH_MIB); wide
- * trees get 1.  The result does not depend on it bit for bit: the k-split of
- * every step, the kernels and the order in which slices are added are those of
- * one launch sequence per slice. */
+ * (and a quarter of the free device memory) of arena replicas (environment:
+ * CTG_SLICE_BATCH, CTG_SLICE_BATCH_MIB); wide trees get 1.  The result does not
+ * depend on it bit for bit: the k-split of every step is a function of the plan
+ * (the step's shape and the plan's nominal batch min(64, nslices, 8 GiB / arena)
+ * -- not of the environment, the free memory or the launch at hand), the kernels
+ * and the order in which slices are added are those of one launch sequence per
+ * slice. */
 int ctg_exec_slice_batch(ctg_exec* exec, int64_t* batch);
 
 /* Steps of one slice and the kernel launches they take.  Independent small steps
