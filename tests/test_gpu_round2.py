@@ -444,3 +444,35 @@ def test_grouped_launches_do_not_change_a_bit(monkeypatch, dtype):
         assert s0 == s1 == l1 and l0 <= s0
         if name.startswith("C"):
             assert l0 * 2 <= s0, (name, counts)
+
+
+@pytest.mark.parametrize(
+    "env",
+    [{"CTG_GRAPH": "1", "CTG_SLICE_BATCH": "1"}, {"CTG_NO_LANE_TABLES": "1"}, {"CTG_NO_FAST_GROUPS": "1"}],
+    ids=["graph-replay", "no-lane-tables", "no-fast-groups"],
+)
+def test_development_switches_keep_the_bits(monkeypatch, env):
+    """The development switches of INTEGRATION.md select other launch mechanics
+    (captured slice graph, per-block lane constants, fewer shared launches),
+    never other arithmetic: identical results."""
+    for name in ["lattice8x8_sliced", "C2_lattice8x8_d4"]:
+        c = case_named(name)
+        outs = []
+        for on in (False, True):
+            for k, v in env.items():
+                if on:
+                    monkeypatch.setenv(k, v)
+                else:
+                    monkeypatch.delenv(k, raising=False)
+            tree = G.tree_of(c)
+            arrays = [a.astype("complex64") for a in G.arrays_of(c, "complex128", tree)]
+            fn = HipContractor(tree)
+            st = fn.setup(*arrays)
+            ex = st["exec"]
+            ex.zero_result()
+            ex.run_slices(0, tree.nslices, 1)
+            ex.run_slices(0, tree.nslices, 1)   # (a second pass: the graph is replayed, not captured)
+            outs.append(np.array(ex.download_result()))
+            fn.close()
+        assert np.array_equal(outs[0], outs[1]), (name, env)
+        assert np.all(np.isfinite(outs[0])) and np.any(outs[0] != 0)
