@@ -1434,7 +1434,10 @@ static hipError_t launch_stream_t(const StepArgs& p, const MfmaHints& h, int KP,
     }
     const int64_t n_groups = (p.R + 31) / 32;
     int64_t blocks = (n_groups + 3) / 4;
-    const int64_t cap = 256ll * bpc;  // persistent: exactly the resident blocks
+    // persistent: exactly the resident blocks (CTG_STREAM_OVERSUB=n, experiments: n times as
+    // many, each with 1/n of the row groups, the hardware scheduler balancing them)
+    static const int64_t oversub = getenv("CTG_STREAM_OVERSUB") ? atoll(getenv("CTG_STREAM_OVERSUB")) : 1;
+    const int64_t cap = 256ll * bpc * (oversub > 0 ? oversub : 1);
     if (blocks > cap) blocks = cap;
     // the slices of a batch divide the resident blocks among themselves (every block
     // strides over the row groups of its slice, whatever their number)

@@ -303,3 +303,85 @@ def test_committed_bench_line_follows_the_contract():
     for name in ("C2", "C3", "C5"):
         cfg = d["configs"][name]
         assert cfg["ms"] > 0 and 0 < cfg["mixed_roofline_frac"] <= 1 and cfg["cpu_oracle_ms"] > 0
+
+
+# ---------------------------------------------------------------------- #
+# wave-front planning (the executor's build_groups relies on these properties)
+# ---------------------------------------------------------------------- #
+
+
+def _memory_independent(x, y):
+    """No read-after-write, write-after-read or write-after-write between two steps
+    (the interval test ctg_runtime.hip:build_groups applies)."""
+
+    def iv(t):
+        return (t.space, t.offset, t.offset + t.size)
+
+    def ov(p, q):
+        return p[0] == q[0] and p[1] < q[2] and q[1] < p[2]
+
+    return not (
+        ov(iv(y.a), iv(x.c)) or ov(iv(y.b), iv(x.c)) or ov(iv(y.c), iv(x.a)) or ov(iv(y.c), iv(x.b))
+        or ov(iv(y.c), iv(x.c))
+    )
+
+
+@pytest.mark.parametrize("name", ["C2_lattice8x8_d4", "C5_hyper200", "lattice8x8_sliced"])
+def test_small_trees_are_planned_level_by_level(name):
+    """A small tree is emitted level by level (level = 1 + the deeper child) and
+    operands are recycled only when their level is done: all pair steps of one
+    level are pairwise independent in memory, so the executor may send them out
+    in shared launches.  The depth-first order stays available, and both orders
+    hold the same steps."""
+    import golden_util as G
+    from cotengra_amd import plan as P
+
+    case = next(c for c in G.cases("tree") if c["name"] == name)
+    tree = G.tree_of(case)
+    level = {}
+    for p, l, r in tree.traverse():
+        level[p] = 1 + max(level.get(l, 0), level.get(r, 0))
+    pl = P.compile_tree(tree, "complex64")
+    pairs = [s for s in pl.steps if s.kind == P.KIND_PAIR]
+    seq = [level[s.node] for s in pairs]
+    assert seq == sorted(seq), "steps are not in level order"
+    by_level = {}
+    for s in pairs:
+        by_level.setdefault(level[s.node], []).append(s)
+    for steps in by_level.values():
+        for i, x in enumerate(steps):
+            for y in steps[i + 1:]:
+                assert _memory_independent(x, y), (x.label, y.label)
+    dfs = P.compile_tree(tree, "complex64", order="dfs")
+    assert sorted(s.node for s in dfs.steps) == sorted(s.node for s in pl.steps)
+    assert pl.macs_per_slice == dfs.macs_per_slice
+    assert dfs.arena_elems <= pl.arena_elems <= 2 * dfs.arena_elems
+    # consecutive independent thread-per-output steps form the shared launches
+    launches, i = 0, 0
+    live = [s for s in pl.steps if not s.invariant]
+    groupable = lambda s: (s.kind == P.KIND_PAIR and s.kernel == P.KERNEL_VALU  # noqa: E731
+                           and not (s.K >= 256 and s.R * s.N <= 32768))
+    while i < len(live):
+        j = i + 1
+        if groupable(live[i]):
+            while j < len(live) and groupable(live[j]) and all(_memory_independent(live[q], live[j]) for q in range(i, j)):
+                j += 1
+        launches += 1
+        i = j
+    if name.startswith("C"):
+        assert launches * 2 <= len(live), (launches, len(live))
+
+
+def test_wide_trees_keep_the_depth_first_order():
+    """Level order is for trees whose largest intermediate is small; a wide tree
+    keeps the reference's depth-first order (and its smaller peak memory)."""
+    import cotengra_amd as ca
+    from cotengra_amd import plan as P
+
+    rec = ca.load_network(os.path.join(ROOT, "tests", "golden", "trees", "sycamore_m20_w30.json"))
+    tree = ca.tree_from_record(rec)
+    assert tree.max_size() > P.LEVEL_ORDER_MAX_ELEMS
+    a = P.compile_tree(tree, "complex64")
+    b = P.compile_tree(tree, "complex64", order="dfs")
+    assert [s.node for s in a.steps] == [s.node for s in b.steps]
+    assert a.arena_elems == b.arena_elems
