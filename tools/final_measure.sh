@@ -37,5 +37,13 @@ for tree in sycamore_m20_w32_c512 sycamore_m20_native; do
   timeout 600 python bench.py --steps 1 --warmup 1 --no-cpu-baseline --tree tests/golden/trees/$tree.json --dump-steps $O/steps_$tree.json > /dev/null 2>&1
   python tools/steps_report.py $O/steps_$tree.json 40 > $O/steps_$tree.txt 2>&1
 done
+# the small configurations: kernel timeline of one contraction / slice batch, per-kernel
+# summary, per-step times with the slices batched
+bash tools/exp_small_trace.sh C2 C3 C5 > $O/small_trace.log 2>&1
+for W in C2 C3 C5; do
+  cp $R/gpurun_out/trace_$W/timeline.txt $O/timeline_$W.txt 2>/dev/null
+  cp $R/gpurun_out/trace_$W/sum_kernels.txt $O/kernels_$W.txt 2>/dev/null
+  timeout 300 python tools/steps_batched.py $W 40 2>&1 | grep -v amdgpu.ids > $O/steps_batched_$W.txt
+done
 find $O -name "*.db" -delete
 find $O -type d -empty -delete

@@ -21,6 +21,10 @@ pairs = {
 for tree in ("sycamore_m20_w32_c512", "sycamore_m20_native"):
     pairs[f"pmc_summary_{tree}.json"] = f"pmc_summary_{tree}.json"   # (read by bench.py: roofline.traffic)
     pairs[f"steps_{tree}.txt"] = f"{tag}_steps_{tree}.txt"
+for w in ("C2", "C3", "C5"):
+    pairs[f"timeline_{w}.txt"] = f"{tag}_timeline_{w}.txt"
+    pairs[f"kernels_{w}.txt"] = f"{tag}_kernels_{w}.txt"
+    pairs[f"steps_batched_{w}.txt"] = f"{tag}_steps_batched_{w}.txt"
 for a, b in pairs.items():
     if os.path.exists(os.path.join(SRC, a)):
         shutil.copyfile(os.path.join(SRC, a), os.path.join(DST, b))
