@@ -72,6 +72,7 @@ struct ctg_exec {
     hipGraphExec_t gexec = nullptr;
     hipEvent_t ev_in = nullptr, ev_out = nullptr;
     bool warm = false;
+    bool soff_static = false;      // unsliced tree: the (all-zero) leaf offsets are in place
     bool graph_off = false;
     // strip_exponent state
     int strip = 0, check_zero = 0;

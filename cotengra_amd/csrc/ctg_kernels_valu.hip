@@ -349,11 +349,34 @@ __global__ __launch_bounds__(256) void accum_kernel(StepArgs p, const StripState
         int64_t hi, lo;
         split_row(p, row, hi, lo);
         const int64_t ra = p.rowA.hi[hi] + p.rowA.lo[lo], rc = p.rowC.hi[hi] + p.rowC.lo[lo];
-        for (int64_t z = p.z0; z < p.z0 + p.nz; ++z) {
-            const T a = ((const T*)p.A + p.soffA[z * p.zsA] + z * p.zA)[ra];
-            T* c = (T*)p.C + p.soffC[z * p.zsC] + z * p.zC + rc;
-            *c = add_of(*c, st ? scale_of(a, coef) : a);
+        // The slices of a batch are added in slice order, as one launch per slice would;
+        // their values are fetched eight at a time (independent loads) and a result
+        // element that consecutive slices share (inner-sliced indices: all of them) stays
+        // in a register between them instead of going through memory 64 times.
+        T* cur = nullptr;
+        T sum = zero_of(T{});
+        const int64_t z_end = (int64_t)p.z0 + p.nz;
+        for (int64_t z0 = p.z0; z0 < z_end; z0 += 8) {
+            T av[8];
+            T* cp[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int64_t z = z0 + i < z_end ? z0 + i : z_end - 1;
+                av[i] = ((const T*)p.A + p.soffA[z * p.zsA] + z * p.zA)[ra];
+                cp[i] = (T*)p.C + p.soffC[z * p.zsC] + z * p.zC + rc;
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                if (z0 + i >= z_end) break;
+                if (cp[i] != cur) {
+                    if (cur) *cur = sum;
+                    cur = cp[i];
+                    sum = *cur;
+                }
+                sum = add_of(sum, st ? scale_of(av[i], coef) : av[i]);
+            }
         }
+        if (cur) *cur = sum;
     }
 }
 

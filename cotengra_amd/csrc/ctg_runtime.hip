@@ -1142,9 +1142,13 @@ int ctg_exec_run_slices(ctg_exec* e, int64_t first, int64_t count, int64_t strid
     }
     // slices sid, sid + stride, ... (nb of them) through one launch sequence
     auto eager = [&](int64_t sid, int nb = 1) -> int {
-        hipError_t err = launch_prologue(e->meta, e->d_state, e->d_soff, sid, e->stream, nb, stride);
-        if (err != hipSuccess)
-            return fail(CTG_E_HIP, "prologue launch failed: %s", hipGetErrorString(err));
+        // (an unsliced tree has one set of leaf offsets -- all zero: computed once)
+        if (p->n_sliced > 0 || e->strip || !e->soff_static) {
+            hipError_t err = launch_prologue(e->meta, e->d_state, e->d_soff, sid, e->stream, nb, stride);
+            if (err != hipSuccess)
+                return fail(CTG_E_HIP, "prologue launch failed: %s", hipGetErrorString(err));
+            e->soff_static = p->n_sliced == 0 && !e->strip;
+        }
         for (const ctg_exec::Issue& q : e->issue) {
             const int rc = launch_issue(e, q, nb, e->stream);
             if (rc != CTG_OK) return rc;
