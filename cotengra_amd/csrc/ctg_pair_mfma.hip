@@ -1740,8 +1740,8 @@ static hipError_t launch_skinny(const StepArgs& p, hipStream_t stream) {
 // Row-wise kernel for tall steps with a handful of multiply-adds per row and
 // no structure to exploit: K <= 32, N <= 16, any extents (3s of hyper networks),
 // any layout.  One thread per row: its A and C row offsets through the two-level
-// tables (once), K element loads, K * N complex FMAs against B broadcast from
-// LDS, N element stores.  Neighbouring threads are neighbouring rows, so loads
+// tables (once), K element loads, K * N complex FMAs (two packed v_pk_fma_f32
+// each) against B broadcast from LDS, N element stores.  Neighbouring threads are neighbouring rows, so loads
 // and stores coalesce whenever a kept index is the fastest in memory.  The
 // matrix-core kernels pad such a step to 16 x 16 tiles and, when 32-row groups
 // are not base + constant, fall back to per-group table lookups.
@@ -1756,12 +1756,14 @@ static hipError_t launch_skinny(const StepArgs& p, hipStream_t stream) {
 template <int NN, bool TS>
 __global__ __launch_bounds__(256) void pair_rowwise_kernel(StepArgs p) {
     constexpr int KMAX = 32;
-    constexpr int CS = NN + 1;   // padded row of the result tile (float2 units)
-    __shared__ float2 Bs[KMAX * NN];
+    typedef float v2f __attribute__((ext_vector_type(2)));
+    // B as (Re, Im, -Im, Re): one complex multiply-add = two packed FMAs (v_pk_fma_f32)
+    // on a (Re, Im) accumulator, a.re * (b.re, b.im) + a.im * (-b.im, b.re)
+    __shared__ f32x4 Bs[KMAX * NN];
     __shared__ int64_t kofs[KMAX];
     __shared__ int64_t ncol[NN];
     __shared__ int64_t roff[TS ? 256 : 1];
-    __shared__ float2 tile[TS ? 256 * CS : 1];
+    extern __shared__ float2 tile[];   // TS: 256 rows of N | 1 results (odd stride: two-way bank conflicts at most)
     const int64_t bz = blockIdx.z;
     const c64* __restrict__ A = (const c64*)p.A + zoffA(p) + p.bA[bz];
     const c64* __restrict__ B = (const c64*)p.B + zoffB(p) + p.bB[bz];
@@ -1786,7 +1788,7 @@ __global__ __launch_bounds__(256) void pair_rowwise_kernel(StepArgs p) {
             split_k(p, k, kh, kl);
             v = B[p.nB[n] + p.kB.hi[kh] + p.kB.lo[kl]];
         }
-        Bs[e] = float2{v.re, v.im};
+        Bs[e] = f32x4{v.re, v.im, -v.im, v.re};
     }
     if (tid < K) {
         int64_t kh, kl;
@@ -1796,9 +1798,9 @@ __global__ __launch_bounds__(256) void pair_rowwise_kernel(StepArgs p) {
     if (tid >= 64 && tid < 64 + NN) ncol[tid - 64] = tid - 64 < N ? p.nC[tid - 64] : 0;
     __syncthreads();
     const float alpha = (float)step_alpha(p);
-    float accr[NN], acci[NN];
+    v2f acc[NN];
 #pragma unroll
-    for (int n = 0; n < NN; ++n) accr[n] = acci[n] = 0.f;
+    for (int n = 0; n < NN; ++n) acc[n] = v2f{0.f, 0.f};
     if (live) {
         const c64* a = A + a_off;
         for (int k0 = 0; k0 < K; k0 += 8) {
@@ -1808,23 +1810,24 @@ __global__ __launch_bounds__(256) void pair_rowwise_kernel(StepArgs p) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 if (k0 + j >= K) break;   // (wave-uniform)
-                const float2* b = Bs + (k0 + j) * NN;
+                const f32x4* b = Bs + (k0 + j) * NN;
+                const v2f ar = {av[j].re, av[j].re}, ai = {av[j].im, av[j].im};
 #pragma unroll
                 for (int n = 0; n < NN; ++n) {
-                    const float2 bv = b[n];
-                    accr[n] = fmaf(av[j].re, bv.x, accr[n]);
-                    accr[n] = fmaf(-av[j].im, bv.y, accr[n]);
-                    acci[n] = fmaf(av[j].re, bv.y, acci[n]);
-                    acci[n] = fmaf(av[j].im, bv.x, acci[n]);
+                    const f32x4 bv = b[n];
+                    acc[n] = __builtin_elementwise_fma(ar, v2f{bv[0], bv[1]}, acc[n]);
+                    acc[n] = __builtin_elementwise_fma(ai, v2f{bv[2], bv[3]}, acc[n]);
                 }
             }
         }
     }
     if (TS) {
         const int rows_here = (int)(p.R - row0 < 256 ? p.R - row0 : 256);
+        const int CS = N | 1;
         roff[tid] = c_off;
 #pragma unroll
-        for (int n = 0; n < NN; ++n) tile[tid * CS + n] = float2{accr[n] * alpha, acci[n] * alpha};
+        for (int n = 0; n < NN; ++n)
+            if (n < N) tile[tid * CS + n] = float2{acc[n][0] * alpha, acc[n][1] * alpha};
         __syncthreads();
         const unsigned inv = 0xffffffffu / (unsigned)N + 1u;   // exact e / N for e < 2^16 (N >= 2)
         const int total = rows_here * N;
@@ -1837,7 +1840,7 @@ __global__ __launch_bounds__(256) void pair_rowwise_kernel(StepArgs p) {
         c64* c = C + c_off;
 #pragma unroll
         for (int n = 0; n < NN; ++n)
-            if (n < N) c[ncol[n]] = c64{accr[n] * alpha, acci[n] * alpha};
+            if (n < N) c[ncol[n]] = c64{acc[n][0] * alpha, acc[n][1] * alpha};
     }
 }
 
@@ -1847,8 +1850,9 @@ bool rowwise_ok(const StepArgs& p) {
 
 template <int NN>
 static void launch_rowwise_t(const StepArgs& p, bool ts, dim3 grid, hipStream_t stream) {
-    if (ts) hipLaunchKernelGGL((pair_rowwise_kernel<NN, true>), grid, dim3(256), 0, stream, p);
-    else hipLaunchKernelGGL((pair_rowwise_kernel<NN, false>), grid, dim3(256), 0, stream, p);
+    const size_t lds = ts ? (size_t)256 * (size_t)(p.N | 1) * sizeof(float2) : 0;
+    if (ts) hipLaunchKernelGGL((pair_rowwise_kernel<NN, true>), grid, dim3(256), lds, stream, p);
+    else hipLaunchKernelGGL((pair_rowwise_kernel<NN, false>), grid, dim3(256), lds, stream, p);
 }
 
 // flags (MfmaHints::vecA of a row-wise step): bit 0 = the output columns are the
@@ -1860,6 +1864,7 @@ static hipError_t launch_rowwise(const StepArgs& p, int flags, hipStream_t strea
     const bool ts = (flags & 1) && p.N >= 2;
     if (p.N <= 4) launch_rowwise_t<4>(p, ts, grid, stream);
     else if (p.N <= 8) launch_rowwise_t<8>(p, ts, grid, stream);
+    else if (p.N <= 12) launch_rowwise_t<12>(p, ts, grid, stream);
     else launch_rowwise_t<16>(p, ts, grid, stream);
     return hipGetLastError();
 }

@@ -1287,7 +1287,8 @@ int ctg_exec_step_kernel(ctg_exec* e, int64_t step, char* buf, int64_t buflen) {
     } else if (r[W_KERNEL] == KERNEL_MFMA) {
         const MfmaHints& h = e->hints[step];
         if (h.stream == 4)
-            snprintf(name, sizeof(name), "pair_rowwise_kernel<%d>", r[W_N] <= 4 ? 4 : (r[W_N] <= 8 ? 8 : 16));
+            snprintf(name, sizeof(name), "pair_rowwise_kernel<%d>",
+                     r[W_N] <= 4 ? 4 : (r[W_N] <= 8 ? 8 : (r[W_N] <= 12 ? 12 : 16)));
         else if (h.stream == 3)
             snprintf(name, sizeof(name), "pair_skinny_kernel<%d,%d>", (int)r[W_K], (int)r[W_N]);
         else if (h.stream == 2)
