@@ -267,7 +267,7 @@ struct MfmaHints {
     int stream;      // 1: tall-skinny streaming kernel (row tile 32, B resident in LDS);
                      // 2: k-streaming kernel (R, N <= 32, both operands stream along K)
                      // 3: skinny FMA kernel (K <= 16, N <= 4: far below one MFMA tile)
-                     // 4: row-wise FMA kernel (K <= 32, N <= 16, any extents and layout)
+                     // 4: row-wise FMA kernel (K <= 32, N <= 32, any extents and layout)
     int additive32;  // 1: row offsets are tile-additive for 32-row groups
     int fast;        // 1: full tiles + tile-additive 32-bit offsets (tiled fast path)
     const void* lane;  // fast path: per-thread gather / staging constants, built once per

@@ -1738,7 +1738,7 @@ static hipError_t launch_skinny(const StepArgs& p, hipStream_t stream) {
 
 // ------------------------------------------------------------------------- //
 // Row-wise kernel for tall steps with a handful of multiply-adds per row and
-// no structure to exploit: K <= 32, N <= 16, any extents (3s of hyper networks),
+// no structure to exploit: K <= 32, N <= 32, any extents (3s of hyper networks),
 // any layout.  One thread per row: its A and C row offsets through the two-level
 // tables (once), K element loads, K * N complex FMAs (two packed v_pk_fma_f32
 // each) against B broadcast from LDS, N element stores.  Neighbouring threads are neighbouring rows, so loads
@@ -1752,7 +1752,8 @@ static hipError_t launch_skinny(const StepArgs& p, hipStream_t stream) {
 // (measured on the 200-tensor hyper network: 2.4 -> 4.6 TB/s at N = 8).  The
 // same for the loads when a contracted index is the fastest one of A measured
 // slower than the plain per-thread loads (L1 serves the k-neighbours) and is
-// not built.  blockIdx.z: batch index of the step.
+// not built.  blockIdx.z: batch index of the step (folding a batch index that is
+// the fastest one in memory into the thread index was tried as well: no gain).
 template <int NN, bool TS>
 __global__ __launch_bounds__(256) void pair_rowwise_kernel(StepArgs p) {
     constexpr int KMAX = 32;
@@ -1845,7 +1846,7 @@ __global__ __launch_bounds__(256) void pair_rowwise_kernel(StepArgs p) {
 }
 
 bool rowwise_ok(const StepArgs& p) {
-    return p.Bt >= 1 && p.Bt <= 65535 && p.K >= 1 && p.K <= 32 && p.N >= 1 && p.N <= 16;
+    return p.Bt >= 1 && p.Bt <= 65535 && p.K >= 1 && p.K <= 32 && p.N >= 1 && p.N <= 32;
 }
 
 template <int NN>
@@ -1865,7 +1866,9 @@ static hipError_t launch_rowwise(const StepArgs& p, int flags, hipStream_t strea
     if (p.N <= 4) launch_rowwise_t<4>(p, ts, grid, stream);
     else if (p.N <= 8) launch_rowwise_t<8>(p, ts, grid, stream);
     else if (p.N <= 12) launch_rowwise_t<12>(p, ts, grid, stream);
-    else launch_rowwise_t<16>(p, ts, grid, stream);
+    else if (p.N <= 16) launch_rowwise_t<16>(p, ts, grid, stream);
+    else if (p.N <= 24) launch_rowwise_t<24>(p, ts, grid, stream);
+    else launch_rowwise_t<32>(p, ts, grid, stream);
     return hipGetLastError();
 }
 

@@ -553,7 +553,7 @@ int build_hints_into(ctg_exec* e, std::vector<MfmaHints>& hints, int64_t zmult,
             // streaming kernel does not take.  CTG_ROWWISE=0 turns the kernel off, 2 sends
             // every step of its shape there (experiments).
             static const int rw = getenv("CTG_ROWWISE") ? atoi(getenv("CTG_ROWWISE")) : 1;
-            const bool shape = r[W_K] <= 32 && r[W_N] <= 16 && r[W_R] >= 8192;
+            const bool shape = r[W_K] <= 32 && r[W_N] <= 32 && r[W_R] >= 8192;
             const bool pick = (h.stream == 1 && ((r[W_K] <= 8 && r[W_N] <= 8) ||
                                                  (!h.additive32 && r[W_K] < MFMA_BK) || rw >= 2)) ||
                               (h.stream == 0 && r[W_BT] > 1);
@@ -1288,7 +1288,7 @@ int ctg_exec_step_kernel(ctg_exec* e, int64_t step, char* buf, int64_t buflen) {
         const MfmaHints& h = e->hints[step];
         if (h.stream == 4)
             snprintf(name, sizeof(name), "pair_rowwise_kernel<%d>",
-                     r[W_N] <= 4 ? 4 : (r[W_N] <= 8 ? 8 : (r[W_N] <= 12 ? 12 : 16)));
+                     r[W_N] <= 4 ? 4 : (r[W_N] <= 8 ? 8 : (r[W_N] <= 12 ? 12 : (r[W_N] <= 16 ? 16 : (r[W_N] <= 24 ? 24 : 32)))));
         else if (h.stream == 3)
             snprintf(name, sizeof(name), "pair_skinny_kernel<%d,%d>", (int)r[W_K], (int)r[W_N]);
         else if (h.stream == 2)

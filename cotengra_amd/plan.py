@@ -407,7 +407,7 @@ def choose_kernel(dtype, Bt, M, K, N):
     if Bt == 1 and 2 <= K <= 128 and N <= 64 and M >= 8192:  # (stream or tiled, runtime picks)
         return KERNEL_MFMA
     # the same with a batch index: row-wise FMA kernel (csrc: pair_rowwise_kernel)
-    if 2 <= K <= 32 and N <= 16 and M >= 8192:
+    if 2 <= K <= 32 and N <= 32 and M >= 8192:
         return KERNEL_MFMA
     return KERNEL_VALU
 
