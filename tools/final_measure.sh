@@ -12,6 +12,7 @@ if [ "$1" != "notests" ]; then
   timeout 1500 python -m pytest tests -x -q -m gpu --durations=8 > $O/tests.log 2>&1
   grep -E "passed|failed|error" $O/tests.log | tail -2
 fi
+timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -1
 timeout 900 python bench.py > $O/bench.log 2>&1
 tail -1 $O/bench.log > $O/bench_line.json
 cut -c1-400 $O/bench_line.json; echo
