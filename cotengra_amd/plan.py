@@ -38,6 +38,7 @@ from __future__ import annotations
 from dataclasses import dataclass, field
 
 import math
+import os
 
 import numpy as np
 
@@ -648,9 +649,11 @@ def compile_tree(tree, dtype, order=None, force_kernel=None):
     persistent_refs = []
     parena = Arena()
 
-    def arena_factory(force_order=None, invariant=False):
+    def arena_factory(force_order=None, invariant=False, reorder=None):
         def make(inds, natural):
             order_ = force_order if force_order is not None else natural
+            if force_order is None and reorder is not None:
+                order_ = reorder(natural)
             shape = [size_dict[ix] for ix in order_]
             n = prod(shape)
             # invariant outputs live in their own region placed behind the
@@ -729,6 +732,30 @@ def compile_tree(tree, dtype, order=None, force_kernel=None):
             level[p] = 1 + max(level.get(l, 0), level.get(r, 0))
         order = lambda node: (level[node], tree.get_flops(node))  # noqa: E731
 
+    # Consumer-aware layouts (experiment, CTG_PLAN_CONSUMER_ORDER=1, small trees only): an
+    # intermediate keeps the indices its parent step keeps first and the ones it contracts
+    # last, in one canonical order -- both operands of the parent step are then contiguous
+    # along k.  Any order is legal (every kernel gathers through tables); the default is
+    # the reference's [kept-left..., kept-right...] (core.py:1035-1051).
+    consumer_order = None
+    if level is not None and os.environ.get("CTG_PLAN_CONSUMER_ORDER", "0") not in ("", "0"):
+        parent_of = {}
+        for p, l, r in tree.traverse():
+            parent_of[l] = parent_of[r] = p
+
+        def consumer_order(node):
+            up = parent_of.get(node)
+            if up is None:
+                return None
+            kept_up = set(root_order) if up == tree.root else set(tree.get_legs(up))
+
+            def reorder(natural):
+                return tuple(ix for ix in natural if ix in kept_up) + tuple(
+                    sorted((ix for ix in natural if ix not in kept_up), key=str)
+                )
+
+            return reorder
+
     if N == 1:
         step = build_single_step(
             size_dict, tensors[0], root_order, arena_factory(), node=tree.root
@@ -746,7 +773,11 @@ def compile_tree(tree, dtype, order=None, force_kernel=None):
             is_root = p == tree.root
             depends[p] = depends[l] or depends[r] or is_root
             inv = not depends[p]
-            factory = arena_factory(root_order if is_root else None, invariant=inv)
+            factory = arena_factory(
+                root_order if is_root else None,
+                invariant=inv,
+                reorder=consumer_order(p) if consumer_order is not None else None,
+            )
             p_inds = root_order if is_root else tuple(tree.get_legs(p))
             step = build_pair_step(
                 dtype,
