@@ -19,7 +19,8 @@ import sys
 
 def step_kernel_name(rocprof_name):
     """Normalise a rocprof kernel name to the ctg_exec_step_kernel() spelling."""
-    m = re.match(r"(pair_mfma_(?:fast|c64)_kernel)<ctg::MfmaCfg<(\d+), (\d+), (\d+), \d+, \d+>, (true|false)>", rocprof_name)
+    # (the fast kernel carries a third template argument since round 2: GROUPED)
+    m = re.match(r"(pair_mfma_(?:fast|c64)_kernel)<ctg::MfmaCfg<(\d+), (\d+), (\d+), \d+, \d+>, (true|false)(?:, (?:true|false))?>", rocprof_name)
     if m:
         return f"{m.group(1)}<{m.group(2)},{m.group(3)},{m.group(4)}>,{m.group(5)}"
     m = re.match(r"pair_mfma_stream_kernel<(\d+), (true|false), (true|false), (true|false), (\d+)>", rocprof_name)
@@ -28,6 +29,9 @@ def step_kernel_name(rocprof_name):
     m = re.match(r"pair_mfma_kstream_kernel<(\d+), (true|false)>", rocprof_name)
     if m:
         return f"pair_mfma_kstream_kernel<{m.group(1)},{m.group(2)}>"
+    m = re.match(r"pair_rowwise_kernel<(\d+), (?:true|false)>", rocprof_name)
+    if m:
+        return f"pair_rowwise_kernel<{m.group(1)}>"
     m = re.match(r"pair_skinny_kernel<(\d+), (\d+)>", rocprof_name)
     if m:
         return f"pair_skinny_kernel<{m.group(1)},{m.group(2)}>"
