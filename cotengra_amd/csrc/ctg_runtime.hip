@@ -1017,7 +1017,8 @@ int ctg_exec_create(const ctg_plan* p, int device, void* stream, void* ext_resul
                             hipMemcpyHostToDevice));
     }
     // Replaying a captured slice graph measured SLOWER than eager launches on
-    // ROCm 7.2 / MI355X (C2: 622 vs 523 us per contraction, m20: 92.0 vs 91.4
+    // ROCm 7.2 / MI355X (C2: 622 vs 523 us per contraction in round 1, 243 vs 183 us
+    // with the 18 shared launches of round 2; m20: 92.0 vs 91.4
     // ms per slice): the host already runs ahead of the device and the tiny
     // kernels are bound by their dependent-load latency, not by launch cost.
     // The path stays available behind CTG_GRAPH=1.
