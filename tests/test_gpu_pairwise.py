@@ -44,6 +44,14 @@ CASES = [
     ("ak,kb->ab", dict(a=20, k=1 << 17, b=9)),                        # 28: k-streaming, ragged R / N
     ("ka,bk->ab", dict(a=32, k=1 << 16, b=16)),                       # 29: k-streaming, k slowest in A
     ("aklm,mlkb->ba", dict(a=8, k=64, l=64, m=32, b=32)),             # 30: k-streaming, 3 contracted indices
+    # row-wise FMA kernel: tall steps, a handful of multiply-adds per row, odd extents / batch index
+    ("abkc,kn->abcn", dict(a=27, b=32, c=27, k=4, n=4)),              # rows 3^6 * 2^5, 4 columns
+    ("akbc,knm->abcnm", dict(a=16, b=8, c=81, k=6, n=3, m=3)),         # K = 6, N = 9 (12-column variant)
+    ("abkc,knm->abcnm", dict(a=32, b=8, c=36, k=12, n=6, m=3)),       # K = 12, N = 18 (24-column variant)
+    ("xabk,xkn->xabn", dict(x=3, a=128, b=64, k=8, n=3)),             # batch index, 8192 rows per entry
+    ("abck,kn->abcn", dict(a=32, b=32, c=16, k=8, n=8)),              # powers of two, K, N <= 8
+    ("abkc,kn->nabc", dict(a=27, b=32, c=27, k=4, n=4)),              # columns slowest in the output
+    ("abkc,knm->abcnm", dict(a=27, b=32, c=12, k=9, n=5, m=6)),       # K = 9, N = 30 (32-column variant)
 ]
 
 
@@ -148,3 +156,25 @@ def test_strip_exponent_toggle_on_live_executor():
     assert np.abs(np.asarray(m) * 10.0**e - ref).max() <= tol
     assert np.abs(np.asarray(fn(*arrays)) - ref).max() <= tol
     fn.close()
+
+
+@pytest.mark.parametrize("case", range(len(CASES) - 7, len(CASES)))
+def test_rowwise_kernel_takes_these_steps(case):
+    """The row-wise cases above are served by pair_rowwise_kernel (complex64): K, N <= 8,
+    or 32-row groups that are not base + constant (an odd extent fastest among the
+    rows) with K < 16, or a batch index."""
+    import torch
+
+    from cotengra_amd.contractor import HipContractor
+
+    eq, sizes = CASES[case]
+    (ta, tb), out = ca.eq_to_inputs_output(eq)
+    tree = ca.ContractionTree.from_path([ta, tb], out, sizes, path=[(0, 1)])
+    rng = np.random.default_rng(case)
+    arrays = [(rng.normal(size=[sizes[i] for i in t]) + 1j * rng.normal(size=[sizes[i] for i in t])).astype("complex64")
+              for t in (ta, tb)]
+    fn = HipContractor(tree)
+    st = fn.setup(*[torch.as_tensor(a, device="cuda") for a in arrays])
+    names = st["exec"].step_kernels()
+    fn.close()
+    assert any(n.startswith("pair_rowwise_kernel") for n in names), names
