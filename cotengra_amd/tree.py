@@ -542,33 +542,81 @@ class ContractionTree:
             frames.append((kids[walked], 0))
 
     def _traverse_ordered(self, order):
-        """Children before parents, and among the contractions that are ready
-        always the one with the lowest ``order(node)`` (ties: the one that
-        became ready first): a priority-queue topological sort.  This honours
-        the contract of the reference's ordered traversal (core.py:1801-1832:
-        "minimise order(node) but produce children before parents") and is the
-        greedy schedule for it; the reference's insertion-based construction
-        can emit a different -- equally valid -- sequence.  The contracted
-        values do not depend on the sequence, only tensor lifetimes do."""
-        import heapq
+        """The reference's ordered traversal, sequence for sequence
+        (core.py:1801-1832) -- ``get_path(order=f)``, ``peak_size(order=f)``
+        and ``print_contractions`` are index outputs and must agree with it.
+
+        The schedule is a line-up that starts as just the root and is swept
+        from the front again and again.  A contraction met for the first time
+        is *opened*: each of its children that is itself a contraction is
+        slotted in somewhere in front of it -- at the upper-bound position of
+        its score in the part of the line-up ahead of the parent, found by
+        binary search.  That part is in general NOT sorted (a parent keeps its
+        place when its own children go in front of it), so the outcome is
+        defined by the bisection itself and the stdlib's ``bisect_right`` is
+        used on the live list with ``hi = position of the parent``.  Children
+        land ahead of the sweep position and wait for the next sweep; once
+        every contraction has been opened the line-up is the order.
+
+        The planner's *own* level order (plan.compile_tree) does not use
+        this."""
+        from bisect import bisect_right
 
         children = self.children
-        parent_of = {}
-        waiting = {}
-        for node, (l, r) in children.items():
-            parent_of[l] = parent_of[r] = node
-            waiting[node] = (l in children) + (r in children)
-        ticket = itertools.count()
-        ready = [(order(n), next(ticket), n) for n, w in waiting.items() if w == 0]
-        heapq.heapify(ready)
-        while ready:
-            _, _, node = heapq.heappop(ready)
+        if order == "surface_order":
+            order = self.surface_order
+
+        lineup = [self.root]
+        keys = [order(self.root)]
+        opened = set()
+        while len(opened) < len(children):
+            at = 0
+            while at < len(lineup):
+                node = lineup[at]
+                if node not in opened:
+                    opened.add(node)
+                    for kid in children[node]:
+                        if kid not in children:  # a leaf: nothing to schedule
+                            continue
+                        key = order(kid)
+                        slot = bisect_right(keys, key, 0, at)
+                        keys.insert(slot, key)
+                        lineup.insert(slot, kid)
+                        at += 1  # the parent has been pushed one place back
+                at += 1
+        for node in lineup:
             yield (node, *children[node])
-            up = parent_of.get(node)
-            if up is not None:
-                waiting[up] -= 1
-                if waiting[up] == 0:
-                    heapq.heappush(ready, (order(up), next(ticket), up))
+
+    def surface_order(self, node):
+        """Score used by ``order="surface_order"``.  The reference's default
+        (core.py:3261: extent, then hypergraph centrality) belongs to its
+        compressed-contraction machinery, which is out of scope (SURVEY §2);
+        what is supported is the explicit form, an order installed from a
+        path with ``set_surface_order_from_path``."""
+        raise NotImplementedError(
+            "order='surface_order' needs set_surface_order_from_path(ssa_path) "
+            "first: centrality-based surface orders are part of the "
+            "reference's compressed contraction, which this package does not "
+            "rebuild."
+        )
+
+    def set_surface_order_from_path(self, ssa_path):
+        """Score every contraction by its position in ``ssa_path`` (those the
+        path does not produce: +inf) -- reference core.py:3264-3283."""
+        by_pair = {frozenset(kids): p for p, kids in self.children.items()}
+        node_of = dict(enumerate(self.gen_leaves()))
+        rank = {}
+        for step, ids in enumerate(ssa_path):
+            parent = by_pair[frozenset(node_of[i] for i in ids)]
+            rank[parent] = step
+            node_of[self.N + step] = parent
+        self.surface_order = lambda node: rank.get(node, float("inf"))
+
+    def get_path_surface(self):
+        return self.get_path(order=self.surface_order)
+
+    def get_ssa_path_surface(self):
+        return self.get_ssa_path(order=self.surface_order)
 
     def traverse(self, order=None):
         """Generate ``(parent, left, right)`` merges bottom-up."""
@@ -578,7 +626,7 @@ class ContractionTree:
             order = self.get_default_order()
         if order == "dfs":
             yield from self._traverse_dfs()
-        elif callable(order):
+        elif callable(order) or order == "surface_order":
             yield from self._traverse_ordered(order)
         else:
             raise ValueError(f"Unknown traversal order {order!r}.")

@@ -76,3 +76,18 @@ def relerr(x, ref):
     assert x.shape == ref.shape, (x.shape, ref.shape)
     scale = max(float(np.abs(ref).max()) if ref.size else 0.0, 1e-300)
     return float(np.abs(x - ref).max() / scale) if ref.size else 0.0
+
+
+NORTH_STAR = 1e-5
+
+
+def single_gate(ref, numpy_single):
+    """Tolerance (relative to max|ref|) of a single-precision device result:
+    the north-star 1e-5, or -- where numpy itself, running the same contraction
+    in the same single precision, is further than 1.25e-6 from the double
+    precision reference -- eight times numpy's own error.  One rule for every
+    single-precision comparison in the GPU suite (tree level since round 2,
+    kernel-shape tests since round 3)."""
+    if numpy_single is None:
+        return NORTH_STAR
+    return max(NORTH_STAR, 8.0 * relerr(np.asarray(numpy_single), ref))

@@ -7,9 +7,19 @@ import cotengra_amd as ca
 from cotengra_amd.contractor import HipContractor
 from oracle import contract_ref as orc
 
+import golden_util as G
+
 pytestmark = pytest.mark.gpu
 
-TOL = {"float32": 2e-4, "complex64": 2e-4, "float64": 1e-11, "complex128": 1e-11}
+TOL = {"float64": 1e-11, "complex128": 1e-11}
+
+
+def gate(tree, arrays, dtype, ref):
+    """Double precision: 1e-11.  Single precision: max(1e-5, 8 x the error of the numpy
+    oracle run in the same single precision) -- golden_util.single_gate."""
+    if dtype in TOL:
+        return TOL[dtype]
+    return G.single_gate(ref, orc.contract(tree, arrays))
 
 
 def greedy_path(inputs, output, size_dict):
@@ -44,7 +54,7 @@ def test_lattice(dtype, nsl, force):
     ref = orc.contract(tree, [a.astype("complex128" if "complex" in dtype else "float64") for a in arrays])
     fn = HipContractor(tree, force_kernel=force)
     out = fn(*arrays)
-    assert relerr(out, ref) < TOL[dtype]
+    assert relerr(out, ref) <= gate(tree, arrays, dtype, ref)
     fn.close()
 
 
@@ -54,7 +64,7 @@ def test_lattice_8x8_d4(dtype):
     arrays = ca.make_arrays_from_inputs(tree.inputs, tree.size_dict, seed=42, dtype=dtype, rescale=True)
     ref = orc.contract(tree, [a.astype("complex128") for a in arrays])
     out = HipContractor(tree)(*arrays)
-    assert relerr(out, ref) < TOL[dtype]
+    assert relerr(out, ref) <= gate(tree, arrays, dtype, ref)
 
 
 def test_open_output_sliced_outer():

@@ -6,6 +6,7 @@ import numpy as np
 import pytest
 
 import cotengra_amd as ca
+import golden_util as G
 from cotengra_amd.interface import einsum
 
 pytestmark = pytest.mark.gpu
@@ -75,11 +76,12 @@ def test_pairwise(case, dtype):
     got = einsum(eq, a, b, optimize=[(0, 1)])
     assert np.shape(got) == np.shape(ref)
     scale = np.abs(ref).max()
-    tol = 3e-5 if dtype in ("complex64", "float32") else 1e-12
-    # long single-precision reductions accumulate rounding ~ sqrt(K) eps
-    if dtype in ("complex64", "float32") and case in (4, 5, 6):
-        tol = 3e-4
-    assert np.abs(np.asarray(got) - ref).max() <= tol * scale
+    tol = 1e-12
+    if dtype in ("complex64", "float32"):
+        # numpy's own single-precision einsum of the same operands sets the scale of
+        # what rounding may cost on this shape (long reductions: ~ sqrt(K) eps)
+        tol = G.single_gate(ref, np.einsum(eq, a, b, optimize=True))
+    assert np.abs(np.asarray(got) - ref).max() <= tol * scale, (np.abs(np.asarray(got) - ref).max() / scale, tol)
 
 
 SKINNY = [
@@ -113,10 +115,11 @@ def test_skinny_kernel(case):
     got = np.asarray(fn(*arrays))
     ref = np.einsum(eq, *[x.astype("complex128") for x in arrays], optimize=True)
     assert got.shape == ref.shape
-    assert np.abs(got - ref).max() <= 3e-5 * np.abs(ref).max()
+    tol = G.single_gate(ref, np.einsum(eq, *arrays, optimize=True)) * np.abs(ref).max()
+    assert np.abs(got - ref).max() <= tol
     # with strip_exponent the step scales by 1 / (facA * facB)
     m, e = fn(*arrays, strip_exponent=True)
-    assert np.abs(np.asarray(m) * 10.0**e - ref).max() <= 3e-5 * np.abs(ref).max()
+    assert np.abs(np.asarray(m) * 10.0**e - ref).max() <= tol
     fn.close()
 
 
@@ -150,7 +153,7 @@ def test_strip_exponent_toggle_on_live_executor():
     ]
     ref = np.einsum(eq, *[x.astype("complex128") for x in arrays], optimize=True)
     fn = HipContractor(ca.ContractionTree.from_path([ta, tb], out, sizes, path=[(0, 1)]))
-    tol = 3e-5 * np.abs(ref).max()
+    tol = G.single_gate(ref, np.einsum(eq, *arrays, optimize=True)) * np.abs(ref).max()
     assert np.abs(np.asarray(fn(*arrays)) - ref).max() <= tol
     m, e = fn(*arrays, strip_exponent=True)
     assert np.abs(np.asarray(m) * 10.0**e - ref).max() <= tol

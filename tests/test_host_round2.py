@@ -2,7 +2,7 @@
 
 * projected OUTPUT indices keep a size-1 axis (golden from the reference);
 * projections survive every path that rebuilds a tree;
-* the ordered traversal is a valid, greedy topological order;
+* (the ordered traversal moved to test_host_round3.py: reference-frozen sequences);
 * the per-op plug-in ``implementation=(einsum, tensordot)`` (contract.py:775-776)
   driven with numpy's functions against the oracle;
 * checkpoint files: signature, atomic replace, mismatch;
@@ -81,31 +81,6 @@ def test_projection_survives_tree_rebuilds():
     adopted = ca.array_contract_tree(tree.inputs, tree.output, tree.size_dict, optimize=foreign)
     assert {ix: si.project for ix, si in adopted.sliced_inds.items()} == proj
     assert np.allclose(orc.contract(adopted, arrays), ref, rtol=1e-12, atol=1e-15)
-
-
-def test_ordered_traversal_is_greedy_topological():
-    inputs, output, shapes, size_dict = ca.lattice_equation([4, 4], d_min=2, d_max=3, seed=1)
-    t = ca.ContractionTree.from_path(inputs, output, size_dict, path=ca.greedy_path(inputs, output, size_dict))
-    order = t.get_size
-    seq = list(t.traverse(order=order))
-    assert sorted(p for p, _, _ in seq) == sorted(p for p, _, _ in t.traverse())
-    done = set(range(t.N))
-    pending = {p: (l, r) for p, l, r in seq}
-    for p, l, r in seq:
-        assert l in done and r in done
-        # no other ready contraction had a strictly lower score
-        ready = [q for q, (a, b) in pending.items() if a in done and b in done]
-        assert order(p) == min(order(q) for q in ready)
-        done.add(p)
-        del pending[p]
-    # the schedule changes lifetimes only, never values
-    arrays = ca.make_arrays_from_inputs(inputs, size_dict, seed=0)
-    assert np.allclose(orc.contract(t, arrays, order=order), orc.contract(t, arrays), rtol=1e-12)
-    # depth-first: every node directly after its whole right subtree
-    dfs = [p for p, _, _ in t.traverse()]
-    for p, l, r in t.traverse():
-        if r >= t.N and r in dfs:
-            assert dfs.index(r) == dfs.index(p) - 1
 
 
 def _np_pair():
