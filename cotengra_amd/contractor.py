@@ -91,6 +91,8 @@ class HipContractor:
         handle_slicing=True,
         device=None,
         force_kernel=None,
+        fuse=None,
+        fuse_min_elems=None,
     ):
         self._origin = tree  # whose ``contraction_cores`` hold this contractor's siblings
         if handle_slicing or not tree.sliced_inds:
@@ -103,6 +105,9 @@ class HipContractor:
         self.progbar = progbar
         self.device = device
         self.force_kernel = force_kernel
+        # fused stem pairs (plan.compile_tree): None = the default rule
+        self.fuse = fuse
+        self.fuse_min_elems = fuse_min_elems
         self._plans = {}  # dtype -> (Plan, DevicePlan)
         self._execs = {}  # (dtype, device, torch?) -> state dict
 
@@ -113,7 +118,8 @@ class HipContractor:
             return self._plans[dtype]
         except KeyError:
             plan = compile_tree(
-                self.tree, dtype, order=self.order, force_kernel=self.force_kernel
+                self.tree, dtype, order=self.order, force_kernel=self.force_kernel,
+                fuse=self.fuse, fuse_min_elems=self.fuse_min_elems,
             )
             entry = self._plans[dtype] = (plan, runtime.DevicePlan(plan))
             return entry

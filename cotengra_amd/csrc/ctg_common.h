@@ -28,10 +28,29 @@ enum StepWord {
     W_K_LO = 36, W_KA_HI = 37, W_KB_HI = 38, W_K_HI_LEN = 39,
     W_A_PROD = 40, W_B_PROD = 41,  // step that produced the operand (-1: input / preprocessing)
     W_INVARIANT = 42,              // 1: does not depend on sliced inputs, run once per upload
+    W_STEM = 43,                   // KIND_STEM2: word offset of the descriptor in the table blob
     STEP_WORDS = 48
 };
 
-enum Kind { KIND_SINGLE = 0, KIND_PAIR = 1, KIND_ACCUM = 2 };
+// KIND_STEM2: two consecutive pair steps of a stem as one launch (plan: cotengra_amd/stem.py,
+// kernel: ctg_stem.hip).  A / B / C of the record are the big operand, the first small
+// operand and the result; everything else is in the descriptor.
+enum Kind { KIND_SINGLE = 0, KIND_PAIR = 1, KIND_ACCUM = 2, KIND_STEM2 = 3 };
+
+// header of a STEM2 descriptor (int64 words; stem.py: serialise_stem)
+enum StemWord {
+    SW_MAGIC = 0, SW_K1 = 1, SW_N1 = 2, SW_K2 = 3, SW_N2 = 4, SW_NR1 = 5, SW_ROWS2 = 6, SW_NG2 = 7,
+    SW_NTILES = 8, SW_GLO = 9, SW_LD2 = 10, SW_LDS = 11,
+    SW_B2_SPACE = 12, SW_B2_OFF = 13, SW_B2_LEAF = 14, SW_B2_SIZE = 15, SW_B2_PROD = 16,
+    SW_TABS = 20,   // 14 table offsets: gA_hi gA_lo gC_hi gC_lo ord lane_a rt_a chunk_a
+                    //                   b1_off b2_off mid_row mid_col out_row out_col
+    STEM_WORDS = 40
+};
+constexpr int64_t STEM_MAGIC = 0x53544D32;
+enum StemTab {
+    ST_GA_HI = 0, ST_GA_LO, ST_GC_HI, ST_GC_LO, ST_ORD, ST_LANE_A, ST_RT_A, ST_CHUNK_A,
+    ST_B1_OFF, ST_B2_OFF, ST_MID_ROW, ST_MID_COL, ST_OUT_ROW, ST_OUT_COL, ST_COUNT
+};
 enum Kernel { KERNEL_VALU = 0, KERNEL_MFMA = 1 };
 enum Space { SPACE_INPUTS = 0, SPACE_ARENA = 1, SPACE_RESULT = 2 };
 
@@ -88,6 +107,46 @@ struct StepArgs {
                             // heuristics are computed with): how many slices fit one launch
     int64_t zA, zB, zC;     // arena replica strides (elements)
     int64_t zsA, zsB, zsC;  // strides of the soff arrays (entries)
+};
+
+// Kernel arguments of a STEM2 step.
+struct StemArgs {
+    const void* A;
+    const void* B1;
+    const void* B2;
+    void* C;
+    const int64_t* soffA;
+    const int64_t* soffB1;
+    const int64_t* soffB2;
+    const int64_t* soffC;
+    int32_t K1, N1, K2, N2;
+    int32_t nr1;        // log2 of the tile rows of step 1 (8 or 9)
+    int32_t rows2;      // rows of the intermediate tile as step 2 sees it
+    int32_t ng2;        // 32-column groups of step 2
+    int32_t ld2;        // K2 + 4
+    int64_t n_tiles, g_lo;
+    int32_t g_lo_shift;
+    int32_t check_zero;
+    const int64_t* gA_hi;
+    const int64_t* gA_lo;
+    const int64_t* gC_hi;
+    const int64_t* gC_lo;
+    const int64_t* ord;
+    const int64_t* lane_a;
+    const int64_t* rt_a;
+    const int64_t* chunk_a;
+    const int64_t* b1_off;
+    const int64_t* b2_off;
+    const int64_t* mid_row;
+    const int64_t* mid_col;
+    const int64_t* out_row;
+    const int64_t* out_col;
+    const double* facA;   // strip_exponent: max|.| of the three operands' producers (or null)
+    const double* facB1;
+    const double* facB2;
+    int32_t nz, z0;       // slice batching, as StepArgs
+    int64_t zA, zB1, zB2, zC;
+    int64_t zsA, zsB1, zsB2, zsC;
 };
 
 // element offset of an operand for the slice-in-batch this block works on
@@ -391,6 +450,10 @@ hipError_t launch_fast_lane_consts(const StepArgs& p, const MfmaHints& h, void* 
 hipError_t launch_pair_mfma_c128(const StepArgs& p, int flags, hipStream_t stream);
 // float32 / float64 on the 16x16x4 matrix-core instructions
 hipError_t launch_pair_mfma_real(int dtype, const StepArgs& p, int flags, hipStream_t stream);
+// fused stem pair (ctg_stem.hip)
+bool stem2_supported(const StemArgs& p);
+size_t stem2_lds_bytes(const StemArgs& p);
+hipError_t launch_stem2(const StemArgs& p, hipStream_t stream);
 hipError_t launch_single(int dtype, const StepArgs& p, hipStream_t stream);
 hipError_t launch_accum(int dtype, const StepArgs& p, const StripState* st, hipStream_t stream);
 

@@ -78,6 +78,71 @@ int64_t space_elems(const ctg_plan* p, int64_t space) {
     return -1;
 }
 
+// A fused stem pair: every table inside the blob, every address inside its buffer, the
+// tile geometry one the kernel takes.
+int validate_stem(const ctg_plan* p, int64_t s) {
+    const int64_t* r = &p->steps[s * STEP_WORDS];
+    const long long sl = (long long)s;
+    if (p->dtype != CTG_C64) return fail(CTG_E_INVALID, "step %lld: fused stem pairs are complex64 only", sl);
+    const int64_t d = r[W_STEM];
+    if (!tab_ok(p, d, STEM_WORDS)) return fail(CTG_E_BOUNDS, "step %lld: stem descriptor outside the blob", sl);
+    const int64_t* h = &p->tables[d];
+    if (h[SW_MAGIC] != STEM_MAGIC) return fail(CTG_E_INVALID, "step %lld: bad stem descriptor", sl);
+    const int64_t K1 = h[SW_K1], N1 = h[SW_N1], K2 = h[SW_K2], N2 = h[SW_N2], nr1 = h[SW_NR1],
+                  rows2 = h[SW_ROWS2], n_tiles = h[SW_NTILES], g_lo = h[SW_GLO];
+    StemArgs a{};
+    a.K1 = (int)K1; a.N1 = (int)N1; a.K2 = (int)K2; a.N2 = (int)N2; a.nr1 = (int)nr1;
+    a.rows2 = (int)rows2; a.ng2 = (int)h[SW_NG2]; a.ld2 = (int)h[SW_LD2];
+    if (K1 < 1 || K1 > 128 || N1 < 1 || N1 > 128 || K2 < 1 || K2 > 128 || N2 < 1 || N2 > 128 || nr1 < 5 ||
+        nr1 > 9 || rows2 < 1 || rows2 > (1 << 16) || !stem2_supported(a))
+        return fail(CTG_E_INVALID, "step %lld: stem pair shape the kernel does not take", sl);
+    if (n_tiles < 1 || g_lo < 1 || log2_exact(g_lo) < 0 || n_tiles % g_lo != 0 || log2_exact(n_tiles) < 0)
+        return fail(CTG_E_INVALID, "step %lld: bad stem grid", sl);
+    const int64_t rows1 = 1ll << nr1;
+    const int64_t len[ST_COUNT] = {n_tiles / g_lo, g_lo, n_tiles / g_lo, g_lo, 512, 256, rows1 / 32, K1 / 16,
+                                   K1 * N1, K2 * N2, rows1, N1, rows2, N2};
+    int64_t mx[ST_COUNT], mn[ST_COUNT];
+    for (int t = 0; t < ST_COUNT; ++t) {
+        if (!tab_ok(p, h[SW_TABS + t], len[t]))
+            return fail(CTG_E_BOUNDS, "step %lld: stem table outside the blob", sl);
+        mx[t] = tab_max(p, h[SW_TABS + t], len[t], &mn[t]);
+        if (mn[t] < 0) return fail(CTG_E_BOUNDS, "step %lld: negative stem offset", sl);
+    }
+    // the order table: every (row, k) of a 32 x 16 task exactly once
+    {
+        char seen[512] = {0};
+        for (int i = 0; i < 512; ++i) {
+            const int64_t v = p->tables[h[SW_TABS + ST_ORD] + i];
+            if (v < 0 || v >= 512 || seen[v])
+                return fail(CTG_E_INVALID, "step %lld: bad stem order table", sl);
+            seen[v] = 1;
+        }
+    }
+    if (mx[ST_MID_ROW] + mx[ST_MID_COL] >= rows2 * (K2 + 4))
+        return fail(CTG_E_BOUNDS, "step %lld: intermediate tile overflows its LDS", sl);
+    struct Op { int64_t space, off, leaf, size, top; char name; };
+    const Op ops[4] = {
+        {r[W_A_SPACE], r[W_A_OFF], r[W_A_LEAF], r[W_A_SIZE],
+         mx[ST_GA_HI] + mx[ST_GA_LO] + mx[ST_RT_A] + mx[ST_CHUNK_A] + mx[ST_LANE_A] + 1, 'A'},
+        {r[W_B_SPACE], r[W_B_OFF], r[W_B_LEAF], r[W_B_SIZE], mx[ST_B1_OFF], 'B'},
+        {h[SW_B2_SPACE], h[SW_B2_OFF], h[SW_B2_LEAF], h[SW_B2_SIZE], mx[ST_B2_OFF], 'b'},
+        {r[W_C_SPACE], r[W_C_OFF], r[W_C_LEAF], r[W_C_SIZE],
+         mx[ST_GC_HI] + mx[ST_GC_LO] + mx[ST_OUT_ROW] + mx[ST_OUT_COL], 'C'},
+    };
+    for (const Op& op : ops) {
+        const int64_t cap = space_elems(p, op.space);
+        if (cap < 0) return fail(CTG_E_INVALID, "step %lld: bad space", sl);
+        if (op.leaf < -1 || op.leaf > p->n_inputs) return fail(CTG_E_INVALID, "step %lld: bad leaf", sl);
+        if (op.name == 'C' && op.space == SPACE_INPUTS)
+            return fail(CTG_E_INVALID, "step %lld: writes into the inputs space", sl);
+        const int64_t hi = op.off + (op.leaf >= 0 ? p->max_soff[op.leaf] : 0) + op.top;
+        if (op.off < 0 || hi >= cap)
+            return fail(CTG_E_BOUNDS, "step %lld: stem operand %c reaches element %lld of a space of %lld",
+                        sl, op.name, (long long)hi, (long long)cap);
+    }
+    return CTG_OK;
+}
+
 int validate_plan(ctg_plan* p) {
     if (p->dtype < 0 || p->dtype > 3) return fail(CTG_E_INVALID, "bad dtype %d", p->dtype);
     if (p->n_inputs < 1) return fail(CTG_E_INVALID, "plan needs at least one input");
@@ -105,7 +170,12 @@ int validate_plan(ctg_plan* p) {
     for (int64_t s = 0; s < p->n_steps; ++s) {
         const int64_t* r = &p->steps[s * STEP_WORDS];
         const int64_t kind = r[W_KIND];
-        if (kind < 0 || kind > 2) return fail(CTG_E_INVALID, "step %lld: bad kind", (long long)s);
+        if (kind < 0 || kind > 3) return fail(CTG_E_INVALID, "step %lld: bad kind", (long long)s);
+        if (kind == KIND_STEM2) {
+            const int rc = validate_stem(p, s);
+            if (rc != CTG_OK) return rc;
+            continue;
+        }
         if (r[W_KERNEL] < 0 || r[W_KERNEL] > 1)
             return fail(CTG_E_INVALID, "step %lld: bad kernel", (long long)s);
         if (r[W_KERNEL] == KERNEL_MFMA && kind != KIND_PAIR)
@@ -177,6 +247,7 @@ void resolve_args(ctg_exec* e) {
     const ctg_plan* p = e->plan;
     const int64_t isz = kItemSize[p->dtype];
     e->args.resize(p->n_steps);
+    e->stem_args.resize(p->n_steps);
     // (hints depend on the plan only: kept when the arguments are re-resolved,
     // e.g. by ctg_exec_set_strip_exponent on a live executor)
     if ((int64_t)e->hints.size() != p->n_steps)
@@ -259,6 +330,43 @@ void resolve_args(ctg_exec* e) {
             };
             a.facA = fac(W_A_PROD);
             a.facB = fac(W_B_PROD);
+        }
+        if (r[W_KIND] == KIND_STEM2) {
+            const int64_t* h = &p->tables[r[W_STEM]];
+            StemArgs& q = e->stem_args[s];
+            memset(&q, 0, sizeof(q));
+            q.A = a.A;
+            q.B1 = a.B;
+            q.C = a.C;
+            q.B2 = (char*)space_ptr(e, h[SW_B2_SPACE]) + h[SW_B2_OFF] * isz;
+            q.soffA = a.soffA;
+            q.soffB1 = a.soffB;
+            q.soffC = a.soffC;
+            q.soffB2 = h[SW_B2_LEAF] >= 0 ? e->d_soff + h[SW_B2_LEAF] : e->d_zero;
+            q.K1 = (int)h[SW_K1]; q.N1 = (int)h[SW_N1]; q.K2 = (int)h[SW_K2]; q.N2 = (int)h[SW_N2];
+            q.nr1 = (int)h[SW_NR1]; q.rows2 = (int)h[SW_ROWS2]; q.ng2 = (int)h[SW_NG2]; q.ld2 = (int)h[SW_LD2];
+            q.n_tiles = h[SW_NTILES];
+            q.g_lo = h[SW_GLO];
+            q.g_lo_shift = log2_exact(q.g_lo);
+            q.check_zero = e->check_zero;
+            const int64_t** tabs[ST_COUNT] = {&q.gA_hi, &q.gA_lo, &q.gC_hi, &q.gC_lo, &q.ord, &q.lane_a, &q.rt_a,
+                                              &q.chunk_a, &q.b1_off, &q.b2_off, &q.mid_row, &q.mid_col,
+                                              &q.out_row, &q.out_col};
+            for (int t = 0; t < ST_COUNT; ++t) *tabs[t] = T + h[SW_TABS + t];
+            q.nz = 1;
+            q.z0 = 0;
+            q.zA = a.zA; q.zB1 = a.zB; q.zC = a.zC;
+            q.zB2 = per_slice(h[SW_B2_SPACE], h[SW_B2_OFF]);
+            q.zsA = a.zsA; q.zsB1 = a.zsB; q.zsC = a.zsC;
+            q.zsB2 = h[SW_B2_LEAF] >= 0 ? p->n_inputs + 1 : 0;
+            if (e->strip) {
+                auto fac = [&](int64_t w) -> const double* {
+                    return (w >= 0 && w < p->n_steps) ? e->d_fac + w : e->d_fac + p->n_steps;
+                };
+                q.facA = fac(r[W_A_PROD]);
+                q.facB1 = fac(r[W_B_PROD]);
+                q.facB2 = fac(h[SW_B2_PROD]);
+            }
         }
     }
 }
@@ -623,6 +731,17 @@ int launch_step(ctg_exec* e, int64_t s, hipStream_t stream) {
                 err = launch_accum(p->dtype, e->args[s], nullptr, stream);
             }
             break;
+        case KIND_STEM2: {
+            // (slices of a batch one after the other: the workgroups are persistent)
+            const int nz = e->args[s].nz;
+            for (int z = 0; z < nz && err == hipSuccess; ++z) {
+                StemArgs q = e->stem_args[s];
+                q.z0 = e->args[s].z0 + z;
+                q.nz = 1;
+                err = launch_stem2(q, stream);
+            }
+            break;
+        }
         case KIND_PAIR:
             if (r[W_KERNEL] == KERNEL_MFMA && p->dtype == CTG_C128)
                 err = launch_pair_mfma_c128(e->args[s], e->hints[s].vecA /* = stride flags */, stream);
@@ -636,7 +755,7 @@ int launch_step(ctg_exec* e, int64_t s, hipStream_t stream) {
                 err = launch_pair_valu(p->dtype, e->args[s], e->d_scratch, kScratchBytes, stream);
             break;
     }
-    if (err == hipSuccess && e->strip && r[W_KIND] == KIND_PAIR) {
+    if (err == hipSuccess && e->strip && (r[W_KIND] == KIND_PAIR || r[W_KIND] == KIND_STEM2)) {
         // factor = max|p| of the freshly written intermediate (contiguous in the arena)
         const char* c = (const char*)space_ptr(e, r[W_C_SPACE]) + r[W_C_OFF] * kItemSize[p->dtype];
         err = launch_maxabs(p->dtype, c, r[W_C_SIZE], e->d_fac + s, stream);
@@ -1000,7 +1119,7 @@ int ctg_exec_create(const ctg_plan* p, int device, void* stream, void* ext_resul
         for (int64_t st = 0; st < p->n_steps; ++st) {
             const int64_t* r = &p->steps[st * STEP_WORDS];
             e->invariant[st] = r[W_INVARIANT] != 0 && r[W_KIND] != KIND_ACCUM;
-            if (r[W_KIND] == KIND_PAIR) {
+            if (r[W_KIND] == KIND_PAIR || r[W_KIND] == KIND_STEM2) {
                 counted[st] = 1;
                 fac_zero[st] = e->invariant[st] ? 0 : 1;
                 e->root_step = st;  // the last pair step produces the slice output
@@ -1281,6 +1400,10 @@ int ctg_exec_step_kernel(ctg_exec* e, int64_t step, char* buf, int64_t buflen) {
         snprintf(name, sizeof(name), "single_kernel");
     } else if (r[W_KIND] == KIND_ACCUM) {
         snprintf(name, sizeof(name), "accum_kernel");
+    } else if (r[W_KIND] == KIND_STEM2) {
+        const int64_t* h = &p->tables[r[W_STEM]];
+        snprintf(name, sizeof(name), "stem2_kernel<k%d n%d | k%d n%d>", (int)h[SW_K1], (int)h[SW_N1],
+                 (int)h[SW_K2], (int)h[SW_N2]);
     } else if (r[W_KERNEL] == KERNEL_MFMA && p->dtype == CTG_C128) {
         snprintf(name, sizeof(name), "pair_mfma_c128_kernel");
     } else if (r[W_KERNEL] == KERNEL_MFMA && p->dtype != CTG_C64) {

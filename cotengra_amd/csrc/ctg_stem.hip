@@ -1,0 +1,377 @@
+// ctg_stem.hip -- two consecutive steps of a contraction stem in one launch (gfx950).
+//
+//   C1[r1, n1] = sum_k1  A[r1, k1] B1[k1, n1]
+//   C2[r2, n2] = sum_k2 C1[r2, k2] B2[k2, n2]          r2 u k2 = r1 u n1
+//
+// A and C2 are the big tensors of a sliced Sycamore contraction (2^31-2^32
+// elements); B1, B2 hold a few hundred to a few thousand.  Run as two steps
+// (reference: two turns of the loop in cotengra/contract.py:788-832) the
+// intermediate C1 is written to HBM and read back; here it lives in LDS.  The
+// planner (cotengra_amd/stem.py) splits the binary index digits of A into tile
+// bits -- all of k1, the digits of k2 that are on A, and enough of A's
+// lowest-stride digits to make 256 (512) tile rows -- and grid bits; one
+// workgroup of 8 waves takes one grid value at a time:
+//
+//   step 1   wave w gathers rows [32 w, 32 w + 32) x K1 of the tile from HBM, 16 k at
+//            a time, in address-sorted 16-byte loads two tasks ahead, transposes
+//            them through its private LDS patch into fragments and multiplies by
+//            B1 (resident in LDS);
+//   barrier  (every wave is done reading the previous tile's intermediate)
+//   scatter  the 32 x N1 accumulators go to the shared intermediate tile at
+//            mid_row[row] + mid_col[n] = row2 * (K2 + 4) + k2: the layout step 2
+//            wants, whatever index permutation lies between the two steps;
+//   barrier
+//   step 2   work items (32-row tile, 32-column group) of the intermediate are
+//            multiplied by B2 and stored: 8 bytes per lane, 256 B runs.
+//
+// Complex on the real matrix cores, second formulation (the first one is in
+// ctg_pair_mfma.hip).  v_mfma_f32_32x32x2_f32: D(32x32) += A'(32x2) B'(2x32).  Here a
+// pair of tiles X / Y holds the REAL and the IMAGINARY parts of 32 complex
+// columns:   X: A' = (Re a, -Im a), B' rows (Re b, Im b)
+//            Y: A' = (Re a,  Im a), B' rows (Im b, Re b)
+// so B needs only its two planes in LDS (the interleaved formulation needs four),
+// the sign lives in one XOR per A fragment register, and a lane ends up with Re
+// and Im of the same element -- an 8-byte store without any lane exchange.  With
+// 16 columns both halves share one tile (columns 16-31 = imaginary parts): A' =
+// (Re a, Im a), B' rows (Re b | Im b) and (-Im b | Re b), a third plane of 16 x K.
+#include "ctg_common.h"
+
+#include <type_traits>
+
+namespace ctg {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+constexpr int SW = 8;            // waves per workgroup
+constexpr int SLD = 16 + 4;      // staging row: 16 k + pad (floats)
+constexpr int STAGE_FLOATS = 2 * 32 * SLD;
+
+__device__ __forceinline__ f32x16 mfma(float a, float b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+}
+
+// row of accumulator register t within a 32-row tile, for the lanes with kk = 0
+__device__ __forceinline__ constexpr int rowmap(int t) { return (t & 3) + 8 * (t >> 2); }
+
+__device__ __forceinline__ float flip(float v, unsigned mask) {
+    return __builtin_bit_cast(float, __builtin_bit_cast(unsigned, v) ^ mask);
+}
+
+// planes of a small operand in LDS: plane p, column n, k contiguous
+//   [np][N][K + 4], np = 2 (Re, Im) or 3 (Re, Im, -Im) for 16 columns
+__device__ __forceinline__ void load_b_planes(float* P, const c64* __restrict__ B, const int64_t* off, int K,
+                                              int N, bool pack, int tid) {
+    const int LDB = K + 4;
+    for (int e = tid; e < K * N; e += SW * 64) {
+        const int k = e / N, n = e - k * N;
+        const c64 v = B[off[e]];
+        P[n * LDB + k] = v.re;
+        P[(N + n) * LDB + k] = v.im;
+        if (pack) P[(2 * N + n) * LDB + k] = -v.im;
+    }
+}
+
+}  // namespace
+
+// PACK1 / PACK2: the first / second step has 16 output columns (one tile holds Re | Im).
+// RT1: 32-row tiles of step 1 per wave and tile (1: 256 tile rows, 2: 512).
+template <bool PACK1, bool PACK2, int RT1>
+__global__ __launch_bounds__(SW * 64, 1) void stem2_kernel(StemArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int DEPTH = 2;   // tasks (32 rows x 16 k = 4 KB) in flight per wave
+    const int K1 = p.K1, N1 = p.N1, K2 = p.K2, N2 = p.N2;
+    const int LDB1 = K1 + 4, LDB2 = K2 + 4, LD2 = p.ld2;
+    const int PLANE = p.rows2 * LD2;                       // floats per plane of the intermediate
+    float* P1 = (float*)smem;                              // [2|3][N1][LDB1]
+    float* P2 = P1 + (PACK1 ? 3 : 2) * N1 * LDB1;          // [2|3][N2][LDB2]
+    float* mid = P2 + (PACK2 ? 3 : 2) * N2 * LDB2;         // [2][rows2][LD2]
+    float* stage = mid + 2 * PLANE;                        // [SW][2][32][SLD]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int kk = lane >> 5;
+    const int l31 = lane & 31;
+
+    const int64_t z = (int64_t)p.z0 + blockIdx.y;
+    const c64* __restrict__ A = (const c64*)p.A + (sload64(p.soffA + z * p.zsA) + z * p.zA);
+    const c64* __restrict__ B1 = (const c64*)p.B1 + (sload64(p.soffB1 + z * p.zsB1) + z * p.zB1);
+    const c64* __restrict__ B2 = (const c64*)p.B2 + (sload64(p.soffB2 + z * p.zsB2) + z * p.zB2);
+    float* __restrict__ C = (float*)((c64*)p.C + (sload64(p.soffC + z * p.zsC) + z * p.zC));
+
+    load_b_planes(P1, B1, p.b1_off, K1, N1, PACK1, tid);
+    load_b_planes(P2, B2, p.b2_off, K2, N2, PACK2, tid);
+
+    // ---- per-lane constants ---------------------------------------------------
+    // gather: slot j of this lane is tile element (r, c) of a task; 16-byte load j
+    // fetches slots 2j, 2j + 1 (adjacent in memory)
+    int a_pk[8];
+    int64_t a_off[4];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int v = (int)p.ord[lane * 8 + j];
+        a_pk[j] = (v >> 4) * SLD + (v & 15);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) a_off[j] = p.lane_a[lane * 4 + j];
+    // fragments: A' is (Re, +-Im) by lane half; the sign of Im for the X tile
+    const unsigned sgn = kk ? 0x80000000u : 0u;
+    // B fragments of step 1: plane by (tile, lane half, column half)
+    const float* b1x;
+    const float* b1y = nullptr;
+    if (PACK1) {
+        const int n = l31 & 15, h = l31 >> 4;
+        const int plane = kk == 0 ? (h ? 1 : 0) : (h ? 0 : 2);
+        b1x = P1 + (plane * N1 + n) * LDB1;
+    } else {
+        b1x = P1 + ((kk ? 1 : 0) * N1 + l31) * LDB1;
+        b1y = P1 + ((kk ? 0 : 1) * N1 + l31) * LDB1;
+    }
+    const float* b2x;
+    const float* b2y = nullptr;
+    if (PACK2) {
+        const int n = l31 & 15, h = l31 >> 4;
+        const int plane = kk == 0 ? (h ? 1 : 0) : (h ? 0 : 2);
+        b2x = P2 + (plane * N2 + n) * LDB2;
+    } else {
+        b2x = P2 + ((kk ? 1 : 0) * N2 + l31) * LDB2;
+        b2y = P2 + ((kk ? 0 : 1) * N2 + l31) * LDB2;
+    }
+    // scatter of the step-1 accumulators: lane part of mid_row[row] + mid_col[n]
+    int mid_lane;
+    if (PACK1) mid_lane = (int)p.mid_col[l31 & 15] + (l31 >> 4) * PLANE + (int)p.mid_row[4 * kk];
+    else mid_lane = (int)p.mid_col[l31] + (int)p.mid_row[4 * kk];
+    int mid_t[16];
+#pragma unroll
+    for (int t = 0; t < 16; ++t) mid_t[t] = (int)sload64(p.mid_row + rowmap(t));
+    // store of the step-2 accumulators: lane part of out_row[row2] + out_col[n2]
+    // (PACK2: the lanes of columns 16-31 take the odd rows of each row pair)
+    int64_t out_lane = p.out_row[4 * kk];
+    if (PACK2) out_lane += (l31 >> 4) ? p.out_row[1] : 0;
+    int64_t out_t[16];
+#pragma unroll
+    for (int t = 0; t < 16; ++t) out_t[t] = sload64(p.out_row + rowmap(t));
+
+    float alpha = 1.f;
+    if (p.facA != nullptr) {
+        const double f = (*p.facA) * (*p.facB1) * (*p.facB2);
+        alpha = (f == 0.0 && p.check_zero) ? 0.f : (float)(1.0 / f);
+    }
+    __syncthreads();
+
+    float* As = stage + wave * STAGE_FLOATS;
+    const int nch = K1 >> 4;                         // 16-deep chunks of the first contraction
+    const int n_rt2 = p.rows2 >> 5;
+    const int n_items = n_rt2 * p.ng2;
+    const int64_t n_tiles = p.n_tiles;
+    const int64_t tile0 = blockIdx.x, tile_step = gridDim.x;
+
+    // ---- gather pipeline: tasks (tile, row tile m, chunk) in order -------------
+    c64 regs[DEPTH][8];
+    int64_t ig = tile0;   // cursor of the next task to issue
+    int im = 0, ic = 0;
+    auto issue = [&](c64 (&r)[8]) __attribute__((always_inline)) {
+        if (ig < n_tiles) {
+            const int64_t gh = ig >> p.g_lo_shift, gl = ig & (p.g_lo - 1);
+            const int64_t base = sload64(p.gA_hi + uniform64(gh)) + sload64(p.gA_lo + uniform64(gl)) +
+                                 sload64(p.rt_a + (wave + SW * im)) + sload64(p.chunk_a + ic);
+            const c64* src = A + base;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const f32x4 v = *(const f32x4*)(src + a_off[j]);
+                r[2 * j] = c64{v[0], v[1]};
+                r[2 * j + 1] = c64{v[2], v[3]};
+            }
+            if (++ic == nch) {
+                ic = 0;
+                if (++im == RT1) {
+                    im = 0;
+                    ig += tile_step;
+                }
+            }
+        }
+    };
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d) issue(regs[d]);
+
+    int slot = 0;   // register set of the task consumed next (compile-time after unrolling by DEPTH)
+    for (int64_t g = tile0; g < n_tiles; g += tile_step) {
+        // ================= step 1 =================
+        f32x16 ax[RT1], ay[RT1];
+#pragma unroll
+        for (int m = 0; m < RT1; ++m) {
+#pragma unroll
+            for (int t = 0; t < 16; ++t) {
+                ax[m][t] = 0.f;
+                if (!PACK1) ay[m][t] = 0.f;
+            }
+            for (int ch = 0; ch < nch; ++ch) {
+                auto consume = [&](c64 (&r)[8]) __attribute__((always_inline)) {
+                    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        As[a_pk[j]] = r[j].re;
+                        As[32 * SLD + a_pk[j]] = r[j].im;
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                    issue(r);   // refill this register set DEPTH tasks ahead
+                    const float* a_base = As + kk * 32 * SLD + l31 * SLD;
+                    const int kb = ch * 16;
+#pragma unroll
+                    for (int kq = 0; kq < 4; ++kq) {
+                        const f32x4 af = *(const f32x4*)(a_base + kq * 4);
+                        const f32x4 bx = *(const f32x4*)(b1x + kb + kq * 4);
+                        if (PACK1) {
+#pragma unroll
+                            for (int t = 0; t < 4; ++t) ax[m] = mfma(af[t], bx[t], ax[m]);
+                        } else {
+                            const f32x4 by = *(const f32x4*)(b1y + kb + kq * 4);
+#pragma unroll
+                            for (int t = 0; t < 4; ++t) {
+                                ax[m] = mfma(flip(af[t], sgn), bx[t], ax[m]);
+                                ay[m] = mfma(af[t], by[t], ay[m]);
+                            }
+                        }
+                    }
+                };
+                if (slot == 0) consume(regs[0]);
+                else consume(regs[1]);
+                slot ^= 1;
+            }
+        }
+        // ================= scatter into the intermediate tile =================
+        __syncthreads();   // all waves have finished step 2 of the previous tile
+#pragma unroll
+        for (int m = 0; m < RT1; ++m) {
+            const int rt_part = (int)sload64(p.mid_row + 32 * (wave + SW * m));
+            float* dst = mid + (mid_lane + rt_part);
+#pragma unroll
+            for (int t = 0; t < 16; ++t) {
+                dst[mid_t[t]] = ax[m][t];
+                if (!PACK1) dst[PLANE + mid_t[t]] = ay[m][t];
+            }
+        }
+        __syncthreads();
+        // ================= step 2 =================
+        const int64_t gh = g >> p.g_lo_shift, gl = g & (p.g_lo - 1);
+        const int64_t c_tile = sload64(p.gC_hi + uniform64(gh)) + sload64(p.gC_lo + uniform64(gl));
+        for (int item = wave; item < n_items; item += SW) {
+            const int cg = item / n_rt2, rt2 = item - cg * n_rt2;
+            f32x16 cx, cy;
+#pragma unroll
+            for (int t = 0; t < 16; ++t) {
+                cx[t] = 0.f;
+                if (!PACK2) cy[t] = 0.f;
+            }
+            const float* a_base = mid + kk * PLANE + (rt2 * 32 + l31) * LD2;
+            const float* bxp = b2x + cg * 32 * LDB2;
+            const float* byp = PACK2 ? nullptr : b2y + cg * 32 * LDB2;
+            for (int kq = 0; kq < (K2 >> 2); ++kq) {
+                const f32x4 af = *(const f32x4*)(a_base + kq * 4);
+                const f32x4 bx = *(const f32x4*)(bxp + kq * 4);
+                if (PACK2) {
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) cx = mfma(af[t], bx[t], cx);
+                } else {
+                    const f32x4 by = *(const f32x4*)(byp + kq * 4);
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        cx = mfma(flip(af[t], sgn), bx[t], cx);
+                        cy = mfma(af[t], by[t], cy);
+                    }
+                }
+            }
+            // epilogue
+            const int64_t c_row = c_tile + sload64(p.out_row + 32 * rt2);
+            if (PACK2) {
+                // lane c < 16 holds Re of column c, lane c + 16 its Im: lanes below 16
+                // store row t, the others row t + 1 of each pair
+                const bool hi = (l31 >> 4) != 0;
+                float* dst = C + 2 * (c_row + out_lane + p.out_col[l31 & 15]);
+#pragma unroll
+                for (int t = 0; t < 16; t += 2) {
+                    const float mine = hi ? cx[t] : cx[t + 1];   // what the partner needs
+                    const float got = __builtin_bit_cast(
+                        float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, mine), 0x401F));
+                    float2 v;
+                    v.x = hi ? got : cx[t];
+                    v.y = hi ? cx[t + 1] : got;
+                    v.x *= alpha;
+                    v.y *= alpha;
+                    *(float2*)(dst + 2 * out_t[t]) = v;
+                }
+            } else {
+                float* dst = C + 2 * (c_row + out_lane + p.out_col[cg * 32 + l31]);
+#pragma unroll
+                for (int t = 0; t < 16; ++t) {
+                    float2 v;
+                    v.x = cx[t] * alpha;
+                    v.y = cy[t] * alpha;
+                    *(float2*)(dst + 2 * out_t[t]) = v;
+                }
+            }
+        }
+    }
+}
+
+size_t stem2_lds_bytes(const StemArgs& p) {
+    const size_t b1 = (size_t)(p.N1 == 16 ? 3 : 2) * p.N1 * (p.K1 + 4);
+    const size_t b2 = (size_t)(p.N2 == 16 ? 3 : 2) * p.N2 * (p.K2 + 4);
+    const size_t mid = (size_t)2 * p.rows2 * p.ld2;
+    return 4 * (b1 + b2 + mid + (size_t)SW * STAGE_FLOATS);
+}
+
+template <bool PACK1, bool PACK2, int RT1>
+static hipError_t launch_stem2_t(const StemArgs& p, hipStream_t stream) {
+    auto kern = stem2_kernel<PACK1, PACK2, RT1>;
+    static bool ready = false;
+    if (!ready) {
+        const hipError_t e =
+            hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+        ready = true;
+    }
+    const size_t smem = stem2_lds_bytes(p);
+    // persistent: one workgroup per CU (the tile owns most of the CU's LDS)
+    int64_t blocks = p.n_tiles < 256 ? p.n_tiles : 256;
+    if (p.nz > 1 && blocks * p.nz > 256) blocks = 256 / p.nz > 0 ? 256 / p.nz : 1;
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks, (unsigned)p.nz), dim3(SW * 64), smem, stream, p);
+    return hipGetLastError();
+}
+
+bool stem2_supported(const StemArgs& p) {
+    auto k_ok = [](int k) { return k == 16 || k == 32 || k == 64 || k == 128; };
+    if (!k_ok(p.K1) || !k_ok(p.K2)) return false;
+    if (p.N1 != 16 && p.N1 != 32) return false;
+    if (p.N2 != 16 && p.N2 != 32 && p.N2 != 64 && p.N2 != 128) return false;
+    if (p.nr1 != 8 && p.nr1 != 9) return false;
+    if (p.rows2 < 32 || (p.rows2 & 31) || p.ld2 != p.K2 + 4) return false;
+    if ((int64_t)(1 << p.nr1) * p.N1 != (int64_t)p.rows2 * p.K2) return false;
+    if (p.ng2 != (p.N2 >= 32 ? p.N2 / 32 : 1)) return false;
+    return stem2_lds_bytes(p) <= 160 * 1024;
+}
+
+hipError_t launch_stem2(const StemArgs& p, hipStream_t stream) {
+    if (!stem2_supported(p)) return hipErrorInvalidValue;
+    const bool p1 = p.N1 == 16, p2 = p.N2 == 16;
+    const int rt1 = 1 << (p.nr1 - 8);
+#define CTG_STEM_CASE(P1, P2, R)                                   \
+    if (p1 == P1 && p2 == P2 && rt1 == R) return launch_stem2_t<P1, P2, R>(p, stream);
+    CTG_STEM_CASE(false, false, 1)
+    CTG_STEM_CASE(false, false, 2)
+    CTG_STEM_CASE(false, true, 1)
+    CTG_STEM_CASE(false, true, 2)
+    CTG_STEM_CASE(true, false, 1)
+    CTG_STEM_CASE(true, false, 2)
+    CTG_STEM_CASE(true, true, 1)
+    CTG_STEM_CASE(true, true, 2)
+#undef CTG_STEM_CASE
+    return hipErrorInvalidValue;
+}
+
+}  // namespace ctg

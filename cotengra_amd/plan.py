@@ -52,6 +52,7 @@ DTYPE_ITEMSIZE = {"float32": 4, "float64": 8, "complex64": 8, "complex128": 16}
 KIND_SINGLE = 0  # out[o] = sum_s in[offO(o) + offS(s)]
 KIND_PAIR = 1  # gather-GEMM, see module docstring
 KIND_ACCUM = 2  # result[chunk + offR(o)] += src[o]
+KIND_STEM2 = 3  # two consecutive pair steps of a stem as one launch (stem.py)
 
 KERNEL_VALU = 0  # one thread per output element, any dtype / any shape
 KERNEL_MFMA = 1  # matrix-core kernels (complex64 on fp32 MFMA, complex128 on fp64 MFMA)
@@ -61,6 +62,7 @@ SPACE_ARENA = 1
 SPACE_RESULT = 2
 
 STEP_WORDS = 48  # int64 words per serialised step record
+W_STEM = 43  # STEM2 steps: word offset of the descriptor in the table blob (stem.serialise_stem)
 LO_MAX = 4096  # target size of the fast ('lo') level of a row table
 ARENA_ALIGN = 64  # elements; keeps every intermediate 256-B aligned
 # trees whose largest intermediate is at most this are emitted level by level (compile_tree)
@@ -154,6 +156,13 @@ class Step:
     # True if the step does not depend on any sliced input: it is executed once
     # per upload instead of once per slice and its output is never recycled
     invariant: bool = False
+    # STEM2 (stem.py): the second step's small operand, its producer, the tile
+    # geometry + tables; elems_rw counts BOTH steps as if unfused (the roofline's
+    # algorithmic bytes), elems_moved what the fused launch really moves
+    b2: TensorRef = None
+    b2_prod: int = -1
+    stem: dict = None
+    elems_moved: int = 0
 
 
 class Arena:
@@ -221,6 +230,9 @@ class Plan:
         # accounting
         self.macs_per_slice = 0
         self.elems_rw_per_slice = 0
+        # elements a slice really moves: less than elems_rw_per_slice when stem pairs
+        # are fused (their intermediate stays on the chip)
+        self.elems_moved_per_slice = 0
 
     # ------------------------------------------------------------------ #
 
@@ -283,6 +295,21 @@ class Plan:
         for i, s in enumerate(self.steps):
             r = recs[i]
             r[0], r[1] = s.kind, s.kernel
+            if s.kind == KIND_STEM2:
+                from .stem import serialise_stem
+
+                for base, t in ((2, s.a), (5, s.b), (8, s.c)):
+                    r[base : base + 3] = (t.space, t.offset, t.leaf)
+                r[11], r[12], r[13], r[14] = s.R, 1, s.K, s.N
+                r[15] = r[16] = r[36] = r[39] = 1
+                r[17:30] = -1
+                r[30], r[31], r[32] = s.a.size, s.b.size, s.c.size
+                r[33], r[34], r[35] = s.macs, s.elems_rw, s.node
+                r[37] = r[38] = -1
+                r[40], r[41] = s.a_prod, s.b_prod
+                r[42] = 1 if s.invariant else 0
+                r[W_STEM] = serialise_stem(s, put)
+                continue
             for base, t in ((2, s.a), (5, s.b), (8, s.c)):
                 if t is not None:
                     r[base : base + 3] = (t.space, t.offset, t.leaf)
@@ -349,7 +376,7 @@ class Plan:
             rows.append(
                 {
                     "step": i,
-                    "kind": ("single", "pair", "accum")[s.kind],
+                    "kind": ("single", "pair", "accum", "stem2")[s.kind],
                     "kernel": ("valu", "mfma")[s.kernel],
                     "R": s.R,
                     "Bt": s.Bt,
@@ -411,6 +438,15 @@ def choose_kernel(dtype, Bt, M, K, N):
     if 2 <= K <= 32 and N <= 32 and M >= 8192:
         return KERNEL_MFMA
     return KERNEL_VALU
+
+
+def pick_rows_operand(size_dict, l, r, out_inds):
+    """``(A, B)``: the operand with more kept elements supplies the GEMM rows
+    (ties: the left one) -- the rule of build_pair_step."""
+    l_set, r_set, o_set = set(l.inds), set(r.inds), set(out_inds)
+    rows_l = prod(size_dict[ix] for ix in dict.fromkeys(l.inds) if ix in o_set and ix not in r_set)
+    rows_r = prod(size_dict[ix] for ix in dict.fromkeys(r.inds) if ix in o_set and ix not in l_set)
+    return (r, l) if rows_r > rows_l else (l, r)
 
 
 def build_pair_step(
@@ -583,7 +619,10 @@ def build_single_step(size_dict, src, out_inds, out_ref_factory, node=-1):
 # --------------------------------------------------------------------------- #
 
 
-def compile_tree(tree, dtype, order=None, force_kernel=None):
+FUSE_MIN_ELEMS = 1 << 24  # stem pairs are fused when the big operand has at least this many elements
+
+
+def compile_tree(tree, dtype, order=None, force_kernel=None, fuse=None, fuse_min_elems=None, _pairs=None):
     """Compile ``tree`` (possibly sliced) into a :class:`Plan` that computes
     ONE slice and accumulates it into the full result tensor.
 
@@ -591,7 +630,31 @@ def compile_tree(tree, dtype, order=None, force_kernel=None):
     reference's ``extract_contractions`` (contract.py:573-651): optional
     per-leaf single-term preprocessing, then one pairwise step per tree
     node, bottom-up.
+
+    ``fuse`` (default: on for complex64 unless ``CTG_NO_FUSE`` is set): pairs of
+    consecutive stem steps are emitted as one STEM2 step (stem.py) -- the tree is
+    compiled once without, the pairs are chosen on that plan's steps, and the
+    tree is compiled again with them.
     """
+    if fuse is None:
+        fuse = os.environ.get("CTG_NO_FUSE", "0") in ("", "0")
+    if _pairs is None and fuse and dtype == "complex64" and force_kernel is None and tree.N > 2:
+        from .stem import find_pairs
+
+        base = compile_tree(tree, dtype, order, force_kernel, fuse=False)
+        pairs = find_pairs(
+            base, tree.size_dict,
+            min_elems=(
+                int(os.environ.get("CTG_FUSE_MIN_ELEMS", FUSE_MIN_ELEMS))
+                if fuse_min_elems is None else fuse_min_elems
+            ),
+        )
+        if not pairs:
+            return base
+        return compile_tree(tree, dtype, order, force_kernel, fuse=False, _pairs=pairs)
+    pairs = _pairs or {}
+    pair_second = {v: k for k, v in pairs.items()}
+    stem_pending = {}  # first node of a pair -> (A, B1, legs of the intermediate)
     plan = Plan(dtype)
     size_dict = tree.size_dict
     N = tree.N
@@ -638,6 +701,14 @@ def compile_tree(tree, dtype, order=None, force_kernel=None):
 
     arena = Arena()
     arena_live = {}  # id(TensorRef) -> (offset, nelems)
+    # Wide trees keep their small per-slice intermediates in a pool of their own
+    # (placed behind the large ones): a few KB allocated first-fit at the start of
+    # a 34 GB hole would make that hole useless for the next 34 GB tensor, and the
+    # arena a third larger than the two big tensors it has to hold at once.
+    small_limit = (tree.max_size() >> 6) if (N > 1 and tree.max_size() >= (1 << 26)) else 0
+    sarena = Arena()
+    small = set()  # id(TensorRef) of per-slice tensors in the small pool
+    small_refs = []
 
     # Slice-invariant subtrees: a node none of whose
     # leaves is sliced evaluates to the same tensor in every slice; the
@@ -659,7 +730,8 @@ def compile_tree(tree, dtype, order=None, force_kernel=None):
             # invariant outputs live in their own region placed behind the
             # per-slice arena (relocated below once its peak is known): they
             # must survive the per-slice recycling of every later slice
-            off = (parena if invariant else arena).alloc(n)
+            pool = parena if invariant else (sarena if n < small_limit else arena)
+            off = pool.alloc(n)
             ref = TensorRef(
                 SPACE_ARENA, off, -1, tuple(order_), _row_major_strides(shape), n
             )
@@ -667,6 +739,9 @@ def compile_tree(tree, dtype, order=None, force_kernel=None):
             if invariant:
                 persistent.add(id(ref))
                 persistent_refs.append(ref)
+            elif pool is sarena:
+                small.add(id(ref))
+                small_refs.append(ref)
             return ref
 
         return make
@@ -674,7 +749,7 @@ def compile_tree(tree, dtype, order=None, force_kernel=None):
     def release(ref):
         if ref.space == SPACE_ARENA and id(ref) not in persistent:
             off, n = arena_live.pop(id(ref))
-            arena.release(off, n)
+            (sarena if id(ref) in small else arena).release(off, n)
 
     producer = {}  # id(TensorRef) -> index of the pair step that wrote it
 
@@ -683,9 +758,15 @@ def compile_tree(tree, dtype, order=None, force_kernel=None):
             step.a_prod = producer.get(id(step.a), -1)
             step.b_prod = producer.get(id(step.b), -1)
             producer[id(step.c)] = len(plan.steps)
+        if step.kind == KIND_STEM2:
+            step.a_prod = producer.get(id(step.a), -1)
+            step.b_prod = producer.get(id(step.b), -1)
+            step.b2_prod = producer.get(id(step.b2), -1)
+            producer[id(step.c)] = len(plan.steps)
         plan.steps.append(step)
         plan.macs_per_slice += step.macs
         plan.elems_rw_per_slice += step.elems_rw
+        plan.elems_moved_per_slice += step.elems_moved if step.kind == KIND_STEM2 else step.elems_rw
 
     # -- leaves: strided views of the resident inputs
     tensors = {}
@@ -779,23 +860,57 @@ def compile_tree(tree, dtype, order=None, force_kernel=None):
                 reorder=consumer_order(p) if consumer_order is not None else None,
             )
             p_inds = root_order if is_root else tuple(tree.get_legs(p))
-            step = build_pair_step(
-                dtype,
-                size_dict,
-                tensors.pop(l),
-                tensors.pop(r),
-                p_inds,
-                factory,
-                node=p,
-                force_kernel=force_kernel,
-            )
-            step.invariant = inv
-            add(step)
-            if level is not None:
-                pending += [step.a, step.b]
-            else:
-                release(step.a)
-                release(step.b)
+            tl, tr = tensors.pop(l), tensors.pop(r)
+            if p in pairs and not is_root:
+                # first step of a fused pair: nothing is emitted, nothing allocated; the
+                # operands stay alive until the second step takes them
+                A1, B1 = pick_rows_operand(size_dict, tl, tr, p_inds)
+                virt = TensorRef(-2, 0, -1, p_inds, (0,) * len(p_inds), prod(size_dict[ix] for ix in p_inds))
+                stem_pending[id(virt)] = (A1, B1, p)
+                tensors[p] = virt
+                continue
+            steps_new = None
+            if p in pair_second:
+                from .stem import build_stem_step
+
+                virt, other = (tl, tr) if id(tl) in stem_pending else (tr, tl)
+                A1, B1, p1 = stem_pending.pop(id(virt))
+                fused = None
+                if pick_rows_operand(size_dict, virt, other, p_inds)[0] is virt:
+                    fused = build_stem_step(size_dict, A1, B1, other, virt.inds, p_inds, factory, node=p)
+                if fused is not None:
+                    steps_new = [fused]
+                else:
+                    # the pair does not fit after all: both steps as usual, one after the other
+                    first = build_pair_step(
+                        dtype, size_dict, A1, B1, virt.inds, arena_factory(invariant=inv), node=p1,
+                    )
+                    if virt is tl:
+                        tl = first.c
+                    else:
+                        tr = first.c
+                    steps_new = [first]
+            if steps_new is None or steps_new[0].kind == KIND_PAIR:
+                steps_new = (steps_new or []) + [build_pair_step(
+                    dtype,
+                    size_dict,
+                    tl,
+                    tr,
+                    p_inds,
+                    factory,
+                    node=p,
+                    force_kernel=force_kernel,
+                )]
+            for step in steps_new:
+                step.invariant = inv
+                add(step)
+                operands = [step.a, step.b] + ([step.b2] if step.kind == KIND_STEM2 else [])
+                if level is not None:
+                    pending += operands
+                else:
+                    for ref in operands:
+                        release(ref)
+            step = steps_new[-1]
             tensors[p] = step.c
             final = step.c
         for ref in pending:
@@ -828,7 +943,10 @@ def compile_tree(tree, dtype, order=None, force_kernel=None):
     add(acc)
     release(final)
 
-    slice_peak = max(arena.peak, ARENA_ALIGN)
+    big_peak = max(arena.peak, ARENA_ALIGN)
+    for ref in small_refs:
+        ref.offset += big_peak
+    slice_peak = big_peak + sarena.peak
     for ref in persistent_refs:
         ref.offset += slice_peak
     plan.arena_elems = slice_peak + parena.peak

@@ -1,0 +1,389 @@
+"""Fused stem pairs: two consecutive pairwise steps of a contraction stem as ONE
+launch whose intermediate never touches HBM.
+
+A sliced Sycamore tree spends its time on a *stem*: a 2^32-element tensor to
+which small tensors (a few hundred to a few thousand elements) are applied one
+after the other, each step contracting 4-7 binary indices of the big tensor and
+putting 4-7 new ones in their place.  Executed step by step (the reference's
+loop, ``cotengra/contract.py:788-832``, one ``tensordot`` per node) every step
+reads the big tensor and writes it back: 4 x 34 GB for two steps.  Here two
+consecutive steps
+
+    C1[r1, n1] = sum_k1  A[r1, k1] B1[k1, n1]
+    C2[r2, n2] = sum_k2 C1[r2, k2] B2[k2, n2]        (r2 u k2 = r1 u n1)
+
+run over *tiles*: the index bits of ``A`` are split into tile bits -- all of
+``k1``, the part of ``k2`` that lives on ``A`` (``k2r``), and the lowest-stride
+bits of ``A`` that fill a tile up to 256 rows (``X``) -- and grid bits ``G``.
+One workgroup (8 waves) takes one value of ``G`` at a time: every wave gathers
+32 rows x K1 of its tile straight from HBM (address-sorted 16-byte loads) and
+multiplies by ``B1`` on the matrix cores; the 256 x N1 result goes to LDS laid
+out as the second step's operand ``[r2][k2]``; the second step reads its
+fragments from there and stores ``C2``.  HBM sees ``A`` once and ``C2`` once.
+
+This module is host-side planning only: which pairs to fuse (``find_pairs``)
+and the offset tables of a fused step (``build_stem_step``); the kernel is
+``csrc/ctg_stem.hip``, the numpy restatement of its addressing
+``oracle/plan_interp.py`` (test infrastructure).  Everything here is index
+work on powers of two: every extent is split into binary digits ("bits") and
+every table is additive over bits, which is what lets the kernel form an
+address as *uniform part + per-lane constant*.
+"""
+
+from __future__ import annotations
+
+import math
+
+import numpy as np
+
+from . import plan as P
+
+WAVES = 8                    # waves of a workgroup = row tiles of step 1 in flight
+LDS_BYTES = 160 * 1024       # per CU (one workgroup per CU)
+LDS_SLACK = 1024
+STAGE_BYTES = WAVES * 2 * 32 * (16 + 4) * 4   # wave-private A staging: [2 planes][32 rows][16 k + 4]
+G_LO_BITS = 12               # fast level of the two-level grid tables
+
+DESC_WORDS = 40              # header of the serialised descriptor (int64 words)
+DESC_MAGIC = 0x53544D32      # "STM2"
+
+# what the kernel is instantiated for (csrc/ctg_stem.hip: launch_stem2)
+K_OK = (16, 32, 64, 128)
+N1_OK = (16, 32)
+N2_OK = (16, 32, 64, 128)
+
+# time model of a fused pair (seconds): matrix cores at this fraction of their
+# 157.3 TFLOP/s while a phase runs, memory at this rate for A in + C2 out
+FUSED_MFMA_RATE = 157.3e12 * 0.70
+FUSED_MEM_RATE = 5.0e12
+MIN_GAIN = 0.05              # fuse only if the model saves at least this fraction
+
+
+def _log2(n):
+    n = int(n)
+    if n < 1 or n & (n - 1):
+        return None
+    return n.bit_length() - 1
+
+
+def _bits_of(inds, size_dict):
+    """Binary digits of an index list, least significant digit of each index
+    first: ``(ix, j)`` stands for the factor ``2^j`` of index ``ix``."""
+    out = []
+    for ix in inds:
+        b = _log2(size_dict[ix])
+        if b is None:
+            return None
+        out += [(ix, j) for j in range(b)]
+    return out
+
+
+def _stride(ref, bit):
+    ix, j = bit
+    return ref.stride_of(ix) << j
+
+
+def _table(bits, strides):
+    """Offset table over an index whose binary digit ``p`` is ``bits[p]``
+    (position 0 = least significant): entry ``i`` = sum of the strides of the
+    digits set in ``i``."""
+    t = np.zeros(1, dtype=np.int64)
+    for s in strides:
+        t = np.concatenate([t, t + int(s)])
+    return t
+
+
+def b_lds_bytes(K, N):
+    """LDS of a small operand's planes: (Re, Im) -- plus -Im when the 16 output
+    columns share one matrix-core tile with their own imaginary parts."""
+    return (3 if N == 16 else 2) * N * (K + 4) * 4
+
+
+class Geometry:
+    """Tile decomposition of one fused pair (all fields are plain data)."""
+
+
+def _classify(step, size_dict):
+    """Index groups of a plain matrix-core pair step, or None if the step has
+    anything a fused pair does not handle (batch indices, indices summed on one
+    operand only, extents that are not powers of two)."""
+    if step.kind != P.KIND_PAIR or step.kernel != P.KERNEL_MFMA or step.Bt != 1:
+        return None
+    a, b, c = step.a, step.b, step.c
+    for t in (a, b, c):
+        if len(set(t.inds)) != len(t.inds):
+            return None
+    a_set, b_set, o_set = set(a.inds), set(b.inds), set(c.inds)
+    if a_set & b_set & o_set:
+        return None
+    con = [ix for ix in a.inds if ix not in o_set]
+    if any(ix not in b_set for ix in con):
+        return None
+    if any(ix not in o_set and ix not in a_set for ix in b.inds):
+        return None
+    keep_b = [ix for ix in b.inds if ix in o_set]
+    keep_a = [ix for ix in a.inds if ix in o_set]
+    if set(keep_a) | set(keep_b) != o_set:
+        return None
+    groups = {"con": con, "keep_a": keep_a, "keep_b": keep_b}
+    for g in groups.values():
+        if _bits_of(g, size_dict) is None:
+            return None
+    return groups
+
+
+def geometry(size_dict, A, B1, B2, c1_inds, c2_inds):
+    """Tile decomposition of the pair ``(A, B1 -> c1_inds)``, ``(C1, B2 ->
+    c2_inds)``; ``None`` if the pair does not fit the kernel."""
+    o1, o2 = set(c1_inds), set(c2_inds)
+    a_bits = _bits_of(A.inds, size_dict)
+    k1 = _bits_of([ix for ix in A.inds if ix not in o1], size_dict)
+    n1 = _bits_of([ix for ix in B1.inds if ix in o1], size_dict)
+    k2 = _bits_of([ix for ix in c1_inds if ix not in o2], size_dict)
+    n2 = _bits_of([ix for ix in B2.inds if ix in o2], size_dict)
+    if None in (a_bits, k1, n1, k2, n2):
+        return None
+    K1, N1, K2, N2 = (1 << len(g) for g in (k1, n1, k2, n2))
+    if K1 not in K_OK or K2 not in K_OK or N1 not in N1_OK or N2 not in N2_OK:
+        return None
+    k1_set, n1_set, k2_set = set(k1), set(n1), set(k2)
+    r1 = [b for b in a_bits if b not in k1_set]
+    k2r = [b for b in k2 if b not in n1_set]
+    k2n = [b for b in k2 if b in n1_set]
+    if any(b not in set(r1) for b in k2r):
+        return None
+
+    def sa(b):
+        return _stride(A, b)
+
+    free = sorted((b for b in r1 if b not in k2_set), key=sa)   # candidates for X, lowest stride first
+    best = None
+    for nr1 in (8, 9):
+        nx = nr1 - len(k2r)
+        if nx < 0 or nx > len(free):
+            continue
+        tm = nr1 + len(n1)
+        rows2_bits = tm - len(k2)
+        if rows2_bits < 5:
+            continue
+        rows2 = 1 << rows2_bits
+        mid_bytes = 2 * rows2 * (K2 + 4) * 4
+        lds = STAGE_BYTES + mid_bytes + b_lds_bytes(K1, N1) + b_lds_bytes(K2, N2) + LDS_SLACK
+        if lds > LDS_BYTES:
+            continue
+        ng2 = max(1, N2 // 32)
+        items = (rows2 // 32) * ng2
+        cand = (min(items, WAVES), -nr1, nr1, nx, rows2_bits, ng2, items, lds)
+        if best is None or cand > best:
+            best = cand
+    if best is None:
+        return None
+    _, _, nr1, nx, rows2_bits, ng2, items, lds = best
+    g = Geometry()
+    g.K1, g.N1, g.K2, g.N2 = K1, N1, K2, N2
+    g.nr1, g.rows2_bits, g.ng2, g.items, g.lds = nr1, rows2_bits, ng2, items, lds
+    g.k1 = sorted(k1, key=sa)                      # k index: digit 0 = lowest stride in A
+    g.n1 = sorted(n1, key=lambda b: _stride(B1, b))
+    x = free[:nx]
+    g.r1 = sorted(k2r + x, key=sa)                 # tile rows of step 1, digit 0 = lowest stride in A
+    r1_set = set(g.r1)
+    g.grid = sorted((b for b in r1 if b not in r1_set), key=sa)
+    g.k2 = k2n + sorted(k2r, key=sa)               # k2 index: the fresh columns first
+    g.r2_members = x + [b for b in g.n1 if b not in k2_set]
+    g.n2 = n2
+    return g
+
+
+def pair_seconds(macs1, macs2, elems_a, elems_c2, items):
+    """Modelled time of a fused pair."""
+    t_mfma = 8.0 * macs1 / FUSED_MFMA_RATE + 8.0 * macs2 / (FUSED_MFMA_RATE * min(1.0, items / WAVES))
+    t_mem = 8.0 * (elems_a + elems_c2) / FUSED_MEM_RATE
+    return max(t_mfma, t_mem)
+
+
+def find_pairs(plan, size_dict, min_elems=1 << 24, model=None):
+    """Which consecutive stem steps of ``plan`` (compiled without fusion) to fuse:
+    ``{node of the first step: node of the second}``.  Candidates are pairs
+    (s1, s2) where s2's row operand is s1's result, both plain matrix-core steps
+    over binary indices with shapes the kernel takes; a chain of candidates is
+    paired off by dynamic programming on the modelled time saved."""
+    if plan.dtype != "complex64":
+        return {}
+    if model is None:
+        from .pathfind import MI355X_C64 as model
+    steps = plan.steps
+    by_out = {id(s.c): i for i, s in enumerate(steps) if s.kind == P.KIND_PAIR}
+    cls = {}
+
+    def classify(i):
+        if i not in cls:
+            cls[i] = _classify(steps[i], size_dict)
+        return cls[i]
+
+    def unfused_seconds(s):
+        return model.step_seconds(s.macs, s.elems_rw, s.K, s.N)
+
+    gain = {}   # i2 -> (i1, seconds saved)
+    for i2, s2 in enumerate(steps):
+        i1 = by_out.get(id(s2.a)) if s2.kind == P.KIND_PAIR else None
+        if i1 is None:
+            continue
+        s1 = steps[i1]
+        if s1.invariant != s2.invariant or s1.a.size < min_elems or s1.a.leaf >= 0:
+            continue
+        if classify(i1) is None or classify(i2) is None:
+            continue
+        geo = geometry(size_dict, s1.a, s1.b, s2.b, s1.c.inds, s2.c.inds)
+        if geo is None:
+            continue
+        before = unfused_seconds(s1) + unfused_seconds(s2)
+        after = pair_seconds(s1.macs, s2.macs, s1.a.size, s2.c.size, geo.items)
+        if before - after >= MIN_GAIN * before:
+            gain[i2] = (i1, before - after)
+    # chains: i1 -> i2 -> i3 ...; a step can be in one pair only
+    best = {}   # step -> (total gain of the chain ending here, pairs chosen)
+    order = sorted(gain)
+    for i2 in order:
+        i1, g12 = gain[i2]
+        skip = best.get(i1, (0.0, ()))                      # i1 free or paired backwards
+        before_i1 = best.get(gain[i1][0], (0.0, ())) if i1 in gain else (0.0, ())
+        take = (before_i1[0] + g12, before_i1[1] + ((i1, i2),))
+        best[i2] = take if take[0] > skip[0] else skip
+    # collect: walk every chain from its last step
+    chosen = {}
+    used = set()
+    for i2 in sorted(best, reverse=True):
+        if i2 in used:
+            continue
+        for a, b in best[i2][1]:
+            if a not in used and b not in used:
+                chosen[steps[a].node] = steps[b].node
+                used.update((a, b))
+        # everything on this chain is settled
+        j = i2
+        while j in gain:
+            used.add(j)
+            j = gain[j][0]
+        used.add(j)
+    return chosen
+
+
+def build_stem_step(size_dict, A, B1, B2, c1_inds, out_inds, out_ref_factory, node=-1):
+    """Lower the pair ``A, B1 -> c1_inds`` then ``C1, B2 -> out_inds`` to one
+    STEM2 step (``None`` if the pair does not fit after all).  ``c1_inds`` is
+    the index set of the intermediate (its order is irrelevant: it never exists
+    in memory)."""
+    geo = geometry(size_dict, A, B1, B2, c1_inds, out_inds)
+    if geo is None:
+        return None
+    o2 = set(out_inds)
+    keep_a2 = [ix for ix in A.inds if ix in o2] + [ix for ix in B1.inds if ix in o2 and ix not in set(A.inds)]
+    keep_b2 = [ix for ix in B2.inds if ix in o2]
+    natural = tuple(keep_a2) + tuple(keep_b2)
+    C = out_ref_factory(tuple(out_inds), natural)
+
+    def sa(b):
+        return _stride(A, b)
+
+    def sc(b):
+        return _stride(C, b)
+
+    K1, N1, K2, N2 = geo.K1, geo.N1, geo.K2, geo.N2
+    r2 = sorted(geo.r2_members, key=sc)            # rows of step 2, digit 0 = lowest stride in C2
+    n2 = sorted(geo.n2, key=sc)
+    ld2 = K2 + 4
+
+    # ---- step 1: what one wave gathers per task = 32 rows x 16 k ------------
+    row_a = _table(geo.r1, [sa(b) for b in geo.r1])            # [2^nr1] tile rows of A
+    k_a = _table(geo.k1, [sa(b) for b in geo.k1])              # [K1]
+    task = (row_a[:32, None] + k_a[None, :16]).reshape(-1)     # element (r, c) at r * 16 + c
+    order = np.argsort(task, kind="stable")
+    srt = task[order]
+    vec = bool(np.all(srt[1::2] == srt[0::2] + 1) and np.all(srt[0::2] % 2 == 0)) and A.offset % 2 == 0
+    if not vec or A.leaf >= 0:
+        return None
+    # lane l, load j (4 loads of 16 bytes) takes the sorted pair j * 64 + l
+    ord_tab = np.zeros(64 * 8, dtype=np.int64)
+    lane_a = np.zeros(64 * 4, dtype=np.int64)
+    for lane in range(64):
+        for j in range(4):
+            p = 2 * (j * 64 + lane)
+            for h in range(2):
+                e = int(order[p + h])
+                ord_tab[lane * 8 + 2 * j + h] = ((e // 16) << 4) | (e % 16)
+            lane_a[lane * 4 + j] = srt[p]
+    rt_a = row_a[::32].copy()                                  # [2^nr1 / 32] first row of every row tile
+    chunk_a = k_a[::16].copy()                                 # [K1 / 16]
+
+    def b_off(ref, kbits, nbits):
+        tk = _table(kbits, [_stride(ref, b) for b in kbits])
+        tn = _table(nbits, [_stride(ref, b) for b in nbits])
+        return (tk[:, None] + tn[None, :]).reshape(-1)
+
+    b1_off = b_off(B1, geo.k1, geo.n1)                         # [k * N1 + n]
+    b2_off = b_off(B2, geo.k2, n2)                             # [k2 * N2 + n2]
+
+    # ---- the intermediate tile in LDS: element -> row2 * ld2 + k2 ------------
+    pos_k2 = {b: p for p, b in enumerate(geo.k2)}
+    pos_r2 = {b: p for p, b in enumerate(r2)}
+
+    def mid_stride(b):
+        return (1 << pos_k2[b]) if b in pos_k2 else (1 << pos_r2[b]) * ld2
+
+    mid_row = _table(geo.r1, [mid_stride(b) for b in geo.r1])  # [2^nr1]
+    mid_col = _table(geo.n1, [mid_stride(b) for b in geo.n1])  # [N1]
+    out_row = _table(r2, [sc(b) for b in r2])                  # [rows2]
+    out_col = _table(n2, [sc(b) for b in n2])                  # [N2]
+
+    # ---- grid: one entry per tile, two-level ---------------------------------
+    g_lo_bits = min(G_LO_BITS, len(geo.grid))
+    glo, ghi = geo.grid[:g_lo_bits], geo.grid[g_lo_bits:]
+    tabs = {
+        "gA_hi": _table(ghi, [sa(b) for b in ghi]), "gA_lo": _table(glo, [sa(b) for b in glo]),
+        "gC_hi": _table(ghi, [sc(b) for b in ghi]), "gC_lo": _table(glo, [sc(b) for b in glo]),
+        "ord": ord_tab, "lane_a": lane_a, "rt_a": rt_a, "chunk_a": chunk_a,
+        "b1_off": b1_off, "b2_off": b2_off, "mid_row": mid_row, "mid_col": mid_col,
+        "out_row": out_row, "out_col": out_col,
+    }
+
+    step = P.Step(kind=P.KIND_STEM2, kernel=P.KERNEL_MFMA, a=A, b=B1, c=C, node=node)
+    step.b2 = B2
+    step.stem = {
+        "K1": K1, "N1": N1, "K2": K2, "N2": N2, "nr1": geo.nr1, "rows2": 1 << geo.rows2_bits,
+        "ng2": geo.ng2, "n_tiles": 1 << len(geo.grid), "g_lo": 1 << g_lo_bits, "ld2": ld2,
+        "lds_bytes": geo.lds, "items": geo.items, "tabs": tabs,
+    }
+    # reporting fields: the second step's shape; work and traffic of BOTH steps as if unfused
+    rows_total = A.size // K1
+    step.R, step.Bt, step.K, step.N = (rows_total * N1) // K2, 1, K2, N2
+    macs1 = rows_total * K1 * N1
+    macs2 = step.R * K2 * N2
+    c1_size = rows_total * N1
+    step.macs = macs1 + macs2
+    b1_elems, b2_elems = K1 * N1, K2 * N2   # (a sliced leaf's .size is that of the unsliced input)
+    step.elems_rw = (A.size + b1_elems + c1_size) + (c1_size + b2_elems + step.R * N2)
+    step.elems_moved = A.size + b1_elems + b2_elems + step.R * N2
+    step.label = f"stem2 k{K1} n{N1} | k{K2} n{N2} rows {rows_total}"
+    return step
+
+
+TAB_ORDER = ("gA_hi", "gA_lo", "gC_hi", "gC_lo", "ord", "lane_a", "rt_a", "chunk_a",
+             "b1_off", "b2_off", "mid_row", "mid_col", "out_row", "out_col")
+
+
+def serialise_stem(step, put):
+    """Descriptor of a STEM2 step in the plan's table blob (``put(array) ->
+    word offset``); returns the offset of its header.  Header layout
+    (csrc/ctg_common.h: StemWord): magic, K1, N1, K2, N2, nr1, rows2, ng2,
+    n_tiles, g_lo, ld2, lds_bytes, B2 space / offset / leaf / size, B2 producer,
+    then the 14 table offsets at words 20..33."""
+    st = step.stem
+    head = np.zeros(DESC_WORDS, dtype=np.int64)
+    head[0] = DESC_MAGIC
+    head[1:12] = (st["K1"], st["N1"], st["K2"], st["N2"], st["nr1"], st["rows2"], st["ng2"],
+                  st["n_tiles"], st["g_lo"], st["ld2"], st["lds_bytes"])
+    head[12:16] = (step.b2.space, step.b2.offset, step.b2.leaf, step.b2.size)
+    head[16] = getattr(step, "b2_prod", -1)
+    for i, name in enumerate(TAB_ORDER):
+        head[20 + i] = put(st["tabs"][name])
+    return put(head)

@@ -45,6 +45,54 @@ def slice_offsets(plan, slice_id):
     return plan.slice_strides @ np.asarray(digits, dtype=np.int64)
 
 
+def run_stem2(step, spaces, base, chunk=256):
+    """A fused stem pair (cotengra_amd/stem.py, csrc/ctg_stem.hip) executed from
+    the very tables the kernel reads, tile by tile:
+
+    * a tile's rows of A: grid offset + row-tile offset + chunk offset + the
+      per-lane offsets of one 32 x 16 task (looked up through the order table);
+    * first product with B1 (``b1_off[k * N1 + n]``);
+    * the intermediate tile laid out at ``mid_row[row] + mid_col[n]`` =
+      ``row2 * ld2 + k2``;
+    * second product with B2, stored at grid + ``out_row[row2] + out_col[n2]``.
+    """
+    st, T = step.stem, step.stem["tabs"]
+    A, B1, B2, C = (spaces[t.space] for t in (step.a, step.b, step.b2, step.c))
+    K1, N1, K2, N2, ld2, rows2 = st["K1"], st["N1"], st["K2"], st["N2"], st["ld2"], st["rows2"]
+    rows1 = 1 << st["nr1"]
+    # offsets of the 32 x 16 elements of a task, as lane / slot constants
+    task = np.zeros((32, 16), dtype=np.int64)
+    seen = np.zeros((32, 16), dtype=bool)
+    for lane in range(64):
+        for j in range(4):
+            for h in range(2):
+                v = int(T["ord"][lane * 8 + 2 * j + h])
+                task[v >> 4, v & 15] = T["lane_a"][lane * 4 + j] + h
+                seen[v >> 4, v & 15] = True
+    assert seen.all()
+    r = np.arange(rows1)
+    k = np.arange(K1)
+    in_tile = (T["rt_a"][r >> 5][:, None] + T["chunk_a"][k >> 4][None, :] + task[(r & 31)[:, None], (k & 15)[None, :]])
+    b1 = B1[base(step.b) + T["b1_off"]].reshape(K1, N1)
+    b2 = B2[base(step.b2) + T["b2_off"]].reshape(K2, N2)
+    mid_at = (T["mid_row"][:, None] + T["mid_col"][None, :]).reshape(-1)
+    assert len(np.unique(mid_at)) == rows1 * N1 and mid_at.max() < rows2 * ld2
+    assert rows1 * N1 == rows2 * K2
+    take = (np.arange(rows2)[:, None] * ld2 + np.arange(K2)[None, :])
+    out_at = T["out_row"][:, None] + T["out_col"][None, :]
+    g_lo = st["g_lo"]
+    for g0 in range(0, st["n_tiles"], chunk):
+        g = np.arange(g0, min(g0 + chunk, st["n_tiles"]))
+        ga = base(step.a) + T["gA_hi"][g // g_lo] + T["gA_lo"][g % g_lo]
+        gc = base(step.c) + T["gC_hi"][g // g_lo] + T["gC_lo"][g % g_lo]
+        a = A[ga[:, None, None] + in_tile[None]]                  # (g, rows1, K1)
+        c1 = a @ b1                                               # (g, rows1, N1)
+        mid = np.zeros((len(g), rows2 * ld2), dtype=c1.dtype)
+        mid[:, mid_at] = c1.reshape(len(g), -1)
+        a2 = mid[:, take]                                         # (g, rows2, K2)
+        C[gc[:, None, None] + out_at[None]] = a2 @ b2
+
+
 def run_plan(plan, arrays, slice_ids=None, result=None):
     """Execute ``plan`` for the given slices, accumulating into ``result``
     (a flat array of ``plan.result_elems``); returns the result reshaped."""
@@ -99,6 +147,8 @@ def run_plan(plan, arrays, slice_ids=None, result=None):
                     ib = base(step.b) + rB[:, None, None] + kB[None, :, None] + nB[None, None, :]
                     ic = base(step.c) + rC[:, None] + nC[None, :]
                     C[ic] = np.einsum("rk,rkn->rn", A[ia], B[ib])
+            elif step.kind == P.KIND_STEM2:
+                run_stem2(step, spaces, base)
             else:
                 raise ValueError(f"bad step kind {step.kind}")
         first = False

@@ -91,3 +91,48 @@ def single_gate(ref, numpy_single):
     if numpy_single is None:
         return NORTH_STAR
     return max(NORTH_STAR, 8.0 * relerr(np.asarray(numpy_single), ref))
+
+
+def stem_network(nq, gates, seed, sliced=0):
+    """A small 'stem': one tensor of ``nq`` binary indices to which tensors are
+    applied one after the other, gate ``(k, n)`` contracting ``k`` randomly chosen
+    indices of the running tensor and adding ``n`` fresh ones (the structure of a
+    sliced Sycamore contraction).  Returns ``(tree, inputs)``
+    with the tree contracting the chain in order and ``sliced`` of the first
+    tensor's indices sliced."""
+    rng = np.random.default_rng(seed)
+    cur = [f"a{i}" for i in range(nq)]
+    inputs = [tuple(cur)]
+    for g, (kin, nout) in enumerate(gates):
+        sel = sorted(int(i) for i in rng.choice(len(cur), size=kin, replace=False))
+        new = [f"g{g}_{j}" for j in range(nout)]
+        inputs.append(tuple(cur[i] for i in rng.permutation(sel)) + tuple(new))
+        cur = [c for i, c in enumerate(cur) if i not in sel] + new
+    # the open indices in a scrambled order: the root's layout is the caller's
+    output = tuple(cur[i] for i in rng.permutation(len(cur)))
+    size_dict = {ix: 2 for t in inputs for ix in t}
+    ssa, cur_id, nxt = [], 0, len(inputs)
+    for i in range(1, len(inputs)):
+        ssa.append((cur_id, i))
+        cur_id, nxt = nxt, nxt + 1
+    tree = ca.ContractionTree.from_path(inputs, output, size_dict, ssa_path=ssa)
+    for ix in inputs[0][:sliced]:
+        tree.remove_ind_(ix)
+    return tree
+
+
+# (nq, gates): every instantiation of the fused kernel -- 16 / 32 columns on either step,
+# 256 and 512 tile rows, K up to 128, N2 up to 128 -- and chains with leftovers
+STEM_CASES = [
+    (16, [(3, 3), (5, 5), (5, 5)]),                    # k32 n32 | k32 n32
+    (16, [(3, 3), (4, 4), (5, 5)]),                    # k16 n16 | k32 n32: 16 columns first, 512 rows
+    (16, [(3, 3), (5, 5), (4, 4)]),                    # k32 n32 | k16 n16: 16 columns last
+    (16, [(3, 3), (4, 4), (4, 4)]),                    # k16 n16 | k16 n16
+    (17, [(3, 3), (5, 5), (6, 6)]),                    # k32 n32 | k64 n64
+    (17, [(3, 3), (7, 5), (5, 5)]),                    # k128 n32 | k32 n32
+    (17, [(3, 3), (5, 5), (5, 6)]),                    # k32 n32 | k32 n64
+    (17, [(3, 3), (6, 5), (6, 6)]),                    # k64 n32 | k64 n64
+    (17, [(3, 3), (4, 5), (5, 7)]),                    # k16 n32 | k32 n128
+    (18, [(3, 3), (6, 4), (5, 4)]),                    # k64 n16 | k32 n16
+    (17, [(3, 3), (5, 5), (5, 5), (4, 4), (5, 5), (6, 6), (5, 5)]),   # a longer stem: pairs + leftovers
+]

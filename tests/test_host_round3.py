@@ -79,3 +79,67 @@ def test_order_changes_lifetimes_not_values():
     ref = orc.contract(tree, arrays)
     for name, make in ORDERS.items():
         assert np.allclose(orc.contract(tree, arrays, order=make(tree)), ref, rtol=1e-12, atol=1e-15), name
+
+
+# ---------------------------------------------------------------------- #
+# fused stem pairs (cotengra_amd/stem.py): planning, tables, accounting
+# ---------------------------------------------------------------------- #
+
+import golden_util as G  # noqa: E402
+from cotengra_amd import plan as P, runtime  # noqa: E402
+from cotengra_amd.plan import compile_tree  # noqa: E402
+from oracle.plan_interp import run_plan  # noqa: E402
+
+
+@pytest.mark.parametrize("sliced", [0, 2])
+@pytest.mark.parametrize("case", range(len(G.STEM_CASES)))
+def test_fused_stem_plan_matches_oracle(case, sliced):
+    """The fused step's tables, interpreted in numpy exactly as the kernel reads
+    them (oracle/plan_interp.run_stem2), give the reference contraction; the plan
+    passes the C ABI's validation; work and algorithmic bytes are those of the
+    unfused plan (the roofline must not shrink because a kernel got smarter)."""
+    nq, gates = G.STEM_CASES[case]
+    tree = G.stem_network(nq, gates, 100 * case, sliced=sliced)
+    arrays = ca.make_arrays_from_inputs(tree.inputs, tree.size_dict, seed=case, dtype="complex128")
+    fused = compile_tree(tree, "complex64", fuse=True, fuse_min_elems=1 << 10)
+    plain = compile_tree(tree, "complex64", fuse=False)
+    n_fused = sum(s.kind == P.KIND_STEM2 for s in fused.steps)
+    assert len(fused.steps) == len(plain.steps) - n_fused
+    if (case, sliced) not in ((1, 2), (6, 2)):
+        assert n_fused >= 1
+    assert fused.macs_per_slice == plain.macs_per_slice
+    assert fused.elems_rw_per_slice == plain.elems_rw_per_slice
+    assert fused.elems_moved_per_slice <= plain.elems_rw_per_slice
+    assert (fused.elems_moved_per_slice < plain.elems_rw_per_slice) == (n_fused > 0)
+    assert fused.arena_elems <= plain.arena_elems
+    runtime.DevicePlan(fused).close()
+    fused.dtype = "complex128"   # interpret in double precision
+    got = run_plan(fused, arrays)
+    ref = orc.contract(tree, arrays)
+    assert np.allclose(got, ref, rtol=1e-12, atol=1e-12 * np.abs(ref).max())
+
+
+def test_fusion_is_off_where_it_does_not_apply():
+    tree = G.stem_network(16, [(3, 3), (5, 5), (5, 5)], 0)
+    for dtype in ("complex128", "float32", "float64"):
+        assert all(s.kind != P.KIND_STEM2 for s in compile_tree(tree, dtype, fuse=True, fuse_min_elems=1 << 10).steps)
+    # default threshold: a 2^16-element stem is left alone
+    assert all(s.kind != P.KIND_STEM2 for s in compile_tree(tree, "complex64").steps)
+    # an extent that is not a power of two anywhere on a step keeps that step out
+    inputs, output, _, size_dict = ca.lattice_equation([4, 4], d_min=3, d_max=3, seed=0)
+    t3 = ca.ContractionTree.from_path(inputs, output, size_dict, path=ca.greedy_path(inputs, output, size_dict))
+    assert all(s.kind != P.KIND_STEM2 for s in compile_tree(t3, "complex64", fuse=True, fuse_min_elems=1).steps)
+
+
+def test_fused_descriptor_is_validated():
+    tree = G.stem_network(16, [(3, 3), (5, 5), (5, 5)], 0)
+    plan = compile_tree(tree, "complex64", fuse=True, fuse_min_elems=1 << 10)
+    st = next(s for s in plan.steps if s.kind == P.KIND_STEM2)
+    for name, how in (("gA_hi", lambda t: t + (1 << 40)), ("ord", lambda t: t * 0), ("mid_row", lambda t: t * 64),
+                      ("out_col", lambda t: t + (1 << 40)), ("b2_off", lambda t: t - 1)):
+        keep = st.stem["tabs"][name]
+        st.stem["tabs"][name] = how(keep.copy())
+        with pytest.raises((runtime.CtgError, ValueError)):   # CTG_E_BOUNDS / CTG_E_INVALID
+            runtime.DevicePlan(plan)
+        st.stem["tabs"][name] = keep
+    runtime.DevicePlan(plan).close()
