@@ -76,12 +76,31 @@ __device__ __forceinline__ void load_b_planes(float* P, const c64* __restrict__ 
 
 }  // namespace
 
+// "use" a value: the compiler has to wait here for the load that produced it, not at
+// its first use inside the tile loop (where s_waitcnt vmcnt(0) would drain the gathers
+// and stores in flight once per tile)
+template <typename T>
+__device__ __forceinline__ void settle(T& v) {
+    asm volatile("" : "+v"(v));
+}
+
 // PACK1 / PACK2: the first / second step has 16 output columns (one tile holds Re | Im).
-// RT1: 32-row tiles of step 1 per wave and tile (1: 256 tile rows, 2: 512).
-template <bool PACK1, bool PACK2, int RT1>
+// RT1: units of step 1 per wave and tile (1 or 2).  CS1: 32-column groups of step 1 -- a
+// unit is (32-row tile, column group), so 64 / 128 columns mean 128 / 64 tile rows whose
+// row tiles are each taken by 2 / 4 waves (each gathers the rows itself: the second
+// fetch comes from the L1 / L2, the matrix cores stay evenly loaded).
+// NCH, IT2: 16-deep chunks of the first contraction and work items of step 2 per wave,
+// known at compile time -- s_waitcnt vmcnt is positional and counts stores too, so only
+// a tile whose sequence of gathers and stores is fixed lets the compiler wait for a
+// gather issued one tile ago WITHOUT waiting for the stores issued since (see the
+// steady-state loop of ctg_pair_mfma.hip's streaming kernel).  NCH = 0: both counts are
+// run-time values (any shape; every wait drains the queue).
+template <bool PACK1, bool PACK2, int RT1, int CS1, int NCH, int IT2>
 __global__ __launch_bounds__(SW * 64, 1) void stem2_kernel(StemArgs p) {
+    static_assert(!PACK1 || CS1 == 1, "16 columns are one group");
+    constexpr int RTW = SW / CS1;   // row tiles the 8 waves cover at once
+    constexpr bool STATIC = NCH > 0;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int DEPTH = 2;   // tasks (32 rows x 16 k = 4 KB) in flight per wave
     const int K1 = p.K1, N1 = p.N1, K2 = p.K2, N2 = p.N2;
     const int LDB1 = K1 + 4, LDB2 = K2 + 4, LD2 = p.ld2;
     const int PLANE = p.rows2 * LD2;                       // floats per plane of the intermediate
@@ -89,12 +108,15 @@ __global__ __launch_bounds__(SW * 64, 1) void stem2_kernel(StemArgs p) {
     float* P2 = P1 + (PACK1 ? 3 : 2) * N1 * LDB1;          // [2|3][N2][LDB2]
     float* mid = P2 + (PACK2 ? 3 : 2) * N2 * LDB2;         // [2][rows2][LD2]
     float* stage = mid + 2 * PLANE;                        // [SW][2][32][SLD]
+    int64_t* oc_s = (int64_t*)(stage + SW * STAGE_FLOATS); // [N2] column offsets of the result
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int kk = lane >> 5;
     const int l31 = lane & 31;
+    const int wrt = wave / CS1;            // this wave's row tile (within a round of RTW)
+    const int wcol = (wave % CS1) * 32;    // ... and first column of step 1
 
     const int64_t z = (int64_t)p.z0 + blockIdx.y;
     const c64* __restrict__ A = (const c64*)p.A + (sload64(p.soffA + z * p.zsA) + z * p.zA);
@@ -104,6 +126,7 @@ __global__ __launch_bounds__(SW * 64, 1) void stem2_kernel(StemArgs p) {
 
     load_b_planes(P1, B1, p.b1_off, K1, N1, PACK1, tid);
     load_b_planes(P2, B2, p.b2_off, K2, N2, PACK2, tid);
+    for (int n = tid; n < N2; n += SW * 64) oc_s[n] = p.out_col[n];
 
     // ---- per-lane constants ---------------------------------------------------
     // gather: slot j of this lane is tile element (r, c) of a task; 16-byte load j
@@ -114,9 +137,13 @@ __global__ __launch_bounds__(SW * 64, 1) void stem2_kernel(StemArgs p) {
     for (int j = 0; j < 8; ++j) {
         const int v = (int)p.ord[lane * 8 + j];
         a_pk[j] = (v >> 4) * SLD + (v & 15);
+        settle(a_pk[j]);
     }
 #pragma unroll
-    for (int j = 0; j < 4; ++j) a_off[j] = p.lane_a[lane * 4 + j];
+    for (int j = 0; j < 4; ++j) {
+        a_off[j] = p.lane_a[lane * 4 + j];
+        settle(a_off[j]);
+    }
     // fragments: A' is (Re, +-Im) by lane half; the sign of Im for the X tile
     const unsigned sgn = kk ? 0x80000000u : 0u;
     // B fragments of step 1: plane by (tile, lane half, column half)
@@ -127,8 +154,8 @@ __global__ __launch_bounds__(SW * 64, 1) void stem2_kernel(StemArgs p) {
         const int plane = kk == 0 ? (h ? 1 : 0) : (h ? 0 : 2);
         b1x = P1 + (plane * N1 + n) * LDB1;
     } else {
-        b1x = P1 + ((kk ? 1 : 0) * N1 + l31) * LDB1;
-        b1y = P1 + ((kk ? 0 : 1) * N1 + l31) * LDB1;
+        b1x = P1 + ((kk ? 1 : 0) * N1 + wcol + l31) * LDB1;
+        b1y = P1 + ((kk ? 0 : 1) * N1 + wcol + l31) * LDB1;
     }
     const float* b2x;
     const float* b2y = nullptr;
@@ -143,7 +170,8 @@ __global__ __launch_bounds__(SW * 64, 1) void stem2_kernel(StemArgs p) {
     // scatter of the step-1 accumulators: lane part of mid_row[row] + mid_col[n]
     int mid_lane;
     if (PACK1) mid_lane = (int)p.mid_col[l31 & 15] + (l31 >> 4) * PLANE + (int)p.mid_row[4 * kk];
-    else mid_lane = (int)p.mid_col[l31] + (int)p.mid_row[4 * kk];
+    else mid_lane = (int)p.mid_col[wcol + l31] + (int)p.mid_row[4 * kk];
+    settle(mid_lane);
     int mid_t[16];
 #pragma unroll
     for (int t = 0; t < 16; ++t) mid_t[t] = (int)sload64(p.mid_row + rowmap(t));
@@ -151,6 +179,7 @@ __global__ __launch_bounds__(SW * 64, 1) void stem2_kernel(StemArgs p) {
     // (PACK2: the lanes of columns 16-31 take the odd rows of each row pair)
     int64_t out_lane = p.out_row[4 * kk];
     if (PACK2) out_lane += (l31 >> 4) ? p.out_row[1] : 0;
+    settle(out_lane);
     int64_t out_t[16];
 #pragma unroll
     for (int t = 0; t < 16; ++t) out_t[t] = sload64(p.out_row + rowmap(t));
@@ -160,24 +189,31 @@ __global__ __launch_bounds__(SW * 64, 1) void stem2_kernel(StemArgs p) {
         const double f = (*p.facA) * (*p.facB1) * (*p.facB2);
         alpha = (f == 0.0 && p.check_zero) ? 0.f : (float)(1.0 / f);
     }
+    const bool scaled = __builtin_amdgcn_readfirstlane(alpha != 1.f);   // (strip_exponent runs only)
     __syncthreads();
 
     float* As = stage + wave * STAGE_FLOATS;
-    const int nch = K1 >> 4;                         // 16-deep chunks of the first contraction
+    const int nch = STATIC ? NCH : (K1 >> 4);        // 16-deep chunks of the first contraction
     const int n_rt2 = p.rows2 >> 5;
     const int n_items = n_rt2 * p.ng2;
     const int64_t n_tiles = p.n_tiles;
     const int64_t tile0 = blockIdx.x, tile_step = gridDim.x;
+    const int64_t my_tiles = (n_tiles - tile0 + tile_step - 1) / tile_step;   // >= 1: grid <= n_tiles
+    const int64_t last_tile = tile0 + (my_tiles - 1) * tile_step;
 
-    // ---- gather pipeline: tasks (tile, row tile m, chunk) in order -------------
-    c64 regs[DEPTH][8];
+    // ---- gather pipeline: tasks (tile, unit m, chunk) in order, two in flight --------
+    c64 regs[2][8];
     int64_t ig = tile0;   // cursor of the next task to issue
     int im = 0, ic = 0;
-    auto issue = [&](c64 (&r)[8]) __attribute__((always_inline)) {
-        if (ig < n_tiles) {
-            const int64_t gh = ig >> p.g_lo_shift, gl = ig & (p.g_lo - 1);
+    // always_tag: the loads are unconditional (past the last tile the last one is fetched
+    // again: the steady state must not contain a conditional memory instruction)
+    auto issue = [&](c64 (&r)[8], auto always_tag) __attribute__((always_inline)) {
+        constexpr bool ALWAYS = decltype(always_tag)::value;
+        if (ALWAYS || ig < n_tiles) {
+            const int64_t g = ALWAYS ? (ig < last_tile ? ig : last_tile) : ig;
+            const int64_t gh = g >> p.g_lo_shift, gl = g & (p.g_lo - 1);
             const int64_t base = sload64(p.gA_hi + uniform64(gh)) + sload64(p.gA_lo + uniform64(gl)) +
-                                 sload64(p.rt_a + (wave + SW * im)) + sload64(p.chunk_a + ic);
+                                 sload64(p.rt_a + (wrt + RTW * im)) + sload64(p.chunk_a + ic);
             const c64* src = A + base;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
@@ -194,61 +230,60 @@ __global__ __launch_bounds__(SW * 64, 1) void stem2_kernel(StemArgs p) {
             }
         }
     };
-#pragma unroll
-    for (int d = 0; d < DEPTH; ++d) issue(regs[d]);
 
-    int slot = 0;   // register set of the task consumed next (compile-time after unrolling by DEPTH)
-    for (int64_t g = tile0; g < n_tiles; g += tile_step) {
-        // ================= step 1 =================
-        f32x16 ax[RT1], ay[RT1];
+    f32x16 ax[RT1], ay[RT1];
+    // one task: registers -> wave-private LDS (fragment layout), refill, 16 k of MFMAs
+    auto consume = [&](c64 (&r)[8], int m, int ch, auto always_tag) __attribute__((always_inline)) {
+        __builtin_amdgcn_wave_barrier();
 #pragma unroll
-        for (int m = 0; m < RT1; ++m) {
-#pragma unroll
-            for (int t = 0; t < 16; ++t) {
-                ax[m][t] = 0.f;
-                if (!PACK1) ay[m][t] = 0.f;
-            }
-            for (int ch = 0; ch < nch; ++ch) {
-                auto consume = [&](c64 (&r)[8]) __attribute__((always_inline)) {
-                    __builtin_amdgcn_wave_barrier();
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) {
-                        As[a_pk[j]] = r[j].re;
-                        As[32 * SLD + a_pk[j]] = r[j].im;
-                    }
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                    __builtin_amdgcn_wave_barrier();
-                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                    issue(r);   // refill this register set DEPTH tasks ahead
-                    const float* a_base = As + kk * 32 * SLD + l31 * SLD;
-                    const int kb = ch * 16;
-#pragma unroll
-                    for (int kq = 0; kq < 4; ++kq) {
-                        const f32x4 af = *(const f32x4*)(a_base + kq * 4);
-                        const f32x4 bx = *(const f32x4*)(b1x + kb + kq * 4);
-                        if (PACK1) {
-#pragma unroll
-                            for (int t = 0; t < 4; ++t) ax[m] = mfma(af[t], bx[t], ax[m]);
-                        } else {
-                            const f32x4 by = *(const f32x4*)(b1y + kb + kq * 4);
-#pragma unroll
-                            for (int t = 0; t < 4; ++t) {
-                                ax[m] = mfma(flip(af[t], sgn), bx[t], ax[m]);
-                                ay[m] = mfma(af[t], by[t], ay[m]);
-                            }
-                        }
-                    }
-                };
-                if (slot == 0) consume(regs[0]);
-                else consume(regs[1]);
-                slot ^= 1;
-            }
+        for (int j = 0; j < 8; ++j) {
+            As[a_pk[j]] = r[j].re;
+            As[32 * SLD + a_pk[j]] = r[j].im;
         }
-        // ================= scatter into the intermediate tile =================
-        __syncthreads();   // all waves have finished step 2 of the previous tile
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        issue(r, always_tag);   // refill this register set two tasks ahead
+        const float* a_base = As + kk * 32 * SLD + l31 * SLD;
+        const float* bxp = b1x + ch * 16;
+        const float* byp = PACK1 ? nullptr : b1y + ch * 16;
+        // fragments of quad q + 1 are read before the MFMAs of quad q are issued
+        f32x4 af[2], bx[2], by[2];
+        af[0] = *(const f32x4*)(a_base);
+        bx[0] = *(const f32x4*)(bxp);
+        if (!PACK1) by[0] = *(const f32x4*)(byp);
+#pragma unroll
+        for (int kq = 0; kq < 4; ++kq) {
+            if (kq + 1 < 4) {
+                af[(kq + 1) & 1] = *(const f32x4*)(a_base + (kq + 1) * 4);
+                bx[(kq + 1) & 1] = *(const f32x4*)(bxp + (kq + 1) * 4);
+                if (!PACK1) by[(kq + 1) & 1] = *(const f32x4*)(byp + (kq + 1) * 4);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                if (PACK1) {
+                    ax[m] = mfma(af[kq & 1][t], bx[kq & 1][t], ax[m]);
+                } else {
+                    ax[m] = mfma(flip(af[kq & 1][t], sgn), bx[kq & 1][t], ax[m]);
+                    ay[m] = mfma(af[kq & 1][t], by[kq & 1][t], ay[m]);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    auto zero_acc = [&](int m) __attribute__((always_inline)) {
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+            ax[m][t] = 0.f;
+            if (!PACK1) ay[m][t] = 0.f;
+        }
+    };
+    // the 32 x (32 | 16) accumulators of every unit -> the shared intermediate tile
+    auto scatter = [&]() __attribute__((always_inline)) {
 #pragma unroll
         for (int m = 0; m < RT1; ++m) {
-            const int rt_part = (int)sload64(p.mid_row + 32 * (wave + SW * m));
+            const int rt_part = (int)sload64(p.mid_row + 32 * (wrt + RTW * m));
             float* dst = mid + (mid_lane + rt_part);
 #pragma unroll
             for (int t = 0; t < 16; ++t) {
@@ -256,43 +291,55 @@ __global__ __launch_bounds__(SW * 64, 1) void stem2_kernel(StemArgs p) {
                 if (!PACK1) dst[PLANE + mid_t[t]] = ay[m][t];
             }
         }
-        __syncthreads();
-        // ================= step 2 =================
-        const int64_t gh = g >> p.g_lo_shift, gl = g & (p.g_lo - 1);
-        const int64_t c_tile = sload64(p.gC_hi + uniform64(gh)) + sload64(p.gC_lo + uniform64(gl));
-        for (int item = wave; item < n_items; item += SW) {
-            const int cg = item / n_rt2, rt2 = item - cg * n_rt2;
-            f32x16 cx, cy;
+    };
+    // one work item of step 2: (32-row tile, 32-column group) of the intermediate x B2
+    auto item2 = [&](int item, int64_t c_tile, auto scaled_tag) __attribute__((always_inline)) {
+        const int cg = item / n_rt2, rt2 = item - cg * n_rt2;
+        f32x16 cx, cy;
 #pragma unroll
-            for (int t = 0; t < 16; ++t) {
-                cx[t] = 0.f;
-                if (!PACK2) cy[t] = 0.f;
-            }
-            const float* a_base = mid + kk * PLANE + (rt2 * 32 + l31) * LD2;
-            const float* bxp = b2x + cg * 32 * LDB2;
-            const float* byp = PACK2 ? nullptr : b2y + cg * 32 * LDB2;
-            for (int kq = 0; kq < (K2 >> 2); ++kq) {
-                const f32x4 af = *(const f32x4*)(a_base + kq * 4);
-                const f32x4 bx = *(const f32x4*)(bxp + kq * 4);
-                if (PACK2) {
+        for (int t = 0; t < 16; ++t) {
+            cx[t] = 0.f;
+            if (!PACK2) cy[t] = 0.f;
+        }
+        const float* a_base = mid + kk * PLANE + (rt2 * 32 + l31) * LD2;
+        const float* bxp = b2x + cg * 32 * LDB2;
+        const float* byp = PACK2 ? nullptr : b2y + cg * 32 * LDB2;
+        // the result's addresses: scalar row base + lane part (LDS copy of the column table)
+        const int64_t c_row = c_tile + sload64(p.out_row + 32 * rt2);
+        const int64_t c_col = oc_s[PACK2 ? (l31 & 15) : cg * 32 + l31];
+        const int nq = K2 >> 2;   // >= 4, even
+        f32x4 af[2], bx[2], by[2];
+        af[0] = *(const f32x4*)(a_base);
+        bx[0] = *(const f32x4*)(bxp);
+        if (!PACK2) by[0] = *(const f32x4*)(byp);
+        for (int kq = 0; kq < nq; kq += 2) {
 #pragma unroll
-                    for (int t = 0; t < 4; ++t) cx = mfma(af[t], bx[t], cx);
-                } else {
-                    const f32x4 by = *(const f32x4*)(byp + kq * 4);
+            for (int h = 0; h < 2; ++h) {
+                // next quad (past the end: the last one again -- no branch in the loop)
+                const int nx = (kq + h + 1 < nq ? kq + h + 1 : nq - 1) * 4;
+                af[(h + 1) & 1] = *(const f32x4*)(a_base + nx);
+                bx[(h + 1) & 1] = *(const f32x4*)(bxp + nx);
+                if (!PACK2) by[(h + 1) & 1] = *(const f32x4*)(byp + nx);
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                    for (int t = 0; t < 4; ++t) {
-                        cx = mfma(flip(af[t], sgn), bx[t], cx);
-                        cy = mfma(af[t], by[t], cy);
+                for (int t = 0; t < 4; ++t) {
+                    if (PACK2) {
+                        cx = mfma(af[h][t], bx[h][t], cx);
+                    } else {
+                        cx = mfma(flip(af[h][t], sgn), bx[h][t], cx);
+                        cy = mfma(af[h][t], by[h][t], cy);
                     }
                 }
+                __builtin_amdgcn_sched_barrier(0);
             }
-            // epilogue
-            const int64_t c_row = c_tile + sload64(p.out_row + 32 * rt2);
+        }
+        {
+            constexpr bool SC = decltype(scaled_tag)::value;
+            float* dst = C + 2 * (c_row + out_lane + c_col);
             if (PACK2) {
                 // lane c < 16 holds Re of column c, lane c + 16 its Im: lanes below 16
                 // store row t, the others row t + 1 of each pair
                 const bool hi = (l31 >> 4) != 0;
-                float* dst = C + 2 * (c_row + out_lane + p.out_col[l31 & 15]);
 #pragma unroll
                 for (int t = 0; t < 16; t += 2) {
                     const float mine = hi ? cx[t] : cx[t + 1];   // what the partner needs
@@ -301,34 +348,106 @@ __global__ __launch_bounds__(SW * 64, 1) void stem2_kernel(StemArgs p) {
                     float2 v;
                     v.x = hi ? got : cx[t];
                     v.y = hi ? cx[t + 1] : got;
-                    v.x *= alpha;
-                    v.y *= alpha;
+                    if (SC) {
+                        v.x *= alpha;
+                        v.y *= alpha;
+                    }
                     *(float2*)(dst + 2 * out_t[t]) = v;
                 }
             } else {
-                float* dst = C + 2 * (c_row + out_lane + p.out_col[cg * 32 + l31]);
 #pragma unroll
                 for (int t = 0; t < 16; ++t) {
                     float2 v;
-                    v.x = cx[t] * alpha;
-                    v.y = cy[t] * alpha;
+                    v.x = SC ? cx[t] * alpha : cx[t];
+                    v.y = SC ? cy[t] * alpha : cy[t];
                     *(float2*)(dst + 2 * out_t[t]) = v;
                 }
             }
         }
+    };
+    auto tile_c = [&](int64_t g) __attribute__((always_inline)) -> int64_t {
+        const int64_t gh = g >> p.g_lo_shift, gl = g & (p.g_lo - 1);
+        return sload64(p.gC_hi + uniform64(gh)) + sload64(p.gC_lo + uniform64(gl));
+    };
+
+    // (the whole tile loop exists twice, with and without the scale factor of a
+    // strip_exponent run: a branch around the stores inside the steady state gives the
+    // compiler paths with fewer stores than there are, and it waits accordingly)
+    auto run = [&](auto scaled_tag) __attribute__((always_inline)) {
+    if constexpr (STATIC) {
+        constexpr int NT = RT1 * NCH;            // tasks per tile and wave
+        constexpr int U = (NT & 1) ? 2 : 1;      // tiles per pass: the register sets alternate
+        issue(regs[0], std::true_type{});
+        issue(regs[1], std::true_type{});
+        int64_t g = tile0;
+        auto tile = [&](auto slot0_tag) __attribute__((always_inline)) {
+            constexpr int SLOT0 = decltype(slot0_tag)::value;
+            static_for<0, RT1>([&](auto mi) __attribute__((always_inline)) {
+                constexpr int M = decltype(mi)::value;
+                zero_acc(M);
+                static_for<0, NCH>([&](auto ci) __attribute__((always_inline)) {
+                    constexpr int CH = decltype(ci)::value;
+                    consume(regs[(SLOT0 + M * NCH + CH) & 1], M, CH, std::true_type{});
+                });
+            });
+            __syncthreads();   // all waves have finished step 2 of the previous tile
+            scatter();
+            __syncthreads();
+            const int64_t c_tile = tile_c(g);
+            static_for<0, IT2>([&](auto ii) __attribute__((always_inline)) {
+                item2(wave + SW * decltype(ii)::value, c_tile, scaled_tag);
+            });
+            g += tile_step;
+        };
+        auto pass = [&]() __attribute__((always_inline)) {
+            static_for<0, U>([&](auto ui) __attribute__((always_inline)) {
+                tile(std::integral_constant<int, (decltype(ui)::value * NT) & 1>{});
+            });
+        };
+        int64_t t = 0;
+        if (my_tiles >= U) {
+            // (first pass peeled: the waits at the loop header must hold for the entry path
+            // as well, where no store has been issued yet -- see the streaming kernel)
+            pass();
+            for (t = U; t + U <= my_tiles; t += U) pass();
+        }
+        if (t < my_tiles) tile(std::integral_constant<int, 0>{});   // (U = 2, odd count; t is even)
+    } else {
+        issue(regs[0], std::false_type{});
+        issue(regs[1], std::false_type{});
+        int slot = 0;
+        for (int64_t g = tile0; g < n_tiles; g += tile_step) {
+#pragma unroll
+            for (int m = 0; m < RT1; ++m) {
+                zero_acc(m);
+                for (int ch = 0; ch < nch; ++ch) {
+                    if (slot == 0) consume(regs[0], m, ch, std::false_type{});
+                    else consume(regs[1], m, ch, std::false_type{});
+                    slot ^= 1;
+                }
+            }
+            __syncthreads();
+            scatter();
+            __syncthreads();
+            const int64_t c_tile = tile_c(g);
+            for (int item = wave; item < n_items; item += SW) item2(item, c_tile, scaled_tag);
+        }
     }
+    };
+    if (scaled) run(std::true_type{});
+    else run(std::false_type{});
 }
 
 size_t stem2_lds_bytes(const StemArgs& p) {
     const size_t b1 = (size_t)(p.N1 == 16 ? 3 : 2) * p.N1 * (p.K1 + 4);
     const size_t b2 = (size_t)(p.N2 == 16 ? 3 : 2) * p.N2 * (p.K2 + 4);
     const size_t mid = (size_t)2 * p.rows2 * p.ld2;
-    return 4 * (b1 + b2 + mid + (size_t)SW * STAGE_FLOATS);
+    return 4 * (b1 + b2 + mid + (size_t)SW * STAGE_FLOATS) + 8 * (size_t)p.N2;
 }
 
-template <bool PACK1, bool PACK2, int RT1>
+template <bool PACK1, bool PACK2, int RT1, int CS1, int NCH, int IT2>
 static hipError_t launch_stem2_t(const StemArgs& p, hipStream_t stream) {
-    auto kern = stem2_kernel<PACK1, PACK2, RT1>;
+    auto kern = stem2_kernel<PACK1, PACK2, RT1, CS1, NCH, IT2>;
     static bool ready = false;
     if (!ready) {
         const hipError_t e =
@@ -339,37 +458,81 @@ static hipError_t launch_stem2_t(const StemArgs& p, hipStream_t stream) {
     const size_t smem = stem2_lds_bytes(p);
     // persistent: one workgroup per CU (the tile owns most of the CU's LDS)
     int64_t blocks = p.n_tiles < 256 ? p.n_tiles : 256;
-    if (p.nz > 1 && blocks * p.nz > 256) blocks = 256 / p.nz > 0 ? 256 / p.nz : 1;
-    hipLaunchKernelGGL(kern, dim3((unsigned)blocks, (unsigned)p.nz), dim3(SW * 64), smem, stream, p);
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks, 1), dim3(SW * 64), smem, stream, p);
     return hipGetLastError();
 }
 
 bool stem2_supported(const StemArgs& p) {
     auto k_ok = [](int k) { return k == 16 || k == 32 || k == 64 || k == 128; };
     if (!k_ok(p.K1) || !k_ok(p.K2)) return false;
-    if (p.N1 != 16 && p.N1 != 32) return false;
+    if (p.N1 != 16 && p.N1 != 32 && p.N1 != 64 && p.N1 != 128) return false;
     if (p.N2 != 16 && p.N2 != 32 && p.N2 != 64 && p.N2 != 128) return false;
-    if (p.nr1 != 8 && p.nr1 != 9) return false;
+    {   // units of step 1 = row tiles x column groups: 8 or 16
+        const int cs1 = p.N1 >= 32 ? p.N1 / 32 : 1;
+        if (p.nr1 < 5 || p.nr1 > 9) return false;
+        const int units = (1 << (p.nr1 - 5)) * cs1;
+        if (units != 8 && units != 16) return false;
+    }
     if (p.rows2 < 32 || (p.rows2 & 31) || p.ld2 != p.K2 + 4) return false;
     if ((int64_t)(1 << p.nr1) * p.N1 != (int64_t)p.rows2 * p.K2) return false;
     if (p.ng2 != (p.N2 >= 32 ? p.N2 / 32 : 1)) return false;
     return stem2_lds_bytes(p) <= 160 * 1024;
 }
 
+// static instantiations: (16 columns first, 16 columns last, units per wave, column groups
+// of step 1, chunks of K1, items per wave) of the pairs the Sycamore m20 trees are made of
+// (tools/stem_shapes.py lists them); anything else runs on the run-time-count variant
+#define CTG_STEM_STATIC(X)                                                                   \
+    X(false, false, 1, 1, 1, 2) X(false, false, 1, 1, 2, 1) X(false, false, 1, 1, 2, 2)       \
+    X(false, false, 1, 1, 4, 1) X(false, false, 1, 1, 4, 2) X(false, false, 1, 1, 8, 1)       \
+    X(false, false, 1, 2, 1, 1) X(false, false, 1, 2, 2, 1) X(false, false, 1, 2, 4, 1)       \
+    X(false, false, 1, 2, 4, 2) X(false, false, 1, 2, 2, 2)                                   \
+    X(false, true, 1, 1, 2, 2) X(false, true, 1, 1, 4, 2) X(false, true, 1, 2, 4, 2)          \
+    X(true, false, 2, 1, 1, 1) X(true, false, 2, 1, 2, 1) X(true, false, 2, 1, 4, 1)          \
+    X(true, true, 1, 1, 1, 1) X(true, true, 2, 1, 4, 1) X(true, true, 2, 1, 1, 2)
+
+int stem2_variant(const StemArgs& p) {
+    const bool p1 = p.N1 == 16, p2 = p.N2 == 16;
+    const int cs1 = p.N1 >= 32 ? p.N1 / 32 : 1;
+    const int rt1 = ((1 << (p.nr1 - 5)) * cs1) / SW;
+    const int nch = p.K1 / 16, items = (p.rows2 / 32) * p.ng2;
+    if (getenv("CTG_STEM_GENERIC") == nullptr && items % SW == 0) {
+        const int it2 = items / SW;
+#define CTG_STEM_HAS(P1, P2, R, CS, NC, IT) \
+    if (p1 == P1 && p2 == P2 && rt1 == R && cs1 == CS && nch == NC && it2 == IT) return 1;
+        CTG_STEM_STATIC(CTG_STEM_HAS)
+#undef CTG_STEM_HAS
+    }
+    return 0;
+}
+
 hipError_t launch_stem2(const StemArgs& p, hipStream_t stream) {
     if (!stem2_supported(p)) return hipErrorInvalidValue;
     const bool p1 = p.N1 == 16, p2 = p.N2 == 16;
-    const int rt1 = 1 << (p.nr1 - 8);
-#define CTG_STEM_CASE(P1, P2, R)                                   \
-    if (p1 == P1 && p2 == P2 && rt1 == R) return launch_stem2_t<P1, P2, R>(p, stream);
-    CTG_STEM_CASE(false, false, 1)
-    CTG_STEM_CASE(false, false, 2)
-    CTG_STEM_CASE(false, true, 1)
-    CTG_STEM_CASE(false, true, 2)
-    CTG_STEM_CASE(true, false, 1)
-    CTG_STEM_CASE(true, false, 2)
-    CTG_STEM_CASE(true, true, 1)
-    CTG_STEM_CASE(true, true, 2)
+    const int cs1 = p.N1 >= 32 ? p.N1 / 32 : 1;
+    const int rt1 = ((1 << (p.nr1 - 5)) * cs1) / SW;
+    if (stem2_variant(p) == 1) {
+        const int nch = p.K1 / 16, it2 = (p.rows2 / 32) * p.ng2 / SW;
+#define CTG_STEM_GO(P1, P2, R, CS, NC, IT)                                                  \
+    if (p1 == P1 && p2 == P2 && rt1 == R && cs1 == CS && nch == NC && it2 == IT)            \
+        return launch_stem2_t<P1, P2, R, CS, NC, IT>(p, stream);
+        CTG_STEM_STATIC(CTG_STEM_GO)
+#undef CTG_STEM_GO
+    }
+#define CTG_STEM_CASE(P1, P2, R, CS)                               \
+    if (p1 == P1 && p2 == P2 && rt1 == R && cs1 == CS) return launch_stem2_t<P1, P2, R, CS, 0, 0>(p, stream);
+#define CTG_STEM_CASES(P2)             \
+    CTG_STEM_CASE(true, P2, 1, 1)      \
+    CTG_STEM_CASE(true, P2, 2, 1)      \
+    CTG_STEM_CASE(false, P2, 1, 1)     \
+    CTG_STEM_CASE(false, P2, 2, 1)     \
+    CTG_STEM_CASE(false, P2, 1, 2)     \
+    CTG_STEM_CASE(false, P2, 2, 2)     \
+    CTG_STEM_CASE(false, P2, 1, 4)     \
+    CTG_STEM_CASE(false, P2, 2, 4)
+    CTG_STEM_CASES(false)
+    CTG_STEM_CASES(true)
+#undef CTG_STEM_CASES
 #undef CTG_STEM_CASE
     return hipErrorInvalidValue;
 }

@@ -49,7 +49,7 @@ DESC_MAGIC = 0x53544D32      # "STM2"
 
 # what the kernel is instantiated for (csrc/ctg_stem.hip: launch_stem2)
 K_OK = (16, 32, 64, 128)
-N1_OK = (16, 32)
+N1_OK = (16, 32, 64, 128)
 N2_OK = (16, 32, 64, 128)
 
 # time model of a fused pair (seconds): matrix cores at this fraction of their
@@ -158,7 +158,9 @@ def geometry(size_dict, A, B1, B2, c1_inds, c2_inds):
 
     free = sorted((b for b in r1 if b not in k2_set), key=sa)   # candidates for X, lowest stride first
     best = None
-    for nr1 in (8, 9):
+    cs1 = max(1, N1 // 32)   # 32-column groups of step 1: a unit = (32-row tile, column group)
+    for units in (WAVES, 2 * WAVES):
+        nr1 = 5 + _log2(units // cs1)
         nx = nr1 - len(k2r)
         if nx < 0 or nx > len(free):
             continue

@@ -135,4 +135,9 @@ STEM_CASES = [
     (17, [(3, 3), (4, 5), (5, 7)]),                    # k16 n32 | k32 n128
     (18, [(3, 3), (6, 4), (5, 4)]),                    # k64 n16 | k32 n16
     (17, [(3, 3), (5, 5), (5, 5), (4, 4), (5, 5), (6, 6), (5, 5)]),   # a longer stem: pairs + leftovers
+    (17, [(3, 3), (6, 6), (5, 5)]),                    # k64 n64 | k32 n32: two waves per row tile
+    (17, [(3, 3), (6, 6), (4, 4)]),                    # k64 n64 | k16 n16
+    (18, [(3, 3), (4, 6), (6, 6)]),                    # k16 n64 | k64 n64
+    (17, [(3, 3), (5, 7), (5, 5)]),                    # k32 n128 | k32 n32: four waves per row tile
+    (18, [(3, 3), (4, 7), (5, 4)]),                    # k16 n128 | k32 n16
 ]

@@ -105,7 +105,7 @@ def test_fused_stem_plan_matches_oracle(case, sliced):
     plain = compile_tree(tree, "complex64", fuse=False)
     n_fused = sum(s.kind == P.KIND_STEM2 for s in fused.steps)
     assert len(fused.steps) == len(plain.steps) - n_fused
-    if (case, sliced) not in ((1, 2), (6, 2)):
+    if sliced == 0:   # (slicing two indices of the first tensor can take a gate below K = 16)
         assert n_fused >= 1
     assert fused.macs_per_slice == plain.macs_per_slice
     assert fused.elems_rw_per_slice == plain.elems_rw_per_slice
