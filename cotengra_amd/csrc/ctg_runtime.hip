@@ -93,6 +93,7 @@ int validate_stem(const ctg_plan* p, int64_t s) {
     StemArgs a{};
     a.K1 = (int)K1; a.N1 = (int)N1; a.K2 = (int)K2; a.N2 = (int)N2; a.nr1 = (int)nr1;
     a.rows2 = (int)rows2; a.ng2 = (int)h[SW_NG2]; a.ld2 = (int)h[SW_LD2];
+    a.n_tiles = n_tiles;
     if (K1 < 1 || K1 > 128 || N1 < 1 || N1 > 128 || K2 < 1 || K2 > 128 || N2 < 1 || N2 > 128 || nr1 < 5 ||
         nr1 > 9 || rows2 < 1 || rows2 > (1 << 16) || !stem2_supported(a))
         return fail(CTG_E_INVALID, "step %lld: stem pair shape the kernel does not take", sl);

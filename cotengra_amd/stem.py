@@ -38,10 +38,11 @@ import numpy as np
 
 from . import plan as P
 
-WAVES = 8                    # waves of a workgroup = row tiles of step 1 in flight
+WAVES = 4                    # waves of a half-workgroup = units of step 1 it has in flight
+GROUPS = 2                   # half-workgroups per workgroup, each with its own tile
 LDS_BYTES = 160 * 1024       # per CU (one workgroup per CU)
-LDS_SLACK = 1024
-STAGE_BYTES = WAVES * 2 * 32 * (16 + 4) * 4   # wave-private A staging: [2 planes][32 rows][16 k + 4]
+LDS_SLACK = 256
+STAGE_BYTES = GROUPS * WAVES * 2 * 32 * (16 + 4) * 4   # wave-private A staging: [2 planes][32 rows][16 k + 4]
 G_LO_BITS = 12               # fast level of the two-level grid tables
 
 DESC_WORDS = 40              # header of the serialised descriptor (int64 words)
@@ -169,8 +170,8 @@ def geometry(size_dict, A, B1, B2, c1_inds, c2_inds):
         if rows2_bits < 5:
             continue
         rows2 = 1 << rows2_bits
-        mid_bytes = 2 * rows2 * (K2 + 4) * 4
-        lds = STAGE_BYTES + mid_bytes + b_lds_bytes(K1, N1) + b_lds_bytes(K2, N2) + LDS_SLACK
+        mid_bytes = GROUPS * 2 * rows2 * (K2 + 4) * 4
+        lds = STAGE_BYTES + mid_bytes + b_lds_bytes(K1, N1) + b_lds_bytes(K2, N2) + 8 * N2 + LDS_SLACK
         if lds > LDS_BYTES:
             continue
         ng2 = max(1, N2 // 32)
@@ -193,6 +194,14 @@ def geometry(size_dict, A, B1, B2, c1_inds, c2_inds):
     g.k2 = k2n + sorted(k2r, key=sa)               # k2 index: the fresh columns first
     g.r2_members = x + [b for b in g.n1 if b not in k2_set]
     g.n2 = n2
+    # what one wave gathers per task = 32 rows x 16 k: the kernel moves it in 16-byte
+    # loads, so the elements must pair up in memory (the stride-1 digit of A is one of
+    # the task's row or k digits -- always the case when the tile has room for X)
+    g.row_a = _table(g.r1, [sa(b) for b in g.r1])              # [2^nr1] tile rows of A
+    g.k_a = _table(g.k1, [sa(b) for b in g.k1])                # [K1]
+    task = np.sort((g.row_a[:32, None] + g.k_a[None, :16]).reshape(-1))
+    if not (np.all(task[1::2] == task[0::2] + 1) and np.all(task[0::2] % 2 == 0)) or A.offset % 2 or A.leaf >= 0:
+        return None
     return g
 
 
@@ -296,14 +305,10 @@ def build_stem_step(size_dict, A, B1, B2, c1_inds, out_inds, out_ref_factory, no
     ld2 = K2 + 4
 
     # ---- step 1: what one wave gathers per task = 32 rows x 16 k ------------
-    row_a = _table(geo.r1, [sa(b) for b in geo.r1])            # [2^nr1] tile rows of A
-    k_a = _table(geo.k1, [sa(b) for b in geo.k1])              # [K1]
+    row_a, k_a = geo.row_a, geo.k_a
     task = (row_a[:32, None] + k_a[None, :16]).reshape(-1)     # element (r, c) at r * 16 + c
     order = np.argsort(task, kind="stable")
     srt = task[order]
-    vec = bool(np.all(srt[1::2] == srt[0::2] + 1) and np.all(srt[0::2] % 2 == 0)) and A.offset % 2 == 0
-    if not vec or A.leaf >= 0:
-        return None
     # lane l, load j (4 loads of 16 bytes) takes the sorted pair j * 64 + l
     ord_tab = np.zeros(64 * 8, dtype=np.int64)
     lane_a = np.zeros(64 * 4, dtype=np.int64)

@@ -105,7 +105,9 @@ def test_fused_stem_plan_matches_oracle(case, sliced):
     plain = compile_tree(tree, "complex64", fuse=False)
     n_fused = sum(s.kind == P.KIND_STEM2 for s in fused.steps)
     assert len(fused.steps) == len(plain.steps) - n_fused
-    if sliced == 0:   # (slicing two indices of the first tensor can take a gate below K = 16)
+    # (slicing two indices of the first tensor can take a gate below K = 16; case 13's second
+    # gate takes six digits of the big tensor: no room in a 64-row tile for its stride-1 digit)
+    if sliced == 0 and case != 13:
         assert n_fused >= 1
     assert fused.macs_per_slice == plain.macs_per_slice
     assert fused.elems_rw_per_slice == plain.elems_rw_per_slice
