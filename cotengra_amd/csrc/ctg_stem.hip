@@ -24,19 +24,6 @@
 //   step 2   work items (32-row tile, 32-column group) of the intermediate are
 //            multiplied by B2 and stored: 8 bytes per lane, 256 B runs.
 //
-// Two half-workgroups, half a tile apart.  Run by all 8 waves in lock step the three
-// phases leave the matrix cores idle a third of the time (scatter, barriers, the
-// latency at the head of every phase: 3-5 us per 10-15 us tile, measured).  So the
-// waves form two groups of four, each with its own tile and its own intermediate
-// buffer (B1 / B2 are shared), and the SAME two workgroup barriers per tile serve
-// both -- with group 1 one phase behind:
-//      group 0:  step 1 + scatter (j) | step 2 (j)             | step 1 + scatter (j+1) | ...
-//      group 1:  step 2 (j-1)         | step 1 + scatter (j)   | step 2 (j)             | ...
-// A group's scatter follows the barrier that ended its own step 2, its step 2 the
-// barrier that ended its own scatter; and in every interval each SIMD holds one wave
-// issuing the MFMAs of a step 1 and one those of a step 2, so the scatter, the stores
-// and the fragment latencies of one hide behind the matrix work of the other.
-//
 // Complex on the real matrix cores, second formulation (the first one is in
 // ctg_pair_mfma.hip).  v_mfma_f32_32x32x2_f32: D(32x32) += A'(32x2) B'(2x32).  Here a
 // pair of tiles X / Y holds the REAL and the IMAGINARY parts of 32 complex
@@ -62,8 +49,16 @@ constexpr int SW = 8;            // waves per workgroup
 constexpr int SLD = 16 + 4;      // staging row: 16 k + pad (floats)
 constexpr int STAGE_FLOATS = 2 * 32 * SLD;
 
+// Knock-out switches of experiment builds (tools/build_variants.py; results are wrong by
+// construction): what does the kernel cost without its matrix instructions / gathers /
+// stores / scatter?  Off in the product.
 __device__ __forceinline__ f32x16 mfma(float a, float b, f32x16 c) {
+#ifdef CTG_STEM_KO_MFMA
+    c[0] = fmaf(a, b, c[0]);   // keeps the data dependences at one VALU op per MFMA
+    return c;
+#else
     return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+#endif
 }
 
 // row of accumulator register t within a 32-row tile, for the lanes with kk = 0
@@ -111,8 +106,7 @@ __device__ __forceinline__ void settle(T& v) {
 template <bool PACK1, bool PACK2, int RT1, int CS1, int NCH, int IT2>
 __global__ __launch_bounds__(SW * 64, 1) void stem2_kernel(StemArgs p) {
     static_assert(!PACK1 || CS1 == 1, "16 columns are one group");
-    constexpr int GW = 4;           // waves per group
-    constexpr int RTW = GW / CS1;   // row tiles the 4 waves of a group cover at once
+    constexpr int RTW = SW / CS1;   // row tiles the 8 waves cover at once
     constexpr bool STATIC = NCH > 0;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int K1 = p.K1, N1 = p.N1, K2 = p.K2, N2 = p.N2;
@@ -120,8 +114,8 @@ __global__ __launch_bounds__(SW * 64, 1) void stem2_kernel(StemArgs p) {
     const int PLANE = p.rows2 * LD2;                       // floats per plane of the intermediate
     float* P1 = (float*)smem;                              // [2|3][N1][LDB1]
     float* P2 = P1 + (PACK1 ? 3 : 2) * N1 * LDB1;          // [2|3][N2][LDB2]
-    float* mid0 = P2 + (PACK2 ? 3 : 2) * N2 * LDB2;        // [2 groups][2][rows2][LD2]
-    float* stage = mid0 + 4 * PLANE;                       // [SW][2][32][SLD]
+    float* mid = P2 + (PACK2 ? 3 : 2) * N2 * LDB2;         // [2][rows2][LD2]
+    float* stage = mid + 2 * PLANE;                        // [SW][2][32][SLD]
     int64_t* oc_s = (int64_t*)(stage + SW * STAGE_FLOATS); // [N2] column offsets of the result
 
     const int tid = threadIdx.x;
@@ -129,10 +123,8 @@ __global__ __launch_bounds__(SW * 64, 1) void stem2_kernel(StemArgs p) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int kk = lane >> 5;
     const int l31 = lane & 31;
-    const int group = wave >> 2;           // 0 / 1: the half-workgroup
-    const int wig = wave & 3;              // wave in group
-    const int wrt = wig / CS1;             // this wave's row tile (within a round of RTW)
-    const int wcol = (wig % CS1) * 32;     // ... and first column of step 1
+    const int wrt = wave / CS1;            // this wave's row tile (within a round of RTW)
+    const int wcol = (wave % CS1) * 32;    // ... and first column of step 1
 
     const int64_t z = (int64_t)p.z0 + blockIdx.y;
     const c64* __restrict__ A = (const c64*)p.A + (sload64(p.soffA + z * p.zsA) + z * p.zA);
@@ -209,28 +201,23 @@ __global__ __launch_bounds__(SW * 64, 1) void stem2_kernel(StemArgs p) {
     __syncthreads();
 
     float* As = stage + wave * STAGE_FLOATS;
-    float* mid = mid0 + group * 2 * PLANE;
     const int nch = STATIC ? NCH : (K1 >> 4);        // 16-deep chunks of the first contraction
     const int n_rt2 = p.rows2 >> 5;
     const int n_items = n_rt2 * p.ng2;
-    // tiles come in pairs (even: group 0, odd: group 1); workgroup b takes pairs b, b + grid, ...
-    const int64_t n_pairs = p.n_tiles >> 1;
-    const int64_t pair_step = gridDim.x;
-    const int64_t T = (n_pairs - blockIdx.x + pair_step - 1) / pair_step;   // >= 1: grid <= n_pairs
-    const int64_t tile0 = 2 * (int64_t)blockIdx.x + group, tile_step = 2 * pair_step;
-    const int64_t last_tile = tile0 + (T - 1) * tile_step;
+    const int64_t n_tiles = p.n_tiles;
+    const int64_t tile0 = blockIdx.x, tile_step = gridDim.x;
+    const int64_t my_tiles = (n_tiles - tile0 + tile_step - 1) / tile_step;   // >= 1: grid <= n_tiles
+    const int64_t last_tile = tile0 + (my_tiles - 1) * tile_step;
 
-    // ---- gather pipeline: tasks (tile, unit m, chunk) in order --------------------
-    // two register sets (8 KB in flight per wave); a tile that is a single task keeps one
-    constexpr int SETS = (STATIC && RT1 * NCH == 1) ? 1 : 2;
-    c64 regs[SETS][8];
+    // ---- gather pipeline: tasks (tile, unit m, chunk) in order, two in flight --------
+    c64 regs[2][8];
     int64_t ig = tile0;   // cursor of the next task to issue
     int im = 0, ic = 0;
     // always_tag: the loads are unconditional (past the last tile the last one is fetched
     // again: the steady state must not contain a conditional memory instruction)
     auto issue = [&](c64 (&r)[8], auto always_tag) __attribute__((always_inline)) {
         constexpr bool ALWAYS = decltype(always_tag)::value;
-        if (ALWAYS || ig <= last_tile) {
+        if (ALWAYS || ig < n_tiles) {
             const int64_t g = ALWAYS ? (ig < last_tile ? ig : last_tile) : ig;
             const int64_t gh = g >> p.g_lo_shift, gl = g & (p.g_lo - 1);
             const int64_t base = sload64(p.gA_hi + uniform64(gh)) + sload64(p.gA_lo + uniform64(gl)) +
@@ -238,7 +225,11 @@ __global__ __launch_bounds__(SW * 64, 1) void stem2_kernel(StemArgs p) {
             const c64* src = A + base;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
+#ifdef CTG_STEM_KO_GATHER
+                const f32x4 v = {(float)(uintptr_t)src, 1.f, 2.f, (float)a_off[j]};
+#else
                 const f32x4 v = *(const f32x4*)(src + a_off[j]);
+#endif
                 r[2 * j] = c64{v[0], v[1]};
                 r[2 * j + 1] = c64{v[2], v[3]};
             }
@@ -308,6 +299,9 @@ __global__ __launch_bounds__(SW * 64, 1) void stem2_kernel(StemArgs p) {
             float* dst = mid + (mid_lane + rt_part);
 #pragma unroll
             for (int t = 0; t < 16; ++t) {
+#ifdef CTG_STEM_KO_SCATTER
+                if (ax[m][t] != 12345.678f) continue;
+#endif
                 dst[mid_t[t]] = ax[m][t];
                 if (!PACK1) dst[PLANE + mid_t[t]] = ay[m][t];
             }
@@ -373,6 +367,9 @@ __global__ __launch_bounds__(SW * 64, 1) void stem2_kernel(StemArgs p) {
                         v.x *= alpha;
                         v.y *= alpha;
                     }
+#ifdef CTG_STEM_KO_STORE
+                    if (v.x == 12345.678f)
+#endif
                     *(float2*)(dst + 2 * out_t[t]) = v;
                 }
             } else {
@@ -381,6 +378,9 @@ __global__ __launch_bounds__(SW * 64, 1) void stem2_kernel(StemArgs p) {
                     float2 v;
                     v.x = SC ? cx[t] * alpha : cx[t];
                     v.y = SC ? cy[t] * alpha : cy[t];
+#ifdef CTG_STEM_KO_STORE
+                    if (v.x == 12345.678f)
+#endif
                     *(float2*)(dst + 2 * out_t[t]) = v;
                 }
             }
@@ -391,88 +391,69 @@ __global__ __launch_bounds__(SW * 64, 1) void stem2_kernel(StemArgs p) {
         return sload64(p.gC_hi + uniform64(gh)) + sload64(p.gC_lo + uniform64(gl));
     };
 
-    // step 1 + scatter of one tile of this group / step 2 of one tile of this group
-    auto phase12 = [&](auto static_tag) __attribute__((always_inline)) {
-        if constexpr (decltype(static_tag)::value) {
+    // (the whole tile loop exists twice, with and without the scale factor of a
+    // strip_exponent run: a branch around the stores inside the steady state gives the
+    // compiler paths with fewer stores than there are, and it waits accordingly)
+    auto run = [&](auto scaled_tag) __attribute__((always_inline)) {
+    if constexpr (STATIC) {
+        constexpr int NT = RT1 * NCH;            // tasks per tile and wave
+        constexpr int U = (NT & 1) ? 2 : 1;      // tiles per pass: the register sets alternate
+        issue(regs[0], std::true_type{});
+        issue(regs[1], std::true_type{});
+        int64_t g = tile0;
+        auto tile = [&](auto slot0_tag) __attribute__((always_inline)) {
+            constexpr int SLOT0 = decltype(slot0_tag)::value;
             static_for<0, RT1>([&](auto mi) __attribute__((always_inline)) {
                 constexpr int M = decltype(mi)::value;
                 zero_acc(M);
-                static_for<0, (NCH > 0 ? NCH : 1)>([&](auto ci) __attribute__((always_inline)) {
+                static_for<0, NCH>([&](auto ci) __attribute__((always_inline)) {
                     constexpr int CH = decltype(ci)::value;
-                    consume(regs[(M * NCH + CH) % SETS], M, CH, std::true_type{});
+                    consume(regs[(SLOT0 + M * NCH + CH) & 1], M, CH, std::true_type{});
                 });
             });
-        } else {
-            // (an odd number of tasks per tile would make the sets alternate from tile to
-            // tile: such a shape keeps a single task in flight, in set 0)
-            const bool two = (RT1 * nch) % 2 == 0;
-            int slot = 0;
+            __syncthreads();   // all waves have finished step 2 of the previous tile
+            scatter();
+            __syncthreads();
+            const int64_t c_tile = tile_c(g);
+            static_for<0, IT2>([&](auto ii) __attribute__((always_inline)) {
+                item2(wave + SW * decltype(ii)::value, c_tile, scaled_tag);
+            });
+            g += tile_step;
+        };
+        auto pass = [&]() __attribute__((always_inline)) {
+            static_for<0, U>([&](auto ui) __attribute__((always_inline)) {
+                tile(std::integral_constant<int, (decltype(ui)::value * NT) & 1>{});
+            });
+        };
+        int64_t t = 0;
+        if (my_tiles >= U) {
+            // (first pass peeled: the waits at the loop header must hold for the entry path
+            // as well, where no store has been issued yet -- see the streaming kernel)
+            pass();
+            for (t = U; t + U <= my_tiles; t += U) pass();
+        }
+        if (t < my_tiles) tile(std::integral_constant<int, 0>{});   // (U = 2, odd count; t is even)
+    } else {
+        issue(regs[0], std::false_type{});
+        issue(regs[1], std::false_type{});
+        int slot = 0;
+        for (int64_t g = tile0; g < n_tiles; g += tile_step) {
 #pragma unroll
             for (int m = 0; m < RT1; ++m) {
                 zero_acc(m);
                 for (int ch = 0; ch < nch; ++ch) {
                     if (slot == 0) consume(regs[0], m, ch, std::false_type{});
-                    else consume(regs[SETS - 1], m, ch, std::false_type{});
-                    if (two) slot ^= 1;
+                    else consume(regs[1], m, ch, std::false_type{});
+                    slot ^= 1;
                 }
             }
-        }
-        scatter();
-    };
-    auto phase3 = [&](int64_t g, auto static_tag, auto scaled_tag) __attribute__((always_inline)) {
-        const int64_t c_tile = tile_c(g);
-        if constexpr (decltype(static_tag)::value) {
-            static_for<0, (IT2 > 0 ? IT2 : 1)>([&](auto ii) __attribute__((always_inline)) {
-                item2(wig + GW * decltype(ii)::value, c_tile, scaled_tag);
-            });
-        } else {
-            for (int item = wig; item < n_items; item += GW) item2(item, c_tile, scaled_tag);
-        }
-    };
-    // (the whole tile loop exists four times -- per group, and with / without the scale
-    // factor of a strip_exponent run: a branch around the stores inside the steady state
-    // gives the compiler paths with fewer stores than there are, and it waits accordingly)
-    auto run = [&](auto scaled_tag) __attribute__((always_inline)) {
-        constexpr std::bool_constant<STATIC> st{};
-        // generic variant with an odd number of tasks per tile: the register sets would
-        // alternate from tile to tile; it simply keeps one task in flight less
-        if constexpr (STATIC) {
-            issue(regs[0], st);
-            if (SETS == 2) issue(regs[SETS - 1], st);
-        } else {
-            issue(regs[0], st);
-            if ((RT1 * nch) % 2 == 0) issue(regs[SETS - 1], st);
-        }
-        int64_t g = tile0;
-        if (group == 0) {
-            auto pass = [&]() __attribute__((always_inline)) {
-                phase12(st);
-                __syncthreads();
-                phase3(g, st, scaled_tag);
-                __syncthreads();
-                g += tile_step;
-            };
-            // (first pass peeled: the waits at the loop header must hold for the entry path
-            // as well, where no store has been issued yet -- see the streaming kernel)
-            pass();
-            for (int64_t j = 1; j < T; ++j) pass();
-        } else {
             __syncthreads();
-            phase12(st);
+            scatter();
             __syncthreads();
-            auto pass = [&]() __attribute__((always_inline)) {
-                phase3(g, st, scaled_tag);
-                __syncthreads();
-                phase12(st);
-                __syncthreads();
-                g += tile_step;
-            };
-            if (T > 1) {
-                pass();
-                for (int64_t j = 2; j < T; ++j) pass();
-            }
-            phase3(g, st, scaled_tag);
+            const int64_t c_tile = tile_c(g);
+            for (int item = wave; item < n_items; item += SW) item2(item, c_tile, scaled_tag);
         }
+    }
     };
     if (scaled) run(std::true_type{});
     else run(std::false_type{});
@@ -481,7 +462,7 @@ __global__ __launch_bounds__(SW * 64, 1) void stem2_kernel(StemArgs p) {
 size_t stem2_lds_bytes(const StemArgs& p) {
     const size_t b1 = (size_t)(p.N1 == 16 ? 3 : 2) * p.N1 * (p.K1 + 4);
     const size_t b2 = (size_t)(p.N2 == 16 ? 3 : 2) * p.N2 * (p.K2 + 4);
-    const size_t mid = (size_t)2 * 2 * p.rows2 * p.ld2;   // one intermediate tile per half-workgroup
+    const size_t mid = (size_t)2 * p.rows2 * p.ld2;
     return 4 * (b1 + b2 + mid + (size_t)SW * STAGE_FLOATS) + 8 * (size_t)p.N2;
 }
 
@@ -496,9 +477,8 @@ static hipError_t launch_stem2_t(const StemArgs& p, hipStream_t stream) {
         ready = true;
     }
     const size_t smem = stem2_lds_bytes(p);
-    // persistent: one workgroup per CU (the tiles own most of the CU's LDS); tiles go in pairs
-    const int64_t n_pairs = p.n_tiles / 2;
-    int64_t blocks = n_pairs < 256 ? n_pairs : 256;
+    // persistent: one workgroup per CU (the tile owns most of the CU's LDS)
+    int64_t blocks = p.n_tiles < 256 ? p.n_tiles : 256;
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks, 1), dim3(SW * 64), smem, stream, p);
     return hipGetLastError();
 }
@@ -508,12 +488,11 @@ bool stem2_supported(const StemArgs& p) {
     if (!k_ok(p.K1) || !k_ok(p.K2)) return false;
     if (p.N1 != 16 && p.N1 != 32 && p.N1 != 64 && p.N1 != 128) return false;
     if (p.N2 != 16 && p.N2 != 32 && p.N2 != 64 && p.N2 != 128) return false;
-    {   // units of step 1 (per half-workgroup) = row tiles x column groups: 4 or 8
+    {   // units of step 1 = row tiles x column groups: 8 or 16
         const int cs1 = p.N1 >= 32 ? p.N1 / 32 : 1;
         if (p.nr1 < 5 || p.nr1 > 9) return false;
         const int units = (1 << (p.nr1 - 5)) * cs1;
-        if (units != 4 && units != 8) return false;
-        if (p.n_tiles < 2 || (p.n_tiles & 1)) return false;
+        if (units != 8 && units != 16) return false;
     }
     if (p.rows2 < 32 || (p.rows2 & 31) || p.ld2 != p.K2 + 4) return false;
     if ((int64_t)(1 << p.nr1) * p.N1 != (int64_t)p.rows2 * p.K2) return false;
@@ -525,21 +504,21 @@ bool stem2_supported(const StemArgs& p) {
 // of step 1, chunks of K1, items per wave) of the pairs the Sycamore m20 trees are made of
 // (tools/stem_shapes.py lists them); anything else runs on the run-time-count variant
 #define CTG_STEM_STATIC(X)                                                                   \
-    X(false, false, 1, 2, 4, 1) X(false, false, 1, 1, 2, 1) X(false, true, 1, 2, 4, 2)        \
-    X(false, false, 1, 1, 2, 2) X(false, true, 1, 1, 2, 2) X(false, false, 1, 2, 2, 1)        \
-    X(true, false, 1, 1, 1, 1) X(true, false, 2, 1, 1, 1) X(false, false, 1, 2, 1, 1)         \
-    X(false, false, 1, 1, 8, 1) X(false, false, 1, 1, 1, 1) X(false, true, 1, 2, 2, 2)        \
-    X(false, false, 1, 1, 4, 1) X(false, true, 1, 2, 2, 1) X(false, false, 1, 1, 1, 2)        \
-    X(false, true, 1, 1, 8, 2) X(true, true, 1, 1, 1, 1) X(false, true, 1, 1, 1, 2)           \
-    X(true, true, 2, 1, 4, 1) X(false, false, 1, 1, 4, 2) X(false, false, 1, 4, 2, 1)
+    X(false, false, 1, 1, 1, 2) X(false, false, 1, 1, 2, 1) X(false, false, 1, 1, 2, 2)       \
+    X(false, false, 1, 1, 4, 1) X(false, false, 1, 1, 4, 2) X(false, false, 1, 1, 8, 1)       \
+    X(false, false, 1, 2, 1, 1) X(false, false, 1, 2, 2, 1) X(false, false, 1, 2, 4, 1)       \
+    X(false, false, 1, 2, 4, 2) X(false, false, 1, 2, 2, 2)                                   \
+    X(false, true, 1, 1, 2, 2) X(false, true, 1, 1, 4, 2) X(false, true, 1, 2, 4, 2)          \
+    X(true, false, 2, 1, 1, 1) X(true, false, 2, 1, 2, 1) X(true, false, 2, 1, 4, 1)          \
+    X(true, true, 1, 1, 1, 1) X(true, true, 2, 1, 4, 1) X(true, true, 2, 1, 1, 2)
 
 int stem2_variant(const StemArgs& p) {
     const bool p1 = p.N1 == 16, p2 = p.N2 == 16;
     const int cs1 = p.N1 >= 32 ? p.N1 / 32 : 1;
-    const int rt1 = ((1 << (p.nr1 - 5)) * cs1) / 4;
+    const int rt1 = ((1 << (p.nr1 - 5)) * cs1) / SW;
     const int nch = p.K1 / 16, items = (p.rows2 / 32) * p.ng2;
-    if (getenv("CTG_STEM_GENERIC") == nullptr && items % 4 == 0) {
-        const int it2 = items / 4;
+    if (getenv("CTG_STEM_GENERIC") == nullptr && items % SW == 0) {
+        const int it2 = items / SW;
 #define CTG_STEM_HAS(P1, P2, R, CS, NC, IT) \
     if (p1 == P1 && p2 == P2 && rt1 == R && cs1 == CS && nch == NC && it2 == IT) return 1;
         CTG_STEM_STATIC(CTG_STEM_HAS)
@@ -552,9 +531,9 @@ hipError_t launch_stem2(const StemArgs& p, hipStream_t stream) {
     if (!stem2_supported(p)) return hipErrorInvalidValue;
     const bool p1 = p.N1 == 16, p2 = p.N2 == 16;
     const int cs1 = p.N1 >= 32 ? p.N1 / 32 : 1;
-    const int rt1 = ((1 << (p.nr1 - 5)) * cs1) / 4;
+    const int rt1 = ((1 << (p.nr1 - 5)) * cs1) / SW;
     if (stem2_variant(p) == 1) {
-        const int nch = p.K1 / 16, it2 = (p.rows2 / 32) * p.ng2 / 4;
+        const int nch = p.K1 / 16, it2 = (p.rows2 / 32) * p.ng2 / SW;
 #define CTG_STEM_GO(P1, P2, R, CS, NC, IT)                                                  \
     if (p1 == P1 && p2 == P2 && rt1 == R && cs1 == CS && nch == NC && it2 == IT)            \
         return launch_stem2_t<P1, P2, R, CS, NC, IT>(p, stream);

@@ -38,11 +38,10 @@ import numpy as np
 
 from . import plan as P
 
-WAVES = 4                    # waves of a half-workgroup = units of step 1 it has in flight
-GROUPS = 2                   # half-workgroups per workgroup, each with its own tile
+WAVES = 8                    # waves of a workgroup = row tiles of step 1 in flight
 LDS_BYTES = 160 * 1024       # per CU (one workgroup per CU)
 LDS_SLACK = 256
-STAGE_BYTES = GROUPS * WAVES * 2 * 32 * (16 + 4) * 4   # wave-private A staging: [2 planes][32 rows][16 k + 4]
+STAGE_BYTES = WAVES * 2 * 32 * (16 + 4) * 4   # wave-private A staging: [2 planes][32 rows][16 k + 4]
 G_LO_BITS = 12               # fast level of the two-level grid tables
 
 DESC_WORDS = 40              # header of the serialised descriptor (int64 words)
@@ -53,11 +52,28 @@ K_OK = (16, 32, 64, 128)
 N1_OK = (16, 32, 64, 128)
 N2_OK = (16, 32, 64, 128)
 
-# time model of a fused pair (seconds): matrix cores at this fraction of their
-# 157.3 TFLOP/s while a phase runs, memory at this rate for A in + C2 out
-FUSED_MFMA_RATE = 157.3e12 * 0.70
-FUSED_MEM_RATE = 5.0e12
+# Time model of a fused pair, from knock-out builds of the kernel on the m20 stem
+# (tools/exp_stem_ko.sh, profiles/r3_stem_knockout.txt): without its memory traffic the
+# kernel runs its matrix work at 0.73 of the 157.3 TFLOP/s peak; without its MFMAs it
+# moves A at a rate set by how many bytes of a wave's 32 x 16 task are contiguous in
+# memory (a tile that has no room for A's lowest-stride digits gathers in 32-byte
+# pieces), C2 at the full rate; together they take the longer of the two plus a fifth
+# of the shorter.
+FUSED_MFMA_RATE = 157.3e12 * 0.73
+FUSED_STORE_RATE = 5.4e12
+FUSED_OVERLAP_LOSS = 0.2
 MIN_GAIN = 0.05              # fuse only if the model saves at least this fraction
+
+
+def gather_rate(run_bytes):
+    """Bytes per second of the A gather by contiguous run length."""
+    if run_bytes >= 256:
+        return 5.4e12
+    if run_bytes >= 128:
+        return 4.8e12
+    if run_bytes >= 64:
+        return 2.85e12
+    return 1.25e12
 
 
 def _log2(n):
@@ -170,7 +186,7 @@ def geometry(size_dict, A, B1, B2, c1_inds, c2_inds):
         if rows2_bits < 5:
             continue
         rows2 = 1 << rows2_bits
-        mid_bytes = GROUPS * 2 * rows2 * (K2 + 4) * 4
+        mid_bytes = 2 * rows2 * (K2 + 4) * 4
         lds = STAGE_BYTES + mid_bytes + b_lds_bytes(K1, N1) + b_lds_bytes(K2, N2) + 8 * N2 + LDS_SLACK
         if lds > LDS_BYTES:
             continue
@@ -202,14 +218,18 @@ def geometry(size_dict, A, B1, B2, c1_inds, c2_inds):
     task = np.sort((g.row_a[:32, None] + g.k_a[None, :16]).reshape(-1))
     if not (np.all(task[1::2] == task[0::2] + 1) and np.all(task[0::2] % 2 == 0)) or A.offset % 2 or A.leaf >= 0:
         return None
+    # bytes of A that are contiguous in memory within one task (the run a wave's load
+    # instruction can coalesce): 8 B x 2^(number of leading contiguous digits)
+    runs = np.flatnonzero(np.diff(task) != 1)
+    g.run_bytes = 8 * int(runs[0] + 1 if len(runs) else len(task))
     return g
 
 
-def pair_seconds(macs1, macs2, elems_a, elems_c2, items):
+def pair_seconds(macs1, macs2, elems_a, elems_c2, items, run_bytes=256):
     """Modelled time of a fused pair."""
     t_mfma = 8.0 * macs1 / FUSED_MFMA_RATE + 8.0 * macs2 / (FUSED_MFMA_RATE * min(1.0, items / WAVES))
-    t_mem = 8.0 * (elems_a + elems_c2) / FUSED_MEM_RATE
-    return max(t_mfma, t_mem)
+    t_mem = 8.0 * elems_a / gather_rate(run_bytes) + 8.0 * elems_c2 / FUSED_STORE_RATE
+    return max(t_mfma, t_mem) + FUSED_OVERLAP_LOSS * min(t_mfma, t_mem)
 
 
 def find_pairs(plan, size_dict, min_elems=1 << 24, model=None):
@@ -248,7 +268,7 @@ def find_pairs(plan, size_dict, min_elems=1 << 24, model=None):
         if geo is None:
             continue
         before = unfused_seconds(s1) + unfused_seconds(s2)
-        after = pair_seconds(s1.macs, s2.macs, s1.a.size, s2.c.size, geo.items)
+        after = pair_seconds(s1.macs, s2.macs, s1.a.size, s2.c.size, geo.items, geo.run_bytes)
         if before - after >= MIN_GAIN * before:
             gain[i2] = (i1, before - after)
     # chains: i1 -> i2 -> i3 ...; a step can be in one pair only
@@ -358,7 +378,7 @@ def build_stem_step(size_dict, A, B1, B2, c1_inds, out_inds, out_ref_factory, no
     step.stem = {
         "K1": K1, "N1": N1, "K2": K2, "N2": N2, "nr1": geo.nr1, "rows2": 1 << geo.rows2_bits,
         "ng2": geo.ng2, "n_tiles": 1 << len(geo.grid), "g_lo": 1 << g_lo_bits, "ld2": ld2,
-        "lds_bytes": geo.lds, "items": geo.items, "tabs": tabs,
+        "lds_bytes": geo.lds, "items": geo.items, "run_bytes": geo.run_bytes, "tabs": tabs,
     }
     # reporting fields: the second step's shape; work and traffic of BOTH steps as if unfused
     rows_total = A.size // K1
