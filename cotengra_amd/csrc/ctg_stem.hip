@@ -213,16 +213,35 @@ __global__ __launch_bounds__(SW * 64, 1) void stem2_kernel(StemArgs p) {
     c64 regs[2][8];
     int64_t ig = tile0;   // cursor of the next task to issue
     int im = 0, ic = 0;
-    // always_tag: the loads are unconditional (past the last tile the last one is fetched
-    // again: the steady state must not contain a conditional memory instruction)
-    auto issue = [&](c64 (&r)[8], auto always_tag) __attribute__((always_inline)) {
+    // prep: address of the next task to gather -- scalar loads, issued early (behind the
+    // last MFMAs of the task before) so that their latency is nobody's problem;
+    // fire: the task's four 16-byte loads.  always_tag: unconditional (past the last tile
+    // the last one is fetched again: the steady state must not contain a conditional
+    // memory instruction)
+    int64_t pend0 = 0, pend1 = 0, pend2 = 0, pend3 = 0;   // (summed where they are used)
+    bool pend_live = false;
+    auto prep = [&](auto always_tag) __attribute__((always_inline)) {
         constexpr bool ALWAYS = decltype(always_tag)::value;
-        if (ALWAYS || ig < n_tiles) {
+        pend_live = ALWAYS || ig < n_tiles;
+        if (pend_live) {
             const int64_t g = ALWAYS ? (ig < last_tile ? ig : last_tile) : ig;
             const int64_t gh = g >> p.g_lo_shift, gl = g & (p.g_lo - 1);
-            const int64_t base = sload64(p.gA_hi + uniform64(gh)) + sload64(p.gA_lo + uniform64(gl)) +
-                                 sload64(p.rt_a + (wrt + RTW * im)) + sload64(p.chunk_a + ic);
-            const c64* src = A + base;
+            pend0 = sload64(p.gA_hi + uniform64(gh));
+            pend1 = sload64(p.gA_lo + uniform64(gl));
+            pend2 = sload64(p.rt_a + (wrt + RTW * im));
+            pend3 = sload64(p.chunk_a + ic);
+            if (++ic == nch) {
+                ic = 0;
+                if (++im == RT1) {
+                    im = 0;
+                    ig += tile_step;
+                }
+            }
+        }
+    };
+    auto fire = [&](c64 (&r)[8], auto always_tag) __attribute__((always_inline)) {
+        if (decltype(always_tag)::value || pend_live) {
+            const c64* src = A + (pend0 + pend1 + pend2 + pend3);
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
 #ifdef CTG_STEM_KO_GATHER
@@ -233,14 +252,11 @@ __global__ __launch_bounds__(SW * 64, 1) void stem2_kernel(StemArgs p) {
                 r[2 * j] = c64{v[0], v[1]};
                 r[2 * j + 1] = c64{v[2], v[3]};
             }
-            if (++ic == nch) {
-                ic = 0;
-                if (++im == RT1) {
-                    im = 0;
-                    ig += tile_step;
-                }
-            }
         }
+    };
+    auto issue = [&](c64 (&r)[8], auto always_tag) __attribute__((always_inline)) {
+        prep(always_tag);
+        fire(r, always_tag);
     };
 
     f32x16 ax[RT1], ay[RT1];
@@ -255,7 +271,8 @@ __global__ __launch_bounds__(SW * 64, 1) void stem2_kernel(StemArgs p) {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        issue(r, always_tag);   // refill this register set two tasks ahead
+        __builtin_amdgcn_sched_barrier(0);   // (the address sum of prep() stays behind the LDS writes)
+        fire(r, always_tag);    // refill this register set two tasks ahead
         const float* a_base = As + kk * 32 * SLD + l31 * SLD;
         const float* bxp = b1x + ch * 16;
         const float* byp = PACK1 ? nullptr : b1y + ch * 16;
@@ -283,6 +300,8 @@ __global__ __launch_bounds__(SW * 64, 1) void stem2_kernel(StemArgs p) {
             }
             __builtin_amdgcn_sched_barrier(0);
         }
+        prep(always_tag);   // (behind the last MFMAs: nothing of this task waits for LDS any more)
+        __builtin_amdgcn_sched_barrier(0);
     };
     auto zero_acc = [&](int m) __attribute__((always_inline)) {
 #pragma unroll
@@ -308,7 +327,13 @@ __global__ __launch_bounds__(SW * 64, 1) void stem2_kernel(StemArgs p) {
         }
     };
     // one work item of step 2: (32-row tile, 32-column group) of the intermediate x B2
-    auto item2 = [&](int item, int64_t c_tile, auto scaled_tag) __attribute__((always_inline)) {
+    auto item_row = [&](int item, int64_t c_tile) __attribute__((always_inline)) -> int64_t {
+        const int cg = item / n_rt2, rt2 = item - cg * n_rt2;
+        int64_t c_row = c_tile + sload64(p.out_row + 32 * rt2);
+        asm volatile("" : "+s"(c_row));   // waited for here, not inside the fragment pipeline
+        return c_row;
+    };
+    auto item2 = [&](int item, int64_t c_row, auto scaled_tag) __attribute__((always_inline)) {
         const int cg = item / n_rt2, rt2 = item - cg * n_rt2;
         f32x16 cx, cy;
 #pragma unroll
@@ -320,7 +345,6 @@ __global__ __launch_bounds__(SW * 64, 1) void stem2_kernel(StemArgs p) {
         const float* bxp = b2x + cg * 32 * LDB2;
         const float* byp = PACK2 ? nullptr : b2y + cg * 32 * LDB2;
         // the result's addresses: scalar row base + lane part (LDS copy of the column table)
-        const int64_t c_row = c_tile + sload64(p.out_row + 32 * rt2);
         const int64_t c_col = oc_s[PACK2 ? (l31 & 15) : cg * 32 + l31];
         const int nq = K2 >> 2;   // >= 4, even
         f32x4 af[2], bx[2], by[2];
@@ -400,6 +424,7 @@ __global__ __launch_bounds__(SW * 64, 1) void stem2_kernel(StemArgs p) {
         constexpr int U = (NT & 1) ? 2 : 1;      // tiles per pass: the register sets alternate
         issue(regs[0], std::true_type{});
         issue(regs[1], std::true_type{});
+        prep(std::true_type{});
         int64_t g = tile0;
         auto tile = [&](auto slot0_tag) __attribute__((always_inline)) {
             constexpr int SLOT0 = decltype(slot0_tag)::value;
@@ -413,10 +438,14 @@ __global__ __launch_bounds__(SW * 64, 1) void stem2_kernel(StemArgs p) {
             });
             __syncthreads();   // all waves have finished step 2 of the previous tile
             scatter();
-            __syncthreads();
             const int64_t c_tile = tile_c(g);
+            int64_t c_rows[IT2 > 0 ? IT2 : 1];
             static_for<0, IT2>([&](auto ii) __attribute__((always_inline)) {
-                item2(wave + SW * decltype(ii)::value, c_tile, scaled_tag);
+                c_rows[decltype(ii)::value] = item_row(wave + SW * decltype(ii)::value, c_tile);
+            });
+            __syncthreads();
+            static_for<0, IT2>([&](auto ii) __attribute__((always_inline)) {
+                item2(wave + SW * decltype(ii)::value, c_rows[decltype(ii)::value], scaled_tag);
             });
             g += tile_step;
         };
@@ -436,6 +465,7 @@ __global__ __launch_bounds__(SW * 64, 1) void stem2_kernel(StemArgs p) {
     } else {
         issue(regs[0], std::false_type{});
         issue(regs[1], std::false_type{});
+        prep(std::false_type{});
         int slot = 0;
         for (int64_t g = tile0; g < n_tiles; g += tile_step) {
 #pragma unroll
@@ -451,7 +481,7 @@ __global__ __launch_bounds__(SW * 64, 1) void stem2_kernel(StemArgs p) {
             scatter();
             __syncthreads();
             const int64_t c_tile = tile_c(g);
-            for (int item = wave; item < n_items; item += SW) item2(item, c_tile, scaled_tag);
+            for (int item = wave; item < n_items; item += SW) item2(item, item_row(item, c_tile), scaled_tag);
         }
     }
     };
