@@ -87,6 +87,12 @@ __device__ __forceinline__ void load_b_planes(float* P, const c64* __restrict__ 
 // "use" a value: the compiler has to wait here for the load that produced it, not at
 // its first use inside the tile loop (where s_waitcnt vmcnt(0) would drain the gathers
 // and stores in flight once per tile)
+#ifdef CTG_STEM_KO_BARRIER
+#define CTG_STEM_SYNC() __builtin_amdgcn_wave_barrier()
+#else
+#define CTG_STEM_SYNC() __syncthreads()
+#endif
+
 template <typename T>
 __device__ __forceinline__ void settle(T& v) {
     asm volatile("" : "+v"(v));
@@ -436,14 +442,14 @@ __global__ __launch_bounds__(SW * 64, 1) void stem2_kernel(StemArgs p) {
                     consume(regs[(SLOT0 + M * NCH + CH) & 1], M, CH, std::true_type{});
                 });
             });
-            __syncthreads();   // all waves have finished step 2 of the previous tile
+            CTG_STEM_SYNC();   // all waves have finished step 2 of the previous tile
             scatter();
             const int64_t c_tile = tile_c(g);
             int64_t c_rows[IT2 > 0 ? IT2 : 1];
             static_for<0, IT2>([&](auto ii) __attribute__((always_inline)) {
                 c_rows[decltype(ii)::value] = item_row(wave + SW * decltype(ii)::value, c_tile);
             });
-            __syncthreads();
+            CTG_STEM_SYNC();
             static_for<0, IT2>([&](auto ii) __attribute__((always_inline)) {
                 item2(wave + SW * decltype(ii)::value, c_rows[decltype(ii)::value], scaled_tag);
             });
@@ -477,9 +483,9 @@ __global__ __launch_bounds__(SW * 64, 1) void stem2_kernel(StemArgs p) {
                     slot ^= 1;
                 }
             }
-            __syncthreads();
+            CTG_STEM_SYNC();
             scatter();
-            __syncthreads();
+            CTG_STEM_SYNC();
             const int64_t c_tile = tile_c(g);
             for (int item = wave; item < n_items; item += SW) item2(item, item_row(item, c_tile), scaled_tag);
         }
