@@ -17,6 +17,8 @@ from __future__ import annotations
 
 import time
 
+import threading
+
 import numpy as np
 
 from . import runtime
@@ -24,6 +26,58 @@ from .plan import DTYPE_CODES, compile_tree
 from .utils import prod
 
 _SUPPORTED = tuple(DTYPE_CODES)
+
+
+class _Progress:
+    """Slice counter of a long sliced run: a ``tqdm`` bar when tqdm is importable (the
+    reference's ``progbar``, contract.py:785-790 / core.py:4010-4013), plain lines on
+    stderr otherwise.  ``progbar`` may also be a callable ``f(done, total)``."""
+
+    def __init__(self, progbar, total, desc="slices"):
+        self.total, self.done, self.bar, self.call = int(total), 0, None, None
+        if callable(progbar):
+            self.call = progbar
+        elif progbar:
+            try:
+                from tqdm import tqdm
+
+                self.bar = tqdm(total=self.total, desc=desc, unit="slice")
+            except ImportError:
+                self.bar = False
+
+    @property
+    def active(self):
+        return self.call is not None or self.bar is not None
+
+    def update(self, n):
+        self.done += n
+        if self.call is not None:
+            self.call(self.done, self.total)
+        elif self.bar:
+            self.bar.update(n)
+        elif self.bar is False:
+            import sys
+
+            print(f"  {self.done} / {self.total} slices", file=sys.stderr, flush=True)
+
+    def close(self):
+        if self.bar:
+            self.bar.close()
+
+
+def inputs_digest(arrays):
+    """sha256 over the shapes, dtypes and bytes of the input tensors (a sliced Sycamore
+    network: 195 KB): what makes a checkpoint belong to THESE inputs, not just this tree."""
+    import hashlib
+
+    h = hashlib.sha256()
+    for x in arrays:
+        if _is_torch(x):
+            x = x.detach().cpu().numpy()
+        x = np.ascontiguousarray(np.asarray(x))
+        h.update(repr((x.shape, str(x.dtype))).encode())
+        h.update(x.tobytes())
+    return h.hexdigest()
 
 
 def _current_device():
@@ -37,6 +91,26 @@ def _current_device():
     except ImportError:
         pass
     return 0
+
+
+def _release_execs(fn):
+    """Close the idle executors of contractor ``fn``: not those another thread is inside
+    of (its lock is held), nor those a suspended ``gen_output_chunks`` generator or a
+    caller-visible state still uses (``pinned``).  True if anything was freed."""
+    execs = getattr(fn, "_execs", None)
+    lock = getattr(fn, "_lock", None)
+    if not execs or lock is None or not lock.acquire(blocking=False):
+        return False
+    freed = False
+    try:
+        for key in [k for k, st in execs.items() if not st.get("pinned")]:
+            st = execs.pop(key)
+            st["exec"].close()
+            st.pop("result", None)
+            freed = True
+    finally:
+        lock.release()
+    return freed
 
 
 def _is_out_of_memory(exc):
@@ -110,6 +184,10 @@ class HipContractor:
         self.fuse_min_elems = fuse_min_elems
         self._plans = {}  # dtype -> (Plan, DevicePlan)
         self._execs = {}  # (dtype, device, torch?) -> state dict
+        # A ctg_exec is confined to one host thread at a time (include/ctg_hip.h); contractors
+        # are cached on the tree and in the expression cache, and the reference's callers may
+        # be multi-threaded (presets.py:77-88): upload -> run -> fetch is one critical section.
+        self._lock = threading.RLock()
 
     # ------------------------------------------------------------------ #
 
@@ -138,7 +216,14 @@ class HipContractor:
             # each dtype) keeps its own arena resident -- tens of GiB for a wide tree.
             # When the device is full, give up the siblings' executors (they are
             # rebuilt on demand) and try once more.
-            if not _is_out_of_memory(exc) or not self._evict_siblings():
+            if not _is_out_of_memory(exc):
+                raise
+            # (also the one-shot expressions the einsum / tensordot front ends keep)
+            from .interface import evict_expression_cache
+
+            freed = self._evict_siblings()
+            freed = evict_expression_cache(keep=self) or freed
+            if not freed:
                 raise
             st = self._new_exec(plan, dplan, dtype, device, use_torch)
         self._execs[key] = st
@@ -151,14 +236,7 @@ class HipContractor:
         freed = False
         cores = getattr(self._origin, "contraction_cores", {})
         for other in list(cores.values()) + [self]:
-            execs = getattr(other, "_execs", None)
-            if not execs:
-                continue
-            for st in execs.values():
-                st["exec"].close()
-                st.pop("result", None)
-                freed = True
-            execs.clear()
+            freed = _release_execs(other) or freed
         if freed:
             try:
                 import torch
@@ -259,43 +337,73 @@ class HipContractor:
             out = out[()]
         return out, exponent
 
+    def run_slices(self, ex, first, count, stride, progbar=False):
+        """``count`` slices ``first, first + stride, ...``; with ``progbar`` in chunks (a
+        multiple of the executor's slice batch, sized for a few updates per second) with a
+        synchronisation in between, so that the counter shows slices that are DONE."""
+        prog = _Progress(progbar, count) if progbar and count > 1 else None
+        if prog is None or not prog.active:
+            ex.run_slices(first, count, stride)
+            return
+        import time
+
+        chunk = max(int(ex.batch()), 1)
+        done = 0
+        try:
+            while done < count:
+                n = min(chunk, count - done)
+                t0 = time.perf_counter()
+                ex.run_slices(first + done * stride, n, stride)
+                ex.sync()
+                dt = time.perf_counter() - t0
+                done += n
+                prog.update(n)
+                if dt < 0.1:   # tiny slices: fewer, larger chunks
+                    chunk *= 2
+        finally:
+            prog.close()
+
     def __call__(self, *arrays, **kwargs):
         backend = kwargs.pop("backend", None)  # noqa: F841  (inferred from arrays)
-        kwargs.pop("progbar", None)
+        progbar = kwargs.pop("progbar", self.progbar)
         check_zero = kwargs.pop("check_zero", self.check_zero)
         strip_exponent = kwargs.pop("strip_exponent", self.strip_exponent)
         kwargs.pop("implementation", None)
         if kwargs:
             raise TypeError(f"Unknown keyword arguments: {kwargs}.")
-        st = self.setup(*arrays)
-        ex = st["exec"]
-        ex.set_strip_exponent(strip_exponent, check_zero)
-        ex.zero_result()
-        ex.run_slices(0, self.tree.multiplicity, 1)
-        return self._finish(st, strip_exponent, check_zero)
+        with self._lock:
+            st = self.setup(*arrays)
+            ex = st["exec"]
+            ex.set_strip_exponent(strip_exponent, check_zero)
+            ex.zero_result()
+            self.run_slices(ex, 0, self.tree.multiplicity, 1, progbar)
+            return self._finish(st, strip_exponent, check_zero)
 
     def contract_slice(self, arrays, i, strip_exponent=False, check_zero=False):
         """Output of slice ``i`` only (sliced output indices removed)."""
-        st = self.setup(*arrays)
-        ex = st["exec"]
-        ex.set_strip_exponent(strip_exponent, check_zero)
-        ex.zero_result()
-        ex.run_slices(int(i), 1, 1)
-        index = _chunk_index(self.tree, self.tree.slice_key(int(i)))
-        return self._finish(st, strip_exponent, check_zero, index=index)
+        with self._lock:
+            st = self.setup(*arrays)
+            ex = st["exec"]
+            ex.set_strip_exponent(strip_exponent, check_zero)
+            ex.zero_result()
+            ex.run_slices(int(i), 1, 1)
+            index = _chunk_index(self.tree, self.tree.slice_key(int(i)))
+            return self._finish(st, strip_exponent, check_zero, index=index)
 
     def profile(self, arrays, slice_id=0):
         """Per-step milliseconds for one slice (see ``Plan.describe_steps``)."""
-        st = self.setup(*arrays)
-        return st["plan"], st["exec"].profile_slice(slice_id)
+        with self._lock:
+            st = self.setup(*arrays)
+            return st["plan"], st["exec"].profile_slice(slice_id)
 
     def close(self):
-        for st in self._execs.values():
-            st["exec"].close()
-        self._execs.clear()
-        for _, dplan in self._plans.values():
-            dplan.close()
-        self._plans.clear()
+        with self._lock:
+            for st in self._execs.values():
+                st["exec"].close()
+            self._execs.clear()
+            for _, dplan in self._plans.values():
+                dplan.close()
+            self._plans.clear()
 
 
 class PerOpContractor:
@@ -501,7 +609,7 @@ def contract_tree(
         if not tree.sliced_inds:
             return core(*arrays)
         slices = (core(*tree.slice_arrays(arrays, i)) for i in range(tree.multiplicity))
-        return gather_slices(tree, slices)
+        return gather_slices(tree, slices, progbar=progbar)
     if implementation not in (None, "auto", "hip"):
         raise ValueError(f"implementation={implementation!r} is not available.")
     fn = _tree_contractor(tree, order)
@@ -509,6 +617,7 @@ def contract_tree(
         *arrays,
         strip_exponent=strip_exponent is not False,
         check_zero=check_zero,
+        progbar=progbar,
     )
 
 
@@ -551,6 +660,18 @@ def gather_slices(tree, slices, backend=None, progbar=False):
     """Host-side gather of explicitly computed slice outputs
     (core.py:3825-3882); ``tree.contract`` never needs it because the device
     accumulates, but it is part of the public surface."""
+    if progbar:
+        prog = _Progress(progbar, tree.nslices)
+
+        def counted(it):
+            try:
+                for x in it:
+                    yield x
+                    prog.update(1)
+            finally:
+                prog.close()
+
+        slices = counted(slices)
     output_pos = {
         ix: i for i, ix in enumerate(tree.output) if ix in tree.sliced_inds
     }
@@ -598,16 +719,25 @@ def gen_output_chunks(tree, arrays, with_key=False, progbar=False, **contract_op
     st = fn.setup(*arrays)
     ex = st["exec"]
     ex.set_strip_exponent(False)
-    for o in range(tree.nslices // stepsize):
-        ex.zero_result()
-        ex.run_slices(o * stepsize, stepsize, 1)
-        loc = tree.slice_key(o * stepsize)
-        index = _chunk_index(tree, loc)
-        chunk = fn._finish(st, False, False, index=index)
-        if with_key:
-            yield chunk, {ix: x for ix, x in loc.items() if ix in tree.output}
-        else:
-            yield chunk
+    prog = _Progress(progbar, tree.nslices)
+    st["pinned"] = st.get("pinned", 0) + 1   # (a suspended generator keeps its executor)
+    try:
+        for o in range(tree.nslices // stepsize):
+            with fn._lock:
+                ex.zero_result()
+                ex.run_slices(o * stepsize, stepsize, 1)
+                loc = tree.slice_key(o * stepsize)
+                index = _chunk_index(tree, loc)
+                chunk = fn._finish(st, False, False, index=index)
+            if prog.active:
+                prog.update(stepsize)
+            if with_key:
+                yield chunk, {ix: x for ix, x in loc.items() if ix in tree.output}
+            else:
+                yield chunk
+    finally:
+        st["pinned"] -= 1
+        prog.close()
 
 
 def benchmark_tree(
@@ -661,9 +791,12 @@ def benchmark_tree(
 # are added in the same order onto the same bits.
 
 
-def tree_signature(tree, dtype, rank=0, world=1, strip_exponent=False, check_zero=False, order=None):
+def tree_signature(tree, dtype, rank=0, world=1, strip_exponent=False, check_zero=False, order=None,
+                   arrays=None):
     """Digest of everything a partial sum depends on: network, schedule,
-    slicing, element type, which share of the slices, stripping options."""
+    slicing, element type, which share of the slices, stripping options -- and,
+    with ``arrays``, the input tensors themselves (``inputs_digest``): the same
+    Sycamore tree contracted for another bitstring must not resume this sum."""
     import hashlib
     import json
 
@@ -676,6 +809,7 @@ def tree_signature(tree, dtype, rank=0, world=1, strip_exponent=False, check_zer
         "dtype": str(dtype),
         "share": [int(rank), int(world)],
         "strip": [bool(strip_exponent), bool(check_zero)],
+        "arrays": inputs_digest(arrays) if arrays is not None else None,
     }
     return hashlib.sha256(json.dumps(doc, sort_keys=True).encode()).hexdigest()
 
@@ -715,15 +849,15 @@ def load_checkpoint(path, signature):
     with np.load(path, allow_pickle=False) as z:
         if str(z["signature"]) != signature:
             raise ValueError(
-                f"checkpoint {path} was written for a different tree / dtype / rank layout "
-                "(signature mismatch); remove it to start over."
+                f"checkpoint {path} was written for a different tree / dtype / rank layout / "
+                "set of input tensors (signature mismatch); remove it to start over."
             )
         return int(z["done"]), z["result"].copy(), float(z["exponent"]), bool(z["zero"])
 
 
 def contract_resumable(
     tree, arrays, checkpoint, every=64, order=None, strip_exponent=False, check_zero=False,
-    rank=0, world=1, stop_after=None, keep=False,
+    rank=0, world=1, stop_after=None, keep=False, progbar=False,
 ):
     """``tree.contract(arrays)`` that survives being killed.
 
@@ -734,16 +868,31 @@ def contract_resumable(
     continues with the first slice not yet summed.  ``stop_after=n`` ends this
     call after at most ``n`` more slices (returns None unless that completed
     the run) -- what a job-time limit or a test uses.  The file is removed when
-    the run completes unless ``keep``.  Returns what ``contract`` returns (this
-    rank's share when ``world > 1``: feed it to the collective)."""
+    the run completes unless ``keep`` (that removal is housekeeping, not a
+    guard: what ties a file to a run is its signature, which covers the tree,
+    the options, the rank's share AND the bytes of the input tensors).  Returns
+    what ``contract`` returns (this rank's share when ``world > 1``: feed it to
+    the collective)."""
     import os
 
     fn = _tree_contractor(tree, order)
+    with fn._lock:
+        return _contract_resumable_locked(
+            fn, tree, arrays, checkpoint, every, order, strip_exponent, check_zero, rank, world,
+            stop_after, keep, progbar,
+        )
+
+
+def _contract_resumable_locked(fn, tree, arrays, checkpoint, every, order, strip_exponent, check_zero,
+                               rank, world, stop_after, keep, progbar):
+    import os
+
     st = fn.setup(*arrays)
     ex = st["exec"]
     ex.set_strip_exponent(strip_exponent, check_zero)
     total = len(range(rank, tree.multiplicity, world))
-    sig = tree_signature(tree, st["plan"].dtype, rank, world, strip_exponent, check_zero, order)
+    sig = tree_signature(tree, st["plan"].dtype, rank, world, strip_exponent, check_zero, order,
+                         arrays=arrays)
     saved = load_checkpoint(checkpoint, sig)
     if saved is None:
         done = 0
@@ -754,13 +903,21 @@ def contract_resumable(
             raise ValueError(f"checkpoint {checkpoint} claims {done} of {total} slices")
         ex.set_state(result, exponent, zero)
     budget = total - done if stop_after is None else min(int(stop_after), total - done)
-    while budget > 0:
-        n = min(int(every), budget)
-        ex.run_slices(rank + done * world, n, world)
-        done += n
-        budget -= n
-        result, exponent, zero = ex.get_state()
-        save_checkpoint(checkpoint, sig, done, result, exponent, zero)
+    prog = _Progress(progbar, total)
+    if prog.active and done:
+        prog.update(done)
+    try:
+        while budget > 0:
+            n = min(int(every), budget)
+            ex.run_slices(rank + done * world, n, world)
+            done += n
+            budget -= n
+            result, exponent, zero = ex.get_state()
+            save_checkpoint(checkpoint, sig, done, result, exponent, zero)
+            if prog.active:
+                prog.update(n)
+    finally:
+        prog.close()
     if done < total:
         return None
     out = fn._finish(st, strip_exponent, check_zero)

@@ -1850,10 +1850,23 @@ bool rowwise_ok(const StepArgs& p) {
 }
 
 template <int NN>
-static void launch_rowwise_t(const StepArgs& p, bool ts, dim3 grid, hipStream_t stream) {
+static hipError_t launch_rowwise_t(const StepArgs& p, bool ts, dim3 grid, hipStream_t stream) {
     const size_t lds = ts ? (size_t)256 * (size_t)(p.N | 1) * sizeof(float2) : 0;
-    if (ts) hipLaunchKernelGGL((pair_rowwise_kernel<NN, true>), grid, dim3(256), lds, stream, p);
-    else hipLaunchKernelGGL((pair_rowwise_kernel<NN, false>), grid, dim3(256), lds, stream, p);
+    if (ts) {
+        // 25-32 columns stage 50-66 KB of results next to 18.5 KB of static LDS: beyond
+        // the default limit of a launch, the kernel has to opt in (the CU has 160 KiB)
+        static bool opted = false;
+        if (lds > 40 * 1024 && !opted) {
+            const hipError_t e = hipFuncSetAttribute((const void*)pair_rowwise_kernel<NN, true>,
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+            if (e != hipSuccess) return e;
+            opted = true;
+        }
+        hipLaunchKernelGGL((pair_rowwise_kernel<NN, true>), grid, dim3(256), lds, stream, p);
+    } else {
+        hipLaunchKernelGGL((pair_rowwise_kernel<NN, false>), grid, dim3(256), lds, stream, p);
+    }
+    return hipGetLastError();
 }
 
 // flags (MfmaHints::vecA of a row-wise step): bit 0 = the output columns are the
@@ -1863,13 +1876,12 @@ static hipError_t launch_rowwise(const StepArgs& p, int flags, hipStream_t strea
     if (blocks > 0x7fffffffll || p.nz > 65535 || !rowwise_ok(p)) return hipErrorInvalidValue;
     const dim3 grid((unsigned)blocks, (unsigned)p.nz, (unsigned)p.Bt);
     const bool ts = (flags & 1) && p.N >= 2;
-    if (p.N <= 4) launch_rowwise_t<4>(p, ts, grid, stream);
-    else if (p.N <= 8) launch_rowwise_t<8>(p, ts, grid, stream);
-    else if (p.N <= 12) launch_rowwise_t<12>(p, ts, grid, stream);
-    else if (p.N <= 16) launch_rowwise_t<16>(p, ts, grid, stream);
-    else if (p.N <= 24) launch_rowwise_t<24>(p, ts, grid, stream);
-    else launch_rowwise_t<32>(p, ts, grid, stream);
-    return hipGetLastError();
+    if (p.N <= 4) return launch_rowwise_t<4>(p, ts, grid, stream);
+    if (p.N <= 8) return launch_rowwise_t<8>(p, ts, grid, stream);
+    if (p.N <= 12) return launch_rowwise_t<12>(p, ts, grid, stream);
+    if (p.N <= 16) return launch_rowwise_t<16>(p, ts, grid, stream);
+    if (p.N <= 24) return launch_rowwise_t<24>(p, ts, grid, stream);
+    return launch_rowwise_t<32>(p, ts, grid, stream);
 }
 
 template <typename Cfg>

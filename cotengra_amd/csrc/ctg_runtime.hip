@@ -662,7 +662,8 @@ int build_hints_into(ctg_exec* e, std::vector<MfmaHints>& hints, int64_t zmult,
             // streaming kernel does not take.  CTG_ROWWISE=0 turns the kernel off, 2 sends
             // every step of its shape there (experiments).
             static const int rw = getenv("CTG_ROWWISE") ? atoi(getenv("CTG_ROWWISE")) : 1;
-            const bool shape = r[W_K] <= 32 && r[W_N] <= 32 && r[W_R] >= 8192;
+            // (the shapes rowwise_ok() takes: the batch index rides in gridDim.z)
+            const bool shape = r[W_K] <= 32 && r[W_N] <= 32 && r[W_R] >= 8192 && r[W_BT] <= 65535;
             const bool pick = (h.stream == 1 && ((r[W_K] <= 8 && r[W_N] <= 8) ||
                                                  (!h.additive32 && r[W_K] < MFMA_BK) || rw >= 2)) ||
                               (h.stream == 0 && r[W_BT] > 1);
@@ -715,10 +716,40 @@ int build_hints(ctg_exec* e) {
     return build_hints_into(e, e->hints_b, e->batch, &e->hints, &e->d_ord_b, &e->d_lane_b);
 }
 
+// does step s write partial results to the scratch buffer?
+bool step_needs_scratch(const ctg_exec* e, int64_t s) {
+    const ctg_plan* p = e->plan;
+    const int64_t* r = &p->steps[s * STEP_WORDS];
+    if (r[W_KIND] != KIND_PAIR) return false;
+    if (r[W_KERNEL] != KERNEL_MFMA) return !valu_thread_per_output(e->args[s]);
+    if (p->dtype != CTG_C64) return false;   // (the real / double kernels have no k-split)
+    auto needs = [](const MfmaHints& h) {
+        if (h.stream == 2) return true;                   // k-streaming: per-wave partial tiles
+        if (h.stream != 0) return false;                  // streaming / skinny / row-wise: none
+        return h.splitk != 1;                             // tiled: slabs of the k-splits
+    };
+    return needs(e->hints[s]) || (!e->hints_b.empty() && needs(e->hints_b[s]));
+}
+
+int ensure_scratch(ctg_exec* e) {
+    if (e->d_scratch) return CTG_OK;
+    if (hipMalloc(&e->d_scratch, e->scratch_total) != hipSuccess) {
+        (void)hipGetLastError();
+        e->d_scratch = nullptr;
+        return fail(CTG_E_NOMEM, "out of device memory allocating %lld bytes of scratch",
+                    (long long)e->scratch_total);
+    }
+    return CTG_OK;
+}
+
 int launch_step(ctg_exec* e, int64_t s, hipStream_t stream) {
     const ctg_plan* p = e->plan;
     const int64_t* r = &p->steps[s * STEP_WORDS];
     hipError_t err = hipSuccess;
+    if (!e->d_scratch && step_needs_scratch(e, s)) {
+        const int rc = ensure_scratch(e);
+        if (rc != CTG_OK) return rc;
+    }
     switch (r[W_KIND]) {
         case KIND_SINGLE: err = launch_single(p->dtype, e->args[s], stream); break;
         case KIND_ACCUM:
@@ -1081,8 +1112,10 @@ int ctg_exec_create(const ctg_plan* p, int device, void* stream, void* ext_resul
     HIP_TRY_E(hipMalloc((void**)&e->d_tables, p->tables.size() * 8));
     // (split heuristics are always computed with kScratchBytes; a batching executor gets
     // more room so that more slices of a split-K / k-reduction step fit one launch)
+    // (allocated by the first launch that needs it -- split-K slabs, k-reduction partials,
+    // k-streaming tiles: an executor of a small one-shot expression never does, and 64 of
+    // those in the expression cache would pin 4 GiB of scratch for nothing)
     e->scratch_total = kScratchBytes * std::min<int64_t>(std::max(e->batch, 1), 8);
-    HIP_TRY_E(hipMalloc(&e->d_scratch, e->scratch_total));
     const int64_t n_leaves = p->n_inputs + 1;
     const int64_t misc_words = 3 + n_leaves * e->batch + 2 * p->n_sliced + n_leaves * p->n_sliced;
     HIP_TRY_E(hipMalloc((void**)&e->d_misc, misc_words * 8));

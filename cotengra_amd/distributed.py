@@ -29,10 +29,14 @@ from __future__ import annotations
 
 import os
 import socket
+import threading
 
 import numpy as np
 
 _COMMS = {}  # id(group) / id(mpi comm) -> runtime.Comm
+# creating a communicator is a collective (every rank must do it exactly once, in the same
+# order): two host threads resolving the same group must not both create one
+_COMMS_LOCK = threading.RLock()
 
 
 def slices_of_rank(nslices, rank, world):
@@ -94,10 +98,11 @@ def _resolve_comm(comm):
         import torch
 
         rank, world = comm.Get_rank(), comm.Get_size()
-        c = _COMMS.get(("mpi", id(comm)))
-        if c is None:
-            uid = comm.bcast(runtime.Comm.unique_id() if rank == 0 else None, root=0)
-            c = _COMMS[("mpi", id(comm))] = runtime.Comm(uid, rank, world, torch.cuda.current_device())
+        with _COMMS_LOCK:
+            c = _COMMS.get(("mpi", id(comm)))
+            if c is None:
+                uid = comm.bcast(runtime.Comm.unique_id() if rank == 0 else None, root=0)
+                c = _COMMS[("mpi", id(comm))] = runtime.Comm(uid, rank, world, torch.cuda.current_device())
         return rank, world, c, None
     import torch.distributed as dist
 
@@ -108,24 +113,26 @@ def _resolve_comm(comm):
     if dist.get_backend(group) != "nccl":
         return rank, world, None, group
     key = ("torch", id(group) if group is not None else 0)
-    c = _COMMS.get(key)
-    if c is None:
-        assert_distinct_devices(group)
-        c = _COMMS[key] = runtime.Comm.from_torch_group(group)
+    with _COMMS_LOCK:
+        c = _COMMS.get(key)
+        if c is None:
+            assert_distinct_devices(group)
+            c = _COMMS[key] = runtime.Comm.from_torch_group(group)
     return rank, world, c, group
 
 
 def close_comms():
     """Destroy the cached RCCL communicators (before
     ``dist.destroy_process_group()``)."""
-    for c in _COMMS.values():
-        c.close()
-    _COMMS.clear()
+    with _COMMS_LOCK:
+        for c in _COMMS.values():
+            c.close()
+        _COMMS.clear()
 
 
 def contract_distributed(
     tree, arrays, group=None, root=None, executor_factory=None, order=None, comm=None,
-    strip_exponent=False, check_zero=False,
+    strip_exponent=False, check_zero=False, progbar=False,
 ):
     """Contract all slices of ``tree`` across the ranks of ``comm`` / ``group``.
 
@@ -158,20 +165,21 @@ def contract_distributed(
     from .contractor import _is_torch, _tree_contractor
 
     fn = _tree_contractor(tree, order)
-    st = fn.setup(*[_to_local_device(x) for x in arrays])
-    ex = st["exec"]
-    ex.set_strip_exponent(strip_exponent, check_zero)
-    ex.zero_result()
-    ex.run_slices(rank, len(mine), world)
-    if ccomm is not None:
-        # RCCL on the executor's stream, in place on the resident result
-        ex.reduce(ccomm, root)
-        if root is not None and rank != root:
-            return None
-        # (a copy: the executor's buffer is rewritten by the next call)
-        return fn._finish(st, strip_exponent, check_zero)
-    # host exchange (gloo): partial (+ exponent) downloaded, summed on the CPU
-    part, exponent, _zero = ex.get_state()
+    with fn._lock:   # (one host thread per executor: upload -> run -> exchange -> fetch)
+        st = fn.setup(*[_to_local_device(x) for x in arrays])
+        ex = st["exec"]
+        ex.set_strip_exponent(strip_exponent, check_zero)
+        ex.zero_result()
+        fn.run_slices(ex, rank, len(mine), world, progbar if rank == 0 else False)
+        if ccomm is not None:
+            # RCCL on the executor's stream, in place on the resident result
+            ex.reduce(ccomm, root)
+            if root is not None and rank != root:
+                return None
+            # (a copy: the executor's buffer is rewritten by the next call)
+            return fn._finish(st, strip_exponent, check_zero)
+        # host exchange (gloo): partial (+ exponent) downloaded, summed on the CPU
+        part, exponent, _zero = ex.get_state()
     as_torch = any(_is_torch(x) and x.is_cuda for x in arrays)
     out = _reduce_host(part, exponent if strip_exponent else None, tgroup, rank, root)
     if out is None:

@@ -17,6 +17,8 @@ subtree reconfiguration, ``search`` -- their results are trees to pass here).
 from __future__ import annotations
 
 import collections
+import os
+import threading
 
 import numpy as np
 
@@ -170,10 +172,23 @@ class ContractExpression:
             tree, strip_exponent=strip_exponent, check_zero=check_zero,
             handle_slicing=True,
         )
+        self._cached = False   # set by _cached_expression
 
     def __call__(self, *arrays, backend=None, **kwargs):
-        return self.fn(*arrays, **kwargs)
+        out = self.fn(*arrays, **kwargs)
+        if self._cached:
+            with _EXPR_LOCK:   # (its plans exist now: the cache's byte bound sees them)
+                _trim_expression_cache(keep=self)
+        return out
 
+    def device_bytes(self):
+        """Device memory this expression's executors hold (``ctg_plan_workspace_bytes`` of
+        every plan that has an executor)."""
+        n = 0
+        for (dtype, _, _), st in list(self.fn._execs.items()):
+            ws = self.fn._plans[dtype][1].workspace_bytes()
+            n += sum(ws.values()) if isinstance(ws, dict) else sum(ws)
+        return n
 
     def close(self):
         self.fn.close()
@@ -185,8 +200,16 @@ class ContractExpression:
 # tensordot)`` use -- finds its plan, tables and device buffers in place instead
 # of rebuilding them (the reference memoises its parsers the same way,
 # contract.py:34, 61, 121, 167: ``lru_cache(2**12)``).
+# The cache is bounded twice: by count and by the device memory its executors hold
+# (inputs, arena, result, tables of every plan an expression has built -- one-shot calls
+# over many shapes, the per-op plug-in's pattern, must not pin the HBM the next big tree
+# needs), and the executor's out-of-memory retry drops it altogether
+# (``evict_expression_cache``).  It is shared by threads: a lock guards the dictionary,
+# every expression's contractor serialises its own upload -> run -> fetch.
 _EXPR_CACHE = collections.OrderedDict()
 _EXPR_CACHE_SIZE = 64
+_EXPR_CACHE_BYTES = int(os.environ.get("CTG_EXPR_CACHE_BYTES", 4 << 30))
+_EXPR_LOCK = threading.RLock()
 
 
 def _cached_expression(inputs, output, size_dict, optimize, strip_exponent, check_zero):
@@ -197,24 +220,51 @@ def _cached_expression(inputs, output, size_dict, optimize, strip_exponent, chec
         hash(key)
     except TypeError:
         key = None  # a tree object or something unhashable: the caller keeps it
-    if key is not None and key in _EXPR_CACHE:
-        _EXPR_CACHE.move_to_end(key)
-        return _EXPR_CACHE[key]
-    tree = array_contract_tree(inputs, output, size_dict, optimize)
-    expr = ContractExpression(tree, strip_exponent, check_zero)
-    if key is not None:
-        _EXPR_CACHE[key] = expr
-        while len(_EXPR_CACHE) > _EXPR_CACHE_SIZE:
-            _, old = _EXPR_CACHE.popitem(last=False)
-            old.close()  # frees the evicted executor's device memory now
-    return expr
+    with _EXPR_LOCK:
+        if key is not None and key in _EXPR_CACHE:
+            _EXPR_CACHE.move_to_end(key)
+            return _EXPR_CACHE[key]
+        tree = array_contract_tree(inputs, output, size_dict, optimize)
+        expr = ContractExpression(tree, strip_exponent, check_zero)
+        if key is not None:
+            expr._cached = True
+            _EXPR_CACHE[key] = expr
+            _trim_expression_cache(keep=expr)
+        return expr
+
+
+def _trim_expression_cache(keep=None):
+    """Least recently used out until the cache is within its count and its bytes."""
+    def total():
+        return sum(e.device_bytes() for e in _EXPR_CACHE.values())
+
+    while len(_EXPR_CACHE) > 1 and (len(_EXPR_CACHE) > _EXPR_CACHE_SIZE or total() > _EXPR_CACHE_BYTES):
+        k, old = next(iter(_EXPR_CACHE.items()))
+        if old is keep:
+            break
+        del _EXPR_CACHE[k]
+        old.close()  # frees the evicted executor's device memory now
 
 
 def clear_expression_cache():
     """Close and drop every cached one-shot expression."""
-    while _EXPR_CACHE:
-        _, old = _EXPR_CACHE.popitem()
-        old.close()
+    with _EXPR_LOCK:
+        while _EXPR_CACHE:
+            _, old = _EXPR_CACHE.popitem()
+            old.close()
+
+
+def evict_expression_cache(keep=None):
+    """Out-of-memory path of an executor (contractor._get_exec): drop every cached
+    expression except the one whose contractor is ``keep`` (it is being built right
+    now).  True if device memory was released."""
+    freed = False
+    with _EXPR_LOCK:
+        for k in [k for k, e in _EXPR_CACHE.items() if e.fn is not keep]:
+            old = _EXPR_CACHE.pop(k)
+            freed = bool(old.fn._execs) or freed
+            old.close()
+    return freed
 
 
 def array_contract_expression(

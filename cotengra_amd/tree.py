@@ -1059,8 +1059,8 @@ class ContractionTree:
         ``order``, ``strip_exponent``, ``check_zero``."""
         from .distributed import contract_distributed
 
-        opts = {k: kwargs.pop(k) for k in ("order", "strip_exponent", "check_zero") if k in kwargs}
-        for k in ("prefer_einsum", "backend", "implementation", "autojit", "progbar"):
+        opts = {k: kwargs.pop(k) for k in ("order", "strip_exponent", "check_zero", "progbar") if k in kwargs}
+        for k in ("prefer_einsum", "backend", "implementation", "autojit"):
             kwargs.pop(k, None)
         if kwargs:
             raise TypeError(f"Unknown keyword arguments: {kwargs}.")

@@ -53,6 +53,10 @@ CASES = [
     ("abck,kn->abcn", dict(a=32, b=32, c=16, k=8, n=8)),              # powers of two, K, N <= 8
     ("abkc,kn->nabc", dict(a=27, b=32, c=27, k=4, n=4)),              # columns slowest in the output
     ("abkc,knm->abcnm", dict(a=27, b=32, c=12, k=9, n=5, m=6)),       # K = 9, N = 30 (32-column variant)
+    # 32 columns that are the fastest index of the result: the LDS-staged store path at its
+    # largest (66 KB of dynamic LDS: the kernel opts in); odd row count so that it IS this kernel
+    ("abkc,knm->abcnm", dict(a=27, b=32, c=12, k=6, n=4, m=8)),       # K = 6, N = 32
+    ("xabk,xkn->xabn", dict(x=3, a=96, b=96, k=8, n=32)),             # the same with a batch index
 ]
 
 

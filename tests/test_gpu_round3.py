@@ -69,3 +69,93 @@ def test_fused_stem_pairs(case, sliced):
         assert G.relerr(parts, ref) <= gate
     fused.close()
     plain.close()
+
+
+# ---------------------------------------------------------------------- #
+# host robustness: threads, checkpoints, progress, cache bounds
+# ---------------------------------------------------------------------- #
+
+
+def test_threads_share_cached_expressions():
+    """Two threads hammering ``ca.einsum`` with the same (cached) expression and different
+    operands: every result is its own thread's (the contractor serialises upload -> run ->
+    fetch; SURVEY 8b: handles thread-confined *or locked*)."""
+    import threading
+
+    from cotengra_amd import interface
+
+    interface.clear_expression_cache()
+    rng = np.random.default_rng(0)
+    eq = "abc,cd,bde->ae"
+    shapes = [(6, 5, 4), (4, 7), (5, 7, 3)]
+    jobs = []
+    for t in range(4):
+        xs = [(rng.normal(size=s) + 1j * rng.normal(size=s)).astype("complex128") for s in shapes]
+        jobs.append((xs, np.einsum(eq, *xs)))
+    errors = []
+
+    def work(t):
+        xs, ref = jobs[t]
+        try:
+            for _ in range(40):
+                got = np.asarray(ca.einsum(eq, *xs))
+                if not np.allclose(got, ref, rtol=1e-10, atol=1e-12):
+                    errors.append((t, float(np.abs(got - ref).max())))
+                    return
+        except Exception as e:  # noqa: BLE001
+            errors.append((t, repr(e)))
+
+    threads = [threading.Thread(target=work, args=(t,)) for t in range(4)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    assert not errors, errors
+    assert len(interface._EXPR_CACHE) == 1   # one expression served all of them
+
+
+def test_expression_cache_is_bounded_by_device_bytes(monkeypatch):
+    from cotengra_amd import interface
+
+    interface.clear_expression_cache()
+    monkeypatch.setattr(interface, "_EXPR_CACHE_BYTES", 3 << 20)
+    rng = np.random.default_rng(1)
+    for n in range(4, 12):   # eight different shapes, each executor ~ 1 MiB of tables + buffers
+        a, b = rng.normal(size=(n, 64)), rng.normal(size=(64, n))
+        assert np.allclose(np.asarray(ca.einsum("ab,bc->ac", a, b)), a @ b)
+        assert sum(e.device_bytes() for e in interface._EXPR_CACHE.values()) <= (3 << 20) or len(interface._EXPR_CACHE) == 1
+    assert 1 <= len(interface._EXPR_CACHE) < 8
+    # the executor's out-of-memory path drops everything but the expression in the making
+    keep = next(reversed(interface._EXPR_CACHE.values()))
+    interface.evict_expression_cache(keep=keep.fn)
+    assert list(interface._EXPR_CACHE.values()) == [keep]
+    interface.clear_expression_cache()
+
+
+def test_checkpoint_refuses_other_inputs(tmp_path):
+    case = next(c for c in G.cases("tree") if c["name"] == "lattice8x8_sliced")
+    tree = G.tree_of(case)
+    arrays = G.arrays_of(case, "complex128", tree)
+    ck = str(tmp_path / "run.npz")
+    assert tree.contract_resumable(arrays, ck, every=1, stop_after=2) is None
+    other = [a.copy() for a in arrays]
+    other[3] = other[3] * 2.0   # "another bitstring": same tree, different tensors
+    with pytest.raises(ValueError, match="signature"):
+        tree.contract_resumable(other, ck, every=1)
+    seen = []
+    out = tree.contract_resumable(arrays, ck, every=1, progbar=lambda d, n: seen.append((d, n)))
+    assert G.relerr(out, G.expected("lattice8x8_sliced/complex128")) < 1e-10
+    assert seen[0][0] == 2 and seen[-1] == (tree.nslices, tree.nslices)   # resumed at 2, counted to the end
+
+
+def test_progress_counts_finished_slices():
+    case = next(c for c in G.cases("tree") if c["name"] == "lattice8x8_sliced")
+    tree = G.tree_of(case)
+    arrays = G.arrays_of(case, "complex128", tree)
+    seen = []
+    out = tree.contract(arrays, progbar=lambda d, n: seen.append((d, n)))
+    assert G.relerr(out, G.expected("lattice8x8_sliced/complex128")) < 1e-10
+    assert seen and seen[-1] == (tree.nslices, tree.nslices)
+    assert all(b[0] > a[0] for a, b in zip(seen, seen[1:]))
+    quiet = tree.contract(arrays)   # same bits with and without the counter
+    assert np.array_equal(np.asarray(out), np.asarray(quiet))

@@ -145,3 +145,51 @@ def test_fused_descriptor_is_validated():
             runtime.DevicePlan(plan)
         st.stem["tabs"][name] = keep
     runtime.DevicePlan(plan).close()
+
+
+# ---------------------------------------------------------------------- #
+# checkpoint signature covers the inputs; progress counter; cache bounds
+# ---------------------------------------------------------------------- #
+
+from cotengra_amd.contractor import _Progress, inputs_digest, tree_signature  # noqa: E402
+
+
+def test_checkpoint_signature_covers_the_inputs():
+    inputs, output, _, size_dict = ca.lattice_equation([3, 3], d_min=2, d_max=2, seed=0)
+    t = ca.ContractionTree.from_path(inputs, output, size_dict, path=ca.greedy_path(inputs, output, size_dict))
+    a = ca.make_arrays_from_inputs(inputs, size_dict, seed=1)
+    b = [x.copy() for x in a]
+    assert inputs_digest(a) == inputs_digest(b)
+    assert tree_signature(t, "complex128", arrays=a) == tree_signature(t, "complex128", arrays=b)
+    b[4] = b[4] * (1 + 1e-15)   # one bit somewhere
+    assert tree_signature(t, "complex128", arrays=a) != tree_signature(t, "complex128", arrays=b)
+    assert tree_signature(t, "complex128", arrays=a) != tree_signature(t, "complex128")
+    # dtype and shape are part of it, not only the bytes
+    assert inputs_digest([np.zeros(4, "float32")]) != inputs_digest([np.zeros(2, "float64")])
+    assert inputs_digest([np.zeros((2, 2))]) != inputs_digest([np.zeros(4)])
+
+
+def test_progress_counter():
+    seen = []
+    p = _Progress(lambda done, total: seen.append((done, total)), 10)
+    assert p.active
+    p.update(4)
+    p.update(6)
+    p.close()
+    assert seen == [(4, 10), (10, 10)]
+    assert not _Progress(False, 10).active
+    bar = _Progress(True, 3)   # tqdm is installed here: a real bar
+    assert bar.active
+    bar.update(3)
+    bar.close()
+    # gather_slices counts the slices it folds
+    inputs, output, _, size_dict = ca.lattice_equation([3, 3], d_min=2, d_max=2, seed=0)
+    t = ca.ContractionTree.from_path(inputs, output, size_dict, path=ca.greedy_path(inputs, output, size_dict))
+    t.remove_ind_(inputs[4][0])
+    arrays = ca.make_arrays_from_inputs(inputs, size_dict, seed=1)
+    seen.clear()
+    total = t.gather_slices(
+        (orc.contract_slice(t, arrays, i) for i in range(t.nslices)),
+        progbar=lambda d, n: seen.append((d, n)),
+    )
+    assert np.allclose(total, orc.contract(t, arrays)) and seen == [(1, 2), (2, 2)]
