@@ -89,3 +89,20 @@ def test_no_cpu_fallback_when_library_missing(monkeypatch):
     monkeypatch.setattr(runtime, "_LIB_PATH", "/nonexistent/libctg_hip.so")
     with pytest.raises(ImportError):
         runtime.load()
+
+
+def test_plain_c_driver_fixture_is_current():
+    """tests/golden/cabi_plan.bin (the plan + inputs + expected result the plain-C driver
+    tests/cabi_reduce.c runs) is what its generator writes for today's plan format."""
+    import importlib.util
+    import os
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location(
+        "make_cabi_plan", os.path.join(root, "tests", "golden", "gen", "make_cabi_plan.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    with open(os.path.join(root, "tests", "golden", "cabi_plan.bin"), "rb") as f:
+        assert f.read() == mod.build()
+    # the driver is C, built by build(): it must exist next to its source
+    assert os.path.exists(os.path.join(root, "tests", "cabi_reduce.c"))

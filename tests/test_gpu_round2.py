@@ -117,6 +117,16 @@ def _rank_main(rank, world, port, q):
 
 
 def test_two_ranks_with_the_hip_executor():
+    """Two processes, each with its own HIP executor on GPU 0, exchanging over gloo.  Not
+    over RCCL, because RCCL refuses two ranks on one device -- measured on the lease
+    (tools/exp_rccl_same_gpu.py, gpurun_out/r2a/rccl_same_gpu.log), both ranks:
+
+        CommError: ncclCommInitRank(rank 1 of 2, device 0) failed: invalid usage
+                   (run with NCCL_DEBUG=WARN for details)
+
+    so on a one-GPU box the RCCL path of the C ABI is exercised with world = 1
+    (test_cabi_collective_single_rank, tests/cabi_reduce.c) and the two-rank logic --
+    round-robin shares, device-side accumulation, exponent merge -- here."""
     import torch.multiprocessing as mp
 
     ctx = mp.get_context("spawn")

@@ -159,3 +159,22 @@ def test_progress_counts_finished_slices():
     assert all(b[0] > a[0] for a, b in zip(seen, seen[1:]))
     quiet = tree.contract(arrays)   # same bits with and without the counter
     assert np.array_equal(np.asarray(out), np.asarray(quiet))
+
+
+def test_plain_c_driver_of_the_collective(tmp_path):
+    """tests/cabi_reduce.c: plan -> exec -> upload -> unique id -> comm -> run_slices(first =
+    rank, stride = world) -> reduce -> download, from plain C with no Python in the process;
+    alone (world = 1: every collective still runs) and with the id handed through a file."""
+    import subprocess
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "tests", "cabi_reduce")
+    if not os.path.exists(exe):
+        import __graft_entry__ as g
+
+        g.build()
+    plan = os.path.join(root, "tests", "golden", "cabi_plan.bin")
+    for extra in ([], ["0", "1", str(tmp_path / "id"), "0"]):
+        r = subprocess.run([exe, plan] + extra, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, (r.stdout, r.stderr)
+        assert "rel err" in r.stdout and "4 of 4 slices" in r.stdout

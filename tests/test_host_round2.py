@@ -246,12 +246,13 @@ def test_full_device_evicts_sibling_executors(monkeypatch):
 
 
 def test_committed_bench_line_follows_the_contract():
-    """The bench line the round published (profiles/r2_bench_line.json, written by
+    """The bench line the round published (profiles/r<N>_bench_line.json, written by
     bench.py on the GPU box) carries every field the driver and the judge read."""
     import json
 
-    path = os.path.join(ROOT, "profiles", "r2_bench_line.json")
-    if not os.path.exists(path):
+    path = next((q for q in (os.path.join(ROOT, "profiles", f"r{n}_bench_line.json") for n in (3, 2))
+                 if os.path.exists(q)), None)
+    if path is None:
         pytest.skip("no published bench line")
     d = json.load(open(path))
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
@@ -273,7 +274,8 @@ def test_committed_bench_line_follows_the_contract():
     # the value is slices x algorithmic flops / time
     assert abs(d["value"] - d["config"]["flops_per_slice"] * d["steps"] / (d["ms_per_step"] * d["steps"] * 1e-3)) < 1e-6 * d["value"]
     assert d["precision"]["rel_err"] <= d["precision"]["gate"]
-    t = d["time_to_solution_tree"]
+    # (round 3 on: the headline IS the time-to-solution tree, the former headline rides along)
+    t = d["peak_rate_tree"] if "peak_rate_tree" in d else d["time_to_solution_tree"]
     assert 0 < t["mixed_roofline_frac"] <= 1 and 0 < t["frac_of_mfma_peak"] <= 1
     for name in ("C2", "C3", "C5"):
         cfg = d["configs"][name]
