@@ -347,7 +347,7 @@ class HipContractor:
             return
         import time
 
-        chunk = max(int(ex.batch()), 1)
+        chunk = max(int(ex.batch), 1)
         done = 0
         try:
             while done < count:

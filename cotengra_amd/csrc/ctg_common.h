@@ -454,6 +454,7 @@ hipError_t launch_pair_mfma_real(int dtype, const StepArgs& p, int flags, hipStr
 bool stem2_supported(const StemArgs& p);
 size_t stem2_lds_bytes(const StemArgs& p);
 hipError_t launch_stem2(const StemArgs& p, hipStream_t stream);
+void stem2_kernel_name(const StemArgs& p, char* buf, size_t n);
 hipError_t launch_single(int dtype, const StepArgs& p, hipStream_t stream);
 hipError_t launch_accum(int dtype, const StepArgs& p, const StripState* st, hipStream_t stream);
 

@@ -1435,9 +1435,7 @@ int ctg_exec_step_kernel(ctg_exec* e, int64_t step, char* buf, int64_t buflen) {
     } else if (r[W_KIND] == KIND_ACCUM) {
         snprintf(name, sizeof(name), "accum_kernel");
     } else if (r[W_KIND] == KIND_STEM2) {
-        const int64_t* h = &p->tables[r[W_STEM]];
-        snprintf(name, sizeof(name), "stem2_kernel<k%d n%d | k%d n%d>", (int)h[SW_K1], (int)h[SW_N1],
-                 (int)h[SW_K2], (int)h[SW_N2]);
+        stem2_kernel_name(e->stem_args[step], name, sizeof(name));
     } else if (r[W_KERNEL] == KERNEL_MFMA && p->dtype == CTG_C128) {
         snprintf(name, sizeof(name), "pair_mfma_c128_kernel");
     } else if (r[W_KERNEL] == KERNEL_MFMA && p->dtype != CTG_C64) {

@@ -36,6 +36,8 @@
 // (Re a, Im a), B' rows (Re b | Im b) and (-Im b | Re b), a third plane of 16 x K.
 #include "ctg_common.h"
 
+#include <cstdio>
+#include <cstdlib>
 #include <type_traits>
 
 namespace ctg {
@@ -561,6 +563,16 @@ int stem2_variant(const StemArgs& p) {
 #undef CTG_STEM_HAS
     }
     return 0;
+}
+
+// the instantiation a step runs on, spelled like its symbol in a kernel trace
+void stem2_kernel_name(const StemArgs& p, char* buf, size_t n) {
+    const bool p1 = p.N1 == 16, p2 = p.N2 == 16;
+    const int cs1 = p.N1 >= 32 ? p.N1 / 32 : 1;
+    const int rt1 = ((1 << (p.nr1 - 5)) * cs1) / SW;
+    const bool st = stem2_variant(p) == 1;
+    snprintf(buf, n, "stem2_kernel<%s,%s,%d,%d,%d,%d>", p1 ? "true" : "false", p2 ? "true" : "false", rt1, cs1,
+             st ? p.K1 / 16 : 0, st ? (p.rows2 / 32) * p.ng2 / SW : 0);
 }
 
 hipError_t launch_stem2(const StemArgs& p, hipStream_t stream) {

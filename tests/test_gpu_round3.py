@@ -65,8 +65,11 @@ def test_fused_stem_pairs(case, sliced):
     assert G.relerr(np.asarray(m).astype("complex128") * 10.0**e, ref) <= gate
     # slice by slice = all slices in one batched run
     if tree.nslices > 1:
-        parts = sum(np.asarray(fused.contract_slice(arrays, i)) for i in range(tree.nslices))
-        assert G.relerr(parts, ref) <= gate
+        a128 = [a.astype("complex128") for a in arrays]
+        for i in range(tree.nslices):   # (a sliced index may be an open one: compare slice by slice)
+            ri = np.asarray(orc.contract_slice(tree, a128, i))
+            gi = max(gate, G.single_gate(ri, orc.contract_slice(tree, arrays, i)))
+            assert G.relerr(np.asarray(fused.contract_slice(arrays, i)), ri) <= gi
     fused.close()
     plain.close()
 
