@@ -551,12 +551,16 @@ def main():
     precision = precision_check(tree, arrays) if (rank == 0 and not args.no_cpu_baseline) else None
     # C3 at N > 1: every rank computes m10 amplitudes (of different bitstrings) on its own
     c3_amp = None
-    if world > 1 and not args.headline_only:
+    # (CTG_BENCH_C3_AMPLITUDES=1: also at N = 1 under a launcher -- how the one-GPU lease tests this leg)
+    if (world > 1 or os.environ.get("CTG_BENCH_C3_AMPLITUDES")) and not args.headline_only:
         mine3 = m10_amplitudes(dev)
         if mine3 is not None:
             t3 = torch.tensor([mine3["amplitudes"], mine3["seconds"]], dtype=torch.float64, device=dev)
             all3 = [torch.zeros_like(t3) for _ in range(world)]
-            dist.all_gather(all3, t3)
+            if dist is not None:
+                dist.all_gather(all3, t3)
+            else:
+                all3 = [t3]
             c3_amp = {
                 "workload": "Sycamore circuit_n53_m10 amplitudes (64 slices each; input upload, all slices, "
                             "fetch per amplitude), every rank its own bitstrings, no exchange",
@@ -663,7 +667,7 @@ def main():
                 out["peak_rate_tree"] = tree_report(PEAK_TREE, dev)
             out["configs"] = other_configs(dev)
         if c3_amp is not None:
-            out["configs"] = {"C3_amplitudes": c3_amp}
+            out.setdefault("configs", {})["C3_amplitudes"] = c3_amp
         print(json.dumps(out))
     else:
         fn.close()
