@@ -298,12 +298,19 @@ __device__ __forceinline__ int d_row(double, int k4, int t) { return k4 + 4 * t;
 // 2) for small steps, 128 x 128 (TM = TN = 4) when the output alone fills the
 // chip -- four times the matrix work per k-step and barrier, twice per gathered
 // element and fragment read.
-template <typename T, int TM, int TN>
+// VEC: both operands are gathered in 16-byte pieces (4 floats / 2 doubles) along their
+// fastest-varying index -- the host has checked that every such piece is contiguous and
+// aligned in memory (ctg_runtime.hip: real_vec_ok).  One load instruction then moves what four
+// (two) did: the element-wise gather, not the matrix cores, is what held float32 at 0.47 of
+// its peak (profiles/r2_f64_kernel_rates.txt).
+template <typename T, int TM, int TN, bool VEC>
 __global__ __launch_bounds__(256, 2) void pair_mfma_real_kernel(StepArgs p, int flags, int64_t tiles_m,
                                                                int64_t tiles_n) {
     constexpr int RBM = 2 * TM * 16, RBN = 2 * TN * 16;
-    constexpr int NA = RBM * RBK / 256, NB = RBN * RBK / 256;
+    constexpr int V = VEC ? 16 / (int)sizeof(T) : 1;   // elements per load
+    constexpr int NA = RBM * RBK / 256 / V, NB = RBN * RBK / 256 / V;   // loads per thread and k-step
     typedef typename Vec4<T>::type V4;
+    typedef T VT __attribute__((ext_vector_type(V > 1 ? V : 2)));
     __shared__ T lds[2 * (RBM + RBN) * RLD];
     __shared__ int64_t rowA_s[RBM];
     __shared__ int64_t rowC_s[RBM];
@@ -364,7 +371,7 @@ __global__ __launch_bounds__(256, 2) void pair_mfma_real_kernel(StepArgs p, int 
     int64_t b_col[NB];
 #pragma unroll
     for (int j = 0; j < NA; ++j) {
-        const int e = j * 256 + tid;
+        const int e = (j * 256 + tid) * V;
         if (a_kfast) {
             a_r[j] = e / RBK;
             a_c[j] = e % RBK;
@@ -375,7 +382,7 @@ __global__ __launch_bounds__(256, 2) void pair_mfma_real_kernel(StepArgs p, int 
     }
 #pragma unroll
     for (int j = 0; j < NB; ++j) {
-        const int e = j * 256 + tid;
+        const int e = (j * 256 + tid) * V;
         if (b_kfast) {
             b_k[j] = e % RBK;
             b_n[j] = e / RBK;
@@ -390,22 +397,31 @@ __global__ __launch_bounds__(256, 2) void pair_mfma_real_kernel(StepArgs p, int 
 #pragma unroll
     for (int j = 0; j < NA; ++j) a_row[j] = rowA_s[a_r[j]];
 
-    T a_reg[NA], b_reg[NB];
+    // (VEC: piece j of a thread starts at tile element (a_r, a_c) and runs along k when k is
+    // the operand's fast index, along the rows / columns otherwise; rows, columns and k's
+    // are valid or not in whole pieces: the host requires R, N, K to be multiples of V)
+    VT a_reg[NA], b_reg[NB];
     auto gather = [&](int64_t step) {
         const int64_t* ka = kofs_s[step % 3][0];
         const int64_t* kb = kofs_s[step % 3][1];
 #pragma unroll
         for (int j = 0; j < NA; ++j) {
             const int64_t ko = ka[a_c[j]];
-            T v = 0;
-            if (a_row[j] >= 0 && ko >= 0) v = A[a_row[j] + ko];
+            VT v = 0;
+            if (a_row[j] >= 0 && ko >= 0) {
+                if constexpr (VEC) v = *(const VT*)(A + a_row[j] + ko);
+                else v[0] = A[a_row[j] + ko];
+            }
             a_reg[j] = v;
         }
 #pragma unroll
         for (int j = 0; j < NB; ++j) {
             const int64_t ko = kb[b_k[j]];
-            T v = 0;
-            if (b_col[j] >= 0 && ko >= 0) v = B[b_col[j] + ko];
+            VT v = 0;
+            if (b_col[j] >= 0 && ko >= 0) {
+                if constexpr (VEC) v = *(const VT*)(B + b_col[j] + ko);
+                else v[0] = B[b_col[j] + ko];
+            }
             b_reg[j] = v;
         }
     };
@@ -413,9 +429,15 @@ __global__ __launch_bounds__(256, 2) void pair_mfma_real_kernel(StepArgs p, int 
         T* As = lds + buf * (RBM + RBN) * RLD;
         T* Bs = As + RBM * RLD;
 #pragma unroll
-        for (int j = 0; j < NA; ++j) As[a_r[j] * RLD + a_c[j]] = a_reg[j];
+        for (int j = 0; j < NA; ++j)
 #pragma unroll
-        for (int j = 0; j < NB; ++j) Bs[b_n[j] * RLD + b_k[j]] = b_reg[j];
+            for (int i = 0; i < V; ++i)
+                As[(a_r[j] + (a_kfast ? 0 : i)) * RLD + a_c[j] + (a_kfast ? i : 0)] = a_reg[j][i];
+#pragma unroll
+        for (int j = 0; j < NB; ++j)
+#pragma unroll
+            for (int i = 0; i < V; ++i)
+                Bs[(b_n[j] + (b_kfast ? 0 : i)) * RLD + b_k[j] + (b_kfast ? i : 0)] = b_reg[j][i];
     };
 
     // float32 with an even number of 16-row / 16-column tiles per wave runs on the 32x32x2
@@ -557,14 +579,19 @@ __global__ __launch_bounds__(256, 2) void pair_mfma_real_kernel(StepArgs p, int 
 
 template <typename T, int TM, int TN>
 static hipError_t launch_real_t(const StepArgs& p, int flags, hipStream_t stream) {
+    const bool vec = (flags & 4) && (flags & 8);   // both operands gather in 16-byte pieces
     constexpr int RBM = 2 * TM * 16, RBN = 2 * TN * 16;
     const int64_t tiles_m = (p.R + RBM - 1) / RBM;
     const int64_t tiles_n = (p.N + RBN - 1) / RBN;
     const int64_t gx = ((tiles_m + 7) / 8) * 8 * tiles_n;
     if (gx > 0x7fffffffll || p.Bt > 65535 || p.nz > 65535) return hipErrorInvalidValue;
     const dim3 grid((unsigned)gx, (unsigned)p.nz, (unsigned)p.Bt);
-    hipLaunchKernelGGL((pair_mfma_real_kernel<T, TM, TN>), grid, dim3(256), 0, stream, p, flags, tiles_m,
-                       tiles_n);
+    if (vec)
+        hipLaunchKernelGGL((pair_mfma_real_kernel<T, TM, TN, true>), grid, dim3(256), 0, stream, p, flags,
+                           tiles_m, tiles_n);
+    else
+        hipLaunchKernelGGL((pair_mfma_real_kernel<T, TM, TN, false>), grid, dim3(256), 0, stream, p, flags,
+                           tiles_m, tiles_n);
     return hipGetLastError();
 }
 

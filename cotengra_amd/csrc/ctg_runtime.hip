@@ -575,6 +575,47 @@ bool skinny_ok(const ctg_plan* p, const int64_t* r) {
     return true;
 }
 
+// Can operand A (which = 0) / B (which = 1) of a real-valued matrix-core step be gathered in
+// pieces of V elements (16 bytes) along its fastest index -- k when `kfast`, else the rows
+// (A) / columns (B)?  Every piece must be contiguous and aligned: the fast table advances by 1
+// inside a piece and starts pieces at multiples of V, every other offset that enters the
+// address (the other groups' tables, the batch table, the operand's base, its slice strides)
+// is a multiple of V, and the extents are whole numbers of pieces.
+bool real_vec_ok(const ctg_plan* p, const int64_t* r, int which, bool kfast, int64_t V) {
+    const auto& T = p->tables;
+    auto all_mult = [&](int64_t off, int64_t len) {
+        if (off < 0) return true;
+        for (int64_t i = 0; i < len; ++i)
+            if (T[off + i] % V) return false;
+        return true;
+    };
+    auto pieces = [&](int64_t off, int64_t len) {   // contiguous, aligned runs of V
+        if (off < 0 || len % V) return false;
+        for (int64_t i = 0; i < len; i += V) {
+            if (T[off + i] % V) return false;
+            for (int64_t j = 1; j < V; ++j)
+                if (T[off + i + j] != T[off + i] + j) return false;
+        }
+        return true;
+    };
+    const int64_t k_lo = r[W_K_LO], k_hi = r[W_K_HI_LEN], row_lo = r[W_ROW_LO], row_hi = r[W_ROW_HI_LEN];
+    const int off_w = which ? W_B_OFF : W_A_OFF, leaf_w = which ? W_B_LEAF : W_A_LEAF;
+    if (r[off_w] % V) return false;
+    if (r[leaf_w] >= 0)
+        for (int64_t j = 0; j < p->n_sliced; ++j)
+            if (p->slice_strides[r[leaf_w] * p->n_sliced + j] % V) return false;
+    if (!all_mult(which ? r[W_BB] : r[W_BA], r[W_BT])) return false;
+    const int64_t klo_w = which ? r[W_KB] : r[W_KA], khi_w = which ? r[W_KB_HI] : r[W_KA_HI];
+    if (!all_mult(khi_w, k_hi)) return false;
+    if (which == 0) {
+        if (!all_mult(r[W_ROWA_HI], row_hi)) return false;
+        if (kfast) return pieces(klo_w, k_lo) && all_mult(r[W_ROWA_LO], row_lo);
+        return pieces(r[W_ROWA_LO], row_lo) && all_mult(klo_w, k_lo);
+    }
+    if (kfast) return pieces(klo_w, k_lo) && all_mult(r[W_NB], r[W_N]);
+    return pieces(r[W_NB], r[W_N]) && all_mult(klo_w, k_lo);
+}
+
 // zmult: how many slices a launch with these hints carries at most (1, or the
 // executor's batch size); `like`: hints already built for zmult = 1, whose k-splits
 // are kept
@@ -598,6 +639,14 @@ int build_hints_into(ctg_exec* e, std::vector<MfmaHints>& hints, int64_t zmult,
             const int64_t ak = stride1(W_KA, r[W_K_LO]), am = stride1(W_ROWA_LO, r[W_ROW_LO]);
             const int64_t bk = stride1(W_KB, r[W_K_LO]), bnn = stride1(W_NB, r[W_N]);
             h.vecA = (ak < am ? 1 : 0) | (bk < bnn ? 2 : 0);
+            // float32 / float64: bit 2 / bit 3 = operand A / B can be gathered in 16-byte
+            // pieces along that fastest index (every piece contiguous and aligned, every
+            // other offset a multiple of the piece)
+            if (p->dtype == CTG_F32 || p->dtype == CTG_F64) {
+                const int64_t V = p->dtype == CTG_F32 ? 4 : 2;
+                if (real_vec_ok(p, r, 0, (h.vecA & 1) != 0, V)) h.vecA |= 4;
+                if (real_vec_ok(p, r, 1, (h.vecA & 2) != 0, V)) h.vecA |= 8;
+            }
             continue;
         }
         h.bn = mfma_pick_bn(r[W_N]);

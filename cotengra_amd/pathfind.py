@@ -189,6 +189,16 @@ MI355X_C64 = MachineModel(
 )
 
 
+# The same machine once consecutive stem steps run fused (stem.py; round 3): a memory-bound
+# step of a pair moves the big tensor once instead of twice, matrix work runs at ~0.73 of peak
+# whatever K from 16 up.  Only an objective for the subtree search (the dynamic programme
+# prices single steps and cannot know which will pair up); `modelled_seconds` prices the plan
+# the executor really builds.
+MI355X_C64_FUSED = MachineModel(
+    [x * 1e12 / 8 for x in (4, 8, 16, 31, 95, 110, 115, 115, 127, 131)], 8.0e12 / 8
+)
+
+
 def subtree_reconfigure(tree, subtree_size=8, maxiter="auto", minimize="flops", inplace=False):
     """Locally optimal re-ordering of the subtrees of ``tree`` (reference
     ``ContractionTree.subtree_reconfigure``, core.py:2316-2449) by the native
@@ -248,16 +258,23 @@ def modelled_seconds(tree, model=None, dtype="complex64"):
     """``(seconds per slice, arena bytes)`` of ``tree`` as the executor would run
     it: the device plan's steps (their real K, N, MACs and bytes, slice-invariant
     steps included) priced by ``model`` (default :data:`MI355X_C64`)."""
-    from .plan import compile_tree
+    from .plan import KIND_STEM2, compile_tree
+    from .stem import pair_seconds
 
     model = MI355X_C64 if model is None else model
     plan = compile_tree(tree, dtype)
     itemsize = plan.itemsize
-    t = sum(
-        model.step_seconds(r["macs"], r["bytes"] / itemsize, r["K"], r["N"])
-        for r in plan.describe_steps()
-        if r["macs"]
-    )
+    t = 0.0
+    for s in plan.steps:
+        if not s.macs:
+            continue
+        if s.kind == KIND_STEM2:
+            # a fused stem pair (stem.py): its own model -- the big tensor moves once
+            st = s.stem
+            macs1 = (s.a.size // st["K1"]) * st["K1"] * st["N1"]
+            t += pair_seconds(macs1, s.macs - macs1, s.a.size, s.c.size, st["items"], st["run_bytes"])
+        else:
+            t += model.step_seconds(s.macs, s.elems_rw, s.K, s.N)
     return t, plan.arena_elems * itemsize
 
 
