@@ -49,6 +49,10 @@ PEAK_HBM_GBS = 8000.0
 TREES = os.path.join(ROOT, "tests", "golden", "trees")
 TREE = os.path.join(TREES, "sycamore_m20_native.json")        # reaches the amplitude first
 PEAK_TREE = os.path.join(TREES, "sycamore_m20_w32_c512.json")  # highest FLOP/s per slice (r1 / r2 headline)
+# the headline tree refined once more for an executor that fuses stem pairs (tests/golden/gen/
+# refine_fused.py): a quarter less work in smaller, memory-bound steps -- fewer FLOP/s, but the
+# amplitude 12 % sooner
+TTS_TREE = os.path.join(TREES, "sycamore_m20_fused.json")
 
 
 # ---------------------------------------------------------------------- #
@@ -663,6 +667,8 @@ def main():
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(tree, arrays)
         if extras and not args.headline_only:
+            if os.path.abspath(args.tree) != os.path.abspath(TTS_TREE) and os.path.exists(TTS_TREE):
+                out["time_to_solution_tree"] = tree_report(TTS_TREE, dev)
             if os.path.abspath(args.tree) != os.path.abspath(PEAK_TREE) and os.path.exists(PEAK_TREE):
                 out["peak_rate_tree"] = tree_report(PEAK_TREE, dev)
             out["configs"] = other_configs(dev)

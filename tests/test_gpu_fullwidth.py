@@ -56,7 +56,7 @@ def rel(a, b):
     return abs(complex(a) - complex(b)) / abs(complex(b))
 
 
-@pytest.mark.parametrize("fixture", ["sycamore_m20_w32_c512.json", "sycamore_m20_native.json"])
+@pytest.mark.parametrize("fixture", ["sycamore_m20_w32_c512.json", "sycamore_m20_native.json", "sycamore_m20_fused.json"])
 @pytest.mark.parametrize("log2_width", [20, 24])
 def test_narrowed_trees_against_oracle(fixture, log2_width):
     """(i): both precisions of the HIP path vs the oracle on the bench tree and
@@ -76,7 +76,7 @@ def test_narrowed_trees_against_oracle(fixture, log2_width):
         assert rel(got64, ref) <= gate, (rel(got64, ref), gate, rel(np64, ref))
 
 
-@pytest.mark.parametrize("fixture", ["sycamore_m20_w32_c512.json", "sycamore_m20_native.json"])
+@pytest.mark.parametrize("fixture", ["sycamore_m20_w32_c512.json", "sycamore_m20_native.json", "sycamore_m20_fused.json"])
 def test_full_width_slice_is_sum_of_double_precision_sub_slices(fixture):
     """(ii): complex64 at width 2^32 vs complex128 at width 2^28."""
     tree, arrays = load(fixture)
