@@ -1,7 +1,7 @@
 #!/bin/bash
 # End-of-round measurement on the GPU box: tests, the bench line, a kernel trace of
 # the same command and the HBM-traffic counter passes (separate --pmc runs, each
-# bounded by its own timeout) for the benchmark tree AND the time-to-solution tree.
+# bounded by its own timeout) for the headline tree, the time-to-solution tree and the peak-rate tree.
 # Outputs land in gpurun_out/final/; tools/publish_profiles.py copies what is to be
 # judged into profiles/.
 R=${GRAFT_REPO_ROOT:-$PWD}
@@ -26,7 +26,7 @@ cd /tmp
 timeout 600 rocprofv3 --kernel-trace --stats -d $O/trace_headline -- python $R/bench.py --headline-only --no-cpu-baseline --steps 4 --warmup 1 > $O/trace_headline.log 2>&1
 cd $R
 python tools/rocprof_summary.py $(find $O/trace_headline -name "*.db" | head -1) $O/kernels_headline > /dev/null 2>&1; head -4 $O/kernels_headline_kernels.txt | cut -c1-190
-for tree in sycamore_m20_w32_c512 sycamore_m20_native; do
+for tree in sycamore_m20_native sycamore_m20_fused sycamore_m20_w32_c512; do
   CMD="python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --tree $R/tests/golden/trees/$tree.json"
   cd /tmp
   timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/pmc_fetch_$tree -- $CMD > $O/pmc_fetch_$tree.log 2>&1

@@ -32,6 +32,9 @@ def step_kernel_name(rocprof_name):
     m = re.match(r"pair_rowwise_kernel<(\d+), (?:true|false)>", rocprof_name)
     if m:
         return f"pair_rowwise_kernel<{m.group(1)}>"
+    m = re.match(r"stem2_kernel<(true|false), (true|false), (\d+), (\d+), (\d+), (\d+)>", rocprof_name)
+    if m:
+        return "stem2_kernel<%s>" % ",".join(m.groups())
     m = re.match(r"pair_skinny_kernel<(\d+), (\d+)>", rocprof_name)
     if m:
         return f"pair_skinny_kernel<{m.group(1)},{m.group(2)}>"
@@ -63,7 +66,7 @@ def main():
         kernels[step_kernel_name(k)] = {"rocprof_name": k, "launches": f[k][0],
                                         "fetch_bytes_corrected": fb, "write_bytes": wb,
                                         "hbm_bytes_per_launch": (fb + wb) / f[k][0]}
-        if "pair_mfma" in k or "pair_skinny" in k:
+        if "pair_mfma" in k or "pair_skinny" in k or "stem2_kernel" in k:
             tot_f += fb
             tot_w += wb
             launches += f[k][0]
