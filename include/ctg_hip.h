@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define CTG_ABI_VERSION 2
+#define CTG_ABI_VERSION 3
 
 /* element types of the tensors (reference tests cover all four:
  * tests/test_compute.py:102-115) */
@@ -51,7 +51,19 @@ enum {
  * `extract_contractions` (contract.py:573-651) plus the per-step index
  * classification of `_parse_eq_to_batch_matmul` (contract.py:168-329), lowered
  * to offset tables; and the slice bookkeeping of `SliceInfo` /
- * `get_slice_strides` / `slice_key` (core.py:99-122, 3775-3800). */
+ * `get_slice_strides` / `slice_key` (core.py:99-122, 3775-3800).
+ *
+ * Step kinds (word 0 of a step record): 0 single-term einsum (contract.py:62-119,
+ * 332-361), 1 pairwise contraction (contract.py:364-411), 2 accumulate the slice
+ * into the result (core.py:3842-3876), and -- ABI 3 -- 3: TWO consecutive pairwise
+ * contractions of a stem executed as one launch whose intermediate never exists in
+ * memory (two turns of the loop contract.py:788-832; complex64 only).  A kind-3
+ * record names the big operand, the first small operand and the result like a
+ * pair step; word 43 points at a descriptor in the table blob (geometry of the
+ * tile decomposition, the second small operand, 14 offset tables: layout in
+ * cotengra_amd/stem.py: serialise_stem, csrc/ctg_common.h: StemWord).  Like every
+ * step it is validated by ctg_plan_create: tables inside the blob, every operand
+ * address inside its buffer, a tile shape the kernel takes. */
 typedef struct ctg_plan_desc {
     int32_t dtype;                /* CTG_F32 .. CTG_C128 */
     int64_t n_inputs;
