@@ -369,6 +369,22 @@ def other_configs(dev):
             "C3", t3, [z[f"t{i}"] for i in range(t3.N)], dev, slices=t3.nslices, reps=25, cpu_slices=2,
             note=f"Sycamore circuit_n53_m10 amplitude, all {t3.nslices} slices (the whole amplitude)",
         )
+    # C3 with 8 open output qubits: one contraction = the batch of 256 amplitudes (the open qubits
+    # give the pairwise steps a real N dimension -- SURVEY section 8f item 3)
+    m10o = os.path.join(TREES, "sycamore_m10_open8.json")
+    arro = os.path.join(ROOT, "tests", "golden", "sycamore_m10_open8_arrays.npz")
+    if os.path.exists(m10o) and os.path.exists(arro):
+        t3o = ca.tree_from_record(ca.load_network(m10o))
+        zo = np.load(arro)
+        cfg = small_config(
+            "C3_batched", t3o, [zo[f"t{i}"] for i in range(t3o.N)], dev, slices=t3o.nslices, reps=25,
+            cpu_slices=1,
+            note=f"Sycamore circuit_n53_m10, 8 open output qubits: 256 amplitudes per contraction, all "
+                 f"{t3o.nslices} slices",
+        )
+        cfg["amplitudes_per_contraction"] = 256
+        cfg["amplitudes_per_sec"] = 256.0 / (cfg["ms"] * 1e-3)
+        out["C3_batched"] = cfg
     c5 = by_name["C5_hyper200"]
     t5 = G.tree_of(c5)
     out["C5"] = small_config(

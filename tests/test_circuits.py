@@ -171,3 +171,45 @@ def test_m10_full_amplitude_on_gpu(dtype):
                 np64 = complex(orc.contract_slice(tree, xs, i))
                 tol = max(1e-5, 8.0 * abs(np64 - complex(exp[key])) / abs(exp[key]))
             assert abs(got - complex(exp[key])) <= tol * abs(exp[key]), (abs(got - complex(exp[key])) / abs(exp[key]), tol)
+
+
+M10_OPEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "trees", "sycamore_m10_open8.json")
+M10_OPEN_ARRAYS = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "sycamore_m10_open8_arrays.npz")
+M10_OPEN_EXPECTED = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "sycamore_m10_open8_expected.npz")
+
+
+def m10_open():
+    tree = ca.tree_from_record(ca.load_network(M10_OPEN))
+    z = np.load(M10_OPEN_ARRAYS)
+    return tree, [z[f"t{i}"] for i in range(tree.N)], np.load(M10_OPEN_EXPECTED)
+
+
+def test_m10_open_fixture_oracle_slice():
+    """Sycamore m10 with 8 open output qubits (tests/golden/gen/make_m10_open.py): a slice of the
+    256-amplitude batch by the oracle == the reference's; amplitude 0...0 of the batch == the
+    committed single m10 amplitude (another network, another tree)."""
+    tree, arrays, exp = m10_open()
+    assert len(tree.output) == 8 and tree.nslices == 8
+    got = np.asarray(orc.contract_slice(tree, arrays, 1))
+    assert got.shape == (2,) * 8
+    assert np.allclose(got, exp["slice1"], rtol=1e-11, atol=1e-14)
+    single = np.load(M10_EXPECTED)["amplitude"]
+    assert abs(exp["amplitudes"].reshape(-1)[0] - single) <= 1e-10 * abs(single)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", ["complex128", "complex64"])
+def test_m10_batched_amplitudes_on_gpu(dtype):
+    """All 256 amplitudes in one contraction on the device vs the reference's."""
+    tree, arrays, exp = m10_open()
+    xs = [a.astype(dtype) for a in arrays]
+    got = np.asarray(tree.contract(xs))
+    ref = exp["amplitudes"]
+    assert got.shape == ref.shape
+    scale = np.abs(ref).max()
+    tol = 1e-10
+    if dtype == "complex64":
+        tol = max(1e-5, 8.0 * np.abs(np.asarray(orc.contract(tree, xs)) - ref).max() / scale)
+    assert np.abs(got - ref).max() <= tol * scale
+    s1 = np.asarray(tree.contract_slice(xs, 1))
+    assert np.abs(s1 - exp["slice1"]).max() <= max(tol, 1e-10) * np.abs(exp["slice1"]).max() * 4
