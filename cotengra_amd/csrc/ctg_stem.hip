@@ -67,7 +67,11 @@ __device__ __forceinline__ f32x16 mfma(float a, float b, f32x16 c) {
 __device__ __forceinline__ constexpr int rowmap(int t) { return (t & 3) + 8 * (t >> 2); }
 
 __device__ __forceinline__ float flip(float v, unsigned mask) {
+#ifdef CTG_STEM_KO_XOR   // (knock-out: what do the sign XORs cost?)
+    return v;
+#else
     return __builtin_bit_cast(float, __builtin_bit_cast(unsigned, v) ^ mask);
+#endif
 }
 
 // planes of a small operand in LDS: plane p, column n, k contiguous
@@ -111,9 +115,18 @@ __device__ __forceinline__ void settle(T& v) {
 // gather issued one tile ago WITHOUT waiting for the stores issued since (see the
 // steady-state loop of ctg_pair_mfma.hip's streaming kernel).  NCH = 0: both counts are
 // run-time values (any shape; every wait drains the queue).
-template <bool PACK1, bool PACK2, int RT1, int CS1, int NCH, int IT2>
+// BR1: the B1 fragments of this wave's columns live in registers for the whole kernel
+// (2 K1 floats, K1 with 16 columns) -- K2Q > 0: likewise the B2 fragments of this wave's
+// column group, K2 = 4 K2Q known at compile time.  The fragments are the same for every
+// tile; re-reading them from LDS for every 8 MFMAs is a third of the kernel's LDS traffic
+// and, with the staging writes and the scatter in the same queue, cost 8 % of a slice
+// (knock-out CTG_STEM_KO_BFRAG, profiles/r3_stem_knockout.txt).  Chosen per shape by the
+// register budget (launch_stem2: at most 96 floats of B per lane).
+template <bool PACK1, bool PACK2, int RT1, int CS1, int NCH, int IT2, bool BR1 = false, int K2Q = 0>
 __global__ __launch_bounds__(SW * 64, 1) void stem2_kernel(StemArgs p) {
     static_assert(!PACK1 || CS1 == 1, "16 columns are one group");
+    static_assert(!BR1 || NCH > 0, "B1 in registers needs the chunk count at compile time");
+    static_assert(K2Q == 0 || PACK2 || IT2 == 1, "B2 in registers: one column group per wave");
     constexpr int RTW = SW / CS1;   // row tiles the 8 waves cover at once
     constexpr bool STATIC = NCH > 0;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -208,6 +221,29 @@ __global__ __launch_bounds__(SW * 64, 1) void stem2_kernel(StemArgs p) {
     const bool scaled = __builtin_amdgcn_readfirstlane(alpha != 1.f);   // (strip_exponent runs only)
     __syncthreads();
 
+#ifdef CTG_STEM_KO_BFRAG
+    f32x4 ko_b = *(const f32x4*)(P1 + 4 * (lane & 3));
+    settle(ko_b);
+#endif
+    // register-resident B fragments: [quad][X | Y]
+    f32x4 b1r[BR1 ? NCH * 4 : 1][PACK1 ? 1 : 2];
+    f32x4 b2r[K2Q > 0 ? K2Q : 1][PACK2 ? 1 : 2];
+    if constexpr (BR1) {
+#pragma unroll
+        for (int q = 0; q < NCH * 4; ++q) {
+            b1r[q][0] = *(const f32x4*)(b1x + 4 * q);
+            if (!PACK1) b1r[q][1] = *(const f32x4*)(b1y + 4 * q);
+        }
+    }
+    if constexpr (K2Q > 0) {
+        // (one item per wave and tile, always the same: its column group is this wave's)
+        const int cg0 = PACK2 ? 0 : wave / (p.rows2 >> 5);
+#pragma unroll
+        for (int q = 0; q < K2Q; ++q) {
+            b2r[q][0] = *(const f32x4*)(b2x + cg0 * 32 * LDB2 + 4 * q);
+            if (!PACK2) b2r[q][1] = *(const f32x4*)(b2y + cg0 * 32 * LDB2 + 4 * q);
+        }
+    }
     float* As = stage + wave * STAGE_FLOATS;
     const int nch = STATIC ? NCH : (K1 >> 4);        // 16-deep chunks of the first contraction
     const int n_rt2 = p.rows2 >> 5;
@@ -287,14 +323,29 @@ __global__ __launch_bounds__(SW * 64, 1) void stem2_kernel(StemArgs p) {
         // fragments of quad q + 1 are read before the MFMAs of quad q are issued
         f32x4 af[2], bx[2], by[2];
         af[0] = *(const f32x4*)(a_base);
-        bx[0] = *(const f32x4*)(bxp);
-        if (!PACK1) by[0] = *(const f32x4*)(byp);
+#ifdef CTG_STEM_KO_BFRAG   // (knock-out: B fragments from registers instead of LDS)
+        bx[0] = bx[1] = ko_b;
+        by[0] = by[1] = ko_b;
+#else
+        if constexpr (!BR1) {
+            bx[0] = *(const f32x4*)(bxp);
+            if (!PACK1) by[0] = *(const f32x4*)(byp);
+        }
+#endif
 #pragma unroll
         for (int kq = 0; kq < 4; ++kq) {
             if (kq + 1 < 4) {
                 af[(kq + 1) & 1] = *(const f32x4*)(a_base + (kq + 1) * 4);
-                bx[(kq + 1) & 1] = *(const f32x4*)(bxp + (kq + 1) * 4);
-                if (!PACK1) by[(kq + 1) & 1] = *(const f32x4*)(byp + (kq + 1) * 4);
+#ifndef CTG_STEM_KO_BFRAG
+                if constexpr (!BR1) {
+                    bx[(kq + 1) & 1] = *(const f32x4*)(bxp + (kq + 1) * 4);
+                    if (!PACK1) by[(kq + 1) & 1] = *(const f32x4*)(byp + (kq + 1) * 4);
+                }
+#endif
+            }
+            if constexpr (BR1) {   // (ch is a compile-time constant here: static variants only)
+                bx[kq & 1] = b1r[ch * 4 + kq][0];
+                if (!PACK1) by[kq & 1] = b1r[ch * 4 + kq][PACK1 ? 0 : 1];
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -357,16 +408,41 @@ __global__ __launch_bounds__(SW * 64, 1) void stem2_kernel(StemArgs p) {
         const int nq = K2 >> 2;   // >= 4, even
         f32x4 af[2], bx[2], by[2];
         af[0] = *(const f32x4*)(a_base);
+        if constexpr (K2Q > 0) {
+            // B2 fragments in registers, K2 known: the quads fully unrolled
+#pragma unroll
+            for (int kq = 0; kq < K2Q; ++kq) {
+                if (kq + 1 < K2Q) af[(kq + 1) & 1] = *(const f32x4*)(a_base + (kq + 1) * 4);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    if (PACK2) {
+                        cx = mfma(af[kq & 1][t], b2r[kq][0][t], cx);
+                    } else {
+                        cx = mfma(flip(af[kq & 1][t], sgn), b2r[kq][0][t], cx);
+                        cy = mfma(af[kq & 1][t], b2r[kq][PACK2 ? 0 : 1][t], cy);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        } else {
+#ifdef CTG_STEM_KO_BFRAG
+        bx[0] = bx[1] = ko_b;
+        by[0] = by[1] = ko_b;
+#else
         bx[0] = *(const f32x4*)(bxp);
         if (!PACK2) by[0] = *(const f32x4*)(byp);
+#endif
         for (int kq = 0; kq < nq; kq += 2) {
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
                 // next quad (past the end: the last one again -- no branch in the loop)
                 const int nx = (kq + h + 1 < nq ? kq + h + 1 : nq - 1) * 4;
                 af[(h + 1) & 1] = *(const f32x4*)(a_base + nx);
+#ifndef CTG_STEM_KO_BFRAG
                 bx[(h + 1) & 1] = *(const f32x4*)(bxp + nx);
                 if (!PACK2) by[(h + 1) & 1] = *(const f32x4*)(byp + nx);
+#endif
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int t = 0; t < 4; ++t) {
@@ -379,6 +455,7 @@ __global__ __launch_bounds__(SW * 64, 1) void stem2_kernel(StemArgs p) {
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
+        }
         }
         {
             constexpr bool SC = decltype(scaled_tag)::value;
@@ -504,9 +581,9 @@ size_t stem2_lds_bytes(const StemArgs& p) {
     return 4 * (b1 + b2 + mid + (size_t)SW * STAGE_FLOATS) + 8 * (size_t)p.N2;
 }
 
-template <bool PACK1, bool PACK2, int RT1, int CS1, int NCH, int IT2>
+template <bool PACK1, bool PACK2, int RT1, int CS1, int NCH, int IT2, bool BR1 = false, int K2Q = 0>
 static hipError_t launch_stem2_t(const StemArgs& p, hipStream_t stream) {
-    auto kern = stem2_kernel<PACK1, PACK2, RT1, CS1, NCH, IT2>;
+    auto kern = stem2_kernel<PACK1, PACK2, RT1, CS1, NCH, IT2, BR1, K2Q>;
     static bool ready = false;
     if (!ready) {
         const hipError_t e =
@@ -550,46 +627,97 @@ bool stem2_supported(const StemArgs& p) {
     X(true, false, 2, 1, 1, 1) X(true, false, 2, 1, 2, 1) X(true, false, 2, 1, 4, 1)          \
     X(true, true, 1, 1, 1, 1) X(true, true, 2, 1, 4, 1) X(true, true, 2, 1, 1, 2)
 
+// the same with the small operands' fragments in registers: (..., B1 in registers, K2 / 4 if
+// B2 is, else 0) -- tools/stem_shapes.py lists what the m20 trees need
+#define CTG_STEM_BREG(X)                                                                              \
+    X(false, false, 1, 1, 2, 1, true, 0) X(false, false, 1, 2, 4, 1, false, 8) X(false, true, 1, 1, 2, 2, true, 4) \
+    X(true, true, 1, 1, 1, 1, true, 4) X(true, false, 2, 1, 1, 1, true, 8) X(false, false, 1, 1, 2, 2, true, 0)     \
+    X(true, false, 1, 1, 1, 1, true, 8) X(false, false, 1, 1, 8, 1, false, 8) X(false, true, 1, 2, 4, 2, false, 4) \
+    X(false, false, 1, 2, 2, 1, true, 0) X(false, false, 1, 2, 1, 1, true, 8) X(false, true, 1, 2, 2, 2, true, 4)   \
+    X(false, true, 1, 1, 1, 2, true, 4) X(false, false, 1, 2, 2, 4, true, 0) X(false, false, 1, 1, 4, 1, false, 8) \
+    X(false, false, 1, 1, 1, 1, true, 8) X(false, true, 1, 1, 8, 2, false, 4) X(false, true, 1, 2, 2, 1, true, 8)  \
+    X(false, false, 1, 1, 1, 2, true, 0) X(true, false, 2, 1, 1, 1, true, 0) X(true, false, 1, 1, 1, 1, true, 4)   \
+    X(false, false, 1, 1, 2, 4, true, 0) X(true, true, 2, 1, 4, 1, true, 8)
+
+namespace {
+struct StemShape {
+    bool p1, p2;
+    int rt1, cs1, nch, it2;   // it2 = 0: the item count is not a multiple of the waves
+    bool br1;
+    int k2q;
+};
+// Which small operand's fragments go to registers: B1 needs 2 K1 floats per lane (K1 with 16
+// columns) and K1 <= 32 (64); B2 2 K2 (K2) and one column group per wave (always with 16 columns,
+// else one item per wave) and K2 <= 32 (64); together at most 96 -- B1 first.
+StemShape stem2_shape(const StemArgs& p) {
+    StemShape s;
+    s.p1 = p.N1 == 16;
+    s.p2 = p.N2 == 16;
+    s.cs1 = p.N1 >= 32 ? p.N1 / 32 : 1;
+    s.rt1 = ((1 << (p.nr1 - 5)) * s.cs1) / SW;
+    s.nch = p.K1 / 16;
+    const int items = (p.rows2 / 32) * p.ng2;
+    s.it2 = items % SW == 0 ? items / SW : 0;
+    int r1 = (s.p1 ? p.K1 <= 64 : p.K1 <= 32) ? (s.p1 ? p.K1 : 2 * p.K1) : 0;
+    int r2 = ((s.p2 && p.K2 <= 64) || (!s.p2 && s.it2 == 1 && p.K2 <= 32)) ? (s.p2 ? p.K2 : 2 * p.K2) : 0;
+    if (r1 && r2 && r1 + r2 > 96) r2 = 0;
+    if (getenv("CTG_STEM_NO_BREG")) r1 = r2 = 0;
+    s.br1 = r1 != 0;
+    s.k2q = r2 ? p.K2 / 4 : 0;
+    return s;
+}
+}  // namespace
+
+// 2: static with register fragments, 1: static, 0: run-time counts
 int stem2_variant(const StemArgs& p) {
-    const bool p1 = p.N1 == 16, p2 = p.N2 == 16;
-    const int cs1 = p.N1 >= 32 ? p.N1 / 32 : 1;
-    const int rt1 = ((1 << (p.nr1 - 5)) * cs1) / SW;
-    const int nch = p.K1 / 16, items = (p.rows2 / 32) * p.ng2;
-    if (getenv("CTG_STEM_GENERIC") == nullptr && items % SW == 0) {
-        const int it2 = items / SW;
-#define CTG_STEM_HAS(P1, P2, R, CS, NC, IT) \
-    if (p1 == P1 && p2 == P2 && rt1 == R && cs1 == CS && nch == NC && it2 == IT) return 1;
-        CTG_STEM_STATIC(CTG_STEM_HAS)
+    const StemShape s = stem2_shape(p);
+    if (getenv("CTG_STEM_GENERIC") != nullptr || s.it2 == 0) return 0;
+#define CTG_STEM_HAS(P1, P2, R, CS, NC, IT, B1, KQ)                                                    \
+    if (s.p1 == P1 && s.p2 == P2 && s.rt1 == R && s.cs1 == CS && s.nch == NC && s.it2 == IT && s.br1 == B1 && \
+        s.k2q == KQ)                                                                                   \
+        return 2;
+    CTG_STEM_BREG(CTG_STEM_HAS)
 #undef CTG_STEM_HAS
-    }
+#define CTG_STEM_HAS(P1, P2, R, CS, NC, IT) \
+    if (s.p1 == P1 && s.p2 == P2 && s.rt1 == R && s.cs1 == CS && s.nch == NC && s.it2 == IT) return 1;
+    CTG_STEM_STATIC(CTG_STEM_HAS)
+#undef CTG_STEM_HAS
     return 0;
 }
 
 // the instantiation a step runs on, spelled like its symbol in a kernel trace
 void stem2_kernel_name(const StemArgs& p, char* buf, size_t n) {
-    const bool p1 = p.N1 == 16, p2 = p.N2 == 16;
-    const int cs1 = p.N1 >= 32 ? p.N1 / 32 : 1;
-    const int rt1 = ((1 << (p.nr1 - 5)) * cs1) / SW;
-    const bool st = stem2_variant(p) == 1;
-    snprintf(buf, n, "stem2_kernel<%s,%s,%d,%d,%d,%d>", p1 ? "true" : "false", p2 ? "true" : "false", rt1, cs1,
-             st ? p.K1 / 16 : 0, st ? (p.rows2 / 32) * p.ng2 / SW : 0);
+    const StemShape s = stem2_shape(p);
+    const int v = stem2_variant(p);
+    if (v == 2)
+        snprintf(buf, n, "stem2_kernel<%s,%s,%d,%d,%d,%d,%s,%d>", s.p1 ? "true" : "false", s.p2 ? "true" : "false",
+                 s.rt1, s.cs1, s.nch, s.it2, s.br1 ? "true" : "false", s.k2q);
+    else
+        snprintf(buf, n, "stem2_kernel<%s,%s,%d,%d,%d,%d,false,0>", s.p1 ? "true" : "false",
+                 s.p2 ? "true" : "false", s.rt1, s.cs1, v ? s.nch : 0, v ? s.it2 : 0);
 }
 
 hipError_t launch_stem2(const StemArgs& p, hipStream_t stream) {
     if (!stem2_supported(p)) return hipErrorInvalidValue;
-    const bool p1 = p.N1 == 16, p2 = p.N2 == 16;
-    const int cs1 = p.N1 >= 32 ? p.N1 / 32 : 1;
-    const int rt1 = ((1 << (p.nr1 - 5)) * cs1) / SW;
-    if (stem2_variant(p) == 1) {
-        const int nch = p.K1 / 16, it2 = (p.rows2 / 32) * p.ng2 / SW;
+    const StemShape s = stem2_shape(p);
+    const int v = stem2_variant(p);
+    if (v == 2) {
+#define CTG_STEM_GO(P1, P2, R, CS, NC, IT, B1, KQ)                                                     \
+    if (s.p1 == P1 && s.p2 == P2 && s.rt1 == R && s.cs1 == CS && s.nch == NC && s.it2 == IT && s.br1 == B1 && \
+        s.k2q == KQ)                                                                                   \
+        return launch_stem2_t<P1, P2, R, CS, NC, IT, B1, KQ>(p, stream);
+        CTG_STEM_BREG(CTG_STEM_GO)
+#undef CTG_STEM_GO
+    }
+    if (v == 1) {
 #define CTG_STEM_GO(P1, P2, R, CS, NC, IT)                                                  \
-    if (p1 == P1 && p2 == P2 && rt1 == R && cs1 == CS && nch == NC && it2 == IT)            \
+    if (s.p1 == P1 && s.p2 == P2 && s.rt1 == R && s.cs1 == CS && s.nch == NC && s.it2 == IT) \
         return launch_stem2_t<P1, P2, R, CS, NC, IT>(p, stream);
         CTG_STEM_STATIC(CTG_STEM_GO)
 #undef CTG_STEM_GO
     }
 #define CTG_STEM_CASE(P1, P2, R, CS)                               \
-    if (p1 == P1 && p2 == P2 && rt1 == R && cs1 == CS) return launch_stem2_t<P1, P2, R, CS, 0, 0>(p, stream);
+    if (s.p1 == P1 && s.p2 == P2 && s.rt1 == R && s.cs1 == CS) return launch_stem2_t<P1, P2, R, CS, 0, 0>(p, stream);
 #define CTG_STEM_CASES(P2)             \
     CTG_STEM_CASE(true, P2, 1, 1)      \
     CTG_STEM_CASE(true, P2, 2, 1)      \

@@ -3,7 +3,7 @@
 # variant library (tools/build_variants.py ko*=-DCTG_STEM_KO_...), fused steps only.
 R=${GRAFT_REPO_ROOT:-$PWD}; O=$R/gpurun_out/${1:-stemko}; mkdir -p $O; cd $R
 T=tests/golden/trees/sycamore_m20_native.json
-for lib in cotengra_amd/lib/libctg_hip.so cotengra_amd/lib/exp/libctg_sko*.so; do
+for lib in cotengra_amd/lib/libctg_hip.so cotengra_amd/lib/exp/libctg_sk*.so; do
   n=$(basename $lib .so); n=${n#libctg_}
   CTG_LIB=$R/$lib timeout 200 python bench.py --tree $T --headline-only --no-cpu-baseline --steps 2 \
      --dump-steps $O/steps_$n.json > $O/bench_$n.log 2>&1
