@@ -637,7 +637,8 @@ bool stem2_supported(const StemArgs& p) {
     X(false, true, 1, 1, 1, 2, true, 4) X(false, false, 1, 2, 2, 4, true, 0) X(false, false, 1, 1, 4, 1, false, 8) \
     X(false, false, 1, 1, 1, 1, true, 8) X(false, true, 1, 1, 8, 2, false, 4) X(false, true, 1, 2, 2, 1, true, 8)  \
     X(false, false, 1, 1, 1, 2, true, 0) X(true, false, 2, 1, 1, 1, true, 0) X(true, false, 1, 1, 1, 1, true, 4)   \
-    X(false, false, 1, 1, 2, 4, true, 0) X(true, true, 2, 1, 4, 1, true, 8)
+    X(false, false, 1, 1, 2, 4, true, 0) X(true, true, 2, 1, 4, 1, true, 8)                                        \
+    X(true, true, 2, 1, 1, 2, true, 4) X(true, false, 2, 1, 1, 2, true, 0)
 
 namespace {
 struct StemShape {

@@ -192,12 +192,16 @@ def geometry(size_dict, A, B1, B2, c1_inds, c2_inds):
             continue
         ng2 = max(1, N2 // 32)
         items = (rows2 // 32) * ng2
-        cand = (min(items, WAVES), -nr1, nr1, nx, rows2_bits, ng2, items, lds)
+        # a 16-deep first contraction is ONE 4 KB task per wave and tile: twice the rows
+        # (two tasks per wave in flight) keep the memory system busier -- 4 KB per wave are
+        # 32 KB per CU, below what the latency-bandwidth product of HBM asks for
+        deep = 1 if (K1 == 16 and units == 2 * WAVES) else 0
+        cand = (min(items, WAVES), deep, -nr1, nr1, nx, rows2_bits, ng2, items, lds)
         if best is None or cand > best:
             best = cand
     if best is None:
         return None
-    _, _, nr1, nx, rows2_bits, ng2, items, lds = best
+    _, _, _, nr1, nx, rows2_bits, ng2, items, lds = best
     g = Geometry()
     g.K1, g.N1, g.K2, g.N2 = K1, N1, K2, N2
     g.nr1, g.rows2_bits, g.ng2, g.items, g.lds = nr1, rows2_bits, ng2, items, lds
