@@ -228,11 +228,17 @@ __global__ __launch_bounds__(SW * 64, 1) void stem2_kernel(StemArgs p) {
     // register-resident B fragments: [quad][X | Y]
     f32x4 b1r[BR1 ? NCH * 4 : 1][PACK1 ? 1 : 2];
     f32x4 b2r[K2Q > 0 ? K2Q : 1][PACK2 ? 1 : 2];
+    // (the X tile's sign -- A' = (Re a, -Im a) -- is folded into the register copy: the lanes of
+    // the second k-row hold -Im b instead, and the loop feeds A' = (Re a, Im a) to both tiles)
     if constexpr (BR1) {
 #pragma unroll
         for (int q = 0; q < NCH * 4; ++q) {
             b1r[q][0] = *(const f32x4*)(b1x + 4 * q);
-            if (!PACK1) b1r[q][1] = *(const f32x4*)(b1y + 4 * q);
+            if (!PACK1) {
+                b1r[q][1] = *(const f32x4*)(b1y + 4 * q);
+#pragma unroll
+                for (int t = 0; t < 4; ++t) b1r[q][0][t] = flip(b1r[q][0][t], sgn);
+            }
         }
     }
     if constexpr (K2Q > 0) {
@@ -241,7 +247,11 @@ __global__ __launch_bounds__(SW * 64, 1) void stem2_kernel(StemArgs p) {
 #pragma unroll
         for (int q = 0; q < K2Q; ++q) {
             b2r[q][0] = *(const f32x4*)(b2x + cg0 * 32 * LDB2 + 4 * q);
-            if (!PACK2) b2r[q][1] = *(const f32x4*)(b2y + cg0 * 32 * LDB2 + 4 * q);
+            if (!PACK2) {
+                b2r[q][1] = *(const f32x4*)(b2y + cg0 * 32 * LDB2 + 4 * q);
+#pragma unroll
+                for (int t = 0; t < 4; ++t) b2r[q][0][t] = flip(b2r[q][0][t], sgn);
+            }
         }
     }
     float* As = stage + wave * STAGE_FLOATS;
@@ -353,7 +363,7 @@ __global__ __launch_bounds__(SW * 64, 1) void stem2_kernel(StemArgs p) {
                 if (PACK1) {
                     ax[m] = mfma(af[kq & 1][t], bx[kq & 1][t], ax[m]);
                 } else {
-                    ax[m] = mfma(flip(af[kq & 1][t], sgn), bx[kq & 1][t], ax[m]);
+                    ax[m] = mfma(BR1 ? af[kq & 1][t] : flip(af[kq & 1][t], sgn), bx[kq & 1][t], ax[m]);
                     ay[m] = mfma(af[kq & 1][t], by[kq & 1][t], ay[m]);
                 }
             }
@@ -419,7 +429,7 @@ __global__ __launch_bounds__(SW * 64, 1) void stem2_kernel(StemArgs p) {
                     if (PACK2) {
                         cx = mfma(af[kq & 1][t], b2r[kq][0][t], cx);
                     } else {
-                        cx = mfma(flip(af[kq & 1][t], sgn), b2r[kq][0][t], cx);
+                        cx = mfma(af[kq & 1][t], b2r[kq][0][t], cx);   // (sign in b2r)
                         cy = mfma(af[kq & 1][t], b2r[kq][PACK2 ? 0 : 1][t], cy);
                     }
                 }
