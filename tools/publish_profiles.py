@@ -32,6 +32,17 @@ for a, b in pairs.items():
         print("missing", a)
 line = json.loads(open(os.path.join(SRC, "bench_line.json")).read())
 r = line["roofline"]
+if r.get("traffic") is None:
+    # bench.py ran before this run's counter passes were summarised (it reads the COMMITTED
+    # summary, whose kernel names may predate a kernel change): resolve the dominant kernel's
+    # HBM bytes per launch from the passes of the same final_measure.sh run
+    pm = os.path.join(SRC, "pmc_summary_%s.json" % os.path.splitext(os.path.basename(line["config"]["tree"]))[0])
+    kv = json.load(open(pm)).get("kernels", {}).get(r["kernel"]) if os.path.exists(pm) else None
+    if kv:
+        r["traffic"] = kv["hbm_bytes_per_launch"]
+        r["traffic_source"] = ("profiles/%s (separate --pmc passes of this tree in the same tools/final_measure.sh "
+                               "run as this line; filled in by tools/publish_profiles.py)" % os.path.basename(pm))
+        json.dump(line, open(os.path.join(DST, f"{tag}_bench_line.json"), "w"))
 print(f"value {line['value']:.4e} {line['unit']}  {line['ms_per_step']:.1f} ms/step  est total {line['est_time_total_s']:.3e} s")
 print(f"dominant {r['kernel']}: {r['achieved']:.1f} {r['unit']} frac {r['frac']:.3f} share {r['share_of_slice_time']:.2f}")
 print("mixed:", r["mixed_per_step"])
