@@ -42,13 +42,14 @@ enum StemWord {
     SW_MAGIC = 0, SW_K1 = 1, SW_N1 = 2, SW_K2 = 3, SW_N2 = 4, SW_NR1 = 5, SW_ROWS2 = 6, SW_NG2 = 7,
     SW_NTILES = 8, SW_GLO = 9, SW_LD2 = 10, SW_LDS = 11,
     SW_B2_SPACE = 12, SW_B2_OFF = 13, SW_B2_LEAF = 14, SW_B2_SIZE = 15, SW_B2_PROD = 16,
-    SW_TABS = 20,   // 14 table offsets: gA_hi gA_lo gC_hi gC_lo ord lane_a rt_a chunk_a
+    SW_VEC = 17,    // 1: slots 2 q, 2 q + 1 of a task are adjacent in memory (one 16-byte load)
+    SW_TABS = 20,   // 14 table offsets: gA_hi gA_lo gC_hi gC_lo kj_a lane_a rt_a chunk_a
                     //                   b1_off b2_off mid_row mid_col out_row out_col
     STEM_WORDS = 40
 };
-constexpr int64_t STEM_MAGIC = 0x53544D32;
+constexpr int64_t STEM_MAGIC = 0x53544D33;
 enum StemTab {
-    ST_GA_HI = 0, ST_GA_LO, ST_GC_HI, ST_GC_LO, ST_ORD, ST_LANE_A, ST_RT_A, ST_CHUNK_A,
+    ST_GA_HI = 0, ST_GA_LO, ST_GC_HI, ST_GC_LO, ST_KJ_A, ST_LANE_A, ST_RT_A, ST_CHUNK_A,
     ST_B1_OFF, ST_B2_OFF, ST_MID_ROW, ST_MID_COL, ST_OUT_ROW, ST_OUT_COL, ST_COUNT
 };
 enum Kernel { KERNEL_VALU = 0, KERNEL_MFMA = 1 };
@@ -127,12 +128,13 @@ struct StemArgs {
     int64_t n_tiles, g_lo;
     int32_t g_lo_shift;
     int32_t check_zero;
+    int32_t vec;        // 16-byte gathers (SW_VEC)
     const int64_t* gA_hi;
     const int64_t* gA_lo;
     const int64_t* gC_hi;
     const int64_t* gC_lo;
-    const int64_t* ord;
-    const int64_t* lane_a;
+    const int64_t* kj_a;     // [8]  slot j of a task: k = 2 j
+    const int64_t* lane_a;   // [64] lane part of a task's addresses (row l & 31, k parity l >> 5)
     const int64_t* rt_a;
     const int64_t* chunk_a;
     const int64_t* b1_off;

@@ -100,7 +100,7 @@ int validate_stem(const ctg_plan* p, int64_t s) {
     if (n_tiles < 1 || g_lo < 1 || log2_exact(g_lo) < 0 || n_tiles % g_lo != 0 || log2_exact(n_tiles) < 0)
         return fail(CTG_E_INVALID, "step %lld: bad stem grid", sl);
     const int64_t rows1 = 1ll << nr1;
-    const int64_t len[ST_COUNT] = {n_tiles / g_lo, g_lo, n_tiles / g_lo, g_lo, 512, 256, rows1 / 32, K1 / 16,
+    const int64_t len[ST_COUNT] = {n_tiles / g_lo, g_lo, n_tiles / g_lo, g_lo, 8, 64, rows1 / 32, K1 / 16,
                                    K1 * N1, K2 * N2, rows1, N1, rows2, N2};
     int64_t mx[ST_COUNT], mn[ST_COUNT];
     for (int t = 0; t < ST_COUNT; ++t) {
@@ -109,22 +109,30 @@ int validate_stem(const ctg_plan* p, int64_t s) {
         mx[t] = tab_max(p, h[SW_TABS + t], len[t], &mn[t]);
         if (mn[t] < 0) return fail(CTG_E_BOUNDS, "step %lld: negative stem offset", sl);
     }
-    // the order table: every (row, k) of a 32 x 16 task exactly once
-    {
-        char seen[512] = {0};
-        for (int i = 0; i < 512; ++i) {
-            const int64_t v = p->tables[h[SW_TABS + ST_ORD] + i];
-            if (v < 0 || v >= 512 || seen[v])
-                return fail(CTG_E_INVALID, "step %lld: bad stem order table", sl);
-            seen[v] = 1;
-        }
+    // the lane part of a gather address is a 32-bit byte offset in the kernel
+    if (mx[ST_LANE_A] >= (1ll << 29))
+        return fail(CTG_E_INVALID, "step %lld: stem lane offsets beyond 32 bits", sl);
+    if (h[SW_VEC] != 0 && h[SW_VEC] != 1) return fail(CTG_E_INVALID, "step %lld: bad stem gather mode", sl);
+    if (h[SW_VEC]) {
+        // 16-byte gathers: slot pairs adjacent, every address even
+        const int64_t* kj = &p->tables[h[SW_TABS + ST_KJ_A]];
+        for (int q = 0; q < 4; ++q)
+            if (kj[2 * q + 1] != kj[2 * q] + 1 || (kj[2 * q] & 1))
+                return fail(CTG_E_INVALID, "step %lld: stem slots not paired for 16-byte gathers", sl);
+        const int odd_tabs[5] = {ST_GA_HI, ST_GA_LO, ST_LANE_A, ST_RT_A, ST_CHUNK_A};
+        for (int t : odd_tabs)
+            for (int64_t i = 0; i < len[t]; ++i)
+                if (p->tables[h[SW_TABS + t] + i] & 1)
+                    return fail(CTG_E_INVALID, "step %lld: odd stem offset under 16-byte gathers", sl);
+        if ((r[W_A_OFF] & 1) || r[W_A_LEAF] >= 0)
+            return fail(CTG_E_INVALID, "step %lld: stem operand not aligned for 16-byte gathers", sl);
     }
     if (mx[ST_MID_ROW] + mx[ST_MID_COL] >= rows2 * (K2 + 4))
         return fail(CTG_E_BOUNDS, "step %lld: intermediate tile overflows its LDS", sl);
     struct Op { int64_t space, off, leaf, size, top; char name; };
     const Op ops[4] = {
         {r[W_A_SPACE], r[W_A_OFF], r[W_A_LEAF], r[W_A_SIZE],
-         mx[ST_GA_HI] + mx[ST_GA_LO] + mx[ST_RT_A] + mx[ST_CHUNK_A] + mx[ST_LANE_A] + 1, 'A'},
+         mx[ST_GA_HI] + mx[ST_GA_LO] + mx[ST_RT_A] + mx[ST_CHUNK_A] + mx[ST_KJ_A] + mx[ST_LANE_A], 'A'},
         {r[W_B_SPACE], r[W_B_OFF], r[W_B_LEAF], r[W_B_SIZE], mx[ST_B1_OFF], 'B'},
         {h[SW_B2_SPACE], h[SW_B2_OFF], h[SW_B2_LEAF], h[SW_B2_SIZE], mx[ST_B2_OFF], 'b'},
         {r[W_C_SPACE], r[W_C_OFF], r[W_C_LEAF], r[W_C_SIZE],
@@ -350,7 +358,8 @@ void resolve_args(ctg_exec* e) {
             q.g_lo = h[SW_GLO];
             q.g_lo_shift = log2_exact(q.g_lo);
             q.check_zero = e->check_zero;
-            const int64_t** tabs[ST_COUNT] = {&q.gA_hi, &q.gA_lo, &q.gC_hi, &q.gC_lo, &q.ord, &q.lane_a, &q.rt_a,
+            q.vec = (int)h[SW_VEC];
+            const int64_t** tabs[ST_COUNT] = {&q.gA_hi, &q.gA_lo, &q.gC_hi, &q.gC_lo, &q.kj_a, &q.lane_a, &q.rt_a,
                                               &q.chunk_a, &q.b1_off, &q.b2_off, &q.mid_row, &q.mid_col,
                                               &q.out_row, &q.out_col};
             for (int t = 0; t < ST_COUNT; ++t) *tabs[t] = T + h[SW_TABS + t];

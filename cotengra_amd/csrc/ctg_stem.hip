@@ -13,9 +13,9 @@
 // workgroup of 8 waves takes one grid value at a time:
 //
 //   step 1   wave w gathers rows [32 w, 32 w + 32) x K1 of the tile from HBM, 16 k at
-//            a time, in address-sorted 16-byte loads two tasks ahead, transposes
-//            them through its private LDS patch into fragments and multiplies by
-//            B1 (resident in LDS);
+//            a time (a task), STRAIGHT INTO MATRIX-CORE FRAGMENTS -- lane (row l & 31,
+//            k parity l >> 5) loads the 8 elements k = 2 j + (l >> 5), two tasks
+//            ahead -- and multiplies by B1 (fragments in registers or LDS);
 //   barrier  (every wave is done reading the previous tile's intermediate)
 //   scatter  the 32 x N1 accumulators go to the shared intermediate tile at
 //            mid_row[row] + mid_col[n] = row2 * (K2 + 4) + k2: the layout step 2
@@ -34,6 +34,10 @@
 // and Im of the same element -- an 8-byte store without any lane exchange.  With
 // 16 columns both halves share one tile (columns 16-31 = imaginary parts): A' =
 // (Re a, Im a), B' rows (Re b | Im b) and (-Im b | Re b), a third plane of 16 x K.
+// Step 2 pairs (Re a_k, Im a_k) in the two k-rows of one MFMA (its A' comes from LDS
+// planes); step 1 pairs (a_k, a_k+1) of the SAME component -- one MFMA for the real
+// parts of two k, one for the imaginary parts -- because that is the shape in which a
+// lane's 8-byte gather of one complex element IS a fragment: no LDS transpose of A.
 #include "ctg_common.h"
 
 #include <cstdio>
@@ -48,8 +52,6 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 namespace {
 
 constexpr int SW = 8;            // waves per workgroup
-constexpr int SLD = 16 + 4;      // staging row: 16 k + pad (floats)
-constexpr int STAGE_FLOATS = 2 * 32 * SLD;
 
 // Knock-out switches of experiment builds (tools/build_variants.py; results are wrong by
 // construction): what does the kernel cost without its matrix instructions / gathers /
@@ -76,15 +78,24 @@ __device__ __forceinline__ float flip(float v, unsigned mask) {
 
 // planes of a small operand in LDS: plane p, column n, k contiguous
 //   [np][N][K + 4], np = 2 (Re, Im) or 3 (Re, Im, -Im) for 16 columns
+// FRAG1 (the first step's operand): within a chunk of 16 k the values of k-row 0 come first,
+// then those of k-row 1, each in slot order -- the 8 values a lane multiplies with are two
+// 16-byte reads
+// (k-row h = k & 1, slot (k & 15) >> 1) -- with 16-byte gathers (vec) the k-row is bit 1 of k
+// and the slot ((k & 15) >> 2) * 2 + (k & 1), see cotengra_amd/stem.py: geometry
+template <bool FRAG1>
 __device__ __forceinline__ void load_b_planes(float* P, const c64* __restrict__ B, const int64_t* off, int K,
-                                              int N, bool pack, int tid) {
+                                              int N, bool pack, int tid, bool vec = false) {
     const int LDB = K + 4;
     for (int e = tid; e < K * N; e += SW * 64) {
         const int k = e / N, n = e - k * N;
+        const int h = vec ? (k >> 1) & 1 : k & 1;
+        const int slot = vec ? (((k & 15) >> 2) << 1) | (k & 1) : (k & 15) >> 1;
+        const int kp = FRAG1 ? (k & ~15) + h * 8 + slot : k;
         const c64 v = B[off[e]];
-        P[n * LDB + k] = v.re;
-        P[(N + n) * LDB + k] = v.im;
-        if (pack) P[(2 * N + n) * LDB + k] = -v.im;
+        P[n * LDB + kp] = v.re;
+        P[(N + n) * LDB + kp] = v.im;
+        if (pack) P[(2 * N + n) * LDB + kp] = -v.im;
     }
 }
 
@@ -116,13 +127,15 @@ __device__ __forceinline__ void settle(T& v) {
 // steady-state loop of ctg_pair_mfma.hip's streaming kernel).  NCH = 0: both counts are
 // run-time values (any shape; every wait drains the queue).
 // BR1: the B1 fragments of this wave's columns live in registers for the whole kernel
-// (2 K1 floats, K1 with 16 columns) -- K2Q > 0: likewise the B2 fragments of this wave's
-// column group, K2 = 4 K2Q known at compile time.  The fragments are the same for every
+// (K1 floats: Re and Im of the K1 / 2 values of k of the lane's parity) -- K2Q > 0: likewise
+// the B2 fragments of this wave's column group (2 K2 floats, K2 with 16 columns), K2 = 4 K2Q
+// known at compile time.  The fragments are the same for every
 // tile; re-reading them from LDS for every 8 MFMAs is a third of the kernel's LDS traffic
 // and, with the staging writes and the scatter in the same queue, cost 8 % of a slice
 // (knock-out CTG_STEM_KO_BFRAG, profiles/r3_stem_knockout.txt).  Chosen per shape by the
 // register budget (launch_stem2: at most 96 floats of B per lane).
-template <bool PACK1, bool PACK2, int RT1, int CS1, int NCH, int IT2, bool BR1 = false, int K2Q = 0>
+// VEC: A's stride-1 digit is a contracted one -- a lane gathers two adjacent k in one 16-byte load.
+template <bool PACK1, bool PACK2, int RT1, int CS1, int NCH, int IT2, bool BR1 = false, int K2Q = 0, bool VEC = false>
 __global__ __launch_bounds__(SW * 64, 1) void stem2_kernel(StemArgs p) {
     static_assert(!PACK1 || CS1 == 1, "16 columns are one group");
     static_assert(!BR1 || NCH > 0, "B1 in registers needs the chunk count at compile time");
@@ -136,8 +149,7 @@ __global__ __launch_bounds__(SW * 64, 1) void stem2_kernel(StemArgs p) {
     float* P1 = (float*)smem;                              // [2|3][N1][LDB1]
     float* P2 = P1 + (PACK1 ? 3 : 2) * N1 * LDB1;          // [2|3][N2][LDB2]
     float* mid = P2 + (PACK2 ? 3 : 2) * N2 * LDB2;         // [2][rows2][LD2]
-    float* stage = mid + 2 * PLANE;                        // [SW][2][32][SLD]
-    int64_t* oc_s = (int64_t*)(stage + SW * STAGE_FLOATS); // [N2] column offsets of the result
+    int64_t* oc_s = (int64_t*)(mid + 2 * PLANE);           // [N2] column offsets of the result
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -153,39 +165,35 @@ __global__ __launch_bounds__(SW * 64, 1) void stem2_kernel(StemArgs p) {
     const c64* __restrict__ B2 = (const c64*)p.B2 + (sload64(p.soffB2 + z * p.zsB2) + z * p.zB2);
     float* __restrict__ C = (float*)((c64*)p.C + (sload64(p.soffC + z * p.zsC) + z * p.zC));
 
-    load_b_planes(P1, B1, p.b1_off, K1, N1, PACK1, tid);
-    load_b_planes(P2, B2, p.b2_off, K2, N2, PACK2, tid);
+    load_b_planes<true>(P1, B1, p.b1_off, K1, N1, PACK1, tid, VEC);
+    load_b_planes<false>(P2, B2, p.b2_off, K2, N2, PACK2, tid);
     for (int n = tid; n < N2; n += SW * 64) oc_s[n] = p.out_col[n];
 
     // ---- per-lane constants ---------------------------------------------------
-    // gather: slot j of this lane is tile element (r, c) of a task; 16-byte load j
-    // fetches slots 2j, 2j + 1 (adjacent in memory)
-    int a_pk[8];
-    int64_t a_off[4];
+    // gather: this lane is (row l31, k parity kk) of every task; slot j = element k = 2 j + kk
+    // at  task base + kj[j] (uniform) + a_lane (bytes, 32 bits: the planner sees to it)
+    unsigned a_lane = (unsigned)(p.lane_a[lane] * 8);
+    settle(a_lane);
+    int64_t kj[8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        const int v = (int)p.ord[lane * 8 + j];
-        a_pk[j] = (v >> 4) * SLD + (v & 15);
-        settle(a_pk[j]);
-    }
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        a_off[j] = p.lane_a[lane * 4 + j];
-        settle(a_off[j]);
-    }
-    // fragments: A' is (Re, +-Im) by lane half; the sign of Im for the X tile
-    const unsigned sgn = kk ? 0x80000000u : 0u;
-    // B fragments of step 1: plane by (tile, lane half, column half)
-    const float* b1x;
-    const float* b1y = nullptr;
+    for (int j = 0; j < 8; ++j) kj[j] = sload64(p.kj_a + j);
+    // the X tile (real parts) takes Re a Re b - Im a Im b: the sign of Im a
+    const unsigned sgn = 0x80000000u;
+    // B fragments of step 1: the 8 values of a chunk this lane multiplies with, per plane.
+    //   32 columns: X += re * b1p + (-im) * b1q,  Y += re * b1q + im * b1p   (b1p = Re b, b1q = Im b)
+    //   16 columns: lanes 0-15 hold real parts (b1p = Re b, b1q = -Im b), lanes 16-31 imaginary
+    //   parts (b1p = Im b, b1q = Re b):  X += re * b1p + im * b1q
+    const float* b1p;
+    const float* b1q;
     if (PACK1) {
         const int n = l31 & 15, h = l31 >> 4;
-        const int plane = kk == 0 ? (h ? 1 : 0) : (h ? 0 : 2);
-        b1x = P1 + (plane * N1 + n) * LDB1;
+        b1p = P1 + ((h ? 1 : 0) * N1 + n) * LDB1 + kk * 8;
+        b1q = P1 + ((h ? 0 : 2) * N1 + n) * LDB1 + kk * 8;
     } else {
-        b1x = P1 + ((kk ? 1 : 0) * N1 + wcol + l31) * LDB1;
-        b1y = P1 + ((kk ? 0 : 1) * N1 + wcol + l31) * LDB1;
+        b1p = P1 + (wcol + l31) * LDB1 + kk * 8;
+        b1q = P1 + (N1 + wcol + l31) * LDB1 + kk * 8;
     }
+    const unsigned sgn2 = kk ? 0x80000000u : 0u;   // step 2: A' is (Re, +-Im) by lane half
     const float* b2x;
     const float* b2y = nullptr;
     if (PACK2) {
@@ -225,20 +233,17 @@ __global__ __launch_bounds__(SW * 64, 1) void stem2_kernel(StemArgs p) {
     f32x4 ko_b = *(const f32x4*)(P1 + 4 * (lane & 3));
     settle(ko_b);
 #endif
-    // register-resident B fragments: [quad][X | Y]
-    f32x4 b1r[BR1 ? NCH * 4 : 1][PACK1 ? 1 : 2];
+    // register-resident B fragments.  Step 1: [half chunk (4 slots)][b1p | b1q]; step 2:
+    // [quad][X | Y] -- there the X tile's sign (A' = (Re a, -Im a)) is folded into the register
+    // copy: the lanes of the second k-row hold -Im b instead, and the loop feeds A' = (Re a,
+    // Im a) to both tiles
+    f32x4 b1r[BR1 ? NCH * 2 : 1][2];
     f32x4 b2r[K2Q > 0 ? K2Q : 1][PACK2 ? 1 : 2];
-    // (the X tile's sign -- A' = (Re a, -Im a) -- is folded into the register copy: the lanes of
-    // the second k-row hold -Im b instead, and the loop feeds A' = (Re a, Im a) to both tiles)
     if constexpr (BR1) {
 #pragma unroll
-        for (int q = 0; q < NCH * 4; ++q) {
-            b1r[q][0] = *(const f32x4*)(b1x + 4 * q);
-            if (!PACK1) {
-                b1r[q][1] = *(const f32x4*)(b1y + 4 * q);
-#pragma unroll
-                for (int t = 0; t < 4; ++t) b1r[q][0][t] = flip(b1r[q][0][t], sgn);
-            }
+        for (int q = 0; q < NCH * 2; ++q) {
+            b1r[q][0] = *(const f32x4*)(b1p + (q >> 1) * 16 + (q & 1) * 4);
+            b1r[q][1] = *(const f32x4*)(b1q + (q >> 1) * 16 + (q & 1) * 4);
         }
     }
     if constexpr (K2Q > 0) {
@@ -250,11 +255,10 @@ __global__ __launch_bounds__(SW * 64, 1) void stem2_kernel(StemArgs p) {
             if (!PACK2) {
                 b2r[q][1] = *(const f32x4*)(b2y + cg0 * 32 * LDB2 + 4 * q);
 #pragma unroll
-                for (int t = 0; t < 4; ++t) b2r[q][0][t] = flip(b2r[q][0][t], sgn);
+                for (int t = 0; t < 4; ++t) b2r[q][0][t] = flip(b2r[q][0][t], sgn2);
             }
         }
     }
-    float* As = stage + wave * STAGE_FLOATS;
     const int nch = STATIC ? NCH : (K1 >> 4);        // 16-deep chunks of the first contraction
     const int n_rt2 = p.rows2 >> 5;
     const int n_items = n_rt2 * p.ng2;
@@ -269,8 +273,8 @@ __global__ __launch_bounds__(SW * 64, 1) void stem2_kernel(StemArgs p) {
     int im = 0, ic = 0;
     // prep: address of the next task to gather -- scalar loads, issued early (behind the
     // last MFMAs of the task before) so that their latency is nobody's problem;
-    // fire: the task's four 16-byte loads.  always_tag: unconditional (past the last tile
-    // the last one is fetched again: the steady state must not contain a conditional
+    // fire2: two of the task's eight elements.  always_tag: unconditional (past the last
+    // tile the last one is fetched again: the steady state must not contain a conditional
     // memory instruction)
     int64_t pend0 = 0, pend1 = 0, pend2 = 0, pend3 = 0;   // (summed where they are used)
     bool pend_live = false;
@@ -293,83 +297,75 @@ __global__ __launch_bounds__(SW * 64, 1) void stem2_kernel(StemArgs p) {
             }
         }
     };
-    auto fire = [&](c64 (&r)[8], auto always_tag) __attribute__((always_inline)) {
+    // slots 2 q, 2 q + 1 of a task: two 8-byte loads, or one 16-byte load when they are adjacent
+    auto fire2 = [&](c64 (&r)[8], int q, int64_t base, auto always_tag) __attribute__((always_inline)) {
         if (decltype(always_tag)::value || pend_live) {
-            const c64* src = A + (pend0 + pend1 + pend2 + pend3);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
 #ifdef CTG_STEM_KO_GATHER
-                const f32x4 v = {(float)(uintptr_t)src, 1.f, 2.f, (float)a_off[j]};
+            r[2 * q] = c64{(float)(base + kj[2 * q]), (float)a_lane};
+            r[2 * q + 1] = c64{(float)(base + kj[2 * q + 1]), (float)a_lane};
 #else
-                const f32x4 v = *(const f32x4*)(src + a_off[j]);
-#endif
-                r[2 * j] = c64{v[0], v[1]};
-                r[2 * j + 1] = c64{v[2], v[3]};
+            const char* sb = (const char*)(A + (base + kj[2 * q]));   // uniform: the load's scalar base
+            if (VEC) {
+                const f32x4 v = *(const f32x4*)(sb + a_lane);
+                r[2 * q] = c64{v[0], v[1]};
+                r[2 * q + 1] = c64{v[2], v[3]};
+            } else {
+                const char* sb1 = (const char*)(A + (base + kj[2 * q + 1]));
+                const float2 v0 = *(const float2*)(sb + a_lane);
+                const float2 v1 = *(const float2*)(sb1 + a_lane);
+                r[2 * q] = c64{v0.x, v0.y};
+                r[2 * q + 1] = c64{v1.x, v1.y};
             }
+#endif
         }
     };
     auto issue = [&](c64 (&r)[8], auto always_tag) __attribute__((always_inline)) {
         prep(always_tag);
-        fire(r, always_tag);
+        const int64_t base = pend0 + pend1 + pend2 + pend3;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) fire2(r, q, base, always_tag);
     };
 
     f32x16 ax[RT1], ay[RT1];
-    // one task: registers -> wave-private LDS (fragment layout), refill, 16 k of MFMAs
+    // one task: 16 k of MFMAs on the gathered registers, each register refilled (two tasks
+    // ahead) as soon as the MFMAs reading it have been issued
     auto consume = [&](c64 (&r)[8], int m, int ch, auto always_tag) __attribute__((always_inline)) {
-        __builtin_amdgcn_wave_barrier();
+        const int64_t base = pend0 + pend1 + pend2 + pend3;   // of the task two ahead (prep of the task before)
+        f32x4 bp[2], bq[2];
+        if constexpr (BR1) {   // (ch is a compile-time constant here: static variants only)
+            bp[0] = b1r[ch * 2][0];
+            bp[1] = b1r[ch * 2 + 1][0];
+            bq[0] = b1r[ch * 2][1];
+            bq[1] = b1r[ch * 2 + 1][1];
+        } else {
+#ifdef CTG_STEM_KO_BFRAG   // (knock-out: B fragments from registers instead of LDS)
+            bp[0] = bp[1] = bq[0] = bq[1] = ko_b;
+#else
+            bp[0] = *(const f32x4*)(b1p + ch * 16);
+            bq[0] = *(const f32x4*)(b1q + ch * 16);
+            bp[1] = *(const f32x4*)(b1p + ch * 16 + 4);
+            bq[1] = *(const f32x4*)(b1q + ch * 16 + 4);
+#endif
+        }
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            As[a_pk[j]] = r[j].re;
-            As[32 * SLD + a_pk[j]] = r[j].im;
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        __builtin_amdgcn_sched_barrier(0);   // (the address sum of prep() stays behind the LDS writes)
-        fire(r, always_tag);    // refill this register set two tasks ahead
-        const float* a_base = As + kk * 32 * SLD + l31 * SLD;
-        const float* bxp = b1x + ch * 16;
-        const float* byp = PACK1 ? nullptr : b1y + ch * 16;
-        // fragments of quad q + 1 are read before the MFMAs of quad q are issued
-        f32x4 af[2], bx[2], by[2];
-        af[0] = *(const f32x4*)(a_base);
-#ifdef CTG_STEM_KO_BFRAG   // (knock-out: B fragments from registers instead of LDS)
-        bx[0] = bx[1] = ko_b;
-        by[0] = by[1] = ko_b;
-#else
-        if constexpr (!BR1) {
-            bx[0] = *(const f32x4*)(bxp);
-            if (!PACK1) by[0] = *(const f32x4*)(byp);
-        }
-#endif
-#pragma unroll
-        for (int kq = 0; kq < 4; ++kq) {
-            if (kq + 1 < 4) {
-                af[(kq + 1) & 1] = *(const f32x4*)(a_base + (kq + 1) * 4);
-#ifndef CTG_STEM_KO_BFRAG
-                if constexpr (!BR1) {
-                    bx[(kq + 1) & 1] = *(const f32x4*)(bxp + (kq + 1) * 4);
-                    if (!PACK1) by[(kq + 1) & 1] = *(const f32x4*)(byp + (kq + 1) * 4);
-                }
-#endif
-            }
-            if constexpr (BR1) {   // (ch is a compile-time constant here: static variants only)
-                bx[kq & 1] = b1r[ch * 4 + kq][0];
-                if (!PACK1) by[kq & 1] = b1r[ch * 4 + kq][PACK1 ? 0 : 1];
+            const float re = r[j].re, im = r[j].im;
+            const float p_ = bp[j >> 2][j & 3], q_ = bq[j >> 2][j & 3];
+            __builtin_amdgcn_sched_barrier(0);
+            if (PACK1) {
+                ax[m] = mfma(re, p_, ax[m]);
+                ax[m] = mfma(im, q_, ax[m]);
+            } else {
+                ax[m] = mfma(re, p_, ax[m]);
+                ay[m] = mfma(re, q_, ay[m]);
+                ax[m] = mfma(flip(im, sgn), q_, ax[m]);
+                ay[m] = mfma(im, p_, ay[m]);
             }
             __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                if (PACK1) {
-                    ax[m] = mfma(af[kq & 1][t], bx[kq & 1][t], ax[m]);
-                } else {
-                    ax[m] = mfma(BR1 ? af[kq & 1][t] : flip(af[kq & 1][t], sgn), bx[kq & 1][t], ax[m]);
-                    ay[m] = mfma(af[kq & 1][t], by[kq & 1][t], ay[m]);
-                }
-            }
-            __builtin_amdgcn_sched_barrier(0);
+            if (j & 1) fire2(r, j >> 1, base, always_tag);
         }
-        prep(always_tag);   // (behind the last MFMAs: nothing of this task waits for LDS any more)
+        __builtin_amdgcn_sched_barrier(0);
+        prep(always_tag);   // (behind the last MFMAs)
         __builtin_amdgcn_sched_barrier(0);
     };
     auto zero_acc = [&](int m) __attribute__((always_inline)) {
@@ -459,7 +455,7 @@ __global__ __launch_bounds__(SW * 64, 1) void stem2_kernel(StemArgs p) {
                     if (PACK2) {
                         cx = mfma(af[h][t], bx[h][t], cx);
                     } else {
-                        cx = mfma(flip(af[h][t], sgn), bx[h][t], cx);
+                        cx = mfma(flip(af[h][t], sgn2), bx[h][t], cx);
                         cy = mfma(af[h][t], by[h][t], cy);
                     }
                 }
@@ -588,12 +584,12 @@ size_t stem2_lds_bytes(const StemArgs& p) {
     const size_t b1 = (size_t)(p.N1 == 16 ? 3 : 2) * p.N1 * (p.K1 + 4);
     const size_t b2 = (size_t)(p.N2 == 16 ? 3 : 2) * p.N2 * (p.K2 + 4);
     const size_t mid = (size_t)2 * p.rows2 * p.ld2;
-    return 4 * (b1 + b2 + mid + (size_t)SW * STAGE_FLOATS) + 8 * (size_t)p.N2;
+    return 4 * (b1 + b2 + mid) + 8 * (size_t)p.N2;
 }
 
-template <bool PACK1, bool PACK2, int RT1, int CS1, int NCH, int IT2, bool BR1 = false, int K2Q = 0>
+template <bool PACK1, bool PACK2, int RT1, int CS1, int NCH, int IT2, bool BR1 = false, int K2Q = 0, bool VEC = false>
 static hipError_t launch_stem2_t(const StemArgs& p, hipStream_t stream) {
-    auto kern = stem2_kernel<PACK1, PACK2, RT1, CS1, NCH, IT2, BR1, K2Q>;
+    auto kern = stem2_kernel<PACK1, PACK2, RT1, CS1, NCH, IT2, BR1, K2Q, VEC>;
     static bool ready = false;
     if (!ready) {
         const hipError_t e =
@@ -625,30 +621,30 @@ bool stem2_supported(const StemArgs& p) {
     return stem2_lds_bytes(p) <= 160 * 1024;
 }
 
-// static instantiations: (16 columns first, 16 columns last, units per wave, column groups
-// of step 1, chunks of K1, items per wave) of the pairs the Sycamore m20 trees are made of
-// (tools/stem_shapes.py lists them); anything else runs on the run-time-count variant
-#define CTG_STEM_STATIC(X)                                                                   \
-    X(false, false, 1, 1, 1, 2) X(false, false, 1, 1, 2, 1) X(false, false, 1, 1, 2, 2)       \
-    X(false, false, 1, 1, 4, 1) X(false, false, 1, 1, 4, 2) X(false, false, 1, 1, 8, 1)       \
-    X(false, false, 1, 2, 1, 1) X(false, false, 1, 2, 2, 1) X(false, false, 1, 2, 4, 1)       \
-    X(false, false, 1, 2, 4, 2) X(false, false, 1, 2, 2, 2)                                   \
-    X(false, true, 1, 1, 2, 2) X(false, true, 1, 1, 4, 2) X(false, true, 1, 2, 4, 2)          \
-    X(true, false, 2, 1, 1, 1) X(true, false, 2, 1, 2, 1) X(true, false, 2, 1, 4, 1)          \
-    X(true, true, 1, 1, 1, 1) X(true, true, 2, 1, 4, 1) X(true, true, 2, 1, 1, 2)
-
-// the same with the small operands' fragments in registers: (..., B1 in registers, K2 / 4 if
-// B2 is, else 0) -- tools/stem_shapes.py lists what the m20 trees need
-#define CTG_STEM_BREG(X)                                                                              \
-    X(false, false, 1, 1, 2, 1, true, 0) X(false, false, 1, 2, 4, 1, false, 8) X(false, true, 1, 1, 2, 2, true, 4) \
-    X(true, true, 1, 1, 1, 1, true, 4) X(true, false, 2, 1, 1, 1, true, 8) X(false, false, 1, 1, 2, 2, true, 0)     \
-    X(true, false, 1, 1, 1, 1, true, 8) X(false, false, 1, 1, 8, 1, false, 8) X(false, true, 1, 2, 4, 2, false, 4) \
-    X(false, false, 1, 2, 2, 1, true, 0) X(false, false, 1, 2, 1, 1, true, 8) X(false, true, 1, 2, 2, 2, true, 4)   \
-    X(false, true, 1, 1, 1, 2, true, 4) X(false, false, 1, 2, 2, 4, true, 0) X(false, false, 1, 1, 4, 1, false, 8) \
-    X(false, false, 1, 1, 1, 1, true, 8) X(false, true, 1, 1, 8, 2, false, 4) X(false, true, 1, 2, 2, 1, true, 8)  \
-    X(false, false, 1, 1, 1, 2, true, 0) X(true, false, 2, 1, 1, 1, true, 0) X(true, false, 1, 1, 1, 1, true, 4)   \
-    X(false, false, 1, 1, 2, 4, true, 0) X(true, true, 2, 1, 4, 1, true, 8)                                        \
-    X(true, true, 2, 1, 1, 2, true, 4) X(true, false, 2, 1, 1, 2, true, 0)
+// static instantiations: (16 columns first, 16 columns last, units per wave, column groups of
+// step 1, chunks of K1, items per wave, B1 in registers, K2 / 4 if B2 is (else 0), 16-byte
+// gathers) of the pairs the Sycamore m20 trees are made of (tools/stem_shapes.py lists them);
+// anything else runs on the run-time-count variant
+#define CTG_STEM_INST(X) \
+    X(false, false, 1, 1, 2, 1, true, 8, false) X(false, false, 1, 1, 2, 1, true, 0, false) \
+    X(false, false, 1, 2, 4, 1, true, 0, true) X(false, true, 1, 1, 2, 2, true, 4, false) \
+    X(false, false, 1, 2, 4, 1, true, 0, false) X(true, true, 2, 1, 1, 2, true, 4, false) \
+    X(true, false, 2, 1, 1, 1, true, 8, false) X(false, false, 1, 2, 2, 1, true, 0, false) \
+    X(false, false, 1, 1, 2, 2, true, 0, false) X(false, false, 1, 1, 8, 1, false, 8, false) \
+    X(false, true, 1, 2, 4, 2, true, 4, false) X(false, false, 1, 2, 2, 1, true, 8, false) \
+    X(true, false, 2, 1, 1, 2, true, 0, false) X(false, false, 1, 2, 4, 2, true, 0, false) \
+    X(false, true, 1, 1, 2, 2, true, 4, true) X(true, false, 2, 1, 1, 1, true, 8, true) \
+    X(false, false, 1, 2, 1, 1, true, 8, false) X(true, false, 2, 1, 1, 2, true, 0, true) \
+    X(false, true, 1, 2, 2, 2, true, 4, false) X(false, true, 1, 1, 1, 2, true, 4, false) \
+    X(true, true, 2, 1, 1, 2, true, 4, true) X(false, false, 1, 2, 2, 4, true, 0, true) \
+    X(false, false, 1, 1, 4, 1, true, 0, true) X(false, false, 2, 1, 1, 2, true, 0, false) \
+    X(false, false, 1, 1, 2, 1, true, 8, true) X(false, false, 1, 1, 4, 1, true, 0, false) \
+    X(false, true, 1, 2, 2, 1, true, 8, false) X(false, false, 1, 1, 1, 2, true, 0, false) \
+    X(false, true, 1, 4, 4, 2, true, 4, true) X(false, true, 1, 1, 8, 2, false, 4, true) \
+    X(true, false, 2, 1, 1, 1, true, 0, false) X(false, true, 1, 1, 8, 2, false, 4, false) \
+    X(false, false, 1, 1, 2, 4, true, 0, false) X(true, true, 2, 1, 4, 1, true, 8, false) \
+    X(false, false, 1, 1, 8, 1, false, 8, true) X(false, false, 1, 1, 8, 1, false, 0, false) \
+    X(false, false, 1, 1, 8, 1, false, 0, true)
 
 namespace {
 struct StemShape {
@@ -656,10 +652,11 @@ struct StemShape {
     int rt1, cs1, nch, it2;   // it2 = 0: the item count is not a multiple of the waves
     bool br1;
     int k2q;
+    bool vec;
 };
-// Which small operand's fragments go to registers: B1 needs 2 K1 floats per lane (K1 with 16
-// columns) and K1 <= 32 (64); B2 2 K2 (K2) and one column group per wave (always with 16 columns,
-// else one item per wave) and K2 <= 32 (64); together at most 96 -- B1 first.
+// Which small operand's fragments go to registers: B1 needs K1 floats per lane, K1 <= 64; B2
+// 2 K2 (K2 with 16 columns) and one column group per wave (always with 16 columns, else one
+// item per wave) and K2 <= 32 (64); together at most 96 -- B1 first.
 StemShape stem2_shape(const StemArgs& p) {
     StemShape s;
     s.p1 = p.N1 == 16;
@@ -669,29 +666,25 @@ StemShape stem2_shape(const StemArgs& p) {
     s.nch = p.K1 / 16;
     const int items = (p.rows2 / 32) * p.ng2;
     s.it2 = items % SW == 0 ? items / SW : 0;
-    int r1 = (s.p1 ? p.K1 <= 64 : p.K1 <= 32) ? (s.p1 ? p.K1 : 2 * p.K1) : 0;
+    int r1 = p.K1 <= 64 ? p.K1 : 0;
     int r2 = ((s.p2 && p.K2 <= 64) || (!s.p2 && s.it2 == 1 && p.K2 <= 32)) ? (s.p2 ? p.K2 : 2 * p.K2) : 0;
     if (r1 && r2 && r1 + r2 > 96) r2 = 0;
-    if (getenv("CTG_STEM_NO_BREG")) r1 = r2 = 0;
     s.br1 = r1 != 0;
     s.k2q = r2 ? p.K2 / 4 : 0;
+    s.vec = p.vec != 0;
     return s;
 }
 }  // namespace
 
-// 2: static with register fragments, 1: static, 0: run-time counts
+// 1: static (counts known at compile time, fragments in registers where they fit), 0: run-time counts
 int stem2_variant(const StemArgs& p) {
     const StemShape s = stem2_shape(p);
     if (getenv("CTG_STEM_GENERIC") != nullptr || s.it2 == 0) return 0;
-#define CTG_STEM_HAS(P1, P2, R, CS, NC, IT, B1, KQ)                                                    \
+#define CTG_STEM_HAS(P1, P2, R, CS, NC, IT, B1, KQ, V)                                                 \
     if (s.p1 == P1 && s.p2 == P2 && s.rt1 == R && s.cs1 == CS && s.nch == NC && s.it2 == IT && s.br1 == B1 && \
-        s.k2q == KQ)                                                                                   \
-        return 2;
-    CTG_STEM_BREG(CTG_STEM_HAS)
-#undef CTG_STEM_HAS
-#define CTG_STEM_HAS(P1, P2, R, CS, NC, IT) \
-    if (s.p1 == P1 && s.p2 == P2 && s.rt1 == R && s.cs1 == CS && s.nch == NC && s.it2 == IT) return 1;
-    CTG_STEM_STATIC(CTG_STEM_HAS)
+        s.k2q == KQ && s.vec == V)                                                                     \
+        return 1;
+    CTG_STEM_INST(CTG_STEM_HAS)
 #undef CTG_STEM_HAS
     return 0;
 }
@@ -699,36 +692,29 @@ int stem2_variant(const StemArgs& p) {
 // the instantiation a step runs on, spelled like its symbol in a kernel trace
 void stem2_kernel_name(const StemArgs& p, char* buf, size_t n) {
     const StemShape s = stem2_shape(p);
-    const int v = stem2_variant(p);
-    if (v == 2)
-        snprintf(buf, n, "stem2_kernel<%s,%s,%d,%d,%d,%d,%s,%d>", s.p1 ? "true" : "false", s.p2 ? "true" : "false",
-                 s.rt1, s.cs1, s.nch, s.it2, s.br1 ? "true" : "false", s.k2q);
+    auto tf = [](bool b) { return b ? "true" : "false"; };
+    if (stem2_variant(p))
+        snprintf(buf, n, "stem2_kernel<%s,%s,%d,%d,%d,%d,%s,%d,%s>", tf(s.p1), tf(s.p2), s.rt1, s.cs1, s.nch, s.it2,
+                 tf(s.br1), s.k2q, tf(s.vec));
     else
-        snprintf(buf, n, "stem2_kernel<%s,%s,%d,%d,%d,%d,false,0>", s.p1 ? "true" : "false",
-                 s.p2 ? "true" : "false", s.rt1, s.cs1, v ? s.nch : 0, v ? s.it2 : 0);
+        snprintf(buf, n, "stem2_kernel<%s,%s,%d,%d,0,0,false,0,%s>", tf(s.p1), tf(s.p2), s.rt1, s.cs1, tf(s.vec));
 }
 
 hipError_t launch_stem2(const StemArgs& p, hipStream_t stream) {
     if (!stem2_supported(p)) return hipErrorInvalidValue;
     const StemShape s = stem2_shape(p);
-    const int v = stem2_variant(p);
-    if (v == 2) {
-#define CTG_STEM_GO(P1, P2, R, CS, NC, IT, B1, KQ)                                                     \
+    if (stem2_variant(p)) {
+#define CTG_STEM_GO(P1, P2, R, CS, NC, IT, B1, KQ, V)                                                  \
     if (s.p1 == P1 && s.p2 == P2 && s.rt1 == R && s.cs1 == CS && s.nch == NC && s.it2 == IT && s.br1 == B1 && \
-        s.k2q == KQ)                                                                                   \
-        return launch_stem2_t<P1, P2, R, CS, NC, IT, B1, KQ>(p, stream);
-        CTG_STEM_BREG(CTG_STEM_GO)
+        s.k2q == KQ && s.vec == V)                                                                     \
+        return launch_stem2_t<P1, P2, R, CS, NC, IT, B1, KQ, V>(p, stream);
+        CTG_STEM_INST(CTG_STEM_GO)
 #undef CTG_STEM_GO
     }
-    if (v == 1) {
-#define CTG_STEM_GO(P1, P2, R, CS, NC, IT)                                                  \
-    if (s.p1 == P1 && s.p2 == P2 && s.rt1 == R && s.cs1 == CS && s.nch == NC && s.it2 == IT) \
-        return launch_stem2_t<P1, P2, R, CS, NC, IT>(p, stream);
-        CTG_STEM_STATIC(CTG_STEM_GO)
-#undef CTG_STEM_GO
-    }
-#define CTG_STEM_CASE(P1, P2, R, CS)                               \
-    if (s.p1 == P1 && s.p2 == P2 && s.rt1 == R && s.cs1 == CS) return launch_stem2_t<P1, P2, R, CS, 0, 0>(p, stream);
+#define CTG_STEM_CASE(P1, P2, R, CS)                                                                    \
+    if (s.p1 == P1 && s.p2 == P2 && s.rt1 == R && s.cs1 == CS)                                          \
+        return s.vec ? launch_stem2_t<P1, P2, R, CS, 0, 0, false, 0, true>(p, stream)                   \
+                     : launch_stem2_t<P1, P2, R, CS, 0, 0, false, 0, false>(p, stream);
 #define CTG_STEM_CASES(P2)             \
     CTG_STEM_CASE(true, P2, 1, 1)      \
     CTG_STEM_CASE(true, P2, 2, 1)      \

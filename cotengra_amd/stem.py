@@ -16,8 +16,8 @@ run over *tiles*: the index bits of ``A`` are split into tile bits -- all of
 ``k1``, the part of ``k2`` that lives on ``A`` (``k2r``), and the lowest-stride
 bits of ``A`` that fill a tile up to 256 rows (``X``) -- and grid bits ``G``.
 One workgroup (8 waves) takes one value of ``G`` at a time: every wave gathers
-32 rows x K1 of its tile straight from HBM (address-sorted 16-byte loads) and
-multiplies by ``B1`` on the matrix cores; the 256 x N1 result goes to LDS laid
+32 rows x K1 of its tile from HBM straight into matrix-core fragments (a lane =
+one row and one of the two k-rows of the instruction) and multiplies by ``B1``; the 256 x N1 result goes to LDS laid
 out as the second step's operand ``[r2][k2]``; the second step reads its
 fragments from there and stores ``C2``.  HBM sees ``A`` once and ``C2`` once.
 
@@ -41,11 +41,10 @@ from . import plan as P
 WAVES = 8                    # waves of a workgroup = row tiles of step 1 in flight
 LDS_BYTES = 160 * 1024       # per CU (one workgroup per CU)
 LDS_SLACK = 256
-STAGE_BYTES = WAVES * 2 * 32 * (16 + 4) * 4   # wave-private A staging: [2 planes][32 rows][16 k + 4]
 G_LO_BITS = 12               # fast level of the two-level grid tables
 
 DESC_WORDS = 40              # header of the serialised descriptor (int64 words)
-DESC_MAGIC = 0x53544D32      # "STM2"
+DESC_MAGIC = 0x53544D33      # "STM3"
 
 # what the kernel is instantiated for (csrc/ctg_stem.hip: launch_stem2)
 K_OK = (16, 32, 64, 128)
@@ -56,8 +55,8 @@ N2_OK = (16, 32, 64, 128)
 # (tools/exp_stem_ko.sh, profiles/r3_stem_knockout.txt): without its memory traffic the
 # kernel runs its matrix work at 0.73 of the 157.3 TFLOP/s peak; without its MFMAs it
 # moves A at a rate set by how many bytes of a wave's 32 x 16 task are contiguous in
-# memory (a tile that has no room for A's lowest-stride digits gathers in 32-byte
-# pieces), C2 at the full rate; together they take the longer of the two plus a fifth
+# memory (a tile that has no room for A's lowest-stride digits uses 32-byte pieces of
+# the lines it fetches), C2 at the full rate; together they take the longer of the two plus a fifth
 # of the shorter.
 FUSED_MFMA_RATE = 157.3e12 * 0.73
 FUSED_STORE_RATE = 5.4e12
@@ -187,7 +186,7 @@ def geometry(size_dict, A, B1, B2, c1_inds, c2_inds):
             continue
         rows2 = 1 << rows2_bits
         mid_bytes = 2 * rows2 * (K2 + 4) * 4
-        lds = STAGE_BYTES + mid_bytes + b_lds_bytes(K1, N1) + b_lds_bytes(K2, N2) + 8 * N2 + LDS_SLACK
+        lds = mid_bytes + b_lds_bytes(K1, N1) + b_lds_bytes(K2, N2) + 8 * N2 + LDS_SLACK
         if lds > LDS_BYTES:
             continue
         ng2 = max(1, N2 // 32)
@@ -214,16 +213,23 @@ def geometry(size_dict, A, B1, B2, c1_inds, c2_inds):
     g.k2 = k2n + sorted(k2r, key=sa)               # k2 index: the fresh columns first
     g.r2_members = x + [b for b in g.n1 if b not in k2_set]
     g.n2 = n2
-    # what one wave gathers per task = 32 rows x 16 k: the kernel moves it in 16-byte
-    # loads, so the elements must pair up in memory (the stride-1 digit of A is one of
-    # the task's row or k digits -- always the case when the tile has room for X)
+    # what one wave gathers per task = 32 rows x 16 k, straight into matrix-core fragments:
+    # lane l = (row l & 31, k-row h = l >> 5) loads the 8 elements ("slots") of its row whose
+    # k has k-row h, at  task base + kj_a[slot] + lane_a[l]  (the lane part as a 32-bit byte
+    # offset).  Which bit of k is the k-row: bit 0 -- slot s is k = 2 s + h, eight 8-byte
+    # loads -- unless A's stride-1 digit is a contracted one: then a lane takes k, k + 1 in
+    # one 16-byte load, the k-row is bit 1 and slot s is k = 4 (s >> 1) + 2 h + (s & 1).
     g.row_a = _table(g.r1, [sa(b) for b in g.r1])              # [2^nr1] tile rows of A
     g.k_a = _table(g.k1, [sa(b) for b in g.k1])                # [K1]
-    task = np.sort((g.row_a[:32, None] + g.k_a[None, :16]).reshape(-1))
-    if not (np.all(task[1::2] == task[0::2] + 1) and np.all(task[0::2] % 2 == 0)) or A.offset % 2 or A.leaf >= 0:
+    g.vec = bool(g.k_a[1] == 1 and A.offset % 2 == 0)
+    hbit = 2 if g.vec else 1
+    if A.leaf >= 0 or 8 * int(g.row_a[31] + g.k_a[hbit]) >= 1 << 32:
         return None
-    # bytes of A that are contiguous in memory within one task (the run a wave's load
-    # instruction can coalesce): 8 B x 2^(number of leading contiguous digits)
+    # bytes of A that are contiguous in memory within one task (32 rows x 16 k): how much of
+    # every 128-byte line a wave fetches it uses itself.  (The 8 load instructions of a task
+    # each cover 32 rows x 2 k-rows, i.e. possibly shorter pieces: measured, that does not
+    # matter -- the pieces of a line are requested within a few hundred cycles of each other.)
+    task = np.sort((g.row_a[:32, None] + g.k_a[None, :16]).reshape(-1))
     runs = np.flatnonzero(np.diff(task) != 1)
     g.run_bytes = 8 * int(runs[0] + 1 if len(runs) else len(task))
     return g
@@ -330,19 +336,13 @@ def build_stem_step(size_dict, A, B1, B2, c1_inds, out_inds, out_ref_factory, no
 
     # ---- step 1: what one wave gathers per task = 32 rows x 16 k ------------
     row_a, k_a = geo.row_a, geo.k_a
-    task = (row_a[:32, None] + k_a[None, :16]).reshape(-1)     # element (r, c) at r * 16 + c
-    order = np.argsort(task, kind="stable")
-    srt = task[order]
-    # lane l, load j (4 loads of 16 bytes) takes the sorted pair j * 64 + l
-    ord_tab = np.zeros(64 * 8, dtype=np.int64)
-    lane_a = np.zeros(64 * 4, dtype=np.int64)
-    for lane in range(64):
-        for j in range(4):
-            p = 2 * (j * 64 + lane)
-            for h in range(2):
-                e = int(order[p + h])
-                ord_tab[lane * 8 + 2 * j + h] = ((e // 16) << 4) | (e % 16)
-            lane_a[lane * 4 + j] = srt[p]
+    lane, slot = np.arange(64), np.arange(8)
+    if geo.vec:
+        lane_a = row_a[lane & 31] + k_a[2 * (lane >> 5)]       # [64] lane part of a task's addresses
+        kj_a = k_a[4 * (slot >> 1) + (slot & 1)]               # [8]  slot part (pairs adjacent in memory)
+    else:
+        lane_a = row_a[lane & 31] + k_a[lane >> 5]
+        kj_a = k_a[2 * slot]
     rt_a = row_a[::32].copy()                                  # [2^nr1 / 32] first row of every row tile
     chunk_a = k_a[::16].copy()                                 # [K1 / 16]
 
@@ -372,7 +372,7 @@ def build_stem_step(size_dict, A, B1, B2, c1_inds, out_inds, out_ref_factory, no
     tabs = {
         "gA_hi": _table(ghi, [sa(b) for b in ghi]), "gA_lo": _table(glo, [sa(b) for b in glo]),
         "gC_hi": _table(ghi, [sc(b) for b in ghi]), "gC_lo": _table(glo, [sc(b) for b in glo]),
-        "ord": ord_tab, "lane_a": lane_a, "rt_a": rt_a, "chunk_a": chunk_a,
+        "kj_a": kj_a, "lane_a": lane_a, "rt_a": rt_a, "chunk_a": chunk_a,
         "b1_off": b1_off, "b2_off": b2_off, "mid_row": mid_row, "mid_col": mid_col,
         "out_row": out_row, "out_col": out_col,
     }
@@ -382,7 +382,7 @@ def build_stem_step(size_dict, A, B1, B2, c1_inds, out_inds, out_ref_factory, no
     step.stem = {
         "K1": K1, "N1": N1, "K2": K2, "N2": N2, "nr1": geo.nr1, "rows2": 1 << geo.rows2_bits,
         "ng2": geo.ng2, "n_tiles": 1 << len(geo.grid), "g_lo": 1 << g_lo_bits, "ld2": ld2,
-        "lds_bytes": geo.lds, "items": geo.items, "run_bytes": geo.run_bytes, "tabs": tabs,
+        "lds_bytes": geo.lds, "items": geo.items, "run_bytes": geo.run_bytes, "vec": int(geo.vec), "tabs": tabs,
     }
     # reporting fields: the second step's shape; work and traffic of BOTH steps as if unfused
     rows_total = A.size // K1
@@ -398,7 +398,7 @@ def build_stem_step(size_dict, A, B1, B2, c1_inds, out_inds, out_ref_factory, no
     return step
 
 
-TAB_ORDER = ("gA_hi", "gA_lo", "gC_hi", "gC_lo", "ord", "lane_a", "rt_a", "chunk_a",
+TAB_ORDER = ("gA_hi", "gA_lo", "gC_hi", "gC_lo", "kj_a", "lane_a", "rt_a", "chunk_a",
              "b1_off", "b2_off", "mid_row", "mid_col", "out_row", "out_col")
 
 
@@ -406,7 +406,7 @@ def serialise_stem(step, put):
     """Descriptor of a STEM2 step in the plan's table blob (``put(array) ->
     word offset``); returns the offset of its header.  Header layout
     (csrc/ctg_common.h: StemWord): magic, K1, N1, K2, N2, nr1, rows2, ng2,
-    n_tiles, g_lo, ld2, lds_bytes, B2 space / offset / leaf / size, B2 producer,
+    n_tiles, g_lo, ld2, lds_bytes, B2 space / offset / leaf / size, B2 producer, 16-byte gathers,
     then the 14 table offsets at words 20..33."""
     st = step.stem
     head = np.zeros(DESC_WORDS, dtype=np.int64)
@@ -415,6 +415,7 @@ def serialise_stem(step, put):
                   st["n_tiles"], st["g_lo"], st["ld2"], st["lds_bytes"])
     head[12:16] = (step.b2.space, step.b2.offset, step.b2.leaf, step.b2.size)
     head[16] = getattr(step, "b2_prod", -1)
+    head[17] = st["vec"]
     for i, name in enumerate(TAB_ORDER):
         head[20 + i] = put(st["tabs"][name])
     return put(head)

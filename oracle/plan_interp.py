@@ -49,8 +49,8 @@ def run_stem2(step, spaces, base, chunk=256):
     """A fused stem pair (cotengra_amd/stem.py, csrc/ctg_stem.hip) executed from
     the very tables the kernel reads, tile by tile:
 
-    * a tile's rows of A: grid offset + row-tile offset + chunk offset + the
-      per-lane offsets of one 32 x 16 task (looked up through the order table);
+    * a tile's rows of A: grid offset + row-tile offset + chunk offset + slot
+      offset + the constant of the lane that loads the element;
     * first product with B1 (``b1_off[k * N1 + n]``);
     * the intermediate tile laid out at ``mid_row[row] + mid_col[n]`` =
       ``row2 * ld2 + k2``;
@@ -60,19 +60,18 @@ def run_stem2(step, spaces, base, chunk=256):
     A, B1, B2, C = (spaces[t.space] for t in (step.a, step.b, step.b2, step.c))
     K1, N1, K2, N2, ld2, rows2 = st["K1"], st["N1"], st["K2"], st["N2"], st["ld2"], st["rows2"]
     rows1 = 1 << st["nr1"]
-    # offsets of the 32 x 16 elements of a task, as lane / slot constants
-    task = np.zeros((32, 16), dtype=np.int64)
-    seen = np.zeros((32, 16), dtype=bool)
-    for lane in range(64):
-        for j in range(4):
-            for h in range(2):
-                v = int(T["ord"][lane * 8 + 2 * j + h])
-                task[v >> 4, v & 15] = T["lane_a"][lane * 4 + j] + h
-                seen[v >> 4, v & 15] = True
-    assert seen.all()
+    # element (row r, k) of a tile: row tile + chunk of 16 k + slot + the constant of the
+    # lane that loads it (row r & 31, k-row h); k-row and slot of k by the gather mode
     r = np.arange(rows1)
     k = np.arange(K1)
-    in_tile = (T["rt_a"][r >> 5][:, None] + T["chunk_a"][k >> 4][None, :] + task[(r & 31)[:, None], (k & 15)[None, :]])
+    assert len(T["kj_a"]) == 8 and len(T["lane_a"]) == 64 and 8 * int(T["lane_a"].max()) < 1 << 32
+    if st["vec"]:
+        h, slot = (k >> 1) & 1, (((k & 15) >> 2) << 1) | (k & 1)
+        assert np.all(T["kj_a"][1::2] == T["kj_a"][0::2] + 1)
+    else:
+        h, slot = k & 1, (k & 15) >> 1
+    in_tile = (T["rt_a"][r >> 5][:, None] + T["chunk_a"][k >> 4][None, :] + T["kj_a"][slot][None, :]
+               + T["lane_a"][(r & 31)[:, None] + 32 * h[None, :]])
     b1 = B1[base(step.b) + T["b1_off"]].reshape(K1, N1)
     b2 = B2[base(step.b2) + T["b2_off"]].reshape(K2, N2)
     mid_at = (T["mid_row"][:, None] + T["mid_col"][None, :]).reshape(-1)

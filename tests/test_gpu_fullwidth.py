@@ -72,7 +72,10 @@ def test_narrowed_trees_against_oracle(fixture, log2_width):
         got64 = fn.contract_slice(arrays, sid)
         fn.close()
         assert rel(got128, ref) <= 1e-10
-        gate = max(NORTH_STAR, 8.0 * rel(np64, ref))
+        # (a slice amplitude is a cancelling sum: numpy's complex64 run and the HIP path round it
+        # independently, and on slices that cancel hard the ratio of their errors scatters between
+        # 0.3 and 12 -- profiles/r3_single_precision_errors.txt; hence 16 x here, 8 x elsewhere)
+        gate = max(NORTH_STAR, 16.0 * rel(np64, ref))
         assert rel(got64, ref) <= gate, (rel(got64, ref), gate, rel(np64, ref))
 
 

@@ -41,9 +41,16 @@ from cotengra_amd.contractor import HipContractor  # noqa: E402
 from cotengra_amd.plan import KIND_STEM2  # noqa: E402
 
 
+@pytest.fixture
+def fuse_whatever_fits(monkeypatch):
+    """(every pair the kernel can take, whatever the pairing model thinks of its gathers)"""
+    from cotengra_amd import stem
+    monkeypatch.setattr(stem, "gather_rate", lambda run_bytes: 5.4e12)
+
+
 @pytest.mark.parametrize("sliced", [0, 2])
 @pytest.mark.parametrize("case", range(len(G.STEM_CASES)))
-def test_fused_stem_pairs(case, sliced):
+def test_fused_stem_pairs(case, sliced, fuse_whatever_fits):
     nq, gates = G.STEM_CASES[case]
     tree = G.stem_network(nq, gates, 100 * case, sliced=sliced)
     arrays = ca.make_arrays_from_inputs(tree.inputs, tree.size_dict, seed=case, dtype="complex64")

@@ -91,9 +91,18 @@ from cotengra_amd.plan import compile_tree  # noqa: E402
 from oracle.plan_interp import run_plan  # noqa: E402
 
 
+@pytest.fixture
+def fuse_whatever_fits(monkeypatch):
+    """The pairing model prices a gather by the contiguous bytes of its load instructions and
+    leaves pairs alone that would gather in small pieces; the shape tests want every pair the
+    kernel can take."""
+    from cotengra_amd import stem
+    monkeypatch.setattr(stem, "gather_rate", lambda run_bytes: 5.4e12)
+
+
 @pytest.mark.parametrize("sliced", [0, 2])
 @pytest.mark.parametrize("case", range(len(G.STEM_CASES)))
-def test_fused_stem_plan_matches_oracle(case, sliced):
+def test_fused_stem_plan_matches_oracle(case, sliced, fuse_whatever_fits):
     """The fused step's tables, interpreted in numpy exactly as the kernel reads
     them (oracle/plan_interp.run_stem2), give the reference contraction; the plan
     passes the C ABI's validation; work and algorithmic bytes are those of the
@@ -105,9 +114,8 @@ def test_fused_stem_plan_matches_oracle(case, sliced):
     plain = compile_tree(tree, "complex64", fuse=False)
     n_fused = sum(s.kind == P.KIND_STEM2 for s in fused.steps)
     assert len(fused.steps) == len(plain.steps) - n_fused
-    # (slicing two indices of the first tensor can take a gate below K = 16; case 13's second
-    # gate takes six digits of the big tensor: no room in a 64-row tile for its stride-1 digit)
-    if sliced == 0 and case != 13:
+    # (slicing two indices of the first tensor can take a gate below K = 16)
+    if sliced == 0:
         assert n_fused >= 1
     assert fused.macs_per_slice == plain.macs_per_slice
     assert fused.elems_rw_per_slice == plain.elems_rw_per_slice
@@ -137,7 +145,8 @@ def test_fused_descriptor_is_validated():
     tree = G.stem_network(16, [(3, 3), (5, 5), (5, 5)], 0)
     plan = compile_tree(tree, "complex64", fuse=True, fuse_min_elems=1 << 10)
     st = next(s for s in plan.steps if s.kind == P.KIND_STEM2)
-    for name, how in (("gA_hi", lambda t: t + (1 << 40)), ("ord", lambda t: t * 0), ("mid_row", lambda t: t * 64),
+    for name, how in (("gA_hi", lambda t: t + (1 << 40)), ("lane_a", lambda t: t + (1 << 29)), ("kj_a", lambda t: t + (1 << 40)),
+                      ("mid_row", lambda t: t * 64),
                       ("out_col", lambda t: t + (1 << 40)), ("b2_off", lambda t: t - 1)):
         keep = st.stem["tabs"][name]
         st.stem["tabs"][name] = how(keep.copy())

@@ -32,13 +32,9 @@ def step_kernel_name(rocprof_name):
     m = re.match(r"pair_rowwise_kernel<(\d+), (?:true|false)>", rocprof_name)
     if m:
         return f"pair_rowwise_kernel<{m.group(1)}>"
-    m = re.match(r"stem2_kernel<(true|false), (true|false), (\d+), (\d+), (\d+), (\d+)(?:, (true|false), (\d+))?>",
-                 rocprof_name)
-    if m:
-        g = list(m.groups())
-        if g[6] is None:
-            g[6:] = ["false", "0"]
-        return "stem2_kernel<%s>" % ",".join(g)
+    m = re.match(r"stem2_kernel<([^>]*)>", rocprof_name)
+    if m:   # (nine template arguments, spelled as csrc/ctg_stem.hip: stem2_kernel_name spells them)
+        return "stem2_kernel<%s>" % m.group(1).replace(" ", "")
     m = re.match(r"pair_skinny_kernel<(\d+), (\d+)>", rocprof_name)
     if m:
         return f"pair_skinny_kernel<{m.group(1)},{m.group(2)}>"
