@@ -329,7 +329,26 @@ __global__ __launch_bounds__(SW * 64, 1) void stem2_kernel(StemArgs p) {
     f32x16 ax[RT1], ay[RT1];
     // one task: 16 k of MFMAs on the gathered registers, each register refilled (two tasks
     // ahead) as soon as the MFMAs reading it have been issued
-    auto consume = [&](c64 (&r)[8], int m, int ch, auto always_tag) __attribute__((always_inline)) {
+    // Deferred stores: the 16 (8) stores of a work item of step 2 are not issued behind its last
+    // MFMA but one or two at a time between the MFMAs of whatever the wave does next (the next
+    // item, else the first task of the next tile).  All 8 waves finish their items together, and
+    // 128 store instructions of 512 B each in one burst keep the CU's memory pipeline busy for
+    // >1000 cycles in which nobody issues an MFMA: knock-out of the stores alone gave 12 % of a
+    // slice, of the gathers alone 6 % (profiles/r3_stem_knockout.txt).
+    constexpr int NST = PACK2 ? 8 : 16;
+    float2 pv[NST];
+    float* pdst = C;
+    auto drain = [&](int lo, int hi) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = lo; i < hi; ++i) {
+#ifdef CTG_STEM_KO_STORE
+            if (pv[i].x == 12345.678f)
+#endif
+            *(float2*)(pdst + 2 * out_t[PACK2 ? 2 * i : i]) = pv[i];
+        }
+    };
+    auto consume = [&](c64 (&r)[8], int m, int ch, auto always_tag, auto drain_tag) __attribute__((always_inline)) {
+        constexpr bool DRAIN = decltype(drain_tag)::value;
         const int64_t base = pend0 + pend1 + pend2 + pend3;   // of the task two ahead (prep of the task before)
         f32x4 bp[2], bq[2];
         if constexpr (BR1) {   // (ch is a compile-time constant here: static variants only)
@@ -363,6 +382,7 @@ __global__ __launch_bounds__(SW * 64, 1) void stem2_kernel(StemArgs p) {
             }
             __builtin_amdgcn_sched_barrier(0);
             if (j & 1) fire2(r, j >> 1, base, always_tag);
+            if constexpr (DRAIN) drain(j * NST / 8, (j + 1) * NST / 8);
         }
         __builtin_amdgcn_sched_barrier(0);
         prep(always_tag);   // (behind the last MFMAs)
@@ -398,7 +418,11 @@ __global__ __launch_bounds__(SW * 64, 1) void stem2_kernel(StemArgs p) {
         asm volatile("" : "+s"(c_row));   // waited for here, not inside the fragment pipeline
         return c_row;
     };
-    auto item2 = [&](int item, int64_t c_row, auto scaled_tag) __attribute__((always_inline)) {
+    // drain_tag: the item before this one left its stores pending; defer_tag: leave this one's
+    auto item2 = [&](int item, int64_t c_row, auto scaled_tag, auto drain_tag, auto defer_tag)
+                     __attribute__((always_inline)) {
+        constexpr bool DRAIN = decltype(drain_tag)::value;
+        if constexpr (DRAIN && K2Q == 0) drain(0, NST);   // (run-time trip count below: no slots to put them in)
         const int cg = item / n_rt2, rt2 = item - cg * n_rt2;
         f32x16 cx, cy;
 #pragma unroll
@@ -430,6 +454,7 @@ __global__ __launch_bounds__(SW * 64, 1) void stem2_kernel(StemArgs p) {
                     }
                 }
                 __builtin_amdgcn_sched_barrier(0);
+                if constexpr (DRAIN) drain(kq * NST / K2Q, (kq + 1) * NST / K2Q);
             }
         } else {
 #ifdef CTG_STEM_KO_BFRAG
@@ -465,7 +490,7 @@ __global__ __launch_bounds__(SW * 64, 1) void stem2_kernel(StemArgs p) {
         }
         {
             constexpr bool SC = decltype(scaled_tag)::value;
-            float* dst = C + 2 * (c_row + out_lane + c_col);
+            pdst = C + 2 * (c_row + out_lane + c_col);
             if (PACK2) {
                 // lane c < 16 holds Re of column c, lane c + 16 its Im: lanes below 16
                 // store row t, the others row t + 1 of each pair
@@ -482,10 +507,7 @@ __global__ __launch_bounds__(SW * 64, 1) void stem2_kernel(StemArgs p) {
                         v.x *= alpha;
                         v.y *= alpha;
                     }
-#ifdef CTG_STEM_KO_STORE
-                    if (v.x == 12345.678f)
-#endif
-                    *(float2*)(dst + 2 * out_t[t]) = v;
+                    pv[t >> 1] = v;
                 }
             } else {
 #pragma unroll
@@ -493,12 +515,10 @@ __global__ __launch_bounds__(SW * 64, 1) void stem2_kernel(StemArgs p) {
                     float2 v;
                     v.x = SC ? cx[t] * alpha : cx[t];
                     v.y = SC ? cy[t] * alpha : cy[t];
-#ifdef CTG_STEM_KO_STORE
-                    if (v.x == 12345.678f)
-#endif
-                    *(float2*)(dst + 2 * out_t[t]) = v;
+                    pv[t] = v;
                 }
             }
+            if constexpr (!decltype(defer_tag)::value) drain(0, NST);
         }
     };
     auto tile_c = [&](int64_t g) __attribute__((always_inline)) -> int64_t {
@@ -517,14 +537,16 @@ __global__ __launch_bounds__(SW * 64, 1) void stem2_kernel(StemArgs p) {
         issue(regs[1], std::true_type{});
         prep(std::true_type{});
         int64_t g = tile0;
-        auto tile = [&](auto slot0_tag) __attribute__((always_inline)) {
+        auto tile = [&](auto slot0_tag, auto first_tag) __attribute__((always_inline)) {
             constexpr int SLOT0 = decltype(slot0_tag)::value;
+            constexpr bool FIRST = decltype(first_tag)::value;   // (no item before this tile: nothing pending)
             static_for<0, RT1>([&](auto mi) __attribute__((always_inline)) {
                 constexpr int M = decltype(mi)::value;
                 zero_acc(M);
                 static_for<0, NCH>([&](auto ci) __attribute__((always_inline)) {
                     constexpr int CH = decltype(ci)::value;
-                    consume(regs[(SLOT0 + M * NCH + CH) & 1], M, CH, std::true_type{});
+                    consume(regs[(SLOT0 + M * NCH + CH) & 1], M, CH, std::true_type{},
+                            std::integral_constant<bool, !FIRST && M == 0 && CH == 0>{});
                 });
             });
             CTG_STEM_SYNC();   // all waves have finished step 2 of the previous tile
@@ -536,23 +558,29 @@ __global__ __launch_bounds__(SW * 64, 1) void stem2_kernel(StemArgs p) {
             });
             CTG_STEM_SYNC();
             static_for<0, IT2>([&](auto ii) __attribute__((always_inline)) {
-                item2(wave + SW * decltype(ii)::value, c_rows[decltype(ii)::value], scaled_tag);
+                item2(wave + SW * decltype(ii)::value, c_rows[decltype(ii)::value], scaled_tag,
+                      std::integral_constant<bool, (decltype(ii)::value > 0)>{}, std::true_type{});
             });
             g += tile_step;
         };
-        auto pass = [&]() __attribute__((always_inline)) {
+        auto pass = [&](auto peel_tag) __attribute__((always_inline)) {
             static_for<0, U>([&](auto ui) __attribute__((always_inline)) {
-                tile(std::integral_constant<int, (decltype(ui)::value * NT) & 1>{});
+                tile(std::integral_constant<int, (decltype(ui)::value * NT) & 1>{},
+                     std::integral_constant<bool, decltype(peel_tag)::value && decltype(ui)::value == 0>{});
             });
         };
         int64_t t = 0;
         if (my_tiles >= U) {
             // (first pass peeled: the waits at the loop header must hold for the entry path
             // as well, where no store has been issued yet -- see the streaming kernel)
-            pass();
-            for (t = U; t + U <= my_tiles; t += U) pass();
+            pass(std::true_type{});
+            for (t = U; t + U <= my_tiles; t += U) pass(std::false_type{});
         }
-        if (t < my_tiles) tile(std::integral_constant<int, 0>{});   // (U = 2, odd count; t is even)
+        if (t < my_tiles) {   // (U = 2, odd count; t is even)
+            if (t == 0) tile(std::integral_constant<int, 0>{}, std::true_type{});
+            else tile(std::integral_constant<int, 0>{}, std::false_type{});
+        }
+        drain(0, NST);   // the last item's
     } else {
         issue(regs[0], std::false_type{});
         issue(regs[1], std::false_type{});
@@ -563,8 +591,8 @@ __global__ __launch_bounds__(SW * 64, 1) void stem2_kernel(StemArgs p) {
             for (int m = 0; m < RT1; ++m) {
                 zero_acc(m);
                 for (int ch = 0; ch < nch; ++ch) {
-                    if (slot == 0) consume(regs[0], m, ch, std::false_type{});
-                    else consume(regs[1], m, ch, std::false_type{});
+                    if (slot == 0) consume(regs[0], m, ch, std::false_type{}, std::false_type{});
+                    else consume(regs[1], m, ch, std::false_type{}, std::false_type{});
                     slot ^= 1;
                 }
             }
@@ -572,7 +600,8 @@ __global__ __launch_bounds__(SW * 64, 1) void stem2_kernel(StemArgs p) {
             scatter();
             CTG_STEM_SYNC();
             const int64_t c_tile = tile_c(g);
-            for (int item = wave; item < n_items; item += SW) item2(item, item_row(item, c_tile), scaled_tag);
+            for (int item = wave; item < n_items; item += SW)
+                item2(item, item_row(item, c_tile), scaled_tag, std::false_type{}, std::false_type{});
         }
     }
     };
