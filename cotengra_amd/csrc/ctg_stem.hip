@@ -129,11 +129,10 @@ __device__ __forceinline__ void settle(T& v) {
 // BR1: the B1 fragments of this wave's columns live in registers for the whole kernel
 // (K1 floats: Re and Im of the K1 / 2 values of k of the lane's parity) -- K2Q > 0: likewise
 // the B2 fragments of this wave's column group (2 K2 floats, K2 with 16 columns), K2 = 4 K2Q
-// known at compile time.  The fragments are the same for every
-// tile; re-reading them from LDS for every 8 MFMAs is a third of the kernel's LDS traffic
-// and, with the staging writes and the scatter in the same queue, cost 8 % of a slice
-// (knock-out CTG_STEM_KO_BFRAG, profiles/r3_stem_knockout.txt).  Chosen per shape by the
-// register budget (launch_stem2: at most 96 floats of B per lane).
+// known at compile time.  The fragments are the same for every tile; re-reading them from LDS
+// for every 8 MFMAs cost 8 % of a slice (knock-out CTG_STEM_KO_BFRAG, profiles/
+// r3_stem_knockout.txt).  Chosen per shape by the register budget (stem2_shape: at most 96
+// floats of B per lane).
 // VEC: A's stride-1 digit is a contracted one -- a lane gathers two adjacent k in one 16-byte load.
 template <bool PACK1, bool PACK2, int RT1, int CS1, int NCH, int IT2, bool BR1 = false, int K2Q = 0, bool VEC = false>
 __global__ __launch_bounds__(SW * 64, 1) void stem2_kernel(StemArgs p) {

@@ -156,6 +156,42 @@ def test_fused_descriptor_is_validated():
     runtime.DevicePlan(plan).close()
 
 
+def test_fused_descriptor_16_byte_gathers_are_validated(fuse_whatever_fits):
+    """Where the big operand's stride-1 index is a contracted one a lane gathers two adjacent k in
+    one 16-byte load (descriptor word 17): slot pairs must be adjacent, every offset even."""
+    nq, gates = G.STEM_CASES[1]
+    plan = compile_tree(G.stem_network(nq, gates, 100), "complex64", fuse=True, fuse_min_elems=1 << 10)
+    st = next(s for s in plan.steps if s.kind == P.KIND_STEM2)
+    assert st.stem["vec"] == 1
+    kj = st.stem["tabs"]["kj_a"]
+    assert np.all(kj[1::2] == kj[0::2] + 1) and not np.any(kj[0::2] & 1)
+    runtime.DevicePlan(plan).close()
+
+    def broken(name, how):
+        keep = st.stem["tabs"][name]
+        st.stem["tabs"][name] = how(keep.copy())
+        with pytest.raises((runtime.CtgError, ValueError)):
+            runtime.DevicePlan(plan)
+        st.stem["tabs"][name] = keep
+
+    def unpair(t):
+        t[1] += 2
+        return t
+
+    def odd(t):
+        t[3] += 1
+        return t
+
+    broken("kj_a", unpair)
+    broken("lane_a", odd)
+    broken("rt_a", lambda t: t + 1)
+    st.stem["vec"] = 2
+    with pytest.raises((runtime.CtgError, ValueError)):
+        runtime.DevicePlan(plan)
+    st.stem["vec"] = 1
+    runtime.DevicePlan(plan).close()
+
+
 # ---------------------------------------------------------------------- #
 # checkpoint signature covers the inputs; progress counter; cache bounds
 # ---------------------------------------------------------------------- #
