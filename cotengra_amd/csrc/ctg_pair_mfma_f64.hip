@@ -408,24 +408,35 @@ __global__ __launch_bounds__(256, 2) void pair_mfma_real_kernel(StepArgs p, int 
         for (int j = 0; j < NA; ++j) {
             const int64_t ko = ka[a_c[j]];
             VT v = 0;
+#ifdef CTG_REAL_KO_GATHER   // (knock-out builds, tools/exp_f32_ko.sh: wrong results by construction)
+            v[0] = (T)(a_row[j] + ko);
+#else
             if (a_row[j] >= 0 && ko >= 0) {
                 if constexpr (VEC) v = *(const VT*)(A + a_row[j] + ko);
                 else v[0] = A[a_row[j] + ko];
             }
+#endif
             a_reg[j] = v;
         }
 #pragma unroll
         for (int j = 0; j < NB; ++j) {
             const int64_t ko = kb[b_k[j]];
             VT v = 0;
+#ifdef CTG_REAL_KO_GATHER
+            v[0] = (T)(b_col[j] + ko);
+#else
             if (b_col[j] >= 0 && ko >= 0) {
                 if constexpr (VEC) v = *(const VT*)(B + b_col[j] + ko);
                 else v[0] = B[b_col[j] + ko];
             }
+#endif
             b_reg[j] = v;
         }
     };
     auto stage = [&](int buf) {
+#ifdef CTG_REAL_KO_STAGE
+        if (a_reg[0][0] != (T)12345.678f) return;
+#endif
         T* As = lds + buf * (RBM + RBN) * RLD;
         T* Bs = As + RBM * RLD;
 #pragma unroll
