@@ -53,6 +53,9 @@ PEAK_TREE = os.path.join(TREES, "sycamore_m20_w32_c512.json")  # highest FLOP/s 
 # refine_fused.py): a quarter less work in smaller, memory-bound steps -- fewer FLOP/s, but the
 # amplitude 12 % sooner
 TTS_TREE = os.path.join(TREES, "sycamore_m20_fused.json")
+# the same with one index less sliced: 2^19 slices of width 2^33 (68 GB tensors, a 161 GiB arena --
+# what 288 GB of HBM are for); the amplitude another 6 % sooner
+TTS33_TREE = os.path.join(TREES, "sycamore_m20_w33_fused.json")
 
 
 # ---------------------------------------------------------------------- #
@@ -685,6 +688,8 @@ def main():
         if extras and not args.headline_only:
             if os.path.abspath(args.tree) != os.path.abspath(TTS_TREE) and os.path.exists(TTS_TREE):
                 out["time_to_solution_tree"] = tree_report(TTS_TREE, dev)
+            if os.path.abspath(args.tree) != os.path.abspath(TTS33_TREE) and os.path.exists(TTS33_TREE):
+                out["time_to_solution_tree_w33"] = tree_report(TTS33_TREE, dev, steps=3)
             if os.path.abspath(args.tree) != os.path.abspath(PEAK_TREE) and os.path.exists(PEAK_TREE):
                 out["peak_rate_tree"] = tree_report(PEAK_TREE, dev)
             out["configs"] = other_configs(dev)

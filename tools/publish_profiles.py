@@ -46,9 +46,10 @@ if r.get("traffic") is None:
 print(f"value {line['value']:.4e} {line['unit']}  {line['ms_per_step']:.1f} ms/step  est total {line['est_time_total_s']:.3e} s")
 print(f"dominant {r['kernel']}: {r['achieved']:.1f} {r['unit']} frac {r['frac']:.3f} share {r['share_of_slice_time']:.2f}")
 print("mixed:", r["mixed_per_step"])
-t = line.get("peak_rate_tree") or line.get("time_to_solution_tree")
-if t:
-    print("other tree:", {k: t[k] for k in ("tree", "ms_per_slice", "tflops", "frac_of_mfma_peak", "mixed_roofline_frac", "est_time_total_s")})
+for key in ("time_to_solution_tree", "time_to_solution_tree_w33", "peak_rate_tree"):
+    t = line.get(key)
+    if t:
+        print(key + ":", {k: t[k] for k in ("tree", "ms_per_slice", "tflops", "frac_of_mfma_peak", "mixed_roofline_frac", "est_time_total_s")})
 for k, v in (line.get("configs") or {}).items():
     print(k, {x: v[x] for x in ("ms", "slices_per_sec", "tflops", "mixed_roofline_frac", "cpu_oracle_ms", "speedup_vs_cpu_oracle")})
 print("precision:", line.get("precision"))
