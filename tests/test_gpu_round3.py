@@ -81,6 +81,28 @@ def test_fused_stem_pairs(case, sliced, fuse_whatever_fits):
     plain.close()
 
 
+@pytest.mark.parametrize("case", [0, 1, 2, 4, 9, 11])
+def test_fused_stem_pairs_run_time_count_variant(case, fuse_whatever_fits, monkeypatch):
+    """Shapes without a static instantiation run the variant whose chunk / item counts are
+    run-time values (every wait drains the queue, stores issued at once); forced here
+    (CTG_STEM_GENERIC, read at every launch) on shapes that normally take a static one: same
+    tables, same arithmetic per element -- the same bits."""
+    nq, gates = G.STEM_CASES[case]
+    tree = G.stem_network(nq, gates, 100 * case)
+    arrays = ca.make_arrays_from_inputs(tree.inputs, tree.size_dict, seed=case, dtype="complex64")
+    fn = HipContractor(tree, fuse=True, fuse_min_elems=1 << 10)
+    static = np.asarray(fn(*arrays))
+    names = [n for n in fn.setup(*arrays)["exec"].step_kernels() if n.startswith("stem2_kernel")]
+    assert names
+    monkeypatch.setenv("CTG_STEM_GENERIC", "1")
+    generic = np.asarray(fn(*arrays))
+    gnames = [n for n in fn.setup(*arrays)["exec"].step_kernels() if n.startswith("stem2_kernel")]
+    assert all(",0,0,false,0," in n for n in gnames), gnames
+    fn.close()
+    assert np.array_equal(static, generic)
+
+
+
 # ---------------------------------------------------------------------- #
 # host robustness: threads, checkpoints, progress, cache bounds
 # ---------------------------------------------------------------------- #
