@@ -152,6 +152,11 @@ def precision_check(tree, arrays, slice_id=3, log2_width=20):
     from oracle import contract_ref as orc
 
     small = shrink_for_cpu(tree, log2_width)
+    # (with the bf16 switch on, the narrowed tree must run fused pairs too -- they start at 2^24
+    # elements by default, above anything a CPU-sized slice has)
+    lowered = "CTG_STEM_BF16X3" in os.environ and "CTG_FUSE_MIN_ELEMS" not in os.environ
+    if lowered:
+        os.environ["CTG_FUSE_MIN_ELEMS"] = str(1 << 12)
     a128 = [a.astype("complex128") for a in arrays]
     with host_threads():
         ref = complex(orc.contract_slice(small, a128, slice_id))
@@ -170,6 +175,12 @@ def precision_check(tree, arrays, slice_id=3, log2_width=20):
         "rel_err_complex128_path": abs(got128 - ref) / abs(ref),
         "gate_complex128_path": 1e-10,
     }
+    if lowered:
+        del os.environ["CTG_FUSE_MIN_ELEMS"]
+        out["check"] += "; stem pairs fused from 2^12 elements, on the bf16 matrix cores"
+        out["fused_pairs_in_check"] = sum(
+            1 for c in small.contraction_cores.values() for pl, _ in getattr(c, "_plans", {}).values()
+            if pl.dtype == "complex64" for s_ in pl.steps if s_.kind == 3)
     for c in list(small.contraction_cores.values()):
         c.close()
     if out["rel_err"] > gate or out["rel_err_complex128_path"] > 1e-10:
@@ -241,9 +252,20 @@ def time_slices(ex, first, count, stride=1):
 # ---------------------------------------------------------------------- #
 
 
-def tree_report(tree_file, dev, steps=5, warmup=1):
+def tree_report(tree_file, dev, steps=5, warmup=1, bf16x3=False):
     """ms/slice, FLOP/s, dominant-kernel and mixed rooflines of another m20
-    tree -- the one that reaches the amplitude first."""
+    tree -- the one that reaches the amplitude first.  ``bf16x3``: with the stem pairs'
+    experiment switch CTG_STEM_BF16X3 on (fp32 products as six bf16 products on the bf16
+    matrix cores, csrc/ctg_stem.hip) for the duration of the report."""
+    if bf16x3:
+        os.environ["CTG_STEM_BF16X3"] = "1"
+        try:
+            out = tree_report(tree_file, dev, steps, warmup)
+        finally:
+            del os.environ["CTG_STEM_BF16X3"]
+        out["arithmetic"] = ("stem pairs: fp32 operands split exactly into 3 bf16 values, 6 of the 9 cross terms on "
+                             "v_mfma_f32_32x32x16_bf16, fp32 accumulation; every other step as in the headline")
+        return out
     import torch
 
     import cotengra_amd as ca
@@ -692,6 +714,12 @@ def main():
                 out["time_to_solution_tree_w33"] = tree_report(TTS33_TREE, dev, steps=3)
             if os.path.abspath(args.tree) != os.path.abspath(PEAK_TREE) and os.path.exists(PEAK_TREE):
                 out["peak_rate_tree"] = tree_report(PEAK_TREE, dev)
+            # experiment switch, NOT the headline's arithmetic: the same trees with the stem pairs on the
+            # bf16 matrix cores (three-way split operands; accuracy in each entry's "precision")
+            out["bf16x3_experiment"] = {
+                os.path.basename(t): tree_report(t, dev, steps=3, bf16x3=True)
+                for t in (args.tree, TTS_TREE, TTS33_TREE) if os.path.exists(t)
+            }
             out["configs"] = other_configs(dev)
         if c3_amp is not None:
             out.setdefault("configs", {})["C3_amplitudes"] = c3_amp

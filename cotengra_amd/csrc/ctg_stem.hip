@@ -99,6 +99,88 @@ __device__ __forceinline__ void load_b_planes(float* P, const c64* __restrict__ 
     }
 }
 
+
+// ---- fp32 products on the bf16 matrix cores (template argument BF3) ------------------------
+// An fp32 value splits EXACTLY into three bfloat16 values (8 + 8 + 8 mantissa bits: two ANDs,
+// two subtractions); products of bf16 values are exact in fp32, so a real multiply-add becomes
+// the 6 cross terms above 2^-24 (the three smallest of the nine are dropped: truncation error
+// 4e-8 against the 1e-6 of fp32 accumulation itself, tools/exp_bf16x3.py) accumulated in fp32 by
+// v_mfma_f32_32x32x16_bf16 -- 16 k per instruction at 16x the fp32 MFMA rate, i.e. 2.7x the fp32
+// matrix peak (measured with the splitting: 1.7x, tools/exp_bf16x3_rate.py).  A lane holds 8
+// values of k per operand; which 8 is the same function of (lane half, position) for both
+// operands, so the k order inside the instruction does not matter.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ constexpr int bf3_ta(int t) { return t == 2 || t == 3 ? 1 : (t == 5 ? 2 : 0); }
+__device__ __forceinline__ constexpr int bf3_tb(int t) { return t == 1 || t == 3 ? 1 : (t == 4 ? 2 : 0); }
+
+__device__ __forceinline__ void split3(const float (&x)[8], bf16x8 (&o)[3]) {
+    unsigned w[3][8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const unsigned h1 = __builtin_bit_cast(unsigned, x[i]) & 0xffff0000u;
+        const float r1 = x[i] - __builtin_bit_cast(float, h1);
+        const unsigned h2 = __builtin_bit_cast(unsigned, r1) & 0xffff0000u;
+        const float r2 = r1 - __builtin_bit_cast(float, h2);
+        w[0][i] = h1;
+        w[1][i] = h2;
+        w[2][i] = __builtin_bit_cast(unsigned, r2);
+    }
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+        u32x4 pk;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) pk[i] = (w[q][2 * i] >> 16) | (w[q][2 * i + 1] & 0xffff0000u);
+        o[q] = __builtin_bit_cast(bf16x8, pk);
+    }
+}
+
+__device__ __forceinline__ f32x16 mfma_bf(bf16x8 a, bf16x8 b, f32x16 c) {
+#ifdef CTG_STEM_KO_MFMA
+    c[0] = fmaf((float)a[0], (float)b[0], c[0]);
+    return c;
+#else
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+#endif
+}
+
+// bf16 x 3 planes of a small operand in LDS -- (Re, Im), plus -Im with 16 columns, as in fp32 --
+// fragment-ready: a lane's 8 values of one split are 16 contiguous bytes.
+//   step 1:  [plane][n][chunk of 16 k][k-row h][split][slot]     row = (K / 16) * 48 + 8 values
+//   step 2:  [plane][n][block of 8 k][split][k & 7]               row = (K / 8) * 24 + 8 values
+__device__ __forceinline__ int bf3_row(int K, bool step1) { return step1 ? (K >> 4) * 48 + 8 : (K >> 3) * 24 + 8; }
+template <bool STEP1>
+__device__ __forceinline__ void load_b_planes_bf3(unsigned short* Q, const c64* __restrict__ B, const int64_t* off, int K,
+                                                  int N, int planes, int tid, bool vec) {
+    const int ROW = bf3_row(K, STEP1);
+    for (int e = tid; e < K * N; e += SW * 64) {
+        const int k = e / N, n = e - k * N;
+        int at;
+        if (STEP1) {
+            const int h = vec ? (k >> 1) & 1 : k & 1;
+            const int slot = vec ? (((k & 15) >> 2) << 1) | (k & 1) : (k & 15) >> 1;
+            at = (k >> 4) * 48 + h * 24 + slot;
+        } else {
+            at = (k >> 3) * 24 + (k & 7);
+        }
+        const c64 v = B[off[e]];
+        const float vals[3] = {v.re, v.im, -v.im};
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) {
+            if (pl >= planes) break;
+            const float x = vals[pl];
+            const unsigned h1 = __builtin_bit_cast(unsigned, x) & 0xffff0000u;
+            const float r1 = x - __builtin_bit_cast(float, h1);
+            const unsigned h2 = __builtin_bit_cast(unsigned, r1) & 0xffff0000u;
+            const float r2 = r1 - __builtin_bit_cast(float, h2);
+            unsigned short* d = Q + (pl * N + n) * ROW + at;
+            d[0] = (unsigned short)(h1 >> 16);
+            d[8] = (unsigned short)(h2 >> 16);
+            d[16] = (unsigned short)(__builtin_bit_cast(unsigned, r2) >> 16);
+        }
+    }
+}
+
 }  // namespace
 
 // "use" a value: the compiler has to wait here for the load that produced it, not at
@@ -134,7 +216,11 @@ __device__ __forceinline__ void settle(T& v) {
 // r3_stem_knockout.txt).  Chosen per shape by the register budget (stem2_shape: at most 96
 // floats of B per lane).
 // VEC: A's stride-1 digit is a contracted one -- a lane gathers two adjacent k in one 16-byte load.
-template <bool PACK1, bool PACK2, int RT1, int CS1, int NCH, int IT2, bool BR1 = false, int K2Q = 0, bool VEC = false>
+// BF3: both steps multiply on the bf16 matrix cores (three-way split, see above); B1 fragments
+// in registers if BR1 (24 registers per chunk), B2 fragments from LDS (K2Q then only says that
+// K2 is known at compile time).
+template <bool PACK1, bool PACK2, int RT1, int CS1, int NCH, int IT2, bool BR1 = false, int K2Q = 0, bool VEC = false,
+          bool BF3 = false>
 __global__ __launch_bounds__(SW * 64, 1) void stem2_kernel(StemArgs p) {
     static_assert(!PACK1 || CS1 == 1, "16 columns are one group");
     static_assert(!BR1 || NCH > 0, "B1 in registers needs the chunk count at compile time");
@@ -148,6 +234,11 @@ __global__ __launch_bounds__(SW * 64, 1) void stem2_kernel(StemArgs p) {
     float* P1 = (float*)smem;                              // [2|3][N1][LDB1]
     float* P2 = P1 + (PACK1 ? 3 : 2) * N1 * LDB1;          // [2|3][N2][LDB2]
     float* mid = P2 + (PACK2 ? 3 : 2) * N2 * LDB2;         // [2][rows2][LD2]
+    // (BF3: the small operands as bf16 x 3 planes instead)
+    const int ROW1 = bf3_row(K1, true), ROW2 = bf3_row(K2, false);
+    unsigned short* Q1 = (unsigned short*)smem;            // [2|3][N1][ROW1]
+    unsigned short* Q2 = Q1 + (PACK1 ? 3 : 2) * N1 * ROW1; // [2|3][N2][ROW2]
+    if constexpr (BF3) mid = (float*)(Q2 + (PACK2 ? 3 : 2) * N2 * ROW2);
     int64_t* oc_s = (int64_t*)(mid + 2 * PLANE);           // [N2] column offsets of the result
 
     const int tid = threadIdx.x;
@@ -164,8 +255,13 @@ __global__ __launch_bounds__(SW * 64, 1) void stem2_kernel(StemArgs p) {
     const c64* __restrict__ B2 = (const c64*)p.B2 + (sload64(p.soffB2 + z * p.zsB2) + z * p.zB2);
     float* __restrict__ C = (float*)((c64*)p.C + (sload64(p.soffC + z * p.zsC) + z * p.zC));
 
-    load_b_planes<true>(P1, B1, p.b1_off, K1, N1, PACK1, tid, VEC);
-    load_b_planes<false>(P2, B2, p.b2_off, K2, N2, PACK2, tid);
+    if constexpr (BF3) {
+        load_b_planes_bf3<true>(Q1, B1, p.b1_off, K1, N1, PACK1 ? 3 : 2, tid, VEC);
+        load_b_planes_bf3<false>(Q2, B2, p.b2_off, K2, N2, PACK2 ? 3 : 2, tid, false);
+    } else {
+        load_b_planes<true>(P1, B1, p.b1_off, K1, N1, PACK1, tid, VEC);
+        load_b_planes<false>(P2, B2, p.b2_off, K2, N2, PACK2, tid);
+    }
     for (int n = tid; n < N2; n += SW * 64) oc_s[n] = p.out_col[n];
 
     // ---- per-lane constants ---------------------------------------------------
@@ -193,6 +289,28 @@ __global__ __launch_bounds__(SW * 64, 1) void stem2_kernel(StemArgs p) {
         b1q = P1 + (N1 + wcol + l31) * LDB1 + kk * 8;
     }
     const unsigned sgn2 = kk ? 0x80000000u : 0u;   // step 2: A' is (Re, +-Im) by lane half
+    // BF3 fragment bases (planes 0 = Re, 1 = Im, 2 = -Im; see load_b_planes_bf3)
+    const unsigned short* q1p;
+    const unsigned short* q1q;
+    const unsigned short* q2x;
+    const unsigned short* q2y = nullptr;
+    {
+        const int h16 = l31 >> 4;
+        if (PACK1) {
+            q1p = Q1 + ((h16 ? 1 : 0) * N1 + (l31 & 15)) * ROW1 + kk * 24;
+            q1q = Q1 + ((h16 ? 0 : 2) * N1 + (l31 & 15)) * ROW1 + kk * 24;
+        } else {
+            q1p = Q1 + (wcol + l31) * ROW1 + kk * 24;
+            q1q = Q1 + (N1 + wcol + l31) * ROW1 + kk * 24;
+        }
+        if (PACK2) {
+            const int plane = kk == 0 ? (h16 ? 1 : 0) : (h16 ? 0 : 2);
+            q2x = Q2 + (plane * N2 + (l31 & 15)) * ROW2;
+        } else {   // X: (Re a, -Im a) x (Re b, Im b);  Y: (Re a, Im a) x (Im b, Re b)
+            q2x = Q2 + ((kk ? 1 : 0) * N2 + l31) * ROW2;
+            q2y = Q2 + ((kk ? 0 : 1) * N2 + l31) * ROW2;
+        }
+    }
     const float* b2x;
     const float* b2y = nullptr;
     if (PACK2) {
@@ -236,16 +354,26 @@ __global__ __launch_bounds__(SW * 64, 1) void stem2_kernel(StemArgs p) {
     // [quad][X | Y] -- there the X tile's sign (A' = (Re a, -Im a)) is folded into the register
     // copy: the lanes of the second k-row hold -Im b instead, and the loop feeds A' = (Re a,
     // Im a) to both tiles
-    f32x4 b1r[BR1 ? NCH * 2 : 1][2];
-    f32x4 b2r[K2Q > 0 ? K2Q : 1][PACK2 ? 1 : 2];
-    if constexpr (BR1) {
+    f32x4 b1r[BR1 && !BF3 ? NCH * 2 : 1][2];
+    f32x4 b2r[K2Q > 0 && !BF3 ? K2Q : 1][PACK2 ? 1 : 2];
+    bf16x8 b1r3[BR1 && BF3 ? NCH : 1][3][2];   // BF3: [chunk][split][b1p | b1q]
+    if constexpr (BR1 && BF3) {
+#pragma unroll
+        for (int c = 0; c < NCH; ++c)
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                b1r3[c][q][0] = *(const bf16x8*)(q1p + c * 48 + q * 8);
+                b1r3[c][q][1] = *(const bf16x8*)(q1q + c * 48 + q * 8);
+            }
+    }
+    if constexpr (BR1 && !BF3) {
 #pragma unroll
         for (int q = 0; q < NCH * 2; ++q) {
             b1r[q][0] = *(const f32x4*)(b1p + (q >> 1) * 16 + (q & 1) * 4);
             b1r[q][1] = *(const f32x4*)(b1q + (q >> 1) * 16 + (q & 1) * 4);
         }
     }
-    if constexpr (K2Q > 0) {
+    if constexpr (K2Q > 0 && !BF3) {
         // (one item per wave and tile, always the same: its column group is this wave's)
         const int cg0 = PACK2 ? 0 : wave / (p.rows2 >> 5);
 #pragma unroll
@@ -349,6 +477,52 @@ __global__ __launch_bounds__(SW * 64, 1) void stem2_kernel(StemArgs p) {
     auto consume = [&](c64 (&r)[8], int m, int ch, auto always_tag, auto drain_tag) __attribute__((always_inline)) {
         constexpr bool DRAIN = decltype(drain_tag)::value;
         const int64_t base = pend0 + pend1 + pend2 + pend3;   // of the task two ahead (prep of the task before)
+        if constexpr (BF3) {
+            // all 8 elements of the task at once: split, refill the registers, 6 cross terms
+            float re[8], im[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                re[j] = r[j].re;
+                im[j] = r[j].im;
+            }
+            bf16x8 r3[3], i3[3], n3[3], bp3[3], bq3[3];
+            split3(re, r3);
+            split3(im, i3);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) fire2(r, q, base, always_tag);
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                if (!PACK1) n3[q] = __builtin_bit_cast(bf16x8, __builtin_bit_cast(u32x4, i3[q]) ^ 0x80008000u);
+                if constexpr (BR1) {
+                    bp3[q] = b1r3[ch][q][0];
+                    bq3[q] = b1r3[ch][q][1];
+                } else {
+                    bp3[q] = *(const bf16x8*)(q1p + ch * 48 + q * 8);
+                    bq3[q] = *(const bf16x8*)(q1q + ch * 48 + q * 8);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int t = 0; t < 6; ++t) {
+                const int ta = bf3_ta(t), tb = bf3_tb(t);
+                if (PACK1) {
+                    ax[m] = mfma_bf(r3[ta], bp3[tb], ax[m]);
+                    ax[m] = mfma_bf(i3[ta], bq3[tb], ax[m]);
+                } else {
+                    ax[m] = mfma_bf(r3[ta], bp3[tb], ax[m]);
+                    ay[m] = mfma_bf(r3[ta], bq3[tb], ay[m]);
+                    ax[m] = mfma_bf(n3[ta], bq3[tb], ax[m]);
+                    ay[m] = mfma_bf(i3[ta], bp3[tb], ay[m]);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                if constexpr (DRAIN) drain(t * NST / 6, (t + 1) * NST / 6);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            prep(always_tag);
+            __builtin_amdgcn_sched_barrier(0);
+            return;
+        }
         f32x4 bp[2], bq[2];
         if constexpr (BR1) {   // (ch is a compile-time constant here: static variants only)
             bp[0] = b1r[ch * 2][0];
@@ -421,7 +595,7 @@ __global__ __launch_bounds__(SW * 64, 1) void stem2_kernel(StemArgs p) {
     auto item2 = [&](int item, int64_t c_row, auto scaled_tag, auto drain_tag, auto defer_tag)
                      __attribute__((always_inline)) {
         constexpr bool DRAIN = decltype(drain_tag)::value;
-        if constexpr (DRAIN && K2Q == 0) drain(0, NST);   // (run-time trip count below: no slots to put them in)
+        if constexpr (DRAIN && (K2Q == 0 || BF3)) drain(0, NST);   // (run-time trip count below: no slots to put them in)
         const int cg = item / n_rt2, rt2 = item - cg * n_rt2;
         f32x16 cx, cy;
 #pragma unroll
@@ -436,6 +610,30 @@ __global__ __launch_bounds__(SW * 64, 1) void stem2_kernel(StemArgs p) {
         const int64_t c_col = oc_s[PACK2 ? (l31 & 15) : cg * 32 + l31];
         const int nq = K2 >> 2;   // >= 4, even
         f32x4 af[2], bx[2], by[2];
+        if constexpr (BF3) {
+            // 8 k per instruction: the row's 8 values of this lane's plane, split; B2 from its planes
+            const unsigned short* bxq = q2x + (PACK2 ? 0 : cg * 32 * ROW2);
+            const unsigned short* byq = PACK2 ? nullptr : q2y + cg * 32 * ROW2;
+            for (int kb = 0; kb < (K2 >> 3); ++kb) {
+                const f32x4 lo = *(const f32x4*)(a_base + 8 * kb), hi = *(const f32x4*)(a_base + 8 * kb + 4);
+                const float a8[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                bf16x8 a3[3], ax3[3], bx3[3], by3[3];
+                split3(a8, a3);
+#pragma unroll
+                for (int q = 0; q < 3; ++q) {
+                    // (the X tile takes -Im a: the lanes of the second k-row flip the sign)
+                    ax3[q] = PACK2 ? a3[q]
+                                   : __builtin_bit_cast(bf16x8, __builtin_bit_cast(u32x4, a3[q]) ^ (sgn2 | (sgn2 >> 16)));
+                    bx3[q] = *(const bf16x8*)(bxq + kb * 24 + q * 8);
+                    if (!PACK2) by3[q] = *(const bf16x8*)(byq + kb * 24 + q * 8);
+                }
+#pragma unroll
+                for (int t = 0; t < 6; ++t) {
+                    cx = mfma_bf(ax3[bf3_ta(t)], bx3[bf3_tb(t)], cx);
+                    if (!PACK2) cy = mfma_bf(a3[bf3_ta(t)], by3[bf3_tb(t)], cy);
+                }
+            }
+        } else {
         af[0] = *(const f32x4*)(a_base);
         if constexpr (K2Q > 0) {
             // B2 fragments in registers, K2 known: the quads fully unrolled
@@ -453,7 +651,7 @@ __global__ __launch_bounds__(SW * 64, 1) void stem2_kernel(StemArgs p) {
                     }
                 }
                 __builtin_amdgcn_sched_barrier(0);
-                if constexpr (DRAIN) drain(kq * NST / K2Q, (kq + 1) * NST / K2Q);
+                if constexpr (DRAIN && !BF3) drain(kq * NST / K2Q, (kq + 1) * NST / K2Q);
             }
         } else {
 #ifdef CTG_STEM_KO_BFRAG
@@ -485,6 +683,7 @@ __global__ __launch_bounds__(SW * 64, 1) void stem2_kernel(StemArgs p) {
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
+        }
         }
         }
         {
@@ -615,9 +814,17 @@ size_t stem2_lds_bytes(const StemArgs& p) {
     return 4 * (b1 + b2 + mid) + 8 * (size_t)p.N2;
 }
 
-template <bool PACK1, bool PACK2, int RT1, int CS1, int NCH, int IT2, bool BR1 = false, int K2Q = 0, bool VEC = false>
+// the same with the small operands as bf16 x 3 planes (BF3)
+static size_t stem2_lds_bytes_bf3(const StemArgs& p) {
+    const size_t q1 = (size_t)(p.N1 == 16 ? 3 : 2) * p.N1 * ((p.K1 >> 4) * 48 + 8);
+    const size_t q2 = (size_t)(p.N2 == 16 ? 3 : 2) * p.N2 * ((p.K2 >> 3) * 24 + 8);
+    return 2 * (q1 + q2) + 4 * (size_t)2 * p.rows2 * p.ld2 + 8 * (size_t)p.N2;
+}
+
+template <bool PACK1, bool PACK2, int RT1, int CS1, int NCH, int IT2, bool BR1 = false, int K2Q = 0, bool VEC = false,
+          bool BF3 = false>
 static hipError_t launch_stem2_t(const StemArgs& p, hipStream_t stream) {
-    auto kern = stem2_kernel<PACK1, PACK2, RT1, CS1, NCH, IT2, BR1, K2Q, VEC>;
+    auto kern = stem2_kernel<PACK1, PACK2, RT1, CS1, NCH, IT2, BR1, K2Q, VEC, BF3>;
     static bool ready = false;
     if (!ready) {
         const hipError_t e =
@@ -625,7 +832,7 @@ static hipError_t launch_stem2_t(const StemArgs& p, hipStream_t stream) {
         if (e != hipSuccess) return e;
         ready = true;
     }
-    const size_t smem = stem2_lds_bytes(p);
+    const size_t smem = BF3 ? stem2_lds_bytes_bf3(p) : stem2_lds_bytes(p);
     // persistent: one workgroup per CU (the tile owns most of the CU's LDS)
     int64_t blocks = p.n_tiles < 256 ? p.n_tiles : 256;
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks, 1), dim3(SW * 64), smem, stream, p);
@@ -717,11 +924,21 @@ int stem2_variant(const StemArgs& p) {
     return 0;
 }
 
+// CTG_STEM_BF16X3 (read at every launch; experiment switch, off by default): static shapes run
+// both steps on the bf16 matrix cores with three-way split operands (stem2_kernel<..., BF3 = true>)
+static bool stem2_bf3(const StemArgs& p) {
+    return getenv("CTG_STEM_BF16X3") != nullptr && stem2_variant(p) && (p.K2 & 7) == 0 &&
+           stem2_lds_bytes_bf3(p) <= 160 * 1024;
+}
+
 // the instantiation a step runs on, spelled like its symbol in a kernel trace
 void stem2_kernel_name(const StemArgs& p, char* buf, size_t n) {
     const StemShape s = stem2_shape(p);
     auto tf = [](bool b) { return b ? "true" : "false"; };
-    if (stem2_variant(p))
+    if (stem2_bf3(p))
+        snprintf(buf, n, "stem2_kernel<%s,%s,%d,%d,%d,%d,%s,0,%s,true>", tf(s.p1), tf(s.p2), s.rt1, s.cs1, s.nch, s.it2,
+                 tf(s.nch <= 2), tf(s.vec));
+    else if (stem2_variant(p))
         snprintf(buf, n, "stem2_kernel<%s,%s,%d,%d,%d,%d,%s,%d,%s>", tf(s.p1), tf(s.p2), s.rt1, s.cs1, s.nch, s.it2,
                  tf(s.br1), s.k2q, tf(s.vec));
     else
@@ -731,6 +948,13 @@ void stem2_kernel_name(const StemArgs& p, char* buf, size_t n) {
 hipError_t launch_stem2(const StemArgs& p, hipStream_t stream) {
     if (!stem2_supported(p)) return hipErrorInvalidValue;
     const StemShape s = stem2_shape(p);
+    if (stem2_bf3(p)) {
+#define CTG_STEM_GO3(P1, P2, R, CS, NC, IT, B1, KQ, V)                                                \
+    if (s.p1 == P1 && s.p2 == P2 && s.rt1 == R && s.cs1 == CS && s.nch == NC && s.it2 == IT && s.vec == V) \
+        return launch_stem2_t<P1, P2, R, CS, NC, IT, (NC <= 2), 0, V, true>(p, stream);
+        CTG_STEM_INST(CTG_STEM_GO3)
+#undef CTG_STEM_GO3
+    }
     if (stem2_variant(p)) {
 #define CTG_STEM_GO(P1, P2, R, CS, NC, IT, B1, KQ, V)                                                  \
     if (s.p1 == P1 && s.p2 == P2 && s.rt1 == R && s.cs1 == CS && s.nch == NC && s.it2 == IT && s.br1 == B1 && \

@@ -170,6 +170,99 @@ extern "C" double ctg_probe_mfma(int which, int chains, int blocks, int iters, f
     return per * chains * (double)iters * 4.0 * blocks;
 }
 
+
+// ---- fp32 products on the bf16 matrix cores --------------------- //
+// WHICH 0: chains of independent v_mfma_f32_32x32x16_bf16 (the instruction's issue rate).
+// WHICH 1: what one task of the stem kernel's first step would do: 16 fp32 values per lane (8
+// complex elements) split exactly into 3 bf16 values each (two ANDs, two SUBs, packing), then the
+// 6 significant cross terms x (X: re Re b, -im Im b; Y: re Im b, im Re b) = 24 MFMAs with B
+// fragments in registers.  Counts 65536 real MACs x 2 per task: the fp32-equivalent rate.
+typedef __bf16 bf16x8p __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4p __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ void split3(const float (&x)[8], bf16x8p (&o)[3]) {
+    unsigned w[3][8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const unsigned u = __builtin_bit_cast(unsigned, x[i]);
+        const unsigned h1 = u & 0xffff0000u;
+        const float r1 = x[i] - __builtin_bit_cast(float, h1);
+        const unsigned h2 = __builtin_bit_cast(unsigned, r1) & 0xffff0000u;
+        const float r2 = r1 - __builtin_bit_cast(float, h2);
+        w[0][i] = h1; w[1][i] = h2; w[2][i] = __builtin_bit_cast(unsigned, r2);
+    }
+#pragma unroll
+    for (int s = 0; s < 3; ++s) {
+        u32x4p pk;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) pk[i] = (w[s][2 * i] >> 16) | (w[s][2 * i + 1] & 0xffff0000u);
+        o[s] = __builtin_bit_cast(bf16x8p, pk);
+    }
+}
+
+template <int WHICH>
+__global__ __launch_bounds__(512, 1) void bf16x3_kernel(float* out, const float* in, int iters) {
+    const int lane = threadIdx.x & 63;
+    f32x16p ax, ay;
+    for (int t = 0; t < 16; ++t) ax[t] = ay[t] = 0.f;
+    bf16x8p bre[3], bim[3];
+    {
+        float t0[8];
+        for (int i = 0; i < 8; ++i) t0[i] = 0.5f - lane * 1e-3f + i;
+        split3(t0, bre);
+        for (int i = 0; i < 8; ++i) t0[i] = 0.25f + lane * 1e-3f - i;
+        split3(t0, bim);
+    }
+    if (WHICH == 0) {
+        f32x16p acc[4];
+        for (int c = 0; c < 4; ++c) acc[c] = ax;
+        for (int i = 0; i < iters; ++i)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bre[c % 3], bim[c % 3], acc[c], 0, 0, 0);
+        float s = 0;
+        for (int c = 0; c < 4; ++c) s += acc[c][0] + acc[c][15];
+        if (s == 12345.678f) out[threadIdx.x] = s;
+    } else {
+        float re[8], im[8];
+        for (int i = 0; i < 8; ++i) {
+            re[i] = in[(threadIdx.x * 16 + i) & 1023];
+            im[i] = in[(threadIdx.x * 16 + 8 + i) & 1023];
+        }
+        for (int it = 0; it < iters; ++it) {
+            bf16x8p r3[3], i3[3], n3[3];
+            split3(re, r3);
+            split3(im, i3);
+#pragma unroll
+            for (int s = 0; s < 3; ++s)
+                n3[s] = __builtin_bit_cast(bf16x8p, __builtin_bit_cast(u32x4p, i3[s]) ^ 0x80008000u);
+            constexpr int TA[6] = {0, 0, 1, 1, 0, 2}, TB[6] = {0, 1, 0, 1, 2, 0};
+#pragma unroll
+            for (int t = 0; t < 6; ++t) {
+                ax = __builtin_amdgcn_mfma_f32_32x32x16_bf16(r3[TA[t]], bre[TB[t]], ax, 0, 0, 0);
+                ay = __builtin_amdgcn_mfma_f32_32x32x16_bf16(r3[TA[t]], bim[TB[t]], ay, 0, 0, 0);
+                ax = __builtin_amdgcn_mfma_f32_32x32x16_bf16(n3[TA[t]], bim[TB[t]], ax, 0, 0, 0);
+                ay = __builtin_amdgcn_mfma_f32_32x32x16_bf16(i3[TA[t]], bre[TB[t]], ay, 0, 0, 0);
+            }
+            // (the next task's values: something the compiler cannot fold)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                re[i] = re[i] * 1.0000001f + 1e-7f;
+                im[i] = im[i] * 0.9999999f - 1e-7f;
+            }
+        }
+        float s = ax[0] + ay[15];
+        if (s == 12345.678f) out[threadIdx.x] = s;
+    }
+}
+
+// returns real flops of the launch: WHICH 0 -> 32768 per MFMA; WHICH 1 -> 2 x 65536 fp32-equivalent per task
+extern "C" double ctg_probe_bf16x3(int which, int blocks, int iters, float* out, const float* in, void* stream) {
+    hipStream_t s = (hipStream_t)stream;
+    if (which == 0) hipLaunchKernelGGL((bf16x3_kernel<0>), dim3(blocks), dim3(512), 0, s, out, in, iters);
+    else hipLaunchKernelGGL((bf16x3_kernel<1>), dim3(blocks), dim3(512), 0, s, out, in, iters);
+    return (which == 0 ? 4 * 65536.0 : 2 * 65536.0) * (double)iters * 8.0 * blocks;
+}
+
 // ---- vector ALU rate: independent FMA chains per lane ---------------------- //
 template <typename T, int CHAINS>
 __global__ __launch_bounds__(256) void valu_rate_kernel(T* out, int iters) {

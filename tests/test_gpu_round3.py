@@ -81,6 +81,31 @@ def test_fused_stem_pairs(case, sliced, fuse_whatever_fits):
     plain.close()
 
 
+@pytest.mark.parametrize("case", range(len(G.STEM_CASES)))
+def test_fused_stem_pairs_on_the_bf16_matrix_cores(case, fuse_whatever_fits, monkeypatch):
+    """CTG_STEM_BF16X3 (experiment switch, off by default): both steps of a pair multiply on the
+    bf16 matrix cores -- every fp32 operand split exactly into three bf16 values, the six
+    significant cross terms accumulated in fp32.  Same gate as the fp32 path against the numpy
+    complex128 oracle; shapes without a static instantiation keep the fp32 kernel."""
+    nq, gates = G.STEM_CASES[case]
+    tree = G.stem_network(nq, gates, 100 * case)
+    arrays = ca.make_arrays_from_inputs(tree.inputs, tree.size_dict, seed=case, dtype="complex64")
+    ref = np.asarray(orc.contract(tree, [a.astype("complex128") for a in arrays]))
+    gate = G.single_gate(ref, orc.contract(tree, arrays))
+    fn = HipContractor(tree, fuse=True, fuse_min_elems=1 << 10)
+    fp32 = np.asarray(fn(*arrays))
+    monkeypatch.setenv("CTG_STEM_BF16X3", "1")
+    got = np.asarray(fn(*arrays))
+    names = [n for n in fn.setup(*arrays)["exec"].step_kernels() if n.startswith("stem2_kernel")]
+    m, e = fn(*arrays, strip_exponent=True)
+    fn.close()
+    assert names
+    if any(n.count(",") == 9 for n in names):   # (ten template arguments: the last one is BF3 = true)
+        assert not np.array_equal(got, fp32)   # (it really ran)
+    assert G.relerr(got, ref) <= gate, (G.relerr(got, ref), gate, G.relerr(fp32, ref))
+    assert G.relerr(np.asarray(m).astype("complex128") * 10.0**e, ref) <= gate
+
+
 @pytest.mark.parametrize("case", [0, 1, 2, 4, 9, 11])
 def test_fused_stem_pairs_run_time_count_variant(case, fuse_whatever_fits, monkeypatch):
     """Shapes without a static instantiation run the variant whose chunk / item counts are
