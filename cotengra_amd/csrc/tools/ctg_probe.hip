@@ -260,7 +260,7 @@ extern "C" double ctg_probe_bf16x3(int which, int blocks, int iters, float* out,
     hipStream_t s = (hipStream_t)stream;
     if (which == 0) hipLaunchKernelGGL((bf16x3_kernel<0>), dim3(blocks), dim3(512), 0, s, out, in, iters);
     else hipLaunchKernelGGL((bf16x3_kernel<1>), dim3(blocks), dim3(512), 0, s, out, in, iters);
-    return (which == 0 ? 4 * 65536.0 : 2 * 65536.0) * (double)iters * 8.0 * blocks;
+    return 2 * 65536.0 * (double)iters * 8.0 * blocks;   // (4 MFMAs of 32768 flops | one task)
 }
 
 // ---- vector ALU rate: independent FMA chains per lane ---------------------- //
