@@ -939,10 +939,10 @@ void stem2_kernel_name(const StemArgs& p, char* buf, size_t n) {
         snprintf(buf, n, "stem2_kernel<%s,%s,%d,%d,%d,%d,%s,0,%s,true>", tf(s.p1), tf(s.p2), s.rt1, s.cs1, s.nch, s.it2,
                  tf(s.nch <= 2), tf(s.vec));
     else if (stem2_variant(p))
-        snprintf(buf, n, "stem2_kernel<%s,%s,%d,%d,%d,%d,%s,%d,%s>", tf(s.p1), tf(s.p2), s.rt1, s.cs1, s.nch, s.it2,
+        snprintf(buf, n, "stem2_kernel<%s,%s,%d,%d,%d,%d,%s,%d,%s,false>", tf(s.p1), tf(s.p2), s.rt1, s.cs1, s.nch, s.it2,
                  tf(s.br1), s.k2q, tf(s.vec));
     else
-        snprintf(buf, n, "stem2_kernel<%s,%s,%d,%d,0,0,false,0,%s>", tf(s.p1), tf(s.p2), s.rt1, s.cs1, tf(s.vec));
+        snprintf(buf, n, "stem2_kernel<%s,%s,%d,%d,0,0,false,0,%s,false>", tf(s.p1), tf(s.p2), s.rt1, s.cs1, tf(s.vec));
 }
 
 hipError_t launch_stem2(const StemArgs& p, hipStream_t stream) {
