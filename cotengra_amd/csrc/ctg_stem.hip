@@ -326,17 +326,26 @@ __global__ __launch_bounds__(SW * 64, 1) void stem2_kernel(StemArgs p) {
     if (PACK1) mid_lane = (int)p.mid_col[l31 & 15] + (l31 >> 4) * PLANE + (int)p.mid_row[4 * kk];
     else mid_lane = (int)p.mid_col[wcol + l31] + (int)p.mid_row[4 * kk];
     settle(mid_lane);
-    int mid_t[16];
+    // (accumulator register t is row rowmap(t) = bits 0, 1, 3, 4 of t's four bits: the tables are
+    // additive over binary digits, so four entries each and a few scalar adds where they are
+    // used replace 16-entry arrays that did not fit the scalar registers)
+    int mid_o[4];
 #pragma unroll
-    for (int t = 0; t < 16; ++t) mid_t[t] = (int)sload64(p.mid_row + rowmap(t));
+    for (int b = 0; b < 4; ++b) mid_o[b] = (int)sload64(p.mid_row + (b < 2 ? 1 << b : 2 << b));
+    auto mid_t = [&](int t) __attribute__((always_inline)) {
+        return ((t & 1) ? mid_o[0] : 0) + ((t & 2) ? mid_o[1] : 0) + ((t & 4) ? mid_o[2] : 0) + ((t & 8) ? mid_o[3] : 0);
+    };
     // store of the step-2 accumulators: lane part of out_row[row2] + out_col[n2]
     // (PACK2: the lanes of columns 16-31 take the odd rows of each row pair)
     int64_t out_lane = p.out_row[4 * kk];
     if (PACK2) out_lane += (l31 >> 4) ? p.out_row[1] : 0;
     settle(out_lane);
-    int64_t out_t[16];
+    int64_t out_o[4];
 #pragma unroll
-    for (int t = 0; t < 16; ++t) out_t[t] = sload64(p.out_row + rowmap(t));
+    for (int b = 0; b < 4; ++b) out_o[b] = sload64(p.out_row + (b < 2 ? 1 << b : 2 << b));
+    auto out_t = [&](int t) __attribute__((always_inline)) {
+        return ((t & 1) ? out_o[0] : 0) + ((t & 2) ? out_o[1] : 0) + ((t & 4) ? out_o[2] : 0) + ((t & 8) ? out_o[3] : 0);
+    };
 
     float alpha = 1.f;
     if (p.facA != nullptr) {
@@ -471,7 +480,7 @@ __global__ __launch_bounds__(SW * 64, 1) void stem2_kernel(StemArgs p) {
 #ifdef CTG_STEM_KO_STORE
             if (pv[i].x == 12345.678f)
 #endif
-            *(float2*)(pdst + 2 * out_t[PACK2 ? 2 * i : i]) = pv[i];
+            *(float2*)(pdst + 2 * out_t(PACK2 ? 2 * i : i)) = pv[i];
         }
     };
     auto consume = [&](c64 (&r)[8], int m, int ch, auto always_tag, auto drain_tag) __attribute__((always_inline)) {
@@ -579,8 +588,8 @@ __global__ __launch_bounds__(SW * 64, 1) void stem2_kernel(StemArgs p) {
 #ifdef CTG_STEM_KO_SCATTER
                 if (ax[m][t] != 12345.678f) continue;
 #endif
-                dst[mid_t[t]] = ax[m][t];
-                if (!PACK1) dst[PLANE + mid_t[t]] = ay[m][t];
+                dst[mid_t(t)] = ax[m][t];
+                if (!PACK1) dst[PLANE + mid_t(t)] = ay[m][t];
             }
         }
     };
