@@ -81,13 +81,21 @@ def test_narrowed_trees_against_oracle(fixture, log2_width):
 
 
 @pytest.mark.parametrize("fixture", ["sycamore_m20_w32_c512.json", "sycamore_m20_native.json", "sycamore_m20_fused.json"])
-def test_full_width_slice_is_sum_of_double_precision_sub_slices(fixture):
-    """(ii): complex64 at width 2^32 vs complex128 at width 2^28."""
+def test_full_width_slice_is_sum_of_double_precision_sub_slices(fixture, monkeypatch):
+    """(ii): complex64 at width 2^32 vs complex128 at width 2^28 -- on the native tree also with
+    the stem pairs on the bf16 matrix cores (CTG_STEM_BF16X3, csrc/ctg_stem.hip: BF3): the same
+    gate at full size."""
     tree, arrays = load(fixture)
     assert tree.max_size() == 2**32
     sid = 5
     coarse = HipContractor(tree)
     full = complex(np.asarray(coarse.contract_slice(arrays, sid)))
+    full_bf3 = None
+    if fixture == "sycamore_m20_native.json":
+        monkeypatch.setenv("CTG_STEM_BF16X3", "1")
+        full_bf3 = complex(np.asarray(coarse.contract_slice(arrays, sid)))
+        monkeypatch.delenv("CTG_STEM_BF16X3")
+        assert full_bf3 != full
     coarse.close()
     fine = tree.slice(target_size=2**28)
     ids = sub_slice_ids(tree, fine, sid)
@@ -107,6 +115,8 @@ def test_full_width_slice_is_sum_of_double_precision_sub_slices(fixture):
     ref = orc.contract_slice(small, a128, 3)
     gate = max(NORTH_STAR, 8.0 * rel(orc.contract_slice(small, arrays, 3), ref))
     assert rel(full, parts) <= gate, (rel(full, parts), gate)
+    if full_bf3 is not None:
+        assert rel(full_bf3, parts) <= gate, (rel(full_bf3, parts), rel(full, parts), gate)
 
 
 def test_double_precision_path_chain_down_to_the_oracle():
