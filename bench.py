@@ -55,7 +55,7 @@ PEAK_TREE = os.path.join(TREES, "sycamore_m20_w32_c512.json")  # highest FLOP/s 
 TTS_TREE = os.path.join(TREES, "sycamore_m20_fused.json")
 # the same with one index less sliced: 2^19 slices of width 2^33 (68 GB tensors, a 161 GiB arena --
 # what 288 GB of HBM are for); the amplitude another 6 % sooner
-TTS33_TREE = os.path.join(TREES, "sycamore_m20_w33_fused.json")
+TTS33_TREE = os.path.join(TREES, "sycamore_m20_w33_bf3.json")   # (refined once more: gen/refine_bf3.py)
 
 
 # ---------------------------------------------------------------------- #

@@ -57,7 +57,7 @@ def rel(a, b):
 
 
 @pytest.mark.parametrize("fixture", ["sycamore_m20_w32_c512.json", "sycamore_m20_native.json", "sycamore_m20_fused.json",
-                                     "sycamore_m20_w33_fused.json"])
+                                     "sycamore_m20_w33_bf3.json"])
 @pytest.mark.parametrize("log2_width", [20, 24])
 def test_narrowed_trees_against_oracle(fixture, log2_width):
     """(i): both precisions of the HIP path vs the oracle on the bench tree and
