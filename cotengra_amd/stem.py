@@ -33,6 +33,7 @@ address as *uniform part + per-lane constant*.
 from __future__ import annotations
 
 import math
+import os
 
 import numpy as np
 
@@ -59,6 +60,11 @@ N2_OK = (16, 32, 64, 128)
 # the lines it fetches), C2 at the full rate; together they take the longer of the two plus a fifth
 # of the shorter.
 FUSED_MFMA_RATE = 157.3e12 * 0.73
+# ... and with the experiment switch CTG_STEM_BF16X3 (csrc/ctg_stem.hip: BF3; fp32 operands split
+# into three bf16 values, products on the bf16 matrix cores): the factor by which the pairs' matrix
+# work speeds up, as measured on whole pairs; tree refinement for that mode
+# (tests/golden/gen/refine_bf3.py) prices pairs with it
+BF16X3_SPEEDUP = 1.6
 FUSED_STORE_RATE = 5.4e12
 FUSED_OVERLAP_LOSS = 0.2
 MIN_GAIN = 0.05              # fuse only if the model saves at least this fraction
@@ -236,8 +242,9 @@ def geometry(size_dict, A, B1, B2, c1_inds, c2_inds):
 
 
 def pair_seconds(macs1, macs2, elems_a, elems_c2, items, run_bytes=256):
-    """Modelled time of a fused pair."""
-    t_mfma = 8.0 * macs1 / FUSED_MFMA_RATE + 8.0 * macs2 / (FUSED_MFMA_RATE * min(1.0, items / WAVES))
+    """Modelled time of a fused pair (``CTG_STEM_BF16X3`` in the environment: of the bf16 mode)."""
+    rate = FUSED_MFMA_RATE * (BF16X3_SPEEDUP if os.environ.get("CTG_STEM_BF16X3") else 1.0)
+    t_mfma = 8.0 * macs1 / rate + 8.0 * macs2 / (rate * min(1.0, items / WAVES))
     t_mem = 8.0 * elems_a / gather_rate(run_bytes) + 8.0 * elems_c2 / FUSED_STORE_RATE
     return max(t_mfma, t_mem) + FUSED_OVERLAP_LOSS * min(t_mfma, t_mem)
 

@@ -1,6 +1,7 @@
 #!/usr/bin/env python
 """Polish the width-2^33 tree once more under a pair model in which the stem pairs multiply on the
-bf16 matrix cores (csrc/ctg_stem.hip: BF3): ``stem.FUSED_MFMA_RATE`` x 1.6,
+bf16 matrix cores (csrc/ctg_stem.hip: BF3): CTG_STEM_BF16X3 in the environment
+makes ``stem.pair_seconds`` price the pairs' matrix work at ``stem.BF16X3_SPEEDUP`` x the fp32 rate,
 everything else as tests/golden/gen/refine_fused.py.  The result is the better tree for BOTH
 arithmetics (measured, round 3: 470 ms per slice with fp32 MFMAs against 487, 408 ms with bf16 x 3
 against 438-449).  Host tools of this package only; about 25 minutes.
@@ -10,8 +11,8 @@ against 438-449).  Host tools of this package only; about 25 minutes.
 import json, math, os, sys, time
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', '..', '..'))
 import cotengra_amd as ca
-from cotengra_amd import pathfind as pf, stem
-stem.FUSED_MFMA_RATE = 157.3e12 * 0.73 * 1.6     # pairs on the bf16 matrix cores
+os.environ["CTG_STEM_BF16X3"] = "1"              # (read by stem.pair_seconds)
+from cotengra_amd import pathfind as pf
 src, dst = sys.argv[1], sys.argv[2]
 rec = ca.load_network(src); tree = ca.tree_from_record(rec)
 t0 = time.time()

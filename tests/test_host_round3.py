@@ -141,6 +141,19 @@ def test_fusion_is_off_where_it_does_not_apply():
     assert all(s.kind != P.KIND_STEM2 for s in compile_tree(t3, "complex64", fuse=True, fuse_min_elems=1).steps)
 
 
+def test_pair_model_of_the_bf16_mode(monkeypatch):
+    """With CTG_STEM_BF16X3 in the environment the pair model prices the pairs' matrix work at
+    BF16X3_SPEEDUP x the fp32 rate (tree refinement for that mode, tests/golden/gen/refine_bf3.py);
+    a memory-bound pair costs the same either way."""
+    from cotengra_amd import stem
+    monkeypatch.delenv("CTG_STEM_BF16X3", raising=False)
+    mfma_bound = stem.pair_seconds(2**27 * 32 * 32, 2**26 * 64 * 64, 2**32, 2**32, 8)
+    mem_bound = stem.pair_seconds(2**28 * 16 * 16, 2**28 * 16 * 16, 2**32, 2**32, 16)
+    monkeypatch.setenv("CTG_STEM_BF16X3", "1")
+    assert stem.pair_seconds(2**27 * 32 * 32, 2**26 * 64 * 64, 2**32, 2**32, 8) < 0.8 * mfma_bound
+    assert stem.pair_seconds(2**28 * 16 * 16, 2**28 * 16 * 16, 2**32, 2**32, 16) >= 0.9 * mem_bound
+
+
 def test_fused_descriptor_is_validated():
     tree = G.stem_network(16, [(3, 3), (5, 5), (5, 5)], 0)
     plan = compile_tree(tree, "complex64", fuse=True, fuse_min_elems=1 << 10)
