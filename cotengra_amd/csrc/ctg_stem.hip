@@ -888,7 +888,8 @@ bool stem2_supported(const StemArgs& p) {
     X(true, false, 2, 1, 1, 1, true, 0, false) X(false, true, 1, 1, 8, 2, false, 4, false) \
     X(false, false, 1, 1, 2, 4, true, 0, false) X(true, true, 2, 1, 4, 1, true, 8, false) \
     X(false, false, 1, 1, 8, 1, false, 8, true) X(false, false, 1, 1, 8, 1, false, 0, false) \
-    X(false, false, 1, 1, 8, 1, false, 0, true)
+    X(false, false, 1, 1, 8, 1, false, 0, true) \
+    X(false, false, 1, 1, 8, 2, false, 0, false) X(true, false, 2, 1, 2, 1, true, 8, false)
 
 namespace {
 struct StemShape {
