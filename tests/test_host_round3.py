@@ -129,6 +129,36 @@ def test_fused_stem_plan_matches_oracle(case, sliced, fuse_whatever_fits):
     assert np.allclose(got, ref, rtol=1e-12, atol=1e-12 * np.abs(ref).max())
 
 
+@pytest.mark.parametrize("seed", range(48))
+def test_random_stems_fused_plan_matches_oracle(seed, fuse_whatever_fits):
+    """Random stems -- 3 to 6 gates of 4 to 7 contracted and 4 to 7 new indices each on a tensor of
+    15 to 18 binary indices, contracted positions and orders drawn at random, up to two indices
+    sliced -- planned with every pair the kernel can take and interpreted in numpy exactly as the
+    kernel reads its tables: the reference contraction, the unfused plan's work and bytes."""
+    rng = np.random.default_rng(1000 + seed)
+    nq = int(rng.integers(15, 19))
+    gates, cur = [(3, 3)], nq
+    for _ in range(int(rng.integers(3, 7))):
+        kin = int(rng.integers(4, 8))
+        nout = int(np.clip(kin + rng.integers(-2, 3), 4, 7))
+        if kin > cur - 6 or cur - kin + nout > 19:
+            continue
+        gates.append((kin, nout))
+        cur += nout - kin
+    tree = G.stem_network(nq, gates, seed, sliced=int(rng.integers(0, 3)))
+    arrays = ca.make_arrays_from_inputs(tree.inputs, tree.size_dict, seed=seed, dtype="complex128")
+    fused = compile_tree(tree, "complex64", fuse=True, fuse_min_elems=1 << 9)
+    plain = compile_tree(tree, "complex64", fuse=False)
+    assert fused.macs_per_slice == plain.macs_per_slice
+    assert fused.elems_rw_per_slice == plain.elems_rw_per_slice
+    assert fused.elems_moved_per_slice <= plain.elems_rw_per_slice
+    runtime.DevicePlan(fused).close()
+    fused.dtype = "complex128"
+    got = run_plan(fused, arrays)
+    ref = orc.contract(tree, arrays)
+    assert np.allclose(got, ref, rtol=1e-12, atol=1e-12 * np.abs(ref).max())
+
+
 def test_fusion_is_off_where_it_does_not_apply():
     tree = G.stem_network(16, [(3, 3), (5, 5), (5, 5)], 0)
     for dtype in ("complex128", "float32", "float64"):
