@@ -121,6 +121,22 @@ def stem_network(nq, gates, seed, sliced=0):
     return tree
 
 
+def random_stem(seed):
+    """A random stem for the fused-pair tests: 3 to 6 gates of 4 to 7 contracted and 4 to 7 new
+    indices on a tensor of 15 to 18 binary indices, up to two indices sliced."""
+    rng = np.random.default_rng(1000 + seed)
+    nq = int(rng.integers(15, 19))
+    gates, cur = [(3, 3)], nq
+    for _ in range(int(rng.integers(3, 7))):
+        kin = int(rng.integers(4, 8))
+        nout = int(np.clip(kin + rng.integers(-2, 3), 4, 7))
+        if kin > cur - 6 or cur - kin + nout > 19:
+            continue
+        gates.append((kin, nout))
+        cur += nout - kin
+    return stem_network(nq, gates, seed, sliced=int(rng.integers(0, 3)))
+
+
 # (nq, gates): every instantiation of the fused kernel -- 16 / 32 columns on either step,
 # 256 and 512 tile rows, K up to 128, N2 up to 128 -- and chains with leftovers
 STEM_CASES = [

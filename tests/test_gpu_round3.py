@@ -106,6 +106,23 @@ def test_fused_stem_pairs_on_the_bf16_matrix_cores(case, fuse_whatever_fits, mon
     assert G.relerr(np.asarray(m).astype("complex128") * 10.0**e, ref) <= gate
 
 
+@pytest.mark.parametrize("seed", range(48))
+def test_random_stems_on_the_fused_kernel(seed, fuse_whatever_fits, monkeypatch):
+    """The 48 random stems of the host suite (58 fused pairs in 50 shapes, most of them on the
+    run-time-count variant) on the device, fp32 matrix cores and bf16 x 3, against the oracle."""
+    tree = G.random_stem(seed)
+    arrays = ca.make_arrays_from_inputs(tree.inputs, tree.size_dict, seed=seed, dtype="complex64")
+    ref = np.asarray(orc.contract(tree, [a.astype("complex128") for a in arrays]))
+    gate = G.single_gate(ref, orc.contract(tree, arrays))
+    fn = HipContractor(tree, fuse=True, fuse_min_elems=1 << 9)
+    got = np.asarray(fn(*arrays))
+    monkeypatch.setenv("CTG_STEM_BF16X3", "1")
+    got3 = np.asarray(fn(*arrays))
+    fn.close()
+    assert G.relerr(got, ref) <= gate, (G.relerr(got, ref), gate)
+    assert G.relerr(got3, ref) <= gate, (G.relerr(got3, ref), gate)
+
+
 @pytest.mark.parametrize("case", [0, 1, 2, 4, 9, 11])
 def test_fused_stem_pairs_run_time_count_variant(case, fuse_whatever_fits, monkeypatch):
     """Shapes without a static instantiation run the variant whose chunk / item counts are

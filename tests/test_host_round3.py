@@ -135,17 +135,7 @@ def test_random_stems_fused_plan_matches_oracle(seed, fuse_whatever_fits):
     15 to 18 binary indices, contracted positions and orders drawn at random, up to two indices
     sliced -- planned with every pair the kernel can take and interpreted in numpy exactly as the
     kernel reads its tables: the reference contraction, the unfused plan's work and bytes."""
-    rng = np.random.default_rng(1000 + seed)
-    nq = int(rng.integers(15, 19))
-    gates, cur = [(3, 3)], nq
-    for _ in range(int(rng.integers(3, 7))):
-        kin = int(rng.integers(4, 8))
-        nout = int(np.clip(kin + rng.integers(-2, 3), 4, 7))
-        if kin > cur - 6 or cur - kin + nout > 19:
-            continue
-        gates.append((kin, nout))
-        cur += nout - kin
-    tree = G.stem_network(nq, gates, seed, sliced=int(rng.integers(0, 3)))
+    tree = G.random_stem(seed)
     arrays = ca.make_arrays_from_inputs(tree.inputs, tree.size_dict, seed=seed, dtype="complex128")
     fused = compile_tree(tree, "complex64", fuse=True, fuse_min_elems=1 << 9)
     plain = compile_tree(tree, "complex64", fuse=False)
