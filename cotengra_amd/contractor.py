@@ -167,6 +167,7 @@ class HipContractor:
         force_kernel=None,
         fuse=None,
         fuse_min_elems=None,
+        stem_bf16x3=False,
     ):
         self._origin = tree  # whose ``contraction_cores`` hold this contractor's siblings
         if handle_slicing or not tree.sliced_inds:
@@ -182,6 +183,8 @@ class HipContractor:
         # fused stem pairs (plan.compile_tree): None = the default rule
         self.fuse = fuse
         self.fuse_min_elems = fuse_min_elems
+        # fused pairs on the bf16 matrix cores, fp32 operands split three ways; off by default
+        self.stem_bf16x3 = bool(stem_bf16x3)
         self._plans = {}  # dtype -> (Plan, DevicePlan)
         self._execs = {}  # (dtype, device, torch?) -> state dict
         # A ctg_exec is confined to one host thread at a time (include/ctg_hip.h); contractors
@@ -263,6 +266,8 @@ class HipContractor:
             )
         else:
             st["exec"] = runtime.Executor(dplan, device=device)
+        if self.stem_bf16x3:
+            st["exec"].set_stem_arithmetic(True)
         return st
 
     def setup(self, *arrays):

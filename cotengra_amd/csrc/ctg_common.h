@@ -129,6 +129,7 @@ struct StemArgs {
     int32_t g_lo_shift;
     int32_t check_zero;
     int32_t vec;        // 16-byte gathers (SW_VEC)
+    int32_t bf3;        // this executor multiplies its pairs on the bf16 matrix cores (ctg_exec_set_stem_arithmetic)
     const int64_t* gA_hi;
     const int64_t* gA_lo;
     const int64_t* gC_hi;

@@ -359,6 +359,7 @@ void resolve_args(ctg_exec* e) {
             q.g_lo_shift = log2_exact(q.g_lo);
             q.check_zero = e->check_zero;
             q.vec = (int)h[SW_VEC];
+            q.bf3 = e->stem_bf16x3;
             const int64_t** tabs[ST_COUNT] = {&q.gA_hi, &q.gA_lo, &q.gC_hi, &q.gC_lo, &q.kj_a, &q.lane_a, &q.rt_a,
                                               &q.chunk_a, &q.b1_off, &q.b2_off, &q.mid_row, &q.mid_col,
                                               &q.out_row, &q.out_col};
@@ -1299,6 +1300,17 @@ int ctg_exec_zero_result(ctg_exec* e) {
     init.coefm = 0.0;
     HIP_TRY(hipStreamSynchronize(e->stream));
     HIP_TRY(hipMemcpy(e->d_strip, &init, sizeof(init), hipMemcpyHostToDevice));
+    return CTG_OK;
+}
+
+int ctg_exec_set_stem_arithmetic(ctg_exec* e, int bf16x3) {
+    if (!e) return fail(CTG_E_INVALID, "null argument");
+    bf16x3 = bf16x3 ? 1 : 0;
+    if (bf16x3 == e->stem_bf16x3) return CTG_OK;
+    HIP_TRY(hipSetDevice(e->device));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    e->stem_bf16x3 = bf16x3;
+    for (auto& q : e->stem_args) q.bf3 = bf16x3;
     return CTG_OK;
 }
 

@@ -934,10 +934,11 @@ int stem2_variant(const StemArgs& p) {
     return 0;
 }
 
-// CTG_STEM_BF16X3 (read at every launch; experiment switch, off by default): static shapes run
-// both steps on the bf16 matrix cores with three-way split operands (stem2_kernel<..., BF3 = true>)
+// ctg_exec_set_stem_arithmetic(exec, 1), or CTG_STEM_BF16X3 in the environment (read at every
+// launch) for every executor -- off by default: static shapes run both steps on the bf16 matrix
+// cores with three-way split operands (stem2_kernel<..., BF3 = true>)
 static bool stem2_bf3(const StemArgs& p) {
-    return getenv("CTG_STEM_BF16X3") != nullptr && stem2_variant(p) && (p.K2 & 7) == 0 &&
+    return (p.bf3 != 0 || getenv("CTG_STEM_BF16X3") != nullptr) && stem2_variant(p) && (p.K2 & 7) == 0 &&
            stem2_lds_bytes_bf3(p) <= 160 * 1024;
 }
 

@@ -29,6 +29,7 @@ SYMBOLS = (
     "ctg_exec_upload_inputs_device",
     "ctg_exec_zero_result",
     "ctg_exec_set_strip_exponent",
+    "ctg_exec_set_stem_arithmetic",
     "ctg_exec_get_exponent",
     "ctg_exec_run_slices",
     "ctg_exec_slice_batch",
@@ -126,6 +127,7 @@ def load():
         "ctg_exec_upload_inputs_device": [vp, C.POINTER(vp)],
         "ctg_exec_zero_result": [vp],
         "ctg_exec_set_strip_exponent": [vp, C.c_int, C.c_int],
+        "ctg_exec_set_stem_arithmetic": [vp, C.c_int],
         "ctg_exec_get_exponent": [vp, C.POINTER(C.c_double), C.POINTER(C.c_int)],
         "ctg_exec_run_slices": [vp, C.c_int64, C.c_int64, C.c_int64],
         "ctg_exec_slice_batch": [vp, i64p],
@@ -287,6 +289,11 @@ class Executor:
 
     def set_strip_exponent(self, strip, check_zero=False):
         _check(load().ctg_exec_set_strip_exponent(self.handle, int(bool(strip)), int(bool(check_zero))))
+
+    def set_stem_arithmetic(self, bf16x3):
+        """Fused stem pairs on the bf16 matrix cores with exactly split fp32 operands (True) or on
+        the fp32 matrix cores (False, the default); include/ctg_hip.h."""
+        _check(load().ctg_exec_set_stem_arithmetic(self.handle, int(bool(bf16x3))))
 
     def get_exponent(self):
         e, z = C.c_double(), C.c_int()

@@ -136,6 +136,14 @@ int ctg_exec_zero_result(ctg_exec* exec);
  * returns the base-10 exponent E (result = mantissa * 10^E; E = -inf and
  * *zero = 1 when check_zero met a zero intermediate in every slice). */
 int ctg_exec_set_strip_exponent(ctg_exec* exec, int strip_exponent, int check_zero);
+
+/* Arithmetic of the fused stem pairs (step kind 3) of this executor.  0 (default): complex64 on the
+ * fp32 matrix cores, an exact-fp32 multiply-add chain like every other step.  1: every fp32 operand
+ * of a pair is split exactly into three bfloat16 values and the six significant cross terms are
+ * accumulated in fp32 on the bf16 matrix cores: the same accuracy against a
+ * double-precision reference, not the same bits.  No reference counterpart (the reference computes in
+ * whatever its array library does); off unless asked for.  Takes effect from the next run. */
+int ctg_exec_set_stem_arithmetic(ctg_exec* exec, int bf16x3);
 int ctg_exec_get_exponent(ctg_exec* exec, double* exponent, int* zero);
 
 /* Contract slices first, first+stride, ... (count of them) and ACCUMULATE each

@@ -104,6 +104,13 @@ def test_fused_stem_pairs_on_the_bf16_matrix_cores(case, fuse_whatever_fits, mon
         assert not np.array_equal(got, fp32)   # (it really ran)
     assert G.relerr(got, ref) <= gate, (G.relerr(got, ref), gate, G.relerr(fp32, ref))
     assert G.relerr(np.asarray(m).astype("complex128") * 10.0**e, ref) <= gate
+    # the same through the C ABI's per-executor option instead of the environment: the same bits
+    monkeypatch.delenv("CTG_STEM_BF16X3")
+    fn2 = HipContractor(tree, fuse=True, fuse_min_elems=1 << 10, stem_bf16x3=True)
+    again = np.asarray(fn2(*arrays))
+    names2 = [n for n in fn2.setup(*arrays)["exec"].step_kernels() if n.startswith("stem2_kernel")]
+    fn2.close()
+    assert names2 == names and np.array_equal(again, got)
 
 
 @pytest.mark.parametrize("seed", range(48))
