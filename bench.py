@@ -154,7 +154,9 @@ def precision_check(tree, arrays, slice_id=3, log2_width=20):
     small = shrink_for_cpu(tree, log2_width)
     # (with the bf16 switch on, the narrowed tree must run fused pairs too -- they start at 2^24
     # elements by default, above anything a CPU-sized slice has)
-    lowered = "CTG_STEM_BF16X3" in os.environ and "CTG_FUSE_MIN_ELEMS" not in os.environ
+    from cotengra_amd.stem import bf16x3_env
+
+    lowered = bf16x3_env() and "CTG_FUSE_MIN_ELEMS" not in os.environ
     if lowered:
         os.environ["CTG_FUSE_MIN_ELEMS"] = str(1 << 12)
     a128 = [a.astype("complex128") for a in arrays]

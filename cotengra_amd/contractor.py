@@ -538,6 +538,10 @@ def _sliced_twin(tree):
     twin._extent = dict(tree._extent)
     twin._next_ssa = tree._next_ssa
     # indices sliced away no longer count as appearances
+    # (explicit index orders -- ``sort_contraction_indices`` -- are part of the schedule)
+    for node, d in tree._info.items():
+        if "inds" in d:
+            twin._info.setdefault(node, {})["inds"] = d["inds"]
     return twin
 
 

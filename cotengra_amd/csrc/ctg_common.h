@@ -6,10 +6,34 @@
 #pragma once
 
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 #include <type_traits>
 #include <stdint.h>
 
 namespace ctg {
+
+// An environment switch is ON when it is set to anything but "" or "0" (the convention of
+// every CTG_* switch, on the Python side as well).
+inline bool env_on(const char* name) {
+    const char* v = getenv(name);
+    return v != nullptr && v[0] != '\0' && !(v[0] == '0' && v[1] == '\0');
+}
+
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) is honoured per device: remember per
+// (kernel instantiation, device) that it was done.  `done` is a per-instantiation bit mask
+// of devices (an executor may be created on any of a node's 8 GPUs in one process).
+inline hipError_t lds_opt_in(const void* kern, int bytes, unsigned long long* done) {
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    const unsigned long long bit = 1ull << (dev & 63);
+    if (__atomic_load_n(done, __ATOMIC_ACQUIRE) & bit) return hipSuccess;
+    e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e != hipSuccess) return e;
+    __atomic_fetch_or(done, bit, __ATOMIC_RELEASE);
+    return hipSuccess;
+}
+
 
 // word offsets of the serialised step record (must match plan.py: Plan.serialise)
 enum StepWord {

@@ -1420,13 +1420,13 @@ static hipError_t launch_stream_t(const StepArgs& p, const MfmaHints& h, int KP,
     auto kern = pair_mfma_stream_kernel<FN, VEC, ADD, SHORTK, NV>;
     static int blocks_per_cu[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};  // by KP / 16
     int& bpc = blocks_per_cu[KP / 16];
+    if (smem > 48 * 1024) {
+        // opt in to more than the default dynamic LDS (the CU has 160 KiB); per device
+        static unsigned long long opted = 0;
+        hipError_t e = lds_opt_in((const void*)kern, 120 * 1024, &opted);
+        if (e != hipSuccess) return e;
+    }
     if (bpc == 0) {
-        if (smem > 48 * 1024) {
-            // opt in to more than the default dynamic LDS (the CU has 160 KiB)
-            hipError_t e = hipFuncSetAttribute((const void*)kern,
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, 120 * 1024);
-            if (e != hipSuccess) return e;
-        }
         int n = 0;
         hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kern, 256, smem);
         if (e != hipSuccess) return e;
@@ -1855,12 +1855,10 @@ static hipError_t launch_rowwise_t(const StepArgs& p, bool ts, dim3 grid, hipStr
     if (ts) {
         // 25-32 columns stage 50-66 KB of results next to 18.5 KB of static LDS: beyond
         // the default limit of a launch, the kernel has to opt in (the CU has 160 KiB)
-        static bool opted = false;
-        if (lds > 40 * 1024 && !opted) {
-            const hipError_t e = hipFuncSetAttribute((const void*)pair_rowwise_kernel<NN, true>,
-                                                     hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+        static unsigned long long opted = 0;   // (bit per device)
+        if (lds > 40 * 1024) {
+            const hipError_t e = lds_opt_in((const void*)pair_rowwise_kernel<NN, true>, 96 * 1024, &opted);
             if (e != hipSuccess) return e;
-            opted = true;
         }
         hipLaunchKernelGGL((pair_rowwise_kernel<NN, true>), grid, dim3(256), lds, stream, p);
     } else {

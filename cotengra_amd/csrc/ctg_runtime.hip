@@ -749,7 +749,7 @@ int build_hints_into(ctg_exec* e, std::vector<MfmaHints>& hints, int64_t zmult,
     }
     // lane-constant tables of the fast tiled steps: built on the device once, read by
     // every block of every launch (the tables they derive from never change)
-    if (n_fast > 0 && getenv("CTG_NO_LANE_TABLES") == nullptr) {
+    if (n_fast > 0 && !env_on("CTG_NO_LANE_TABLES")) {
         const int64_t each = fast_lane_table_bytes();
         HIP_TRY(hipMalloc((void**)d_lane_out, n_fast * each));
         int64_t i = 0;
@@ -805,6 +805,8 @@ int launch_step(ctg_exec* e, int64_t s, hipStream_t stream) {
     const ctg_plan* p = e->plan;
     const int64_t* r = &p->steps[s * STEP_WORDS];
     hipError_t err = hipSuccess;
+    // (allocated by ctg_exec_create for every plan with such a step; a kernel that takes
+    // scratch must never see a null pointer: keep the check next to the launch)
     if (!e->d_scratch && step_needs_scratch(e, s)) {
         const int rc = ensure_scratch(e);
         if (rc != CTG_OK) return rc;
@@ -873,8 +875,8 @@ int build_groups(ctg_exec* e) {
     e->d_group_items = nullptr;
     e->d_fast_items = nullptr;
     // (strip_exponent measures every intermediate right after its step)
-    const bool off = e->strip || getenv("CTG_NO_GROUPS");
-    const bool fast_off = getenv("CTG_NO_FAST_GROUPS") != nullptr;
+    const bool off = e->strip || env_on("CTG_NO_GROUPS");
+    const bool fast_off = env_on("CTG_NO_FAST_GROUPS");
     // class of a step: -1 launches alone, 0 thread-per-output, 1 + key tiled fast kernel
     auto class_of = [&](int64_t s) -> int {
         const int64_t* r = &p->steps[s * STEP_WORDS];
@@ -1158,7 +1160,7 @@ int ctg_exec_create(const ctg_plan* p, int device, void* stream, void* ext_resul
         // on how a run is cut into launches
         const int64_t nominal = std::min<int64_t>({(int64_t)64, p->nslices, ((int64_t)8192 << 20) / per});
         e->batch_nominal = (int)std::max<int64_t>(nominal, 1);
-        if (getenv("CTG_SPLITK_PER_SLICE")) e->batch_nominal = 1;   // (experiments: round-2 rule)
+        if (env_on("CTG_SPLITK_PER_SLICE")) e->batch_nominal = 1;   // (experiments: round-2 rule)
     }
     HIP_TRY_E(hipMalloc((void**)&e->d_inputs, p->inputs_elems * isz));
     HIP_TRY_E(hipMalloc((void**)&e->d_arena, p->arena_elems * isz * e->batch));
@@ -1234,11 +1236,21 @@ int ctg_exec_create(const ctg_plan* p, int device, void* stream, void* ext_resul
     // ms per slice): the host already runs ahead of the device and the tiny
     // kernels are bound by their dependent-load latency, not by launch cost.
     // The path stays available behind CTG_GRAPH=1.
-    e->graph_off = getenv("CTG_GRAPH") == nullptr;
+    e->graph_off = !env_on("CTG_GRAPH");
     resolve_args(e);
     {
         int rc = build_hints(e);
         if (rc == CTG_OK) rc = build_groups(e);
+        // the scratch buffer (split-K slabs, k-reduction partials, k-streaming tiles) is
+        // allocated HERE when any step of the plan writes to it -- not inside the first run,
+        // where the arena already holds the device memory and an out-of-memory error would
+        // bypass the caller's evict-and-retry around executor creation; a plan without such
+        // a step (every small one-shot expression) never allocates it
+        for (int64_t st = 0; rc == CTG_OK && st < p->n_steps; ++st)
+            if (step_needs_scratch(e, st)) {
+                rc = ensure_scratch(e);
+                break;
+            }
         if (rc != CTG_OK) return bail(rc);
     }
     *out = e;
@@ -1447,6 +1459,17 @@ int ctg_exec_launch_count(ctg_exec* e, int64_t* steps, int64_t* launches) {
     }
     *steps = ns;
     *launches = nl;
+    return CTG_OK;
+}
+
+int ctg_exec_device_bytes(ctg_exec* e, int64_t* bytes) {
+    if (!e || !bytes) return fail(CTG_E_INVALID, "null argument");
+    const ctg_plan* p = e->plan;
+    const int64_t isz = kItemSize[p->dtype];
+    int64_t n = p->inputs_elems * isz + p->arena_elems * isz * std::max(e->batch, 1) + (int64_t)p->tables.size() * 8;
+    if (e->owns_result) n += p->result_elems * isz;
+    if (e->d_scratch) n += e->scratch_total;
+    *bytes = n;
     return CTG_OK;
 }
 

@@ -834,12 +834,10 @@ template <bool PACK1, bool PACK2, int RT1, int CS1, int NCH, int IT2, bool BR1 =
           bool BF3 = false>
 static hipError_t launch_stem2_t(const StemArgs& p, hipStream_t stream) {
     auto kern = stem2_kernel<PACK1, PACK2, RT1, CS1, NCH, IT2, BR1, K2Q, VEC, BF3>;
-    static bool ready = false;
-    if (!ready) {
-        const hipError_t e =
-            hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    static unsigned long long ready = 0;   // (bit per device)
+    {
+        const hipError_t e = lds_opt_in((const void*)kern, 160 * 1024, &ready);
         if (e != hipSuccess) return e;
-        ready = true;
     }
     const size_t smem = BF3 ? stem2_lds_bytes_bf3(p) : stem2_lds_bytes(p);
     // persistent: one workgroup per CU (the tile owns most of the CU's LDS)
@@ -924,7 +922,7 @@ StemShape stem2_shape(const StemArgs& p) {
 // 1: static (counts known at compile time, fragments in registers where they fit), 0: run-time counts
 int stem2_variant(const StemArgs& p) {
     const StemShape s = stem2_shape(p);
-    if (getenv("CTG_STEM_GENERIC") != nullptr || s.it2 == 0) return 0;
+    if (env_on("CTG_STEM_GENERIC") || s.it2 == 0) return 0;
 #define CTG_STEM_HAS(P1, P2, R, CS, NC, IT, B1, KQ, V)                                                 \
     if (s.p1 == P1 && s.p2 == P2 && s.rt1 == R && s.cs1 == CS && s.nch == NC && s.it2 == IT && s.br1 == B1 && \
         s.k2q == KQ && s.vec == V)                                                                     \
@@ -934,11 +932,11 @@ int stem2_variant(const StemArgs& p) {
     return 0;
 }
 
-// ctg_exec_set_stem_arithmetic(exec, 1), or CTG_STEM_BF16X3 in the environment (read at every
-// launch) for every executor -- off by default: static shapes run both steps on the bf16 matrix
+// ctg_exec_set_stem_arithmetic(exec, 1), or CTG_STEM_BF16X3 set to anything but "" / "0" in the
+// environment (read at every launch: tests switch it within a process) for every executor -- off by default: static shapes run both steps on the bf16 matrix
 // cores with three-way split operands (stem2_kernel<..., BF3 = true>)
 static bool stem2_bf3(const StemArgs& p) {
-    return (p.bf3 != 0 || getenv("CTG_STEM_BF16X3") != nullptr) && stem2_variant(p) && (p.K2 & 7) == 0 &&
+    return (p.bf3 != 0 || env_on("CTG_STEM_BF16X3")) && stem2_variant(p) && (p.K2 & 7) == 0 &&
            stem2_lds_bytes_bf3(p) <= 160 * 1024;
 }
 

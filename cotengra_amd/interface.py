@@ -117,18 +117,23 @@ def _as_tree(inputs, output, size_dict, optimize):
     return ContractionTree.from_path(inputs, output, size_dict, path=optimize)
 
 
-def array_contract_tree(inputs, output, size_dict, optimize="greedy"):
-    """interface.py:394 -- build the tree for explicit index lists."""
-    return _as_tree(
+def array_contract_tree(inputs, output, size_dict, optimize="greedy", sort_contraction_indices=False):
+    """interface.py:394 -- build the tree for explicit index lists;
+    ``sort_contraction_indices`` calls the tree's method of that name on the result
+    (interface.py:455-456)."""
+    tree = _as_tree(
         [tuple(t) for t in inputs], tuple(output), dict(size_dict), optimize
     )
+    if sort_contraction_indices:
+        tree.sort_contraction_indices()
+    return tree
 
 
-def einsum_tree(eq, *shapes, optimize="greedy"):
+def einsum_tree(eq, *shapes, optimize="greedy", sort_contraction_indices=False):
     """interface.py:875."""
     inputs, output = eq_to_inputs_output(eq)
     size_dict = shapes_inputs_to_size_dict(shapes, inputs)
-    return array_contract_tree(inputs, output, size_dict, optimize)
+    return array_contract_tree(inputs, output, size_dict, optimize, sort_contraction_indices)
 
 
 class Via:
@@ -173,22 +178,34 @@ class ContractExpression:
             handle_slicing=True,
         )
         self._cached = False   # set by _cached_expression
+        self._bytes = 0        # device memory of its executors as of its last call
 
     def __call__(self, *arrays, backend=None, **kwargs):
         out = self.fn(*arrays, **kwargs)
         if self._cached:
-            with _EXPR_LOCK:   # (its plans exist now: the cache's byte bound sees them)
-                _trim_expression_cache(keep=self)
+            self._bytes = self.device_bytes()   # (its executors exist now: the cache's byte bound sees them)
+            with _EXPR_LOCK:
+                victims = _trim_expression_cache(keep=self)
+            _close_all(victims)                 # outside the cache lock, see _trim_expression_cache
         return out
 
     def device_bytes(self):
-        """Device memory this expression's executors hold (``ctg_plan_workspace_bytes`` of
-        every plan that has an executor)."""
-        n = 0
-        for (dtype, _, _), st in list(self.fn._execs.items()):
-            ws = self.fn._plans[dtype][1].workspace_bytes()
-            n += sum(ws.values()) if isinstance(ws, dict) else sum(ws)
-        return n
+        """Device memory this expression's executors hold right now (``ctg_exec_device_bytes``:
+        arena x slice batch, inputs, tables, result, scratch), read under the contractor's lock
+        when it is free and left at the last known value when another thread is inside."""
+        fn = self.fn
+        if not fn._lock.acquire(blocking=False):
+            return self._bytes
+        try:
+            n = 0
+            for st in fn._execs.values():
+                n += st["exec"].device_bytes()
+                res = st.get("result")
+                if res is not None:   # (a torch-owned result buffer)
+                    n += res.numel() * res.element_size()
+            return n
+        finally:
+            fn._lock.release()
 
     def close(self):
         self.fn.close()
@@ -226,44 +243,62 @@ def _cached_expression(inputs, output, size_dict, optimize, strip_exponent, chec
             return _EXPR_CACHE[key]
         tree = array_contract_tree(inputs, output, size_dict, optimize)
         expr = ContractExpression(tree, strip_exponent, check_zero)
+        victims = []
         if key is not None:
             expr._cached = True
             _EXPR_CACHE[key] = expr
-            _trim_expression_cache(keep=expr)
-        return expr
+            victims = _trim_expression_cache(keep=expr)
+    _close_all(victims)
+    return expr
 
 
 def _trim_expression_cache(keep=None):
-    """Least recently used out until the cache is within its count and its bytes."""
-    def total():
-        return sum(e.device_bytes() for e in _EXPR_CACHE.values())
-
-    while len(_EXPR_CACHE) > 1 and (len(_EXPR_CACHE) > _EXPR_CACHE_SIZE or total() > _EXPR_CACHE_BYTES):
+    """Least recently used out until the cache is within its count and its bytes.  Called
+    with ``_EXPR_LOCK`` held; RETURNS the evicted expressions, which the caller closes after
+    releasing the lock (``_close_all``): closing waits for the expression's contractor lock,
+    and a thread that holds a contractor lock may be waiting for ``_EXPR_LOCK`` in the
+    out-of-memory path (``evict_expression_cache``) -- never both at once.  The byte total is
+    the sum of every expression's last known size (``ContractExpression._bytes``, refreshed
+    by its own calls): no ctypes calls, no foreign locks here."""
+    victims = []
+    total = sum(e._bytes for e in _EXPR_CACHE.values())
+    while len(_EXPR_CACHE) > 1 and (len(_EXPR_CACHE) > _EXPR_CACHE_SIZE or total > _EXPR_CACHE_BYTES):
         k, old = next(iter(_EXPR_CACHE.items()))
         if old is keep:
             break
         del _EXPR_CACHE[k]
-        old.close()  # frees the evicted executor's device memory now
+        total -= old._bytes
+        victims.append(old)
+    return victims
+
+
+def _close_all(exprs):
+    """Free the device memory of evicted expressions (no cache lock held)."""
+    for old in exprs:
+        old.close()
 
 
 def clear_expression_cache():
     """Close and drop every cached one-shot expression."""
     with _EXPR_LOCK:
-        while _EXPR_CACHE:
-            _, old = _EXPR_CACHE.popitem()
-            old.close()
+        victims = list(_EXPR_CACHE.values())
+        _EXPR_CACHE.clear()
+    _close_all(victims)
 
 
 def evict_expression_cache(keep=None):
-    """Out-of-memory path of an executor (contractor._get_exec): drop every cached
-    expression except the one whose contractor is ``keep`` (it is being built right
-    now).  True if device memory was released."""
-    freed = False
+    """Out-of-memory path of an executor (contractor._get_exec, which holds ITS contractor's
+    lock): drop every cached expression except the one whose contractor is ``keep`` (it is
+    being built right now) and release the idle executors of the dropped ones without
+    waiting for anybody's lock (``_release_execs``: an expression another thread is inside
+    of keeps its executor and simply leaves the cache).  True if device memory was released."""
+    from .contractor import _release_execs
+
     with _EXPR_LOCK:
-        for k in [k for k, e in _EXPR_CACHE.items() if e.fn is not keep]:
-            old = _EXPR_CACHE.pop(k)
-            freed = bool(old.fn._execs) or freed
-            old.close()
+        victims = [_EXPR_CACHE.pop(k) for k in [k for k, e in _EXPR_CACHE.items() if e.fn is not keep]]
+    freed = False
+    for old in victims:
+        freed = _release_execs(old.fn) or freed
     return freed
 
 
@@ -274,16 +309,17 @@ def array_contract_expression(
 ):
     """interface.py:673.  ``via=(convert_in, convert_out)`` wraps the
     expression like the reference does (interface.py:664-665).
-    ``sort_contraction_indices`` (interface.py:455-456) is accepted and has no
-    effect: the executor never materialises a permutation, see
-    ``ContractionTree.sort_contraction_indices``."""
+    ``sort_contraction_indices`` (interface.py:455-456) sorts the tree's index orders as
+    the reference does (``ContractionTree.sort_contraction_indices``: the tree's reported
+    index algebra changes, the value does not -- the plan compiler chooses its own memory
+    layouts either way); sorted expressions are not shared through the one-shot cache."""
     inputs = [tuple(t) for t in inputs]
     if size_dict is None:
         size_dict = shapes_inputs_to_size_dict(shapes, inputs)
-    if cache_expression:
+    if cache_expression and not sort_contraction_indices:
         expr = _cached_expression(inputs, output, size_dict, optimize, strip_exponent, check_zero)
     else:
-        tree = array_contract_tree(inputs, output, size_dict, optimize)
+        tree = array_contract_tree(inputs, output, size_dict, optimize, sort_contraction_indices)
         expr = ContractExpression(tree, strip_exponent, check_zero)
     if via is not None:
         expr = Via(expr, *via)

@@ -12,7 +12,7 @@ import os
 import numpy as np
 
 _LIB_PATH = os.environ.get("CTG_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libctg_hip.so")
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 # every symbol include/ctg_hip.h declares
 SYMBOLS = (
@@ -33,6 +33,7 @@ SYMBOLS = (
     "ctg_exec_get_exponent",
     "ctg_exec_run_slices",
     "ctg_exec_slice_batch",
+    "ctg_exec_device_bytes",
     "ctg_exec_launch_count",
     "ctg_exec_profile_slice",
     "ctg_exec_step_kernel",
@@ -131,6 +132,7 @@ def load():
         "ctg_exec_get_exponent": [vp, C.POINTER(C.c_double), C.POINTER(C.c_int)],
         "ctg_exec_run_slices": [vp, C.c_int64, C.c_int64, C.c_int64],
         "ctg_exec_slice_batch": [vp, i64p],
+        "ctg_exec_device_bytes": [vp, i64p],
         "ctg_exec_launch_count": [vp, i64p, i64p],
         "ctg_exec_profile_slice": [vp, C.c_int64, C.POINTER(C.c_float)],
         "ctg_exec_step_kernel": [vp, C.c_int64, C.c_char_p, C.c_int64],
@@ -310,6 +312,13 @@ class Executor:
         """Slices that share one launch sequence in ``run_slices`` (1 for wide trees)."""
         n = C.c_int64()
         _check(load().ctg_exec_slice_batch(self.handle, C.byref(n)))
+        return n.value
+
+    def device_bytes(self):
+        """Device memory the executor holds (arena x slice batch, inputs, tables, result,
+        scratch): ``ctg_exec_device_bytes``."""
+        n = C.c_int64()
+        _check(load().ctg_exec_device_bytes(self.handle, C.byref(n)))
         return n.value
 
     def launch_count(self):

@@ -70,6 +70,12 @@ FUSED_OVERLAP_LOSS = 0.2
 MIN_GAIN = 0.05              # fuse only if the model saves at least this fraction
 
 
+def bf16x3_env():
+    """``CTG_STEM_BF16X3`` is on when set to anything but "" or "0" (as ``CTG_NO_FUSE`` and the
+    C side's ``env_on``)."""
+    return os.environ.get("CTG_STEM_BF16X3", "0") not in ("", "0")
+
+
 def gather_rate(run_bytes):
     """Bytes per second of the A gather by contiguous run length."""
     if run_bytes >= 256:
@@ -243,7 +249,7 @@ def geometry(size_dict, A, B1, B2, c1_inds, c2_inds):
 
 def pair_seconds(macs1, macs2, elems_a, elems_c2, items, run_bytes=256):
     """Modelled time of a fused pair (``CTG_STEM_BF16X3`` in the environment: of the bf16 mode)."""
-    rate = FUSED_MFMA_RATE * (BF16X3_SPEEDUP if os.environ.get("CTG_STEM_BF16X3") else 1.0)
+    rate = FUSED_MFMA_RATE * (BF16X3_SPEEDUP if bf16x3_env() else 1.0)
     t_mfma = 8.0 * macs1 / rate + 8.0 * macs2 / (rate * min(1.0, items / WAVES))
     t_mem = 8.0 * elems_a / gather_rate(run_bytes) + 8.0 * elems_c2 / FUSED_STORE_RATE
     return max(t_mfma, t_mem) + FUSED_OVERLAP_LOSS * min(t_mfma, t_mem)

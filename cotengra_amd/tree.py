@@ -1089,14 +1089,105 @@ class ContractionTree:
             **contract_opts,
         )
 
+    def descend(self, mode="dfs"):
+        """Generate ``(parent, left, right)`` merges from the root down, parents before
+        their children; ``mode`` "dfs" pops the newest node, "bfs" the oldest (reference
+        core.py:1866-1896)."""
+        if self.N == 1:
+            return
+        queue = [self.root]
+        while queue:
+            if mode == "dfs":
+                parent = queue.pop(-1)
+            elif mode == "bfs":
+                parent = queue.pop(0)
+            else:
+                raise ValueError(f"Unknown descend mode {mode!r}.")
+            l, r = self.children[parent]
+            yield parent, l, r
+            if not self.is_leaf(l):
+                queue.append(l)
+            if not self.is_leaf(r):
+                queue.append(r)
+
+    def reset_contraction_indices(self):
+        """Forget every explicit index order and everything derived from one -- ``inds``,
+        ``einsum_eq``, ``can_dot``, ``tensordot_axes``, ``tensordot_perm`` of the parents --
+        and the cached contractors (reference core.py:3400-3419).  Legs, involved indices,
+        sizes and flops do not depend on an order and stay."""
+        for node in self.children:
+            d = self._info.get(node)
+            if d:
+                for k in ("inds", "einsum_eq", "can_dot", "tensordot_axes", "tensordot_perm"):
+                    d.pop(k, None)
+        self.contraction_cores.clear()
+
     def sort_contraction_indices(self, priority="flops", make_output_contig=True,
                                  make_contracted_contig=True, reset=True):
-        """Accepted for API compatibility (reference core.py:3421-3506): the
-        reference re-orders every intermediate's indices so that its
-        transposes become cheaper.  The MI355X executor never materialises a
-        permutation -- layouts are chosen by the plan compiler and realised in
-        the kernels' gather addresses -- so there is nothing to sort."""
-        return None
+        """Set an explicit index order on every intermediate so that contracted indices
+        are contiguous in both children of a contraction and / or a parent's indices
+        come in the order of its children's (reference core.py:3421-3506; index work,
+        reproduced exactly: ``get_inds`` / ``get_tensordot_axes`` / ``get_tensordot_perm``
+        / ``get_einsum_eq`` -- hence ``extract_contractions``' IR -- afterwards are the
+        reference's, ``tests/golden/sorted_inds_cases.json``).
+
+        Nodes are visited by ``priority`` -- "flops" / "size": ascending (a stable sort
+        of the parents in the order they were added, so the costliest contraction is
+        handled last and keeps its order), "root": ``traverse()``, "leaves": ``descend()``
+        -- and each visit (i) sorts the parent's indices by ``(position in the right
+        child, position in the left child)`` with -1 for "absent" (not at the root: the
+        output order is the caller's), (ii) sorts the legs of each non-leaf child so that
+        the indices it shares with its sibling come last (left child) resp. first (right
+        child), ties by position in the parent.  Orders are read through the same lazy
+        cache as everywhere else, so a later visit sees what earlier visits set and
+        nothing else -- the outcome depends on it and is the reference's.
+
+        The result of a contraction does not depend on any of this, and the MI355X plan
+        compiler chooses its own memory layouts (no permutation is ever materialised:
+        DESIGN.md section 2); what changes is the tree's reported index algebra, i.e.
+        the per-op plug-in's ``tensordot`` axes / ``einsum`` equations and ``transpose``
+        calls (``PerOpContractor``) and everything printed from them."""
+        if reset:
+            self.reset_contraction_indices()
+
+        if priority == "flops":
+            nodes = sorted(self.children.items(), key=lambda x: self.get_flops(x[0]))
+        elif priority == "size":
+            nodes = sorted(self.children.items(), key=lambda x: self.get_size(x[0]))
+        elif priority == "root":
+            nodes = ((p, (l, r)) for p, l, r in self.traverse())
+        elif priority == "leaves":
+            nodes = ((p, (l, r)) for p, l, r in self.descend())
+        else:
+            raise ValueError(priority)
+
+        def find(inds, ix):   # ``str.find`` on a tuple of labels
+            try:
+                return inds.index(ix)
+            except ValueError:
+                return -1
+
+        for p, kids in nodes:
+            if len(kids) != 2:
+                continue   # (a one-input tree has nothing to sort)
+            l, r = kids
+            p_inds, l_inds, r_inds = map(self.get_inds_tuple, (p, l, r))
+
+            if make_output_contig and not self.is_root(p):
+                p_inds = tuple(sorted(p_inds, key=lambda ix: (find(r_inds, ix), find(l_inds, ix))))
+                self._info.setdefault(p, {})["inds"] = p_inds
+
+            if make_contracted_contig:
+                if not self.is_leaf(l):
+                    l_inds = tuple(sorted(self.get_legs(l), key=lambda ix: (find(r_inds, ix), find(p_inds, ix))))
+                    self._info.setdefault(l, {})["inds"] = l_inds
+                if not self.is_leaf(r):
+                    r_inds = tuple(sorted(self.get_legs(r), key=lambda ix: (find(p_inds, ix), find(l_inds, ix))))
+                    self._info.setdefault(r, {})["inds"] = r_inds
+
+        if not reset:
+            # (still invalidate the compiled contractions)
+            self.contraction_cores.clear()
 
     def print_contractions(self, sort=None, show_brackets=True):
         """Per-step cost table (cf. reference core.py:3508): step, log10

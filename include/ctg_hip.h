@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define CTG_ABI_VERSION 3
+#define CTG_ABI_VERSION 4
 
 /* element types of the tensors (reference tests cover all four:
  * tests/test_compute.py:102-115) */
@@ -169,6 +169,11 @@ int ctg_exec_run_slices(ctg_exec* exec, int64_t first, int64_t count, int64_t st
  * and the order in which slices are added are those of one launch sequence per
  * slice. */
 int ctg_exec_slice_batch(ctg_exec* exec, int64_t* batch);
+/* ABI 4.  Device memory this executor holds right now: inputs space, arena x slice batch,
+ * tables, the result if it owns it, the scratch buffer if the plan has a step that needs one
+ * (allocated by ctg_exec_create).  What a cache of contractors -- the reference keeps them
+ * on the tree, core.py:3708-3722 -- has to count against its budget. */
+int ctg_exec_device_bytes(ctg_exec* exec, int64_t* bytes);
 
 /* Steps of one slice and the kernel launches they take.  Independent small steps
  * (the leaves-upward wave fronts of a tree; the reference contracts them one

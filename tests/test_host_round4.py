@@ -1,0 +1,269 @@
+"""CPU suite, part 7 (round 4).
+
+* ``ContractionTree.sort_contraction_indices`` reproduces the reference's index orders
+  (core.py:3421-3506): ``get_inds`` of every node and the IR derived from them against
+  fixtures frozen from the real reference (tests/golden/gen/make_golden_r4.py), for four
+  priorities x the two switches, and a two-call sequence with ``reset=False``;
+* the per-op plug-in after sorting hands the caller the sorted tensordot axes / perms and
+  still gets the reference-frozen value (numpy as the caller's backend);
+* the one-shot expression cache never holds its own lock and a contractor's at once
+  (lock-order inversion);
+* boolean ``CTG_*`` switches: "0" and "" mean off.
+"""
+import hashlib
+import json
+import os
+import threading
+
+import numpy as np
+import pytest
+
+import cotengra_amd as ca
+from oracle import contract_ref as orc
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+with open(os.path.join(ROOT, "tests", "golden", "sorted_inds_cases.json"), encoding="utf-8") as _f:
+    SORTED = json.load(_f)["cases"]
+EXPECTED = np.load(os.path.join(ROOT, "tests", "golden", "sorted_inds_expected.npz"))
+
+
+def ir_hash(ops):
+    return hashlib.sha256("\n".join(sorted(repr(tuple(op)) for op in ops)).encode()).hexdigest()
+
+
+def build(case):
+    inputs = [tuple(t) for t in case["inputs"]]
+    tree = ca.ContractionTree.from_path(inputs, tuple(case["output"]), case["size_dict"], ssa_path=case["ssa_path"])
+    for ind, project in case["sliced"]:
+        tree.remove_ind_(ind, project=project)
+    return tree
+
+
+def node_inds(tree):
+    return [[list(tree.get_inds_tuple(n)) for n in plr] for plr in tree.traverse()]
+
+
+@pytest.mark.parametrize("case", SORTED, ids=[c["name"] for c in SORTED])
+def test_sorted_contraction_indices_are_the_references(case):
+    tree = build(case)
+    assert node_inds(tree) == case["default"]["inds"]
+    assert ir_hash(orc.extract_contractions(tree)) == case["default"]["ir"]
+    n_changed = 0
+    for want in case["sorted"]:
+        t = build(case)
+        t.get_tensordot_axes(t.root)   # something cached beforehand must not survive the reset
+        t.sort_contraction_indices(priority=want["priority"], make_output_contig=want["make_output_contig"],
+                                   make_contracted_contig=want["make_contracted_contig"])
+        key = (want["priority"], want["make_output_contig"], want["make_contracted_contig"])
+        assert node_inds(t) == want["inds"], key
+        assert ir_hash(orc.extract_contractions(t)) == want["ir"], key
+        n_changed += want["inds"] != case["default"]["inds"]
+        # legs are untouched: every node still carries exactly its legs
+        for p, l, r in t.traverse():
+            for n in (p, l, r):
+                assert sorted(t.get_inds_tuple(n)) == sorted(t.get_legs(n))
+        # the root keeps the caller's output order
+        assert t.get_inds_tuple(t.root) == tuple(ix for ix in t.output if ix not in t.sliced_inds)
+    assert n_changed >= 3   # the fixture exercises the method
+    # a second call without reset starts from the first one's orders (core.py:3455-3456, 3503-3505)
+    t = build(case)
+    t.sort_contraction_indices(priority="size")
+    t.contraction_cores["sentinel"] = object()
+    t.sort_contraction_indices(priority="leaves", make_output_contig=False, reset=False)
+    assert node_inds(t) == case["sequence"]["inds"]
+    assert not t.contraction_cores
+    with pytest.raises(ValueError):
+        t.sort_contraction_indices(priority="bogus")
+
+
+@pytest.mark.parametrize("name", sorted(EXPECTED.files))
+def test_sorted_tree_through_the_per_op_plugin(name):
+    """``implementation=(einsum, tensordot)`` walks the SORTED index algebra (axes, perms,
+    equations differ from the default order's) and lands on the value the reference got
+    from its sorted tree."""
+    case = next(c for c in SORTED if c["name"] == name)
+    tree = build(case)
+    arrays = ca.make_arrays_from_inputs(tree.inputs, tree.size_dict, seed=case["seed"], dtype="complex128")
+    calls = {"tensordot": [], "einsum": []}
+
+    def np_einsum(eq, *xs):
+        calls["einsum"].append(eq)
+        return np.einsum(eq, *xs)
+
+    def np_tensordot(a, b, axes):
+        calls["tensordot"].append(tuple(map(tuple, axes)))
+        return np.tensordot(a, b, axes)
+
+    plain = tree.contract(arrays, implementation=(np_einsum, np_tensordot))
+    seen_plain = {k: list(v) for k, v in calls.items()}
+    axes_before = [tree.get_tensordot_axes(p) if tree.get_can_dot(p) else tree.get_einsum_eq(p)
+                   for p, _, _ in tree.traverse()]
+    calls["tensordot"].clear()
+    calls["einsum"].clear()
+    tree.sort_contraction_indices()
+    got = tree.contract(arrays, implementation=(np_einsum, np_tensordot))
+    want = EXPECTED[name]
+    assert np.asarray(got).shape == want.shape
+    assert np.allclose(got, want, rtol=1e-10, atol=1e-13 * max(1.0, float(np.abs(want).max())))
+    assert np.allclose(plain, want, rtol=1e-10, atol=1e-13 * max(1.0, float(np.abs(want).max())))
+    axes_after = [tree.get_tensordot_axes(p) if tree.get_can_dot(p) else tree.get_einsum_eq(p)
+                  for p, _, _ in tree.traverse()]
+    # the plug-in saw the sorted index algebra (where sorting moved a contracted axis at all)
+    assert (calls != seen_plain) == (axes_after != axes_before)
+    # and the oracle run on the sorted tree agrees (its IR is the reference's, checked above)
+    assert np.allclose(orc.contract(tree, arrays), want, rtol=1e-10, atol=1e-13 * max(1.0, float(np.abs(want).max())))
+
+
+def test_descend_visits_parents_first():
+    case = next(c for c in SORTED if c["name"] == "randreg30_s0")
+    tree = build(case)
+    for mode in ("dfs", "bfs"):
+        seen = {tree.root}
+        n = 0
+        for p, l, r in tree.descend(mode):
+            assert p in seen and (l, r) == tuple(tree.children[p])
+            seen.update((l, r))
+            n += 1
+        assert n == tree.N - 1
+    with pytest.raises(ValueError):
+        list(tree.descend("sideways"))
+
+
+def test_expression_front_end_sorts_when_asked():
+    inputs, output, shapes, size_dict = ca.lattice_equation([3, 3], d_min=2, d_max=3, seed=1)
+    from cotengra_amd.interface import array_contract_tree
+
+    plain = array_contract_tree(inputs, output, size_dict, "greedy")
+    srt = array_contract_tree(inputs, output, size_dict, "greedy", sort_contraction_indices=True)
+    plain.sort_contraction_indices()
+    assert node_inds(srt) == node_inds(plain)
+
+
+# ---- the expression cache and its locks ----------------------------------------------------
+
+class _FakeExec:
+    def __init__(self, n):
+        self.n, self.closed = n, False
+
+    def device_bytes(self):
+        return self.n
+
+    def close(self):
+        self.closed = True
+
+
+class _FakeFn:
+    def __init__(self, nbytes):
+        self._lock = threading.RLock()
+        self._execs = {("complex64", 0, False): {"exec": _FakeExec(nbytes)}}
+        self._plans = {}
+        self.closed = False
+
+    def close(self):
+        with self._lock:
+            for st in self._execs.values():
+                st["exec"].close()
+            self._execs.clear()
+            self.closed = True
+
+
+def _fake_expr(nbytes):
+    from cotengra_amd import interface
+
+    e = interface.ContractExpression.__new__(interface.ContractExpression)
+    e.tree, e.fn, e._cached, e._bytes = None, _FakeFn(nbytes), True, nbytes
+    return e
+
+
+def test_cache_never_waits_for_a_contractor_under_its_own_lock(monkeypatch):
+    """Thread A is inside expression X (holds X's contractor lock) and runs out of memory:
+    ``evict_expression_cache``.  Thread B trims the cache at the same time and picks X as its
+    victim.  Before round 4 B closed X under the cache lock (waiting for A) while A waited
+    for the cache lock: a deadlock.  Now B only unlinks X under the cache lock and closes it
+    afterwards; A never blocks on a contractor lock."""
+    from cotengra_amd import interface
+
+    monkeypatch.setattr(interface, "_EXPR_CACHE", type(interface._EXPR_CACHE)())
+    monkeypatch.setattr(interface, "_EXPR_CACHE_BYTES", 100)
+    x, y, z = _fake_expr(80), _fake_expr(80), _fake_expr(80)
+    interface._EXPR_CACHE.update({"x": x, "y": y})
+    a_inside, b_unlinked, done = threading.Event(), threading.Event(), []
+
+    def thread_a():
+        with x.fn._lock:                      # inside X: upload -> run -> fetch
+            a_inside.set()
+            assert b_unlinked.wait(10)        # B has taken X out of the cache and wants to close it
+            interface.evict_expression_cache(keep=x.fn)   # must not deadlock
+            done.append("a")
+
+    def thread_b():
+        assert a_inside.wait(10)
+        with interface._EXPR_LOCK:
+            interface._EXPR_CACHE["z"] = z
+            victims = interface._trim_expression_cache(keep=z)
+        assert x in victims                   # X, least recently used, is evicted ...
+        b_unlinked.set()
+        interface._close_all(victims)         # ... and closed once A is out of it
+        done.append("b")
+
+    ta, tb = threading.Thread(target=thread_a), threading.Thread(target=thread_b)
+    ta.start()
+    tb.start()
+    ta.join(20)
+    tb.join(20)
+    assert not ta.is_alive() and not tb.is_alive(), "deadlock"
+    assert sorted(done) == ["a", "b"]
+    assert x.fn.closed and list(interface._EXPR_CACHE.values()) == [z] or y.fn.closed
+
+
+def test_evict_skips_expressions_in_use(monkeypatch):
+    from cotengra_amd import interface
+
+    monkeypatch.setattr(interface, "_EXPR_CACHE", type(interface._EXPR_CACHE)())
+    busy, idle, keep = _fake_expr(10), _fake_expr(10), _fake_expr(10)
+    interface._EXPR_CACHE.update({"busy": busy, "idle": idle, "keep": keep})
+    got = []
+
+    def other():
+        got.append(interface.evict_expression_cache(keep=keep.fn))
+
+    with busy.fn._lock:                        # another thread is inside `busy`
+        th = threading.Thread(target=other)
+        th.start()
+        th.join(10)
+        assert not th.is_alive(), "evict blocked on a contractor lock"
+    assert got == [True]
+    assert list(interface._EXPR_CACHE.values()) == [keep]
+    assert not idle.fn._execs and busy.fn._execs   # the idle one freed, the busy one left alone
+
+
+def test_device_bytes_tolerates_a_busy_contractor():
+    e = _fake_expr(123)
+    assert e.device_bytes() == 123
+    e._bytes = 7
+    held = threading.Event()
+    release = threading.Event()
+
+    def hold():
+        with e.fn._lock:
+            held.set()
+            release.wait(10)
+
+    th = threading.Thread(target=hold)
+    th.start()
+    assert held.wait(10)
+    assert e.device_bytes() == 7               # last known value, no waiting
+    release.set()
+    th.join(10)
+
+
+@pytest.mark.parametrize("value,on", [(None, False), ("", False), ("0", False), ("1", True), ("yes", True)])
+def test_boolean_switches_treat_zero_as_off(monkeypatch, value, on):
+    from cotengra_amd import stem
+
+    if value is None:
+        monkeypatch.delenv("CTG_STEM_BF16X3", raising=False)
+    else:
+        monkeypatch.setenv("CTG_STEM_BF16X3", value)
+    assert stem.bf16x3_env() is on
