@@ -383,7 +383,12 @@ class Plan:
                     "K": s.K,
                     "N": s.N,
                     "macs": s.macs,
+                    # algorithmic bytes (every operand read once, every result
+                    # written once, per reference step -- a fused pair counts both of its
+                    # steps) and the bytes the plan really moves (a fused pair: its big
+                    # operand in, its result out, the two small operands)
                     "bytes": s.elems_rw * self.itemsize,
+                    "bytes_moved": (s.elems_moved if s.kind == KIND_STEM2 else s.elems_rw) * self.itemsize,
                     "label": s.label,
                 }
             )

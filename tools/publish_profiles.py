@@ -49,7 +49,7 @@ print("mixed:", r["mixed_per_step"])
 for key in ("time_to_solution_tree", "time_to_solution_tree_w33", "peak_rate_tree"):
     t = line.get(key)
     if t:
-        print(key + ":", {k: t[k] for k in ("tree", "ms_per_slice", "tflops", "frac_of_mfma_peak", "mixed_roofline_frac", "est_time_total_s")})
+        print(key + ":", {k: t.get(k) for k in ("tree", "ms_per_slice", "tflops", "frac_of_mfma_peak", "mixed_bound_frac", "est_time_total_s")})
 for k, v in (line.get("configs") or {}).items():
     print(k, {x: v[x] for x in ("ms", "slices_per_sec", "tflops", "mixed_roofline_frac", "cpu_oracle_ms", "speedup_vs_cpu_oracle")})
 print("precision:", line.get("precision"))

@@ -1,27 +1,61 @@
 """Per-step roofline table of one slice from bench.py --dump-steps JSON:
-python tools/steps_report.py steps.json [n_rows]"""
+python tools/steps_report.py steps.json [n_rows] [--bf16x3]
+
+Two byte columns per step: ``alg`` = the algorithmic bytes of SURVEY 8(d) (every operand read
+once, every result written once PER REFERENCE STEP: a fused pair counts both of its steps, i.e.
+also the intermediate it never writes) and ``moved`` = what the plan really moves (a fused pair:
+big operand in, result out).  THE BOUND of a step is max(flops / matrix peak, moved bytes / 8 TB/s)
+-- a fused pair is priced on the bytes it moves, so no efficiency exceeds 100 %; the unfused
+figure is kept as a second column ("unf": what the reference's step-by-step execution would be
+bound by).  --bf16x3: fused pairs are priced against the bf16 matrix pipe with six products per
+fp32 product (2500 / 6 = 416.7 TFLOP/s fp32-equivalent) instead of the fp32 pipe's 157.3."""
 import json
 import sys
 
-rows = [r for r in json.load(open(sys.argv[1])) if r["ms"] > 0]   # (slice-invariant steps show 0 ms)
+args = [a for a in sys.argv[1:] if not a.startswith("--")]
+BF3 = "--bf16x3" in sys.argv
+rows = [r for r in json.load(open(args[0])) if r["ms"] > 0]   # (slice-invariant steps show 0 ms)
 tot = sum(r["ms"] for r in rows)
-print("total ms", tot)
-P, BW = 157.3e12, 8e12
-roof = sum(max(8 * r["macs"] / P, r["bytes"] / BW) for r in rows) * 1e3
-print("mixed per-step roofline ms", roof, "-> %.1f%% of it" % (100 * roof / tot))
+P32, PBF3, BW = 157.3e12, 2500e12 / 6, 8e12
+
+
+def peak(r):
+    return PBF3 if (BF3 and r.get("kind") == "stem2") else P32
+
+
+def bound_ms(r):
+    return max(8 * r["macs"] / peak(r), r.get("bytes_moved", r["bytes"]) / BW) * 1e3
+
+
+def unfused_ms(r):
+    return max(8 * r["macs"] / P32, r["bytes"] / BW) * 1e3
+
+
+print("total ms %.3f" % tot)
+roof = sum(bound_ms(r) for r in rows)
+unf = sum(unfused_ms(r) for r in rows)
+fl = sum(8 * r["macs"] for r in rows)
+print("flops-only floor (all flops at 157.3 TFLOP/s) ms %.2f -> %.1f%% of the fp32 matrix peak" % (fl / P32 * 1e3, 100 * fl / P32 * 1e3 / tot))
+print("mixed per-step BOUND (moved bytes) ms %.2f -> the slice runs at %.1f%% of it" % (roof, 100 * roof / tot))
+print("mixed per-step roofline of the UNFUSED steps (SURVEY 8d bytes) ms %.2f (the reference's execution model; "
+      "a fused pair may finish below it)" % unf)
 rows.sort(key=lambda r: -r["ms"])
-for r in rows[: int(sys.argv[2]) if len(sys.argv) > 2 else 25]:
-    fl = 8 * r["macs"]
-    rf = max(fl / P, r["bytes"] / BW) * 1e3
-    print(r["step"], r.get("kernel_name", r["kernel"]), "R", r["R"], "K", r["K"], "N", r["N"], "ms=%.2f" % r["ms"],
-          "TF=%.1f" % (fl / r["ms"] / 1e9), "GB/s=%.0f" % (r["bytes"] / r["ms"] / 1e6),
-          "%.1f%%" % (100 * r["ms"] / tot), "roof=%.2f eff=%.0f%%" % (rf, 100 * rf / r["ms"]))
+print("step kernel R K N | ms  share | TFLOP/s  moved GB/s (alg GB/s) | bound ms  eff | unfused roof ms")
+for r in rows[: int(args[1]) if len(args) > 1 else 25]:
+    f = 8 * r["macs"]
+    mv = r.get("bytes_moved", r["bytes"])
+    b = bound_ms(r)
+    print(r["step"], r.get("kernel_name", r["kernel"]), "R", r["R"], "K", r["K"], "N", r["N"], "| ms=%.2f" % r["ms"],
+          "%.1f%%" % (100 * r["ms"] / tot), "| TF=%.1f" % (f / r["ms"] / 1e9), "GB/s=%.0f" % (mv / r["ms"] / 1e6),
+          "(alg %.0f)" % (r["bytes"] / r["ms"] / 1e6), "| bound=%.2f eff=%.0f%%" % (b, 100 * b / r["ms"]),
+          "| unf=%.2f" % unfused_ms(r))
 by = {}
 for r in rows:
-    d = by.setdefault(r.get("kernel_name", r["kernel"]), [0.0, 0.0, 0])
+    d = by.setdefault(r.get("kernel_name", r["kernel"]), [0.0, 0.0, 0, 0.0])
     d[0] += r["ms"]
-    d[1] += max(8 * r["macs"] / P, r["bytes"] / BW) * 1e3
+    d[1] += bound_ms(r)
     d[2] += 1
-print("by kernel: name, launches, ms, roofline ms, fraction of its roofline")
-for k, (ms, rf, n) in sorted(by.items(), key=lambda kv: -kv[1][0]):
-    print("  %-52s %4d %9.3f %9.3f %5.0f%%" % (k, n, ms, rf, 100 * rf / ms))
+    d[3] += 8 * r["macs"]
+print("by kernel: name, launches, ms, bound ms, fraction of its bound, TFLOP/s")
+for k, (ms, rf, n, f) in sorted(by.items(), key=lambda kv: -kv[1][0]):
+    print("  %-56s %4d %9.3f %9.3f %5.0f%% %7.1f" % (k, n, ms, rf, 100 * rf / ms, f / ms / 1e9))
