@@ -158,9 +158,9 @@ def precision_check(tree, arrays, slice_id=3, log2_width=20):
     small = shrink_for_cpu(tree, log2_width)
     # (with the bf16 switch on, the narrowed tree must run fused pairs too -- they start at 2^24
     # elements by default, above anything a CPU-sized slice has)
-    from cotengra_amd.stem import bf16x3_env
+    from cotengra_amd.stem import bf16x3_mode
 
-    lowered = bf16x3_env() and "CTG_FUSE_MIN_ELEMS" not in os.environ
+    lowered = bf16x3_mode() and "CTG_FUSE_MIN_ELEMS" not in os.environ
     if lowered:
         os.environ["CTG_FUSE_MIN_ELEMS"] = str(1 << 12)
     a128 = [a.astype("complex128") for a in arrays]
@@ -205,9 +205,22 @@ def step_table(ex, plan, slice_id=0):
     return rows
 
 
+def is_bf16x3_kernel(name):
+    """stem2_kernel<..., BF3, RI2>: the tenth template argument says whether the instantiation
+    multiplies on the bf16 matrix cores (shapes without such an instantiation keep fp32 products)."""
+    if not name or not name.startswith("stem2_kernel<"):
+        return False
+    args = name[len("stem2_kernel<"):].rstrip(">").split(",")
+    return len(args) >= 10 and args[9].strip() == "true"
+
+
 def step_peak_tflops(r, bf16x3=False):
     """The matrix peak a step is priced against: fp32 MFMA; a fused stem pair running on the
-    bf16 matrix cores with three-way split operands: bf16 peak / 6 products."""
+    bf16 matrix cores with three-way split operands: bf16 peak / 6 products (decided per launch
+    by the kernel's name when the row carries one)."""
+    name = r.get("kernel_name") or r.get("kernel_symbol")
+    if name is not None and name.startswith("stem2_kernel<"):
+        return PEAK_BF16X3_TFLOPS if is_bf16x3_kernel(name) else PEAK_MFMA_F32_TFLOPS
     return PEAK_BF16X3_TFLOPS if (bf16x3 and r.get("kind") == "stem2") else PEAK_MFMA_F32_TFLOPS
 
 
@@ -234,7 +247,7 @@ def dominant_kernel(rows, flops_per_mac):
     by_name = {}
     for r in rows:
         d = by_name.setdefault(r["kernel_name"], {"ms": 0.0, "flops": 0.0, "bytes": 0.0, "moved": 0.0, "n": 0,
-                                                  "kind": r.get("kind")})
+                                                  "kind": r.get("kind"), "kernel_name": r["kernel_name"]})
         d["ms"] += r["ms"]
         d["flops"] += flops_per_mac * r["macs"]
         d["bytes"] += r["bytes"]
@@ -260,10 +273,38 @@ def pmc_traffic_for(tree_file, kernel):
         return None, None
 
 
-def _in_bf16x3_report():
-    from cotengra_amd.stem import bf16x3_env
+class arithmetic:
+    """``with arithmetic("fp32" | "bf16x3" | None)``: the fused stem pairs' arithmetic for the
+    duration (CTG_STEM_BF16X3, which planner and kernel launcher both read); None = leave it."""
 
-    return bf16x3_env()
+    def __init__(self, mode):
+        self.mode = mode
+
+    def __enter__(self):
+        self.old = os.environ.get("CTG_STEM_BF16X3")
+        if self.mode is not None:
+            os.environ["CTG_STEM_BF16X3"] = "1" if self.mode == "bf16x3" else "0"
+        return self
+
+    def __exit__(self, *exc):
+        if self.mode is not None:
+            if self.old is None:
+                del os.environ["CTG_STEM_BF16X3"]
+            else:
+                os.environ["CTG_STEM_BF16X3"] = self.old
+        return False
+
+
+def stem_arithmetic():
+    from cotengra_amd.stem import bf16x3_mode
+
+    return "bf16x3" if bf16x3_mode() else "fp32"
+
+
+BF16X3_NOTE = ("fused stem pairs: fp32 operands split exactly into 3 bf16 limbs, 6 of the 9 cross terms on "
+               "v_mfma_f32_32x32x16_bf16, fp32 accumulation (DESIGN 4b: error bound + adversarial tests); every "
+               "other step: fp32 MFMA")
+FP32_NOTE = "every step on the fp32 matrix cores (v_mfma_f32_32x32x2_f32: an exact-fp32 multiply-add chain)"
 
 
 def time_slices(ex, first, count, stride=1):
@@ -279,20 +320,14 @@ def time_slices(ex, first, count, stride=1):
 # ---------------------------------------------------------------------- #
 
 
-def tree_report(tree_file, dev, steps=5, warmup=1, bf16x3=False):
-    """ms/slice, FLOP/s, dominant-kernel and mixed rooflines of another m20
-    tree -- the one that reaches the amplitude first.  ``bf16x3``: with the stem pairs'
-    experiment switch CTG_STEM_BF16X3 on (fp32 products as six bf16 products on the bf16
-    matrix cores, csrc/ctg_stem.hip) for the duration of the report."""
-    if bf16x3 and not _in_bf16x3_report():
-        os.environ["CTG_STEM_BF16X3"] = "1"
-        try:
-            out = tree_report(tree_file, dev, steps, warmup, bf16x3=True)
-        finally:
-            del os.environ["CTG_STEM_BF16X3"]
-        out["arithmetic"] = ("stem pairs: fp32 operands split exactly into 3 bf16 values, 6 of the 9 cross terms on "
-                             "v_mfma_f32_32x32x16_bf16, fp32 accumulation; every other step as in the headline")
-        return out
+def tree_report(tree_file, dev, steps=5, warmup=1, mode=None):
+    """ms/slice, FLOP/s, dominant-kernel and mixed rooflines of another m20 tree.  ``mode``:
+    "fp32" / "bf16x3" = with the fused stem pairs in that arithmetic for the duration of the
+    report; None = the default (bf16 x 3 since round 4)."""
+    if mode is not None:
+        with arithmetic(mode):
+            return tree_report(tree_file, dev, steps, warmup)
+    bf16x3 = stem_arithmetic() == "bf16x3"
     import torch
 
     import cotengra_amd as ca
@@ -340,11 +375,12 @@ def tree_report(tree_file, dev, steps=5, warmup=1, bf16x3=False):
         },
         "precision": precision_check(tree, arrays),
     }
+    out["arithmetic"] = BF16X3_NOTE if bf16x3 else FP32_NOTE
     if bf16x3:
-        # fp32-equivalent flops on the bf16 pipe: priced against bf16 peak / 6 products; the ratio
-        # to the fp32 pipe's peak is a comparison with the headline's arithmetic, not a bound
+        # fp32-equivalent flops; the fused pairs run on the bf16 pipe and are priced against bf16 peak /
+        # 6 products (per step, in mixed_bound_ms); the ratio to the fp32 pipe's peak is a comparison
+        # with the fp32 arithmetic, not a fraction of a bound
         out["tflops_are"] = "fp32-equivalent (8 real flops per complex MAC; six bf16 products per fp32 product)"
-        out["frac_of_bf16x3_peak"] = flops / dt / 1e12 / PEAK_BF16X3_TFLOPS
         out["bf16x3_peak_tflops"] = PEAK_BF16X3_TFLOPS
         out["ratio_to_fp32_mfma_peak"] = flops / dt / 1e12 / PEAK_MFMA_F32_TFLOPS
     else:
@@ -663,22 +699,35 @@ def main():
     if rank == 0:
         rows = step_table(ex, plan)
         dom_name, dom, by_name = dominant_kernel(rows, 8.0)
-        achieved = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
+        bf3_run = stem_arithmetic() == "bf16x3"
+        dom_peak = step_peak_tflops(dom, bf3_run)
+        achieved_tf = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
+        achieved_gbs = dom["moved"] / (dom["ms"] * 1e-3) / 1e9
+        # which roof binds the dominant kernel: the longer of flops / matrix peak and moved bytes / HBM peak
+        hbm_bound = dom["moved"] / (PEAK_HBM_GBS * 1e9) > dom["flops"] / (dom_peak * 1e12)
         mf = [r for r in rows if r["kernel"] == "mfma"]
         all_flops = sum(8.0 * r["macs"] for r in mf)
         all_ms = sum(r["ms"] for r in mf)
         slice_ms = sum(r["ms"] for r in rows)
-        bound_ms = mixed_roofline_ms(rows, 8.0, moved=True)
+        bound_ms = mixed_roofline_ms(rows, 8.0, moved=True, bf16x3=bf3_run)
         unfused_ms = mixed_roofline_ms(rows, 8.0, moved=False)
         traffic, traffic_all = pmc_traffic_for(args.tree, dom_name)
         step_ms = dt * 1e3 / args.steps
         roofline = {
-            "bound": "mfma",
+            "bound": "hbm" if hbm_bound else "mfma",
             "kernel": dom_name,
-            "achieved": achieved,
-            "peak": PEAK_MFMA_F32_TFLOPS,
-            "unit": "TFLOP/s",
-            "frac": achieved / PEAK_MFMA_F32_TFLOPS,
+            "achieved": achieved_gbs if hbm_bound else achieved_tf,
+            "peak": PEAK_HBM_GBS if hbm_bound else dom_peak,
+            "unit": "GB/s" if hbm_bound else "TFLOP/s",
+            "frac": achieved_gbs / PEAK_HBM_GBS if hbm_bound else achieved_tf / dom_peak,
+            "bound_is": "the longer of flops / matrix peak and MOVED bytes / 8 TB/s for this kernel's launches; "
+                        "both sides follow",
+            # the matrix side: a bf16 x 3 pair is priced against bf16 peak / 6 products (fp32-equivalent
+            # flops), an fp32 kernel against the fp32 matrix peak
+            "matrix_side": {"achieved_tflops": achieved_tf, "peak_tflops": dom_peak, "frac": achieved_tf / dom_peak,
+                            "pipe": "bf16 MFMA, 6 products per fp32 product" if dom_peak != PEAK_MFMA_F32_TFLOPS
+                            else "fp32 MFMA"},
+            "hbm_side": {"achieved_gbs": achieved_gbs, "peak_gbs": PEAK_HBM_GBS, "frac": achieved_gbs / PEAK_HBM_GBS},
             "launches_per_slice": dom["n"],
             "avg_launch_ms": dom["ms"] / dom["n"],
             "flops_per_launch": dom["flops"] / dom["n"],
@@ -687,22 +736,20 @@ def main():
             # the kernel is priced on the latter, cross-checked by `traffic` (PMC)
             "algorithmic_bytes_per_launch": dom["bytes"] / dom["n"],
             "moved_bytes_per_launch": dom["moved"] / dom["n"],
-            "moved_gbs": dom["moved"] / (dom["ms"] * 1e-3) / 1e9,
-            "frac_of_hbm_peak": dom["moved"] / (dom["ms"] * 1e-3) / 1e9 / PEAK_HBM_GBS,
             "share_of_slice_time": dom["ms"] / max(slice_ms, 1e-9),
             "traffic": traffic,
             "traffic_source": "profiles/pmc_summary_%s.json (separate --pmc passes of this tree, committed; "
                               "not measured in this run)" % os.path.splitext(os.path.basename(args.tree))[0],
             "traffic_all_mfma_per_launch": traffic_all,
             "all_mfma_kernels": {
-                "achieved": all_flops / (all_ms * 1e-3) / 1e12,
-                "frac": all_flops / (all_ms * 1e-3) / 1e12 / PEAK_MFMA_F32_TFLOPS,
+                "achieved_tflops": all_flops / (all_ms * 1e-3) / 1e12,
                 "launches_per_slice": len(mf),
                 "share_of_slice_time": all_ms / max(slice_ms, 1e-9),
             },
             "mixed_per_step": {
-                "definition": "THE BOUND: sum over steps of max(flops_i / 157.3 TF, MOVED bytes_i / 8 TB/s) -- a fused "
-                              "pair is priced on the bytes it moves (big operand in, result out)",
+                "definition": "THE BOUND: sum over steps of max(flops_i / matrix peak_i, MOVED bytes_i / 8 TB/s) -- a "
+                              "fused pair is priced on the bytes it moves (big operand in, result out) and, in the "
+                              "bf16 x 3 arithmetic, against bf16 peak / 6; every other step against 157.3 TF",
                 "bound_ms": bound_ms,
                 "frac": bound_ms / step_ms,
                 "unfused_roofline_ms": unfused_ms,
@@ -726,11 +773,14 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "complex64 (fp32 MFMA, 8 real flops per complex MAC)",
+            "dtype": ("complex64, 8 real flops per complex MAC -- " + (BF16X3_NOTE if bf3_run else FP32_NOTE)),
             "data": "synthetic",
             "slices_per_sec": total_slices / dt,
             "tflops": value / 1e12,
-            "frac_of_mfma_peak_whole_job": value / 1e12 / (PEAK_MFMA_F32_TFLOPS * world),
+            # (fp32-equivalent flops over the fp32 matrix peak: a FRACTION of a bound only in the fp32
+            # arithmetic -- with bf16 x 3 pairs it is the ratio to the pipe the reference arithmetic maps to)
+            ("frac_of_mfma_peak_whole_job" if not bf3_run else "ratio_to_fp32_mfma_peak_whole_job"):
+                value / 1e12 / (PEAK_MFMA_F32_TFLOPS * world),
             "cotengra_convention_gigaflops": 4.0 * plan.macs_per_slice * total_slices / dt / 1e9,
             "est_time_total_s": nsl / (total_slices / dt),
             "config": {
@@ -767,10 +817,12 @@ def main():
                 out["time_to_solution_tree_w33"] = tree_report(TTS33_TREE, dev, steps=3)
             if os.path.abspath(args.tree) != os.path.abspath(PEAK_TREE) and os.path.exists(PEAK_TREE):
                 out["peak_rate_tree"] = tree_report(PEAK_TREE, dev)
-            # experiment switch, NOT the headline's arithmetic: the same trees with the stem pairs on the
-            # bf16 matrix cores (three-way split operands; accuracy in each entry's "precision")
-            out["bf16x3_experiment"] = {
-                os.path.basename(t): tree_report(t, dev, steps=3, bf16x3=True)
+            # the other arithmetic of the fused pairs on the same trees (each entry with its own
+            # precision check and rooflines): fp32 products on the fp32 matrix cores when the line
+            # runs bf16 x 3 (the default), and the other way round
+            other = "fp32" if bf3_run else "bf16x3"
+            out[other + "_arithmetic"] = {
+                os.path.basename(t): tree_report(t, dev, steps=3, mode=other)
                 for t in (args.tree, TTS_TREE, TTS33_TREE) if os.path.exists(t)
             }
             out["configs"] = other_configs(dev)

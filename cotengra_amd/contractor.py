@@ -167,7 +167,7 @@ class HipContractor:
         force_kernel=None,
         fuse=None,
         fuse_min_elems=None,
-        stem_bf16x3=False,
+        stem_bf16x3=None,
     ):
         self._origin = tree  # whose ``contraction_cores`` hold this contractor's siblings
         if handle_slicing or not tree.sliced_inds:
@@ -183,8 +183,10 @@ class HipContractor:
         # fused stem pairs (plan.compile_tree): None = the default rule
         self.fuse = fuse
         self.fuse_min_elems = fuse_min_elems
-        # fused pairs on the bf16 matrix cores, fp32 operands split three ways; off by default
-        self.stem_bf16x3 = bool(stem_bf16x3)
+        # arithmetic of the fused pairs: bf16 x 3 -- fp32 operands split exactly three ways, products on
+        # the bf16 matrix cores -- unless switched off here (False) or by CTG_STEM_BF16X3=0
+        # in the environment, which the kernel launcher reads at every launch and which wins
+        self.stem_bf16x3 = None if stem_bf16x3 is None else bool(stem_bf16x3)
         self._plans = {}  # dtype -> (Plan, DevicePlan)
         self._execs = {}  # (dtype, device, torch?) -> state dict
         # A ctg_exec is confined to one host thread at a time (include/ctg_hip.h); contractors
@@ -200,7 +202,7 @@ class HipContractor:
         except KeyError:
             plan = compile_tree(
                 self.tree, dtype, order=self.order, force_kernel=self.force_kernel,
-                fuse=self.fuse, fuse_min_elems=self.fuse_min_elems,
+                fuse=self.fuse, fuse_min_elems=self.fuse_min_elems, stem_bf16x3=self.stem_bf16x3,
             )
             entry = self._plans[dtype] = (plan, runtime.DevicePlan(plan))
             return entry
@@ -266,8 +268,8 @@ class HipContractor:
             )
         else:
             st["exec"] = runtime.Executor(dplan, device=device)
-        if self.stem_bf16x3:
-            st["exec"].set_stem_arithmetic(True)
+        if self.stem_bf16x3 is not None:
+            st["exec"].set_stem_arithmetic(self.stem_bf16x3)
         return st
 
     def setup(self, *arrays):

@@ -29,7 +29,10 @@ inline hipError_t lds_opt_in(const void* kern, int bytes, unsigned long long* do
     const unsigned long long bit = 1ull << (dev & 63);
     if (__atomic_load_n(done, __ATOMIC_ACQUIRE) & bit) return hipSuccess;
     e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
-    if (e != hipSuccess) return e;
+    if (e != hipSuccess) {
+        (void)hipGetLastError();   // (do not leave it for the next launch's error check to find)
+        return e;
+    }
     __atomic_fetch_or(done, bit, __ATOMIC_RELEASE);
     return hipSuccess;
 }
@@ -174,6 +177,8 @@ struct StemArgs {
     int32_t nz, z0;       // slice batching, as StepArgs
     int64_t zA, zB1, zB2, zC;
     int64_t zsA, zsB1, zsB2, zsC;
+    int64_t a_elems, c_elems;   // extents of the big operand and of the result (the bounds-checked
+                                // experiment build -DCTG_STEM_BOUNDS tests every gather and store)
 };
 
 // element offset of an operand for the slice-in-batch this block works on

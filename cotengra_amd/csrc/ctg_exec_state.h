@@ -41,7 +41,7 @@ struct ctg_exec {
     ctg::SliceMeta meta{};
     std::vector<ctg::StepArgs> args;  // resolved per step
     std::vector<ctg::StemArgs> stem_args;  // KIND_STEM2 steps (fused stem pairs)
-    int stem_bf16x3 = 0;                   // ctg_exec_set_stem_arithmetic
+    int stem_bf16x3 = 1;                   // ctg_exec_set_stem_arithmetic (default since round 4: bf16 x 3)
     std::vector<ctg::MfmaHints> hints;  // per step kernel hints (MFMA steps)
     // the same for launches that carry several slices (batch > 1): wider column tiles
     // where one slice alone would not fill the chip; same k-splits, same kernels otherwise

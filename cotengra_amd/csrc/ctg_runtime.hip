@@ -360,6 +360,8 @@ void resolve_args(ctg_exec* e) {
             q.check_zero = e->check_zero;
             q.vec = (int)h[SW_VEC];
             q.bf3 = e->stem_bf16x3;
+            q.a_elems = r[W_A_SIZE];
+            q.c_elems = r[W_C_SIZE];
             const int64_t** tabs[ST_COUNT] = {&q.gA_hi, &q.gA_lo, &q.gC_hi, &q.gC_lo, &q.kj_a, &q.lane_a, &q.rt_a,
                                               &q.chunk_a, &q.b1_off, &q.b2_off, &q.mid_row, &q.mid_col,
                                               &q.out_row, &q.out_col};

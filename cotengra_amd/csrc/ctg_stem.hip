@@ -49,6 +49,15 @@ namespace ctg {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+#ifdef CTG_STEM_BOUNDS
+// Bounds-checked experiment build (tools/build_variants.py bounds=-DCTG_STEM_BOUNDS, tools/
+// check_stem_bounds.py): every gather of the big operand and every store of the result is
+// tested against the tensor's extent; a violation is counted ([0] gathers, [1] stores) and
+// the access skipped.  The host validates the TABLES (ctg_plan_create); this checks the
+// addresses the kernel actually forms from them.
+__device__ unsigned long long ctg_stem_oob[2];
+#endif
+
 namespace {
 
 constexpr int SW = 8;            // waves per workgroup
@@ -149,9 +158,11 @@ __device__ __forceinline__ f32x16 mfma_bf(bf16x8 a, bf16x8 b, f32x16 c) {
 //   step 1:  [plane][n][chunk of 16 k][k-row h][split][slot]     row = (K / 16) * 48 + 8 values
 //   step 2:  [plane][n][block of 8 k][split][k & 7]               row = (K / 8) * 24 + 8 values
 __device__ __forceinline__ int bf3_row(int K, bool step1) { return step1 ? (K >> 4) * 48 + 8 : (K >> 3) * 24 + 8; }
+// (scale: a power of two that brings an operand from the bottom / top of the fp32 range to O(1)
+// before it is split -- exact; see bf3_operand_exponent)
 template <bool STEP1>
 __device__ __forceinline__ void load_b_planes_bf3(unsigned short* Q, const c64* __restrict__ B, const int64_t* off, int K,
-                                                  int N, int planes, int tid, bool vec) {
+                                                  int N, int planes, int tid, bool vec, float scale) {
     const int ROW = bf3_row(K, STEP1);
     for (int e = tid; e < K * N; e += SW * 64) {
         const int k = e / N, n = e - k * N;
@@ -164,7 +175,7 @@ __device__ __forceinline__ void load_b_planes_bf3(unsigned short* Q, const c64* 
             at = (k >> 3) * 24 + (k & 7);
         }
         const c64 v = B[off[e]];
-        const float vals[3] = {v.re, v.im, -v.im};
+        const float vals[3] = {v.re * scale, v.im * scale, -v.im * scale};
 #pragma unroll
         for (int pl = 0; pl < 3; ++pl) {
             if (pl >= planes) break;
@@ -179,6 +190,35 @@ __device__ __forceinline__ void load_b_planes_bf3(unsigned short* Q, const c64* 
             d[16] = (unsigned short)(__builtin_bit_cast(unsigned, r2) >> 16);
         }
     }
+}
+
+// The three-way split is exact as long as the third limb (2^-16 of the value) is a bf16 number,
+// i.e. for |x| >= 2^-110 (measured: below that the limb is lost and the products carry a relative
+// error of up to 2^-15, tests/test_gpu_round4.py).  A SMALL operand whose largest element lies
+// outside [2^-64, 2^64) is therefore multiplied by a power of two that brings it to [1, 2) before
+// the split (exact), and the power goes into the factor the stores apply (alpha).  Returns the
+// exponent to REMOVE (0: leave the operand alone).  All threads of the workgroup call it.
+__device__ __forceinline__ int bf3_operand_exponent(const c64* __restrict__ B, const int64_t* off, int n_el, int tid,
+                                                    float* red) {
+    float mx = 0.f;
+    for (int e = tid; e < n_el; e += SW * 64) {
+        const c64 v = B[off[e]];
+        mx = fmaxf(mx, fmaxf(fabsf(v.re), fabsf(v.im)));
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    if ((tid & 63) == 0) red[tid >> 6] = mx;
+    __syncthreads();
+    mx = red[0];
+#pragma unroll
+    for (int w = 1; w < SW; ++w) mx = fmaxf(mx, red[w]);
+    __syncthreads();   // (red is reused for the other operand)
+    int ex = (int)((__builtin_bit_cast(unsigned, mx) >> 23) & 255u) - 127;
+    if (mx == 0.f || ex == 128 || (ex >= -64 && ex < 64)) return 0;   // (zero, inf / nan, or fine as it is)
+    return ex < -126 ? -126 : (ex > 126 ? 126 : ex);
+}
+__device__ __forceinline__ float pow2f(int ex) {   // 2^ex, -126 <= ex <= 127
+    return __builtin_bit_cast(float, (unsigned)(ex + 127) << 23);
 }
 
 }  // namespace
@@ -219,27 +259,66 @@ __device__ __forceinline__ void settle(T& v) {
 // BF3: both steps multiply on the bf16 matrix cores (three-way split, see above); B1 fragments
 // in registers if BR1 (24 registers per chunk), B2 fragments from LDS (K2Q then only says that
 // K2 is known at compile time).
+// RI2 (round 4; >= 32 columns in step 2, static shapes, fp32 products): step 2 in the
+// ROW-INTERLEAVED form.  A 32 x 32 matrix-core tile holds 16 complex rows -- tile row 2 i is
+// Re c_i, row 2 i + 1 is Im c_i -- times 32 complex columns:
+//     A' row 2 i     = (Re a_ik, -Im a_ik)        B' = (Re b_kn ; Im b_kn)
+//     A' row 2 i + 1 = (Im a_ik,  Re a_ik)
+// one MFMA per complex k (no wasted flops, as before), but B' is ONE value per k and lane (its
+// k-row's plane) instead of two, so the B2 fragments of a wave's column group fit the registers
+// up to K2 = 64 (K2 floats; the X / Y form needs 2 K2), the sign lives in a third plane (-Im) of
+// the intermediate written once by the scatter instead of one XOR per MFMA, and a lane's
+// accumulator registers (t, t + 1) ARE (Re, Im) of one element: the 8-byte stores take them
+// where they are -- no copies into a staging array (32 moves per item in the X / Y form), so
+// the deferred stores only need the accumulators to stay untouched until they are issued (two
+// accumulator sets alternate when a wave has several items per tile).  A work item is still 32
+// complex rows x 32 columns: two accumulators (rows 0-15, 16-31), each with its own A' fragment
+// (one ds_read_b128 per 4 k and accumulator).  Probe of the two forms in isolation
+// (csrc/tools/ctg_probe_loop.hip, profiles/r4_loop_probe.txt): K2 = 64 0.839 -> 0.872 of the
+// fp32 matrix peak, K2 = 32 0.728 -> 0.797.  A wave keeps ONE column group for all its items
+// (item = (row tile, column group) with the column group = wave % ng2).
 template <bool PACK1, bool PACK2, int RT1, int CS1, int NCH, int IT2, bool BR1 = false, int K2Q = 0, bool VEC = false,
-          bool BF3 = false>
+          bool BF3 = false, bool RI2 = false>
 __global__ __launch_bounds__(SW * 64, 1) void stem2_kernel(StemArgs p) {
     static_assert(!PACK1 || CS1 == 1, "16 columns are one group");
     static_assert(!BR1 || NCH > 0, "B1 in registers needs the chunk count at compile time");
-    static_assert(K2Q == 0 || PACK2 || IT2 == 1, "B2 in registers: one column group per wave");
+    static_assert(K2Q == 0 || PACK2 || IT2 == 1 || RI2, "B2 in registers: one column group per wave");
+    static_assert(!RI2 || (!PACK2 && !BF3 && NCH > 0 && IT2 > 0), "row-interleaved step 2: fp32, >= 32 columns, static");
     constexpr int RTW = SW / CS1;   // row tiles the 8 waves cover at once
     constexpr bool STATIC = NCH > 0;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int K1 = p.K1, N1 = p.N1, K2 = p.K2, N2 = p.N2;
-    const int LDB1 = K1 + 4, LDB2 = K2 + 4, LD2 = p.ld2;
+    // (K2 is a compile-time constant where B2's fragments live in registers: LDS offsets that are
+    // multiples of the intermediate's row length then fold into the instructions' immediates)
+    const int K1 = p.K1, N1 = p.N1, K2 = K2Q > 0 ? 4 * K2Q : p.K2, N2 = p.N2;
+    const int LDB1 = K1 + 4, LDB2 = K2 + 4, LD2 = K2Q > 0 ? 4 * K2Q + 4 : p.ld2;
     const int PLANE = p.rows2 * LD2;                       // floats per plane of the intermediate
     float* P1 = (float*)smem;                              // [2|3][N1][LDB1]
     float* P2 = P1 + (PACK1 ? 3 : 2) * N1 * LDB1;          // [2|3][N2][LDB2]
     float* mid = P2 + (PACK2 ? 3 : 2) * N2 * LDB2;         // [2][rows2][LD2]
+    // RI2: three planes (Re, Im, -Im) INTERLEAVED PER ROW -- [rows2][3][LD2], row pitch RP = 3 LD2:
+    // the three values of an element are LD2 floats apart, an immediate offset of the scatter's
+    // ds_write (16 address registers instead of 48; separate planes with or without a bank shift
+    // and other pitches measured the same to 1 %, profiles/r4_loop_probe.txt) -- and, with B2 in
+    // registers, the staging planes of B2 share the intermediate's memory (they are dead once the
+    // fragments are loaded, before the first scatter's barrier)
+    const int RP = 3 * LD2;
+    // an offset row2 * LD2 + k2 of the planner's tables in that layout: row2 * RP + k2
+    auto ri_off = [&](int e) __attribute__((always_inline)) { return RI2 ? (e / LD2) * RP + e % LD2 : e; };
+    int mid_floats = 2 * PLANE;
+    if constexpr (RI2) {
+        mid_floats = 3 * PLANE;
+        if constexpr (K2Q > 0) {
+            mid = P2;
+            const int p2f = 2 * N2 * LDB2;
+            mid_floats = mid_floats > p2f ? mid_floats : p2f;
+        }
+    }
     // (BF3: the small operands as bf16 x 3 planes instead)
     const int ROW1 = bf3_row(K1, true), ROW2 = bf3_row(K2, false);
     unsigned short* Q1 = (unsigned short*)smem;            // [2|3][N1][ROW1]
     unsigned short* Q2 = Q1 + (PACK1 ? 3 : 2) * N1 * ROW1; // [2|3][N2][ROW2]
     if constexpr (BF3) mid = (float*)(Q2 + (PACK2 ? 3 : 2) * N2 * ROW2);
-    int64_t* oc_s = (int64_t*)(mid + 2 * PLANE);           // [N2] column offsets of the result
+    int64_t* oc_s = (int64_t*)(mid + mid_floats);          // [N2] column offsets of the result
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -255,9 +334,14 @@ __global__ __launch_bounds__(SW * 64, 1) void stem2_kernel(StemArgs p) {
     const c64* __restrict__ B2 = (const c64*)p.B2 + (sload64(p.soffB2 + z * p.zsB2) + z * p.zB2);
     float* __restrict__ C = (float*)((c64*)p.C + (sload64(p.soffC + z * p.zsC) + z * p.zC));
 
+    int bf3_ex = 0;   // BF3: power of two taken out of the small operands (goes back in through alpha)
     if constexpr (BF3) {
-        load_b_planes_bf3<true>(Q1, B1, p.b1_off, K1, N1, PACK1 ? 3 : 2, tid, VEC);
-        load_b_planes_bf3<false>(Q2, B2, p.b2_off, K2, N2, PACK2 ? 3 : 2, tid, false);
+        float* bf3_red = (float*)(oc_s + N2);   // (64 bytes behind the column table: stem2_lds_bytes_bf3)
+        const int ex1 = bf3_operand_exponent(B1, p.b1_off, K1 * N1, tid, bf3_red);
+        const int ex2 = bf3_operand_exponent(B2, p.b2_off, K2 * N2, tid, bf3_red);
+        bf3_ex = ex1 + ex2;
+        load_b_planes_bf3<true>(Q1, B1, p.b1_off, K1, N1, PACK1 ? 3 : 2, tid, VEC, pow2f(-ex1));
+        load_b_planes_bf3<false>(Q2, B2, p.b2_off, K2, N2, PACK2 ? 3 : 2, tid, false, pow2f(-ex2));
     } else {
         load_b_planes<true>(P1, B1, p.b1_off, K1, N1, PACK1, tid, VEC);
         load_b_planes<false>(P2, B2, p.b2_off, K2, N2, PACK2, tid);
@@ -322,35 +406,54 @@ __global__ __launch_bounds__(SW * 64, 1) void stem2_kernel(StemArgs p) {
         b2y = P2 + ((kk ? 0 : 1) * N2 + l31) * LDB2;
     }
     // scatter of the step-1 accumulators: lane part of mid_row[row] + mid_col[n]
+    // (RI2 with 16 columns: the lanes of columns 16-31 hold imaginary parts -> plane Im, and
+    // once more negated -> plane -Im)
     int mid_lane;
-    if (PACK1) mid_lane = (int)p.mid_col[l31 & 15] + (l31 >> 4) * PLANE + (int)p.mid_row[4 * kk];
-    else mid_lane = (int)p.mid_col[wcol + l31] + (int)p.mid_row[4 * kk];
+    if (PACK1) mid_lane = ri_off((int)p.mid_col[l31 & 15]) + (l31 >> 4) * (RI2 ? LD2 : PLANE) + ri_off((int)p.mid_row[4 * kk]);
+    else mid_lane = ri_off((int)p.mid_col[wcol + l31]) + ri_off((int)p.mid_row[4 * kk]);
     settle(mid_lane);
     // (accumulator register t is row rowmap(t) = bits 0, 1, 3, 4 of t's four bits: the tables are
     // additive over binary digits, so four entries each and a few scalar adds where they are
     // used replace 16-entry arrays that did not fit the scalar registers)
     int mid_o[4];
 #pragma unroll
-    for (int b = 0; b < 4; ++b) mid_o[b] = (int)sload64(p.mid_row + (b < 2 ? 1 << b : 2 << b));
+    for (int b = 0; b < 4; ++b) mid_o[b] = ri_off((int)sload64(p.mid_row + (b < 2 ? 1 << b : 2 << b)));
+    // (the row tiles' parts, per unit of this wave: scalar, fixed for the whole kernel)
+    int mid_rt[RT1];
+#pragma unroll
+    for (int m = 0; m < RT1; ++m)
+        mid_rt[m] = __builtin_amdgcn_readfirstlane(ri_off((int)sload64(p.mid_row + 32 * (wrt + RTW * m))));
     auto mid_t = [&](int t) __attribute__((always_inline)) {
         return ((t & 1) ? mid_o[0] : 0) + ((t & 2) ? mid_o[1] : 0) + ((t & 4) ? mid_o[2] : 0) + ((t & 8) ? mid_o[3] : 0);
     };
     // store of the step-2 accumulators: lane part of out_row[row2] + out_col[n2]
     // (PACK2: the lanes of columns 16-31 take the odd rows of each row pair)
-    int64_t out_lane = p.out_row[4 * kk];
+    // RI2: register pair p = t >> 1 of accumulator a is complex row (p & 1) + 2 kk + 4 (p >> 1)
+    // + 16 a of the item: the lane's k-row is bit 1, the pair's bits are bits 0, 2, 3, the
+    // accumulator bit 4 (out_o[3] = out_row[16])
+    int64_t out_lane = p.out_row[RI2 ? 2 * kk : 4 * kk];
     if (PACK2) out_lane += (l31 >> 4) ? p.out_row[1] : 0;
     settle(out_lane);
     int64_t out_o[4];
 #pragma unroll
-    for (int b = 0; b < 4; ++b) out_o[b] = sload64(p.out_row + (b < 2 ? 1 << b : 2 << b));
+    for (int b = 0; b < 4; ++b) out_o[b] = sload64(p.out_row + (RI2 ? (b == 0 ? 1 : 2 << b) : (b < 2 ? 1 << b : 2 << b)));
     auto out_t = [&](int t) __attribute__((always_inline)) {
         return ((t & 1) ? out_o[0] : 0) + ((t & 2) ? out_o[1] : 0) + ((t & 4) ? out_o[2] : 0) + ((t & 8) ? out_o[3] : 0);
     };
+    // RI2, step 2: this lane's A' plane -- (row parity, k-row) -> Re, -Im, Im, Re -- and B' plane
+    const int ri_par = l31 & 1;
+    const int ri_plane = (ri_par == kk ? 0 : (ri_par ? 1 : 2)) * LD2;
+    const int ri_cg = RI2 ? wave % p.ng2 : 0;            // this wave's column group, all its items
+    const int ri_rt0 = RI2 ? wave / p.ng2 : 0;           // ... and its first row tile (then + SW / ng2)
+    const int ri_rts = RI2 ? SW / p.ng2 : 0;
+    const float* ri_b = P2 + (kk * N2 + ri_cg * 32 + l31) * LDB2;
 
     float alpha = 1.f;
     if (p.facA != nullptr) {
         const double f = (*p.facA) * (*p.facB1) * (*p.facB2);
-        alpha = (f == 0.0 && p.check_zero) ? 0.f : (float)(1.0 / f);
+        alpha = (f == 0.0 && p.check_zero) ? 0.f : (float)(1.0 / f * (BF3 ? exp2((double)bf3_ex) : 1.0));
+    } else if (BF3 && bf3_ex != 0) {
+        alpha = (float)exp2((double)bf3_ex);
     }
     const bool scaled = __builtin_amdgcn_readfirstlane(alpha != 1.f);   // (strip_exponent runs only)
     __syncthreads();
@@ -382,7 +485,12 @@ __global__ __launch_bounds__(SW * 64, 1) void stem2_kernel(StemArgs p) {
             b1r[q][1] = *(const f32x4*)(b1q + (q >> 1) * 16 + (q & 1) * 4);
         }
     }
-    if constexpr (K2Q > 0 && !BF3) {
+    if constexpr (K2Q > 0 && RI2) {
+        // (one value per k: the lane's k-row's plane of its column)
+#pragma unroll
+        for (int q = 0; q < K2Q; ++q) b2r[q][0] = *(const f32x4*)(ri_b + 4 * q);
+    }
+    if constexpr (K2Q > 0 && !BF3 && !RI2) {
         // (one item per wave and tile, always the same: its column group is this wave's)
         const int cg0 = PACK2 ? 0 : wave / (p.rows2 >> 5);
 #pragma unroll
@@ -441,6 +549,18 @@ __global__ __launch_bounds__(SW * 64, 1) void stem2_kernel(StemArgs p) {
             r[2 * q + 1] = c64{(float)(base + kj[2 * q + 1]), (float)a_lane};
 #else
             const char* sb = (const char*)(A + (base + kj[2 * q]));   // uniform: the load's scalar base
+#ifdef CTG_STEM_BOUNDS
+            {
+                const uint64_t lim = (uint64_t)p.a_elems * 8;
+                const uint64_t o0 = (uint64_t)(sb + a_lane - (const char*)A);
+                const uint64_t o1 = VEC ? o0 + 8 : (uint64_t)((const char*)(A + (base + kj[2 * q + 1])) + a_lane - (const char*)A);
+                if (o0 + 8 > lim || o1 + 8 > lim) {
+                    atomicAdd(&ctg_stem_oob[0], 1ull);
+                    r[2 * q] = r[2 * q + 1] = c64{0.f, 0.f};
+                    return;
+                }
+            }
+#endif
             if (VEC) {
                 const f32x4 v = *(const f32x4*)(sb + a_lane);
                 r[2 * q] = c64{v[0], v[1]};
@@ -472,19 +592,49 @@ __global__ __launch_bounds__(SW * 64, 1) void stem2_kernel(StemArgs p) {
     // >1000 cycles in which nobody issues an MFMA: knock-out of the stores alone gave 12 % of a
     // slice, of the gathers alone 6 % (profiles/r3_stem_knockout.txt).
     constexpr int NST = PACK2 ? 8 : 16;
-    float2 pv[NST];
+    float2 pv[RI2 ? 1 : NST];
     float* pdst = C;
-    auto drain = [&](int lo, int hi) __attribute__((always_inline)) {
+    // RI2: the accumulators of step 2, [set][complex rows 0-15 | 16-31]; the stores of an item read
+    // them in place (registers 2 p, 2 p + 1 = Re, Im), so a set is left alone until its stores are
+    // out: items alternate between two sets when a wave has more than one per tile
+    constexpr int NSET = RI2 ? (IT2 > 1 ? 2 : 1) : 1;
+    f32x16 cr[NSET][2];
+    auto store2 = [&](float* q, float2 v) __attribute__((always_inline)) {
+#ifdef CTG_STEM_BOUNDS
+        if ((uint64_t)((char*)q - (char*)C) + 8 > (uint64_t)p.c_elems * 8) {
+            atomicAdd(&ctg_stem_oob[1], 1ull);
+            return;
+        }
+#endif
+#ifdef CTG_STEM_KO_STORE
+        if (v.x == 12345.678f)
+#endif
+        *(float2*)q = v;
+    };
+    // stores lo .. hi - 1 of the pending item.  set_tag: which accumulator set holds it (RI2);
+    // scaled_tag: a strip_exponent run (RI2 scales at the store; the X / Y form scaled its copy)
+    auto drain = [&](int lo, int hi, auto set_tag, auto scaled_tag) __attribute__((always_inline)) {
+        constexpr int SET = decltype(set_tag)::value < NSET ? decltype(set_tag)::value : 0;
 #pragma unroll
         for (int i = lo; i < hi; ++i) {
-#ifdef CTG_STEM_KO_STORE
-            if (pv[i].x == 12345.678f)
-#endif
-            *(float2*)(pdst + 2 * out_t(PACK2 ? 2 * i : i)) = pv[i];
+            if constexpr (RI2) {
+                // store i: accumulator i >> 3, register pair i & 7 (Re, Im adjacent)
+                float2 v;
+                v.x = cr[SET][i >> 3][2 * (i & 7)];
+                v.y = cr[SET][i >> 3][2 * (i & 7) + 1];
+                if constexpr (decltype(scaled_tag)::value) {
+                    v.x *= alpha;
+                    v.y *= alpha;
+                }
+                store2(pdst + 2 * out_t(i), v);
+            } else {
+                store2(pdst + 2 * out_t(PACK2 ? 2 * i : i), pv[i]);
+            }
         }
     };
-    auto consume = [&](c64 (&r)[8], int m, int ch, auto always_tag, auto drain_tag) __attribute__((always_inline)) {
-        constexpr bool DRAIN = decltype(drain_tag)::value;
+    auto consume = [&](c64 (&r)[8], int m, int ch, auto always_tag, auto drain_tag, auto scaled_tag)
+                       __attribute__((always_inline)) {
+        constexpr bool DRAIN = decltype(drain_tag)::value >= 0;   // (-1: nothing pending, else the set)
         const int64_t base = pend0 + pend1 + pend2 + pend3;   // of the task two ahead (prep of the task before)
         if constexpr (BF3) {
             // all 8 elements of the task at once: split, refill the registers, 6 cross terms
@@ -525,7 +675,7 @@ __global__ __launch_bounds__(SW * 64, 1) void stem2_kernel(StemArgs p) {
                     ay[m] = mfma_bf(i3[ta], bp3[tb], ay[m]);
                 }
                 __builtin_amdgcn_sched_barrier(0);
-                if constexpr (DRAIN) drain(t * NST / 6, (t + 1) * NST / 6);
+                if constexpr (DRAIN) drain(t * NST / 6, (t + 1) * NST / 6, drain_tag, scaled_tag);
             }
             __builtin_amdgcn_sched_barrier(0);
             prep(always_tag);
@@ -564,7 +714,7 @@ __global__ __launch_bounds__(SW * 64, 1) void stem2_kernel(StemArgs p) {
             }
             __builtin_amdgcn_sched_barrier(0);
             if (j & 1) fire2(r, j >> 1, base, always_tag);
-            if constexpr (DRAIN) drain(j * NST / 8, (j + 1) * NST / 8);
+            if constexpr (DRAIN) drain(j * NST / 8, (j + 1) * NST / 8, drain_tag, scaled_tag);
         }
         __builtin_amdgcn_sched_barrier(0);
         prep(always_tag);   // (behind the last MFMAs)
@@ -581,15 +731,24 @@ __global__ __launch_bounds__(SW * 64, 1) void stem2_kernel(StemArgs p) {
     auto scatter = [&]() __attribute__((always_inline)) {
 #pragma unroll
         for (int m = 0; m < RT1; ++m) {
-            const int rt_part = (int)sload64(p.mid_row + 32 * (wrt + RTW * m));
-            float* dst = mid + (mid_lane + rt_part);
+            float* dst = mid + (mid_lane + mid_rt[m]);
 #pragma unroll
             for (int t = 0; t < 16; ++t) {
 #ifdef CTG_STEM_KO_SCATTER
                 if (ax[m][t] != 12345.678f) continue;
 #endif
                 dst[mid_t(t)] = ax[m][t];
-                if (!PACK1) dst[PLANE + mid_t(t)] = ay[m][t];
+                if constexpr (RI2) {
+                    // third plane: -Im (16 columns: the lanes of columns 16-31 hold the imaginary parts)
+                    if constexpr (PACK1) {
+                        if (l31 >> 4) dst[LD2 + mid_t(t)] = -ax[m][t];
+                    } else {
+                        dst[LD2 + mid_t(t)] = ay[m][t];
+                        dst[2 * LD2 + mid_t(t)] = -ay[m][t];
+                    }
+                } else {
+                    if (!PACK1) dst[PLANE + mid_t(t)] = ay[m][t];
+                }
             }
         }
     };
@@ -601,10 +760,73 @@ __global__ __launch_bounds__(SW * 64, 1) void stem2_kernel(StemArgs p) {
         return c_row;
     };
     // drain_tag: the item before this one left its stores pending; defer_tag: leave this one's
+    // RI2: one work item = 32 complex rows (row tile rt2) x this wave's 32 columns into accumulator
+    // set SET; the stores of the item before (set_prev >= 0) are issued between its MFMAs
+    auto item2r = [&](int rt2, int64_t c_row, auto set_tag, auto prev_tag, auto scaled_tag) __attribute__((always_inline)) {
+        constexpr int SET = decltype(set_tag)::value;
+        constexpr bool DRAIN = decltype(prev_tag)::value >= 0;
+        const float* a0p = mid + ri_plane + (rt2 * 32 + (l31 >> 1)) * RP;
+        const float* a1p = a0p + 16 * RP;
+        const int64_t c_col = oc_s[ri_cg * 32 + l31];
+        f32x4 a0[2], a1[2], bq[2];
+        a0[0] = *(const f32x4*)(a0p);
+        a1[0] = *(const f32x4*)(a1p);
+        constexpr int NQ = K2Q > 0 ? K2Q : 1;
+        if constexpr (K2Q > 0) {
+            // K2 known, B2 in registers: fully unrolled, first MFMA of each accumulator takes C = 0
+            static_for<0, NQ>([&](auto qi) __attribute__((always_inline)) {
+                constexpr int q = decltype(qi)::value;
+                if (q + 1 < NQ) {
+                    a0[(q + 1) & 1] = *(const f32x4*)(a0p + (q + 1) * 4);
+                    a1[(q + 1) & 1] = *(const f32x4*)(a1p + (q + 1) * 4);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    if (q == 0 && t == 0) {
+                        f32x16 z;
+#pragma unroll
+                        for (int u = 0; u < 16; ++u) z[u] = 0.f;
+                        cr[SET][0] = mfma(a0[0][0], b2r[0][0][0], z);
+                        cr[SET][1] = mfma(a1[0][0], b2r[0][0][0], z);
+                    } else {
+                        cr[SET][0] = mfma(a0[q & 1][t], b2r[q][0][t], cr[SET][0]);
+                        cr[SET][1] = mfma(a1[q & 1][t], b2r[q][0][t], cr[SET][1]);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                if constexpr (DRAIN) drain(q * NST / NQ, (q + 1) * NST / NQ, prev_tag, scaled_tag);
+            });
+        } else {
+            // B2 from LDS (K2 = 128, or no registers left): one 16-byte read per 4 k serves both accumulators
+            if constexpr (DRAIN) drain(0, NST, prev_tag, scaled_tag);
+#pragma unroll
+            for (int u = 0; u < 16; ++u) cr[SET][0][u] = cr[SET][1][u] = 0.f;
+            const int nq = K2 >> 2;   // >= 4, even
+            bq[0] = *(const f32x4*)(ri_b);
+            for (int kq = 0; kq < nq; kq += 2) {
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int nx = (kq + h + 1 < nq ? kq + h + 1 : nq - 1) * 4;
+                    a0[(h + 1) & 1] = *(const f32x4*)(a0p + nx);
+                    a1[(h + 1) & 1] = *(const f32x4*)(a1p + nx);
+                    bq[(h + 1) & 1] = *(const f32x4*)(ri_b + nx);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        cr[SET][0] = mfma(a0[h][t], bq[h][t], cr[SET][0]);
+                        cr[SET][1] = mfma(a1[h][t], bq[h][t], cr[SET][1]);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        }
+        pdst = C + 2 * (c_row + out_lane + c_col);   // (this item's stores are left pending)
+    };
     auto item2 = [&](int item, int64_t c_row, auto scaled_tag, auto drain_tag, auto defer_tag)
                      __attribute__((always_inline)) {
         constexpr bool DRAIN = decltype(drain_tag)::value;
-        if constexpr (DRAIN && (K2Q == 0 || BF3)) drain(0, NST);   // (run-time trip count below: no slots to put them in)
+        if constexpr (DRAIN && (K2Q == 0 || BF3)) drain(0, NST, std::integral_constant<int, 0>{}, scaled_tag);   // (run-time trip count below: no slots to put them in)
         const int cg = item / n_rt2, rt2 = item - cg * n_rt2;
         f32x16 cx, cy;
 #pragma unroll
@@ -660,7 +882,7 @@ __global__ __launch_bounds__(SW * 64, 1) void stem2_kernel(StemArgs p) {
                     }
                 }
                 __builtin_amdgcn_sched_barrier(0);
-                if constexpr (DRAIN && !BF3) drain(kq * NST / K2Q, (kq + 1) * NST / K2Q);
+                if constexpr (DRAIN && !BF3) drain(kq * NST / K2Q, (kq + 1) * NST / K2Q, std::integral_constant<int, 0>{}, scaled_tag);
             }
         } else {
 #ifdef CTG_STEM_KO_BFRAG
@@ -725,7 +947,7 @@ __global__ __launch_bounds__(SW * 64, 1) void stem2_kernel(StemArgs p) {
                     pv[t] = v;
                 }
             }
-            if constexpr (!decltype(defer_tag)::value) drain(0, NST);
+            if constexpr (!decltype(defer_tag)::value) drain(0, NST, std::integral_constant<int, 0>{}, scaled_tag);
         }
     };
     auto tile_c = [&](int64_t g) __attribute__((always_inline)) -> int64_t {
@@ -740,6 +962,7 @@ __global__ __launch_bounds__(SW * 64, 1) void stem2_kernel(StemArgs p) {
     if constexpr (STATIC) {
         constexpr int NT = RT1 * NCH;            // tasks per tile and wave
         constexpr int U = (NT & 1) ? 2 : 1;      // tiles per pass: the register sets alternate
+        constexpr int LASTSET = RI2 ? ((IT2 > 0 ? IT2 - 1 : 0) & (NSET - 1)) : 0;
         issue(regs[0], std::true_type{});
         issue(regs[1], std::true_type{});
         prep(std::true_type{});
@@ -752,8 +975,10 @@ __global__ __launch_bounds__(SW * 64, 1) void stem2_kernel(StemArgs p) {
                 zero_acc(M);
                 static_for<0, NCH>([&](auto ci) __attribute__((always_inline)) {
                     constexpr int CH = decltype(ci)::value;
+                    // (the first task of a tile issues the stores the tile before left pending:
+                    // those of its last item, accumulator set LASTSET)
                     consume(regs[(SLOT0 + M * NCH + CH) & 1], M, CH, std::true_type{},
-                            std::integral_constant<bool, !FIRST && M == 0 && CH == 0>{});
+                            std::integral_constant<int, (!FIRST && M == 0 && CH == 0) ? LASTSET : -1>{}, scaled_tag);
                 });
             });
             CTG_STEM_SYNC();   // all waves have finished step 2 of the previous tile
@@ -761,12 +986,23 @@ __global__ __launch_bounds__(SW * 64, 1) void stem2_kernel(StemArgs p) {
             const int64_t c_tile = tile_c(g);
             int64_t c_rows[IT2 > 0 ? IT2 : 1];
             static_for<0, IT2>([&](auto ii) __attribute__((always_inline)) {
-                c_rows[decltype(ii)::value] = item_row(wave + SW * decltype(ii)::value, c_tile);
+                constexpr int I = decltype(ii)::value;
+                if constexpr (RI2) {
+                    int64_t c_row = c_tile + sload64(p.out_row + 32 * (ri_rt0 + ri_rts * I));
+                    asm volatile("" : "+s"(c_row));   // waited for here, not inside the fragment pipeline
+                    c_rows[I] = c_row;
+                } else {
+                    c_rows[I] = item_row(wave + SW * I, c_tile);
+                }
             });
             CTG_STEM_SYNC();
             static_for<0, IT2>([&](auto ii) __attribute__((always_inline)) {
-                item2(wave + SW * decltype(ii)::value, c_rows[decltype(ii)::value], scaled_tag,
-                      std::integral_constant<bool, (decltype(ii)::value > 0)>{}, std::true_type{});
+                constexpr int I = decltype(ii)::value;
+                if constexpr (RI2)
+                    item2r(ri_rt0 + ri_rts * I, c_rows[I], std::integral_constant<int, I & (NSET - 1)>{},
+                           std::integral_constant<int, (I > 0) ? ((I - 1) & (NSET - 1)) : -1>{}, scaled_tag);
+                else
+                    item2(wave + SW * I, c_rows[I], scaled_tag, std::integral_constant<bool, (I > 0)>{}, std::true_type{});
             });
             g += tile_step;
         };
@@ -787,7 +1023,7 @@ __global__ __launch_bounds__(SW * 64, 1) void stem2_kernel(StemArgs p) {
             if (t == 0) tile(std::integral_constant<int, 0>{}, std::true_type{});
             else tile(std::integral_constant<int, 0>{}, std::false_type{});
         }
-        drain(0, NST);   // the last item's
+        drain(0, NST, std::integral_constant<int, LASTSET>{}, scaled_tag);   // the last item's
     } else {
         issue(regs[0], std::false_type{});
         issue(regs[1], std::false_type{});
@@ -798,8 +1034,8 @@ __global__ __launch_bounds__(SW * 64, 1) void stem2_kernel(StemArgs p) {
             for (int m = 0; m < RT1; ++m) {
                 zero_acc(m);
                 for (int ch = 0; ch < nch; ++ch) {
-                    if (slot == 0) consume(regs[0], m, ch, std::false_type{}, std::false_type{});
-                    else consume(regs[1], m, ch, std::false_type{}, std::false_type{});
+                    if (slot == 0) consume(regs[0], m, ch, std::false_type{}, std::integral_constant<int, -1>{}, scaled_tag);
+                    else consume(regs[1], m, ch, std::false_type{}, std::integral_constant<int, -1>{}, scaled_tag);
                     slot ^= 1;
                 }
             }
@@ -816,6 +1052,20 @@ __global__ __launch_bounds__(SW * 64, 1) void stem2_kernel(StemArgs p) {
     else run(std::false_type{});
 }
 
+#ifdef CTG_STEM_BOUNDS
+}  // namespace ctg
+// (experiment build only; not in include/ctg_hip.h) out-of-bounds counters: [0] gathers, [1] stores
+extern "C" int ctg_debug_stem_oob(unsigned long long out[2], int reset) {
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(ctg::ctg_stem_oob), 16) != hipSuccess) return -1;
+    if (reset) {
+        const unsigned long long z[2] = {0, 0};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(ctg::ctg_stem_oob), z, 16) != hipSuccess) return -1;
+    }
+    return 0;
+}
+namespace ctg {
+#endif
+
 size_t stem2_lds_bytes(const StemArgs& p) {
     const size_t b1 = (size_t)(p.N1 == 16 ? 3 : 2) * p.N1 * (p.K1 + 4);
     const size_t b2 = (size_t)(p.N2 == 16 ? 3 : 2) * p.N2 * (p.K2 + 4);
@@ -827,19 +1077,28 @@ size_t stem2_lds_bytes(const StemArgs& p) {
 static size_t stem2_lds_bytes_bf3(const StemArgs& p) {
     const size_t q1 = (size_t)(p.N1 == 16 ? 3 : 2) * p.N1 * ((p.K1 >> 4) * 48 + 8);
     const size_t q2 = (size_t)(p.N2 == 16 ? 3 : 2) * p.N2 * ((p.K2 >> 3) * 24 + 8);
-    return 2 * (q1 + q2) + 4 * (size_t)2 * p.rows2 * p.ld2 + 8 * (size_t)p.N2;
+    return 2 * (q1 + q2) + 4 * (size_t)2 * p.rows2 * p.ld2 + 8 * (size_t)p.N2 + 64;   // (+ the reduction scratch)
+}
+
+// ... and of the row-interleaved step 2 (RI2): three planes of the intermediate; B2's staging
+// planes share them when its fragments go to registers
+static size_t stem2_lds_bytes_ri2(const StemArgs& p, bool b2_in_regs) {
+    const size_t b1 = (size_t)(p.N1 == 16 ? 3 : 2) * p.N1 * (p.K1 + 4);
+    const size_t b2 = (size_t)2 * p.N2 * (p.K2 + 4);
+    const size_t mid = (size_t)3 * p.rows2 * p.ld2;
+    return 4 * (b1 + (b2_in_regs ? (mid > b2 ? mid : b2) : b2 + mid)) + 8 * (size_t)p.N2;
 }
 
 template <bool PACK1, bool PACK2, int RT1, int CS1, int NCH, int IT2, bool BR1 = false, int K2Q = 0, bool VEC = false,
-          bool BF3 = false>
+          bool BF3 = false, bool RI2 = false>
 static hipError_t launch_stem2_t(const StemArgs& p, hipStream_t stream) {
-    auto kern = stem2_kernel<PACK1, PACK2, RT1, CS1, NCH, IT2, BR1, K2Q, VEC, BF3>;
+    auto kern = stem2_kernel<PACK1, PACK2, RT1, CS1, NCH, IT2, BR1, K2Q, VEC, BF3, RI2>;
     static unsigned long long ready = 0;   // (bit per device)
     {
         const hipError_t e = lds_opt_in((const void*)kern, 160 * 1024, &ready);
         if (e != hipSuccess) return e;
     }
-    const size_t smem = BF3 ? stem2_lds_bytes_bf3(p) : stem2_lds_bytes(p);
+    const size_t smem = BF3 ? stem2_lds_bytes_bf3(p) : (RI2 ? stem2_lds_bytes_ri2(p, K2Q > 0) : stem2_lds_bytes(p));
     // persistent: one workgroup per CU (the tile owns most of the CU's LDS)
     int64_t blocks = p.n_tiles < 256 ? p.n_tiles : 256;
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks, 1), dim3(SW * 64), smem, stream, p);
@@ -863,31 +1122,49 @@ bool stem2_supported(const StemArgs& p) {
     return stem2_lds_bytes(p) <= 160 * 1024;
 }
 
-// static instantiations: (16 columns first, 16 columns last, units per wave, column groups of
-// step 1, chunks of K1, items per wave, B1 in registers, K2 / 4 if B2 is (else 0), 16-byte
-// gathers) of the pairs the Sycamore m20 trees are made of (tools/stem_shapes.py lists them);
-// anything else runs on the run-time-count variant
+// static instantiations of the pairs the Sycamore m20 trees are made of (tools/stem_shapes.py
+// prints both lists from the tree fixtures with the rules of stem2_shape below); anything else
+// runs on the run-time-count variant.
+//   CTG_STEM_INST: fp32 products -- (16 columns first, 16 columns last, units per wave, column
+//   groups of step 1, chunks of K1, items per wave, B1 in registers, K2 / 4 if B2 is (else 0),
+//   16-byte gathers, step 2 row-interleaved)
+//   CTG_STEM_GEO: the geometries (16 columns first, last, units per wave, column groups, chunks,
+//   items per wave, 16-byte gathers) -- the bf16 x 3 instantiations (B1 in registers up to two
+//   chunks, B2 from LDS, X / Y form)
 #define CTG_STEM_INST(X) \
-    X(false, false, 1, 1, 2, 1, true, 8, false) X(false, false, 1, 1, 2, 1, true, 0, false) \
-    X(false, false, 1, 2, 4, 1, true, 0, true) X(false, true, 1, 1, 2, 2, true, 4, false) \
-    X(false, false, 1, 2, 4, 1, true, 0, false) X(true, true, 2, 1, 1, 2, true, 4, false) \
-    X(true, false, 2, 1, 1, 1, true, 8, false) X(false, false, 1, 2, 2, 1, true, 0, false) \
-    X(false, false, 1, 1, 2, 2, true, 0, false) X(false, false, 1, 1, 8, 1, false, 8, false) \
-    X(false, true, 1, 2, 4, 2, true, 4, false) X(false, false, 1, 2, 2, 1, true, 8, false) \
-    X(true, false, 2, 1, 1, 2, true, 0, false) X(false, false, 1, 2, 4, 2, true, 0, false) \
-    X(false, true, 1, 1, 2, 2, true, 4, true) X(true, false, 2, 1, 1, 1, true, 8, true) \
-    X(false, false, 1, 2, 1, 1, true, 8, false) X(true, false, 2, 1, 1, 2, true, 0, true) \
-    X(false, true, 1, 2, 2, 2, true, 4, false) X(false, true, 1, 1, 1, 2, true, 4, false) \
-    X(true, true, 2, 1, 1, 2, true, 4, true) X(false, false, 1, 2, 2, 4, true, 0, true) \
-    X(false, false, 1, 1, 4, 1, true, 0, true) X(false, false, 2, 1, 1, 2, true, 0, false) \
-    X(false, false, 1, 1, 2, 1, true, 8, true) X(false, false, 1, 1, 4, 1, true, 0, false) \
-    X(false, true, 1, 2, 2, 1, true, 8, false) X(false, false, 1, 1, 1, 2, true, 0, false) \
-    X(false, true, 1, 4, 4, 2, true, 4, true) X(false, true, 1, 1, 8, 2, false, 4, true) \
-    X(true, false, 2, 1, 1, 1, true, 0, false) X(false, true, 1, 1, 8, 2, false, 4, false) \
-    X(false, false, 1, 1, 2, 4, true, 0, false) X(true, true, 2, 1, 4, 1, true, 8, false) \
-    X(false, false, 1, 1, 8, 1, false, 8, true) X(false, false, 1, 1, 8, 1, false, 0, false) \
-    X(false, false, 1, 1, 8, 1, false, 0, true) \
-    X(false, false, 1, 1, 8, 2, false, 0, false) X(true, false, 2, 1, 2, 1, true, 8, false)
+    X(false, false, 1, 1, 2, 1, true, 8, false, true) X(false, true, 1, 1, 2, 2, true, 4, false, false) \
+    X(false, false, 1, 2, 4, 1, true, 8, false, true) X(true, true, 2, 1, 1, 2, true, 4, false, false) \
+    X(false, true, 1, 1, 2, 2, true, 4, true, false) X(false, false, 1, 1, 2, 1, true, 16, false, true) \
+    X(true, false, 2, 1, 1, 1, true, 8, false, true) X(false, false, 1, 2, 4, 1, true, 8, true, true) \
+    X(false, false, 1, 2, 2, 1, true, 8, false, true) X(true, true, 2, 1, 1, 2, true, 4, true, false) \
+    X(true, false, 2, 1, 1, 1, true, 8, true, true) X(false, false, 1, 1, 2, 2, true, 8, false, true) \
+    X(false, true, 1, 1, 1, 2, true, 4, false, false) X(false, false, 1, 2, 2, 1, true, 16, false, true) \
+    X(false, true, 1, 2, 2, 2, true, 4, false, false) X(true, false, 2, 1, 1, 2, true, 8, true, true) \
+    X(false, false, 1, 1, 8, 1, false, 8, false, true) X(false, true, 1, 2, 4, 2, true, 4, false, false) \
+    X(false, false, 1, 1, 4, 1, true, 8, true, true) X(false, false, 1, 2, 4, 2, true, 0, false, false) \
+    X(false, false, 1, 2, 1, 1, true, 8, false, true) X(false, false, 1, 1, 8, 2, false, 8, false, true) \
+    X(true, false, 2, 1, 1, 2, true, 8, false, true) X(false, false, 1, 2, 2, 4, true, 4, true, true) \
+    X(false, false, 1, 1, 2, 1, true, 8, true, true) X(true, false, 2, 1, 1, 2, true, 16, false, true) \
+    X(false, false, 2, 1, 1, 2, true, 0, false, false) X(false, false, 1, 1, 1, 2, true, 8, false, true) \
+    X(false, false, 1, 1, 4, 1, true, 0, false, true) X(true, false, 2, 1, 2, 1, true, 8, false, true) \
+    X(false, true, 1, 2, 2, 1, true, 8, false, false) X(false, true, 1, 4, 4, 2, true, 4, true, false) \
+    X(false, true, 1, 1, 8, 2, false, 4, true, false) X(true, false, 2, 1, 1, 2, true, 4, false, true) \
+    X(true, false, 2, 1, 1, 1, true, 16, false, true) X(false, true, 1, 1, 8, 2, false, 4, false, false) \
+    X(false, false, 1, 1, 2, 4, true, 4, false, true) X(false, false, 1, 1, 2, 4, true, 8, false, true) \
+    X(false, false, 1, 1, 2, 2, true, 4, false, true) X(true, true, 2, 1, 4, 1, true, 8, false, false)
+
+#define CTG_STEM_GEO(G) \
+    G(false, false, 1, 1, 1, 2, false) G(false, false, 1, 1, 2, 1, false) G(false, false, 1, 1, 2, 1, true) \
+    G(false, false, 1, 1, 2, 2, false) G(false, false, 1, 1, 2, 4, false) G(false, false, 1, 1, 4, 1, false) \
+    G(false, false, 1, 1, 4, 1, true) G(false, false, 1, 1, 8, 1, false) G(false, false, 1, 1, 8, 2, false) \
+    G(false, false, 1, 2, 1, 1, false) G(false, false, 1, 2, 2, 1, false) G(false, false, 1, 2, 2, 4, true) \
+    G(false, false, 1, 2, 4, 1, false) G(false, false, 1, 2, 4, 1, true) G(false, false, 1, 2, 4, 2, false) \
+    G(false, false, 2, 1, 1, 2, false) G(false, true, 1, 1, 1, 2, false) G(false, true, 1, 1, 2, 2, false) \
+    G(false, true, 1, 1, 2, 2, true) G(false, true, 1, 1, 8, 2, false) G(false, true, 1, 1, 8, 2, true) \
+    G(false, true, 1, 2, 2, 1, false) G(false, true, 1, 2, 2, 2, false) G(false, true, 1, 2, 4, 2, false) \
+    G(false, true, 1, 4, 4, 2, true) G(true, false, 2, 1, 1, 1, false) G(true, false, 2, 1, 1, 1, true) \
+    G(true, false, 2, 1, 1, 2, false) G(true, false, 2, 1, 1, 2, true) G(true, false, 2, 1, 2, 1, false) \
+    G(true, true, 2, 1, 1, 2, false) G(true, true, 2, 1, 1, 2, true) G(true, true, 2, 1, 4, 1, false)
 
 namespace {
 struct StemShape {
@@ -896,11 +1173,18 @@ struct StemShape {
     bool br1;
     int k2q;
     bool vec;
+    bool ri2;                 // step 2 in the row-interleaved form
 };
-// Which small operand's fragments go to registers: B1 needs K1 floats per lane, K1 <= 64; B2
-// 2 K2 (K2 with 16 columns) and one column group per wave (always with 16 columns, else one
-// item per wave) and K2 <= 32 (64); together at most 96 -- B1 first.
-StemShape stem2_shape(const StemArgs& p) {
+// Which small operand's fragments go to registers.  X / Y form of step 2: B1 needs K1 floats per
+// lane, K1 <= 64; B2 2 K2 (K2 with 16 columns) and one column group per wave (always with 16
+// columns, else one item per wave) and K2 <= 32 (64); together at most 96 -- B1 first.
+// Row-interleaved form (>= 32 columns in step 2, static item count, column groups dividing the
+// waves): B2 needs K2 floats, K2 <= 64, whatever the item count; the budget is what a wave's 256
+// registers leave after the accumulators (step 1: 32 -- 16 with 16 columns -- per unit; step 2: 32,
+// or 64 when the items alternate between two sets), the 32 gather registers and ~40 of addresses
+// and fragments in flight -- B1 first; and the three planes of the intermediate must fit the LDS
+// (else the X / Y form).
+StemShape stem2_shape(const StemArgs& p, bool bf3 = false) {
     StemShape s;
     s.p1 = p.N1 == 16;
     s.p2 = p.N2 == 16;
@@ -909,12 +1193,26 @@ StemShape stem2_shape(const StemArgs& p) {
     s.nch = p.K1 / 16;
     const int items = (p.rows2 / 32) * p.ng2;
     s.it2 = items % SW == 0 ? items / SW : 0;
+    s.vec = p.vec != 0;
+    s.ri2 = !bf3 && !s.p2 && s.it2 > 0 && p.ng2 >= 1 && p.ng2 <= SW && SW % p.ng2 == 0 && !env_on("CTG_STEM_NO_RI2");
+    if (s.ri2) {
+        const int fixed = s.rt1 * (s.p1 ? 16 : 32) + (s.it2 > 1 ? 64 : 32) + 32 + 40;
+        int r1 = p.K1 <= 64 ? p.K1 : 0;
+        int r2 = p.K2 <= 64 ? p.K2 : 0;
+        if (fixed + r1 + r2 > 256) r2 = 0;
+        if (fixed + r1 > 256) r1 = 0;
+        if (stem2_lds_bytes_ri2(p, r2 != 0) <= 160 * 1024) {
+            s.br1 = r1 != 0;
+            s.k2q = r2 ? p.K2 / 4 : 0;
+            return s;
+        }
+        s.ri2 = false;
+    }
     int r1 = p.K1 <= 64 ? p.K1 : 0;
     int r2 = ((s.p2 && p.K2 <= 64) || (!s.p2 && s.it2 == 1 && p.K2 <= 32)) ? (s.p2 ? p.K2 : 2 * p.K2) : 0;
     if (r1 && r2 && r1 + r2 > 96) r2 = 0;
     s.br1 = r1 != 0;
     s.k2q = r2 ? p.K2 / 4 : 0;
-    s.vec = p.vec != 0;
     return s;
 }
 }  // namespace
@@ -923,21 +1221,34 @@ StemShape stem2_shape(const StemArgs& p) {
 int stem2_variant(const StemArgs& p) {
     const StemShape s = stem2_shape(p);
     if (env_on("CTG_STEM_GENERIC") || s.it2 == 0) return 0;
-#define CTG_STEM_HAS(P1, P2, R, CS, NC, IT, B1, KQ, V)                                                 \
+#define CTG_STEM_HAS(P1, P2, R, CS, NC, IT, B1, KQ, V, RI)                                             \
     if (s.p1 == P1 && s.p2 == P2 && s.rt1 == R && s.cs1 == CS && s.nch == NC && s.it2 == IT && s.br1 == B1 && \
-        s.k2q == KQ && s.vec == V)                                                                     \
+        s.k2q == KQ && s.vec == V && s.ri2 == RI)                                                      \
         return 1;
     CTG_STEM_INST(CTG_STEM_HAS)
 #undef CTG_STEM_HAS
     return 0;
 }
 
-// ctg_exec_set_stem_arithmetic(exec, 1), or CTG_STEM_BF16X3 set to anything but "" / "0" in the
-// environment (read at every launch: tests switch it within a process) for every executor -- off by default: static shapes run both steps on the bf16 matrix
-// cores with three-way split operands (stem2_kernel<..., BF3 = true>)
+// does the geometry have a bf16 x 3 instantiation?
+static bool stem2_has_geo(const StemShape& s) {
+    if (env_on("CTG_STEM_GENERIC") || s.it2 == 0) return false;
+#define CTG_STEM_HASG(P1, P2, R, CS, NC, IT, V)                                                         \
+    if (s.p1 == P1 && s.p2 == P2 && s.rt1 == R && s.cs1 == CS && s.nch == NC && s.it2 == IT && s.vec == V) return true;
+    CTG_STEM_GEO(CTG_STEM_HASG)
+#undef CTG_STEM_HASG
+    return false;
+}
+
+// Arithmetic of a fused pair.  Default (round 4): bf16 x 3 -- static shapes run both steps on the
+// bf16 matrix cores with three-way split operands (stem2_kernel<..., BF3 = true>); the executor's
+// option ctg_exec_set_stem_arithmetic(exec, 0) selects fp32 products on the fp32 matrix cores; the
+// environment variable CTG_STEM_BF16X3, when SET, overrides both ("0" / "" = fp32, anything else =
+// bf16 x 3) and is read at every launch (tests switch it within a process).
 static bool stem2_bf3(const StemArgs& p) {
-    return (p.bf3 != 0 || env_on("CTG_STEM_BF16X3")) && stem2_variant(p) && (p.K2 & 7) == 0 &&
-           stem2_lds_bytes_bf3(p) <= 160 * 1024;
+    const char* v = getenv("CTG_STEM_BF16X3");
+    const bool want = v != nullptr ? !(v[0] == '\0' || (v[0] == '0' && v[1] == '\0')) : p.bf3 != 0;
+    return want && stem2_has_geo(stem2_shape(p, true)) && (p.K2 & 7) == 0 && stem2_lds_bytes_bf3(p) <= 160 * 1024;
 }
 
 // the instantiation a step runs on, spelled like its symbol in a kernel trace
@@ -945,30 +1256,32 @@ void stem2_kernel_name(const StemArgs& p, char* buf, size_t n) {
     const StemShape s = stem2_shape(p);
     auto tf = [](bool b) { return b ? "true" : "false"; };
     if (stem2_bf3(p))
-        snprintf(buf, n, "stem2_kernel<%s,%s,%d,%d,%d,%d,%s,0,%s,true>", tf(s.p1), tf(s.p2), s.rt1, s.cs1, s.nch, s.it2,
-                 tf(s.nch <= 2), tf(s.vec));
+        snprintf(buf, n, "stem2_kernel<%s,%s,%d,%d,%d,%d,%s,0,%s,true,false>", tf(s.p1), tf(s.p2), s.rt1, s.cs1, s.nch,
+                 s.it2, tf(s.nch <= 2), tf(s.vec));
     else if (stem2_variant(p))
-        snprintf(buf, n, "stem2_kernel<%s,%s,%d,%d,%d,%d,%s,%d,%s,false>", tf(s.p1), tf(s.p2), s.rt1, s.cs1, s.nch, s.it2,
-                 tf(s.br1), s.k2q, tf(s.vec));
+        snprintf(buf, n, "stem2_kernel<%s,%s,%d,%d,%d,%d,%s,%d,%s,false,%s>", tf(s.p1), tf(s.p2), s.rt1, s.cs1, s.nch,
+                 s.it2, tf(s.br1), s.k2q, tf(s.vec), tf(s.ri2));
     else
-        snprintf(buf, n, "stem2_kernel<%s,%s,%d,%d,0,0,false,0,%s,false>", tf(s.p1), tf(s.p2), s.rt1, s.cs1, tf(s.vec));
+        snprintf(buf, n, "stem2_kernel<%s,%s,%d,%d,0,0,false,0,%s,false,false>", tf(s.p1), tf(s.p2), s.rt1, s.cs1,
+                 tf(s.vec));
 }
 
 hipError_t launch_stem2(const StemArgs& p, hipStream_t stream) {
     if (!stem2_supported(p)) return hipErrorInvalidValue;
-    const StemShape s = stem2_shape(p);
     if (stem2_bf3(p)) {
-#define CTG_STEM_GO3(P1, P2, R, CS, NC, IT, B1, KQ, V)                                                \
+        const StemShape s = stem2_shape(p, true);
+#define CTG_STEM_GO3(P1, P2, R, CS, NC, IT, V)                                                          \
     if (s.p1 == P1 && s.p2 == P2 && s.rt1 == R && s.cs1 == CS && s.nch == NC && s.it2 == IT && s.vec == V) \
         return launch_stem2_t<P1, P2, R, CS, NC, IT, (NC <= 2), 0, V, true>(p, stream);
-        CTG_STEM_INST(CTG_STEM_GO3)
+        CTG_STEM_GEO(CTG_STEM_GO3)
 #undef CTG_STEM_GO3
     }
+    const StemShape s = stem2_shape(p);
     if (stem2_variant(p)) {
-#define CTG_STEM_GO(P1, P2, R, CS, NC, IT, B1, KQ, V)                                                  \
+#define CTG_STEM_GO(P1, P2, R, CS, NC, IT, B1, KQ, V, RI)                                              \
     if (s.p1 == P1 && s.p2 == P2 && s.rt1 == R && s.cs1 == CS && s.nch == NC && s.it2 == IT && s.br1 == B1 && \
-        s.k2q == KQ && s.vec == V)                                                                     \
-        return launch_stem2_t<P1, P2, R, CS, NC, IT, B1, KQ, V>(p, stream);
+        s.k2q == KQ && s.vec == V && s.ri2 == RI)                                                      \
+        return launch_stem2_t<P1, P2, R, CS, NC, IT, B1, KQ, V, false, RI>(p, stream);
         CTG_STEM_INST(CTG_STEM_GO)
 #undef CTG_STEM_GO
     }

@@ -141,15 +141,15 @@ extern "C" double ctg_probe_loop(int variant, int blocks, int items, float* out,
 //         value per k, always in registers; two accumulators (complex rows 0-15, 16-31); a lane's
 //         registers (t, t + 1) are (Re, Im) of one element: 8-byte stores without any copy
 // Both store every item's 32 x 32 complex results (8 bytes per lane and store, 16 stores).
-template <int FORM, bool BLDS, int K2>
+template <int FORM, bool BLDS, int K2, int LAY = 0>
 __global__ __launch_bounds__(512, 1) void step2_kernel(float* out, int items) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int LD = K2 + 4, ROWS = 128, PL = ROWS * LD + 32, NQ = K2 / 4;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int kk = lane >> 5, l31 = lane & 31;
     float* mid = lds;                      // [3][PL]
-    float* P2 = lds + 3 * PL;              // [2][64][LD]
-    for (int i = tid; i < 3 * PL + 2 * 64 * LD; i += 512) lds[i] = 1.0f + 1e-3f * (i & 1023);
+    float* P2 = lds + 3 * (ROWS * (K2 + 9) + 32);   // [2][64][LD]
+    for (int i = tid; i < 3 * (ROWS * (K2 + 9) + 32) + 2 * 64 * LD; i += 512) lds[i] = 1.0f + 1e-3f * (i & 1023);
     __syncthreads();
     float* dst = out + ((size_t)blockIdx.x * 8 + wave) * 2048 + 2 * lane;   // 8 KB per wave
     const int rt = wave & 3;
@@ -211,7 +211,14 @@ __global__ __launch_bounds__(512, 1) void step2_kernel(float* out, int items) {
         // plane of this lane's A' values: (row parity, k-row) -> Re, -Im, Im, Re
         const int par = l31 & 1;
         const int plane = par == kk ? 0 : (par ? 1 : 2);
-        const float* a_base = mid + plane * PL + (rt * 32 + (l31 >> 1)) * LD;
+        // LAY 0: three planes, 32 floats of bank shift between them; 4: no shift; 1-3: the planes
+        // interleaved per row, [row][plane][LDI] with row pitch PITCH
+        constexpr int LDI = LAY == 2 ? K2 + 8 : K2 + 4;
+        constexpr int PITCH = LAY == 3 ? 3 * LDI + 4 : 3 * LDI;
+        const float* a_base = (LAY == 0 || LAY == 4)
+                                  ? mid + plane * (LAY == 0 ? PL : ROWS * LD) + (rt * 32 + (l31 >> 1)) * LD
+                                  : mid + (rt * 32 + (l31 >> 1)) * PITCH + plane * LDI;
+        constexpr int A1OFF = (LAY == 0 || LAY == 4) ? 16 * LD : 16 * PITCH;
         const float* bp = P2 + (kk * 64 + l31) * LD;
         f32x4 br[NQ];
 #pragma unroll
@@ -222,12 +229,12 @@ __global__ __launch_bounds__(512, 1) void step2_kernel(float* out, int items) {
             for (int t = 0; t < 16; ++t) c0[t] = c1[t] = 0.f;
             f32x4 a0[2], a1[2];
             a0[0] = *(const f32x4*)(a_base);
-            a1[0] = *(const f32x4*)(a_base + 16 * LD);
+            a1[0] = *(const f32x4*)(a_base + A1OFF);
 #pragma unroll
             for (int q = 0; q < NQ; ++q) {
                 const int nx = (q + 1 < NQ ? q + 1 : NQ - 1) * 4;
                 a0[(q + 1) & 1] = *(const f32x4*)(a_base + nx);
-                a1[(q + 1) & 1] = *(const f32x4*)(a_base + 16 * LD + nx);
+                a1[(q + 1) & 1] = *(const f32x4*)(a_base + A1OFF + nx);
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int t = 0; t < 4; ++t) {
@@ -253,11 +260,11 @@ __global__ __launch_bounds__(512, 1) void step2_kernel(float* out, int items) {
 extern "C" double ctg_probe_step2(int variant, int blocks, int items, float* out, void* stream) {
     hipStream_t s = (hipStream_t)stream;
     int k2 = 64;
-#define GO2(V, F, B, K)                                                                                \
+#define GO2(V, F, B, K, ...)                                                                           \
     if (variant == V) {                                                                                \
-        auto k = step2_kernel<F, B, K>;                                                                \
+        auto k = step2_kernel<F, B, K, ##__VA_ARGS__>;                                                 \
         (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
-        const size_t smem = (3 * (128 * (K + 4) + 32) + 2 * 64 * (K + 4)) * 4;                         \
+        const size_t smem = (3 * (128 * (K + 9) + 32) + 2 * 64 * (K + 4)) * 4;                         \
         hipLaunchKernelGGL(k, dim3(blocks), dim3(512), smem, s, out, items);                           \
         k2 = K;                                                                                        \
     }
@@ -267,6 +274,12 @@ extern "C" double ctg_probe_step2(int variant, int blocks, int items, float* out
     GO2(3, 1, false, 32)    // row-interleaved (32 floats)
     GO2(4, 0, true, 32)     // current, B' from LDS (K2 = 32 with two items per wave today)
     GO2(5, 0, false, 64)    // current with 128 floats of B' in registers (what fits if nothing else is live)
+    GO2(6, 1, false, 64, 1)   // row-interleaved, planes interleaved per row, LD = K2 + 4
+    GO2(7, 1, false, 64, 2)   // ... LD = K2 + 8
+    GO2(8, 1, false, 64, 3)   // ... LD = K2 + 4, row pitch + 4
+    GO2(9, 1, false, 64, 4)   // three planes without the bank shift
+    GO2(10, 1, false, 32, 1)  // K2 = 32, planes interleaved per row
+    GO2(11, 1, false, 32, 3)
 #undef GO2
     if (hipGetLastError() != hipSuccess) return -1.0;
     return 4096.0 * 2.0 * k2 * (double)items * 8.0 * blocks;

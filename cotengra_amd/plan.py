@@ -627,7 +627,8 @@ def build_single_step(size_dict, src, out_inds, out_ref_factory, node=-1):
 FUSE_MIN_ELEMS = 1 << 24  # stem pairs are fused when the big operand has at least this many elements
 
 
-def compile_tree(tree, dtype, order=None, force_kernel=None, fuse=None, fuse_min_elems=None, _pairs=None):
+def compile_tree(tree, dtype, order=None, force_kernel=None, fuse=None, fuse_min_elems=None, _pairs=None,
+                 stem_bf16x3=None):
     """Compile ``tree`` (possibly sliced) into a :class:`Plan` that computes
     ONE slice and accumulates it into the full result tensor.
 
@@ -653,6 +654,7 @@ def compile_tree(tree, dtype, order=None, force_kernel=None, fuse=None, fuse_min
                 int(os.environ.get("CTG_FUSE_MIN_ELEMS", FUSE_MIN_ELEMS))
                 if fuse_min_elems is None else fuse_min_elems
             ),
+            bf16x3=stem_bf16x3,   # (the pairs are priced in the arithmetic they will run in)
         )
         if not pairs:
             return base

@@ -60,20 +60,28 @@ N2_OK = (16, 32, 64, 128)
 # the lines it fetches), C2 at the full rate; together they take the longer of the two plus a fifth
 # of the shorter.
 FUSED_MFMA_RATE = 157.3e12 * 0.73
-# ... and with the experiment switch CTG_STEM_BF16X3 (csrc/ctg_stem.hip: BF3; fp32 operands split
-# into three bf16 values, products on the bf16 matrix cores): the factor by which the pairs' matrix
-# work speeds up, as measured on whole pairs; tree refinement for that mode
-# (tests/golden/gen/refine_bf3.py) prices pairs with it
+# ... and in the bf16 x 3 arithmetic (csrc/ctg_stem.hip: BF3; fp32 operands split into three bf16
+# values, products on the bf16 matrix cores -- the default since round 4, ``bf16x3_mode``): the
+# factor by which the pairs' matrix work speeds up, as measured on whole pairs (DESIGN.md section
+# 4b); tree refinement for that mode (tests/golden/gen/refine_bf3.py) prices pairs with it
 BF16X3_SPEEDUP = 1.6
 FUSED_STORE_RATE = 5.4e12
 FUSED_OVERLAP_LOSS = 0.2
 MIN_GAIN = 0.05              # fuse only if the model saves at least this fraction
 
 
-def bf16x3_env():
-    """``CTG_STEM_BF16X3`` is on when set to anything but "" or "0" (as ``CTG_NO_FUSE`` and the
-    C side's ``env_on``)."""
-    return os.environ.get("CTG_STEM_BF16X3", "0") not in ("", "0")
+def bf16x3_mode(flag=None):
+    """Arithmetic of the fused stem pairs.  Since round 4 the default is
+    bf16 x 3: fp32 operands split exactly into three bfloat16 limbs, six products on the bf16
+    matrix cores, fp32 accumulation -- the fp32 kernel's accuracy on every adversarial test,
+    11-13 % less time per slice.  ``CTG_STEM_BF16X3`` in the environment decides when it is set
+    ("0" / "" = fp32 products on the fp32 matrix cores, anything else = bf16 x 3; the C side
+    reads it at every launch the same way), else the caller's ``flag``
+    (``HipContractor(stem_bf16x3=...)``, ``ctg_exec_set_stem_arithmetic``), else the default."""
+    v = os.environ.get("CTG_STEM_BF16X3")
+    if v is not None:
+        return v not in ("", "0")
+    return True if flag is None else bool(flag)
 
 
 def gather_rate(run_bytes):
@@ -247,15 +255,15 @@ def geometry(size_dict, A, B1, B2, c1_inds, c2_inds):
     return g
 
 
-def pair_seconds(macs1, macs2, elems_a, elems_c2, items, run_bytes=256):
-    """Modelled time of a fused pair (``CTG_STEM_BF16X3`` in the environment: of the bf16 mode)."""
-    rate = FUSED_MFMA_RATE * (BF16X3_SPEEDUP if bf16x3_env() else 1.0)
+def pair_seconds(macs1, macs2, elems_a, elems_c2, items, run_bytes=256, bf16x3=None):
+    """Modelled time of a fused pair in the arithmetic ``bf16x3_mode(bf16x3)`` says."""
+    rate = FUSED_MFMA_RATE * (BF16X3_SPEEDUP if bf16x3_mode(bf16x3) else 1.0)
     t_mfma = 8.0 * macs1 / rate + 8.0 * macs2 / (rate * min(1.0, items / WAVES))
     t_mem = 8.0 * elems_a / gather_rate(run_bytes) + 8.0 * elems_c2 / FUSED_STORE_RATE
     return max(t_mfma, t_mem) + FUSED_OVERLAP_LOSS * min(t_mfma, t_mem)
 
 
-def find_pairs(plan, size_dict, min_elems=1 << 24, model=None):
+def find_pairs(plan, size_dict, min_elems=1 << 24, model=None, bf16x3=None):
     """Which consecutive stem steps of ``plan`` (compiled without fusion) to fuse:
     ``{node of the first step: node of the second}``.  Candidates are pairs
     (s1, s2) where s2's row operand is s1's result, both plain matrix-core steps
@@ -291,7 +299,7 @@ def find_pairs(plan, size_dict, min_elems=1 << 24, model=None):
         if geo is None:
             continue
         before = unfused_seconds(s1) + unfused_seconds(s2)
-        after = pair_seconds(s1.macs, s2.macs, s1.a.size, s2.c.size, geo.items, geo.run_bytes)
+        after = pair_seconds(s1.macs, s2.macs, s1.a.size, s2.c.size, geo.items, geo.run_bytes, bf16x3=bf16x3)
         if before - after >= MIN_GAIN * before:
             gain[i2] = (i1, before - after)
     # chains: i1 -> i2 -> i3 ...; a step can be in one pair only

@@ -137,12 +137,15 @@ int ctg_exec_zero_result(ctg_exec* exec);
  * *zero = 1 when check_zero met a zero intermediate in every slice). */
 int ctg_exec_set_strip_exponent(ctg_exec* exec, int strip_exponent, int check_zero);
 
-/* Arithmetic of the fused stem pairs (step kind 3) of this executor.  0 (default): complex64 on the
- * fp32 matrix cores, an exact-fp32 multiply-add chain like every other step.  1: every fp32 operand
- * of a pair is split exactly into three bfloat16 values and the six significant cross terms are
- * accumulated in fp32 on the bf16 matrix cores: the same accuracy against a
- * double-precision reference, not the same bits.  No reference counterpart (the reference computes in
- * whatever its array library does); off unless asked for.  Takes effect from the next run. */
+/* Arithmetic of the fused stem pairs (step kind 3) of this executor.  1 (the default since ABI 4):
+ * every fp32 operand of a pair is split EXACTLY into three bfloat16 values and the six significant
+ * cross terms are accumulated in fp32 on the bf16 matrix cores (error bound,
+ * domain -- operands above 2^-110, small operands rescaled by a power of two inside the kernel --
+ * and the adversarial tests that hold it to the fp32 kernel's own error); the same accuracy against
+ * a double-precision reference as 0, not the same bits, 11-13 % less time per slice.  0: complex64 on
+ * the fp32 matrix cores, an exact-fp32 multiply-add chain like every other step.  The environment
+ * variable CTG_STEM_BF16X3, when set, overrides the option ("0" = fp32).  No reference counterpart
+ * (the reference computes in whatever its array library does).  Takes effect from the next run. */
 int ctg_exec_set_stem_arithmetic(ctg_exec* exec, int bf16x3);
 int ctg_exec_get_exponent(ctg_exec* exec, double* exponent, int* zero);
 

@@ -80,26 +80,30 @@ def test_narrowed_trees_against_oracle(fixture, log2_width):
         assert rel(got64, ref) <= gate, (rel(got64, ref), gate, rel(np64, ref))
 
 
-@pytest.mark.parametrize("fixture", ["sycamore_m20_w32_c512.json", "sycamore_m20_native.json", "sycamore_m20_fused.json"])
+@pytest.mark.parametrize("fixture", ["sycamore_m20_w32_c512.json", "sycamore_m20_native.json", "sycamore_m20_fused.json",
+                                     "sycamore_m20_w33_bf3.json"])
 def test_full_width_slice_is_sum_of_double_precision_sub_slices(fixture, monkeypatch):
-    """(ii): complex64 at width 2^32 vs complex128 at width 2^28 -- on the native tree also with
-    the stem pairs on the bf16 matrix cores (CTG_STEM_BF16X3, csrc/ctg_stem.hip: BF3): the same
-    gate at full size."""
+    """(ii): complex64 at width 2^32 -- and 2^33, the configuration BASELINE calls "sliced to fit
+    288 GB HBM" (68 GB tensors in a 153 GiB arena; round 4) -- vs complex128 at width 2^28, in BOTH
+    arithmetics of the fused stem pairs: bf16 x 3 (the default: what runs when nothing is said) and
+    fp32 products (CTG_STEM_BF16X3=0): the same gate at full size."""
     tree, arrays = load(fixture)
-    assert tree.max_size() == 2**32
+    assert tree.max_size() == (2**33 if "w33" in fixture else 2**32)
     sid = 5
     coarse = HipContractor(tree)
+    full_default = complex(np.asarray(coarse.contract_slice(arrays, sid)))
+    monkeypatch.setenv("CTG_STEM_BF16X3", "0")
     full = complex(np.asarray(coarse.contract_slice(arrays, sid)))
-    full_bf3 = None
-    if fixture == "sycamore_m20_native.json":
-        monkeypatch.setenv("CTG_STEM_BF16X3", "1")
-        full_bf3 = complex(np.asarray(coarse.contract_slice(arrays, sid)))
-        monkeypatch.delenv("CTG_STEM_BF16X3")
-        assert full_bf3 != full
+    monkeypatch.setenv("CTG_STEM_BF16X3", "1")
+    full_bf3 = complex(np.asarray(coarse.contract_slice(arrays, sid)))
+    monkeypatch.delenv("CTG_STEM_BF16X3")
+    n_fused = sum(n.startswith("stem2_kernel") for n in coarse.setup(*arrays)["exec"].step_kernels())
+    if n_fused:
+        assert full_bf3 != full and full_default == full_bf3
     coarse.close()
     fine = tree.slice(target_size=2**28)
     ids = sub_slice_ids(tree, fine, sid)
-    assert len(ids) == fine.nslices // tree.nslices and 16 <= len(ids) <= 1024
+    assert len(ids) == fine.nslices // tree.nslices and 16 <= len(ids) <= 4096
     a128 = [a.astype("complex128") for a in arrays]
     fc = HipContractor(fine)
     st = fc.setup(*a128)
@@ -114,9 +118,9 @@ def test_full_width_slice_is_sum_of_double_precision_sub_slices(fixture, monkeyp
     small = tree.slice(target_size=2**20)
     ref = orc.contract_slice(small, a128, 3)
     gate = max(NORTH_STAR, 8.0 * rel(orc.contract_slice(small, arrays, 3), ref))
+    print(fixture, "fp32", rel(full, parts), "bf16x3", rel(full_bf3, parts), "gate", gate)
     assert rel(full, parts) <= gate, (rel(full, parts), gate)
-    if full_bf3 is not None:
-        assert rel(full_bf3, parts) <= gate, (rel(full_bf3, parts), rel(full, parts), gate)
+    assert rel(full_bf3, parts) <= gate, (rel(full_bf3, parts), rel(full, parts), gate)
 
 
 def test_double_precision_path_chain_down_to_the_oracle():

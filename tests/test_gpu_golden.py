@@ -202,10 +202,19 @@ def test_full_size_properties_m20(fixture):
     arrays2[7] = arrays[7] * np.complex64(0.5 - 2.0j)
     lin = np.asarray(coarse.contract_slice(arrays2, 5))
     coarse.close()
-    # (single precision against single precision: both sides carry the rounding noise
-    # of a 2^32-wide, heavily cancelling sum -- up to 4e-5 on these trees; the
-    # oracle-anchored accuracy tests are tests/test_gpu_fullwidth.py)
-    assert abs(lin - full * (0.5 - 2.0j)) <= 2e-4 * abs(full) * abs(0.5 - 2.0j)
+    # The gate is the sub-slice chain's (tests/test_gpu_fullwidth.py (ii)): a single-precision
+    # slice amplitude is within g = max(1e-5, 8 x the error numpy's own single precision makes on
+    # this tree, narrowed to the width the oracle can run) of the exact value; two single-precision
+    # results of the same exact value are therefore within 2 g of each other.  (Round 3 and before: a
+    # flat 2e-4.)
+    from oracle import contract_ref as orc
+
+    small = tree.slice(target_size=2**20)
+    a128 = [a.astype("complex128") for a in arrays]
+    ref = complex(orc.contract_slice(small, a128, 3))
+    g = max(1e-5, 8.0 * abs(complex(orc.contract_slice(small, arrays, 3)) - ref) / abs(ref))
+    print(fixture, "single-precision gate", g, "linearity", abs(lin - full * (0.5 - 2.0j)) / abs(full * (0.5 - 2.0j)))
+    assert abs(lin - full * (0.5 - 2.0j)) <= 2.0 * g * abs(full) * abs(0.5 - 2.0j)
     # one more sliced index: fine slices 2*5, 2*5+1 ... in the finer tree's numbering
     big = max((p for p, _, _ in tree.traverse()), key=tree.get_size)
     ix = next(iter(tree.get_legs(big)))
@@ -220,7 +229,8 @@ def test_full_size_properties_m20(fixture):
     fc = HipContractor(fine)
     parts = sum(np.asarray(fc.contract_slice(arrays, i)) for i in ids)
     fc.close()
-    assert abs(parts - full) <= 2e-4 * abs(full)
+    print(fixture, "slicing identity", abs(parts - full) / abs(full))
+    assert abs(parts - full) <= 2.0 * g * abs(full)
 
 
 def test_contract_distributed_rccl_single_rank():

@@ -83,24 +83,29 @@ def test_fused_stem_pairs(case, sliced, fuse_whatever_fits):
 
 @pytest.mark.parametrize("case", range(len(G.STEM_CASES)))
 def test_fused_stem_pairs_on_the_bf16_matrix_cores(case, fuse_whatever_fits, monkeypatch):
-    """CTG_STEM_BF16X3 (experiment switch, off by default): both steps of a pair multiply on the
-    bf16 matrix cores -- every fp32 operand split exactly into three bf16 values, the six
-    significant cross terms accumulated in fp32.  Same gate as the fp32 path against the numpy
-    complex128 oracle; shapes without a static instantiation keep the fp32 kernel."""
+    """bf16 x 3 (the default arithmetic of the fused pairs since round 4; CTG_STEM_BF16X3=0 = fp32
+    products): both steps of a pair multiply on the bf16 matrix cores -- every fp32 operand split
+    exactly into three bf16 values, the six significant cross terms accumulated in fp32.  Same gate
+    as the fp32 path against the numpy complex128 oracle; shapes without a static instantiation
+    keep the fp32 kernel."""
     nq, gates = G.STEM_CASES[case]
     tree = G.stem_network(nq, gates, 100 * case)
     arrays = ca.make_arrays_from_inputs(tree.inputs, tree.size_dict, seed=case, dtype="complex64")
     ref = np.asarray(orc.contract(tree, [a.astype("complex128") for a in arrays]))
     gate = G.single_gate(ref, orc.contract(tree, arrays))
     fn = HipContractor(tree, fuse=True, fuse_min_elems=1 << 10)
+    default = np.asarray(fn(*arrays))
+    monkeypatch.setenv("CTG_STEM_BF16X3", "0")
     fp32 = np.asarray(fn(*arrays))
+    assert not any(n.endswith(",true,false>") for n in fn.setup(*arrays)["exec"].step_kernels())
     monkeypatch.setenv("CTG_STEM_BF16X3", "1")
     got = np.asarray(fn(*arrays))
+    assert np.array_equal(got, default)     # (bf16 x 3 is what runs when nothing is said)
     names = [n for n in fn.setup(*arrays)["exec"].step_kernels() if n.startswith("stem2_kernel")]
     m, e = fn(*arrays, strip_exponent=True)
     fn.close()
     assert names
-    if any(n.endswith(",true>") for n in names):   # (the tenth template argument: BF3)
+    if any(n.endswith(",true,false>") for n in names):   # (the tenth template argument: BF3)
         assert not np.array_equal(got, fp32)   # (it really ran)
     assert G.relerr(got, ref) <= gate, (G.relerr(got, ref), gate, G.relerr(fp32, ref))
     assert G.relerr(np.asarray(m).astype("complex128") * 10.0**e, ref) <= gate
@@ -111,6 +116,9 @@ def test_fused_stem_pairs_on_the_bf16_matrix_cores(case, fuse_whatever_fits, mon
     names2 = [n for n in fn2.setup(*arrays)["exec"].step_kernels() if n.startswith("stem2_kernel")]
     fn2.close()
     assert names2 == names and np.array_equal(again, got)
+    fn3 = HipContractor(tree, fuse=True, fuse_min_elems=1 << 10, stem_bf16x3=False)   # ... and off
+    assert np.array_equal(np.asarray(fn3(*arrays)), fp32)
+    fn3.close()
 
 
 @pytest.mark.parametrize("seed", range(48))
@@ -122,6 +130,7 @@ def test_random_stems_on_the_fused_kernel(seed, fuse_whatever_fits, monkeypatch)
     ref = np.asarray(orc.contract(tree, [a.astype("complex128") for a in arrays]))
     gate = G.single_gate(ref, orc.contract(tree, arrays))
     fn = HipContractor(tree, fuse=True, fuse_min_elems=1 << 9)
+    monkeypatch.setenv("CTG_STEM_BF16X3", "0")
     got = np.asarray(fn(*arrays))
     monkeypatch.setenv("CTG_STEM_BF16X3", "1")
     got3 = np.asarray(fn(*arrays))
@@ -135,20 +144,33 @@ def test_fused_stem_pairs_run_time_count_variant(case, fuse_whatever_fits, monke
     """Shapes without a static instantiation run the variant whose chunk / item counts are
     run-time values (every wait drains the queue, stores issued at once); forced here
     (CTG_STEM_GENERIC, read at every launch) on shapes that normally take a static one: same
-    tables, same arithmetic per element -- the same bits."""
+    tables, same arithmetic per element -- the same bits as the static variant in the same
+    (X / Y) form of step 2.  The row-interleaved form of round 4 (the default where it applies)
+    adds the two products of an imaginary part in the other order: the last bit may differ,
+    the gate against the oracle is the same."""
     nq, gates = G.STEM_CASES[case]
     tree = G.stem_network(nq, gates, 100 * case)
     arrays = ca.make_arrays_from_inputs(tree.inputs, tree.size_dict, seed=case, dtype="complex64")
+    ref = np.asarray(orc.contract(tree, [a.astype("complex128") for a in arrays]))
+    gate = G.single_gate(ref, orc.contract(tree, arrays))
+    monkeypatch.setenv("CTG_STEM_BF16X3", "0")     # (fp32 products: what the run-time-count variant has)
     fn = HipContractor(tree, fuse=True, fuse_min_elems=1 << 10)
-    static = np.asarray(fn(*arrays))
+    default = np.asarray(fn(*arrays))
     names = [n for n in fn.setup(*arrays)["exec"].step_kernels() if n.startswith("stem2_kernel")]
     assert names
+    monkeypatch.setenv("CTG_STEM_NO_RI2", "1")
+    static = np.asarray(fn(*arrays))
+    xnames = [n for n in fn.setup(*arrays)["exec"].step_kernels() if n.startswith("stem2_kernel")]
+    assert all(n.endswith(",false>") for n in xnames), xnames
     monkeypatch.setenv("CTG_STEM_GENERIC", "1")
     generic = np.asarray(fn(*arrays))
     gnames = [n for n in fn.setup(*arrays)["exec"].step_kernels() if n.startswith("stem2_kernel")]
     assert all(",0,0,false,0," in n for n in gnames), gnames
     fn.close()
     assert np.array_equal(static, generic)
+    assert G.relerr(default, ref) <= gate and G.relerr(static, ref) <= gate
+    if any(n.endswith(",true>") for n in names):   # (the eleventh template argument: RI2)
+        assert G.relerr(default, static) <= 4e-6
 
 
 
@@ -199,12 +221,20 @@ def test_expression_cache_is_bounded_by_device_bytes(monkeypatch):
     from cotengra_amd import interface
 
     interface.clear_expression_cache()
-    monkeypatch.setattr(interface, "_EXPR_CACHE_BYTES", 3 << 20)
     rng = np.random.default_rng(1)
-    for n in range(4, 12):   # eight different shapes, each executor ~ 1 MiB of tables + buffers
+    # the first expression tells what one of these executors really holds (ctg_exec_device_bytes:
+    # inputs, arena, tables, result -- a few hundred KB; no scratch: no step of theirs needs any);
+    # the bound is set to three and a half of them
+    a, b = rng.normal(size=(4, 64)), rng.normal(size=(64, 4))
+    assert np.allclose(np.asarray(ca.einsum("ab,bc->ac", a, b)), a @ b)
+    one = next(iter(interface._EXPR_CACHE.values())).device_bytes()
+    assert 0 < one < (8 << 20)
+    bound = int(3.5 * one)
+    monkeypatch.setattr(interface, "_EXPR_CACHE_BYTES", bound)
+    for n in range(5, 12):   # seven more shapes of about the same size
         a, b = rng.normal(size=(n, 64)), rng.normal(size=(64, n))
         assert np.allclose(np.asarray(ca.einsum("ab,bc->ac", a, b)), a @ b)
-        assert sum(e.device_bytes() for e in interface._EXPR_CACHE.values()) <= (3 << 20) or len(interface._EXPR_CACHE) == 1
+        assert sum(e.device_bytes() for e in interface._EXPR_CACHE.values()) <= bound + one or len(interface._EXPR_CACHE) == 1
     assert 1 <= len(interface._EXPR_CACHE) < 8
     # the executor's out-of-memory path drops everything but the expression in the making
     keep = next(reversed(interface._EXPR_CACHE.values()))

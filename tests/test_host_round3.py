@@ -162,16 +162,21 @@ def test_fusion_is_off_where_it_does_not_apply():
 
 
 def test_pair_model_of_the_bf16_mode(monkeypatch):
-    """With CTG_STEM_BF16X3 in the environment the pair model prices the pairs' matrix work at
-    BF16X3_SPEEDUP x the fp32 rate (tree refinement for that mode, tests/golden/gen/refine_bf3.py);
-    a memory-bound pair costs the same either way."""
+    """In the bf16 x 3 arithmetic (the default since round 4; CTG_STEM_BF16X3=0 or ``bf16x3=False``
+    = fp32 products) the pair model prices the pairs' matrix work at BF16X3_SPEEDUP x the fp32 rate
+    (tree refinement for that mode, tests/golden/gen/refine_bf3.py); a memory-bound pair costs the
+    same either way.  The environment, when set, wins over the caller's flag."""
     from cotengra_amd import stem
-    monkeypatch.delenv("CTG_STEM_BF16X3", raising=False)
+    monkeypatch.setenv("CTG_STEM_BF16X3", "0")
     mfma_bound = stem.pair_seconds(2**27 * 32 * 32, 2**26 * 64 * 64, 2**32, 2**32, 8)
     mem_bound = stem.pair_seconds(2**28 * 16 * 16, 2**28 * 16 * 16, 2**32, 2**32, 16)
+    assert stem.pair_seconds(2**27 * 32 * 32, 2**26 * 64 * 64, 2**32, 2**32, 8, bf16x3=True) == mfma_bound
     monkeypatch.setenv("CTG_STEM_BF16X3", "1")
     assert stem.pair_seconds(2**27 * 32 * 32, 2**26 * 64 * 64, 2**32, 2**32, 8) < 0.8 * mfma_bound
     assert stem.pair_seconds(2**28 * 16 * 16, 2**28 * 16 * 16, 2**32, 2**32, 16) >= 0.9 * mem_bound
+    monkeypatch.delenv("CTG_STEM_BF16X3")
+    assert stem.pair_seconds(2**27 * 32 * 32, 2**26 * 64 * 64, 2**32, 2**32, 8) < 0.8 * mfma_bound           # the default
+    assert stem.pair_seconds(2**27 * 32 * 32, 2**26 * 64 * 64, 2**32, 2**32, 8, bf16x3=False) == mfma_bound
 
 
 def test_fused_descriptor_is_validated():

@@ -258,12 +258,17 @@ def test_device_bytes_tolerates_a_busy_contractor():
     th.join(10)
 
 
-@pytest.mark.parametrize("value,on", [(None, False), ("", False), ("0", False), ("1", True), ("yes", True)])
+@pytest.mark.parametrize("value,on", [(None, True), ("", False), ("0", False), ("1", True), ("yes", True)])
 def test_boolean_switches_treat_zero_as_off(monkeypatch, value, on):
+    """CTG_STEM_BF16X3: unset = the default arithmetic of the fused pairs (bf16 x 3 since round 4)
+    unless the caller's flag says otherwise; set = it decides, "0" and "" meaning off -- the rule
+    the C side's launcher applies at every launch (csrc/ctg_stem.hip: stem2_bf3)."""
     from cotengra_amd import stem
 
     if value is None:
         monkeypatch.delenv("CTG_STEM_BF16X3", raising=False)
+        assert stem.bf16x3_mode(False) is False and stem.bf16x3_mode(True) is True
     else:
         monkeypatch.setenv("CTG_STEM_BF16X3", value)
-    assert stem.bf16x3_env() is on
+        assert stem.bf16x3_mode(not on) is on      # the environment wins
+    assert stem.bf16x3_mode() is on

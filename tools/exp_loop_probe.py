@@ -41,7 +41,7 @@ def smi():
         return f"(rocm-smi: {e})"
 
 
-for blocks in (256,):
+for blocks in ():
     for v in sorted(NAMES):
         lib.ctg_probe_loop(v, blocks, 50, out.data_ptr(), None)
         torch.cuda.synchronize()
@@ -71,6 +71,12 @@ N2 = {
     3: "row-interleaved, K2 = 32, B' in registers (32 floats)",
     4: "X/Y form, K2 = 32, B' from LDS + xor",
     5: "X/Y form, K2 = 64, B' in registers (128 floats)",
+    6: "row-interleaved, K2 = 64, planes interleaved per row, LD = K2 + 4",
+    7: "row-interleaved, K2 = 64, planes interleaved per row, LD = K2 + 8",
+    8: "row-interleaved, K2 = 64, planes interleaved per row, pitch 3 LD + 4",
+    9: "row-interleaved, K2 = 64, three planes WITHOUT the bank shift",
+    10: "row-interleaved, K2 = 32, planes interleaved per row",
+    11: "row-interleaved, K2 = 32, planes interleaved per row, pitch 3 LD + 4",
 }
 for blocks in (256,):
     for v in sorted(N2):

@@ -11,6 +11,40 @@ sys.path.insert(0, ROOT)
 import cotengra_amd as ca  # noqa: E402
 from cotengra_amd.plan import KIND_STEM2, compile_tree  # noqa: E402
 
+SW, LDS = 8, 160 * 1024
+
+
+def lds_ri2(st, b2_in_regs):
+    b1 = (3 if st["N1"] == 16 else 2) * st["N1"] * (st["K1"] + 4)
+    b2 = 2 * st["N2"] * (st["K2"] + 4)
+    mid = 3 * st["rows2"] * st["ld2"]
+    return 4 * (b1 + (max(mid, b2) if b2_in_regs else b2 + mid)) + 8 * st["N2"]
+
+
+def shape(st):
+    """csrc/ctg_stem.hip: stem2_shape, restated."""
+    cs1 = max(1, st["N1"] // 32)
+    p1, p2 = st["N1"] == 16, st["N2"] == 16
+    rt1 = (1 << (st["nr1"] - 5)) * cs1 // SW
+    nch, it2 = st["K1"] // 16, (st["items"] // SW if st["items"] % SW == 0 else 0)
+    ng2 = st["ng2"]
+    if not p2 and it2 > 0 and 1 <= ng2 <= SW and SW % ng2 == 0:
+        fixed = rt1 * (16 if p1 else 32) + (64 if it2 > 1 else 32) + 32 + 40
+        r1 = st["K1"] if st["K1"] <= 64 else 0
+        r2 = st["K2"] if st["K2"] <= 64 else 0
+        if fixed + r1 + r2 > 256:
+            r2 = 0
+        if fixed + r1 > 256:
+            r1 = 0
+        if lds_ri2(st, r2 != 0) <= LDS:
+            return (p1, p2, rt1, cs1, nch, it2, bool(r1), st["K2"] // 4 if r2 else 0, bool(st["vec"]), True)
+    r1 = st["K1"] if st["K1"] <= 64 else 0
+    r2 = (st["K2"] if p2 else 2 * st["K2"]) if ((p2 and st["K2"] <= 64) or (not p2 and it2 == 1 and st["K2"] <= 32)) else 0
+    if r1 and r2 and r1 + r2 > 96:
+        r2 = 0
+    return (p1, p2, rt1, cs1, nch, it2, bool(r1), st["K2"] // 4 if r2 else 0, bool(st["vec"]), False)
+
+
 need = {}
 for f in sorted(glob.glob(os.path.join(ROOT, "tests", "golden", "trees", "sycamore_m20*.json"))):
     tree = ca.tree_from_record(json.load(open(f)))
@@ -19,18 +53,18 @@ for f in sorted(glob.glob(os.path.join(ROOT, "tests", "golden", "trees", "sycamo
         if s.kind != KIND_STEM2:
             continue
         st = s.stem
-        cs1 = max(1, st["N1"] // 32)
-        p1, p2 = st["N1"] == 16, st["N2"] == 16
-        nch, it2 = st["K1"] // 16, (st["items"] // 8 if st["items"] % 8 == 0 else -st["items"])
-        # which small operand's fragments live in registers (csrc/ctg_stem.hip: stem2_breg)
-        r1 = st["K1"] if st["K1"] <= 64 else 0
-        r2 = (st["K2"] if p2 else 2 * st["K2"]) if ((p2 and st["K2"] <= 64) or (not p2 and it2 == 1 and st["K2"] <= 32)) else 0
-        if r1 and r2 and r1 + r2 > 96:
-            r2 = 0
-        key = (p1, p2, (1 << (st["nr1"] - 5)) * cs1 // 8, cs1, nch, it2, bool(r1), st["K2"] // 4 if r2 else 0, bool(st["vec"]))
+        key = shape(st)
+        if key[5] == 0:
+            continue   # (item count not a multiple of the waves: the run-time-count variant)
         d = need.setdefault(key, [0, set()])
         d[0] += s.macs
         d[1].add((os.path.basename(f)[13:-5], st["K1"], st["N1"], st["K2"], st["N2"]))
+lo = lambda b: str(b).lower()   # noqa: E731
+print("// fp32 instantiations (P1, P2, RT1, CS1, NCH, IT2, BR1, K2Q, VEC, RI2), by share of the work")
 for key, (macs, where) in sorted(need.items(), key=lambda kv: -kv[1][0]):
-    print("X(%s, %s, %d, %d, %d, %d, %s, %d, %s)" % (str(key[0]).lower(), str(key[1]).lower(), *key[2:6], str(key[6]).lower(), key[7], str(key[8]).lower()),
-          "%.2e" % macs, sorted(where)[:4])
+    print("X(%s, %s, %d, %d, %d, %d, %s, %d, %s, %s)" % (lo(key[0]), lo(key[1]), *key[2:6], lo(key[6]), key[7], lo(key[8]), lo(key[9])),
+          "// %.2e" % macs, sorted(where)[:3])
+geo = sorted({(k[0], k[1], k[2], k[3], k[4], k[5], k[8]) for k in need})
+print("// geometries (P1, P2, RT1, CS1, NCH, IT2, VEC): the bf16 x 3 instantiations")
+for g in geo:
+    print("G(%s, %s, %d, %d, %d, %d, %s)" % (lo(g[0]), lo(g[1]), *g[2:6], lo(g[6])))
