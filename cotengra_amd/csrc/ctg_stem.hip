@@ -283,7 +283,11 @@ __global__ __launch_bounds__(SW * 64, 1) void stem2_kernel(StemArgs p) {
     static_assert(!PACK1 || CS1 == 1, "16 columns are one group");
     static_assert(!BR1 || NCH > 0, "B1 in registers needs the chunk count at compile time");
     static_assert(K2Q == 0 || PACK2 || IT2 == 1 || RI2, "B2 in registers: one column group per wave");
-    static_assert(!RI2 || (!PACK2 && !BF3 && NCH > 0 && IT2 > 0), "row-interleaved step 2: fp32, >= 32 columns, static");
+    static_assert(!RI2 || (!PACK2 && NCH > 0 && IT2 > 0), "row-interleaved step 2: fp32 products, >= 32 columns, static");
+    // BF3 && RI2: the MIXED arithmetic -- step 1 on the bf16 matrix cores (its splits work on gathered
+    // registers, its B1 fragments live in registers), step 2 row-interleaved on the fp32 matrix cores
+    // (no split of the intermediate per column group, no bf16 planes of B2 in LDS)
+    constexpr bool BF3S2 = BF3 && !RI2;   // step 2 on the bf16 matrix cores
     constexpr int RTW = SW / CS1;   // row tiles the 8 waves cover at once
     constexpr bool STATIC = NCH > 0;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -294,6 +298,11 @@ __global__ __launch_bounds__(SW * 64, 1) void stem2_kernel(StemArgs p) {
     const int PLANE = p.rows2 * LD2;                       // floats per plane of the intermediate
     float* P1 = (float*)smem;                              // [2|3][N1][LDB1]
     float* P2 = P1 + (PACK1 ? 3 : 2) * N1 * LDB1;          // [2|3][N2][LDB2]
+    // (BF3: the small operands as bf16 x 3 planes instead -- mixed arithmetic: B1 only)
+    const int ROW1 = bf3_row(K1, true), ROW2 = bf3_row(K2, false);
+    unsigned short* Q1 = (unsigned short*)smem;            // [2|3][N1][ROW1]
+    unsigned short* Q2 = Q1 + (PACK1 ? 3 : 2) * N1 * ROW1; // [2|3][N2][ROW2]
+    if constexpr (BF3 && RI2) P2 = (float*)Q2;             // (a multiple of 16 bytes behind Q1)
     float* mid = P2 + (PACK2 ? 3 : 2) * N2 * LDB2;         // [2][rows2][LD2]
     // RI2: three planes (Re, Im, -Im) INTERLEAVED PER ROW -- [rows2][3][LD2], row pitch RP = 3 LD2:
     // the three values of an element are LD2 floats apart, an immediate offset of the scatter's
@@ -313,11 +322,7 @@ __global__ __launch_bounds__(SW * 64, 1) void stem2_kernel(StemArgs p) {
             mid_floats = mid_floats > p2f ? mid_floats : p2f;
         }
     }
-    // (BF3: the small operands as bf16 x 3 planes instead)
-    const int ROW1 = bf3_row(K1, true), ROW2 = bf3_row(K2, false);
-    unsigned short* Q1 = (unsigned short*)smem;            // [2|3][N1][ROW1]
-    unsigned short* Q2 = Q1 + (PACK1 ? 3 : 2) * N1 * ROW1; // [2|3][N2][ROW2]
-    if constexpr (BF3) mid = (float*)(Q2 + (PACK2 ? 3 : 2) * N2 * ROW2);
+    if constexpr (BF3S2) mid = (float*)(Q2 + (PACK2 ? 3 : 2) * N2 * ROW2);
     int64_t* oc_s = (int64_t*)(mid + mid_floats);          // [N2] column offsets of the result
 
     const int tid = threadIdx.x;
@@ -338,10 +343,11 @@ __global__ __launch_bounds__(SW * 64, 1) void stem2_kernel(StemArgs p) {
     if constexpr (BF3) {
         float* bf3_red = (float*)(oc_s + N2);   // (64 bytes behind the column table: stem2_lds_bytes_bf3)
         const int ex1 = bf3_operand_exponent(B1, p.b1_off, K1 * N1, tid, bf3_red);
-        const int ex2 = bf3_operand_exponent(B2, p.b2_off, K2 * N2, tid, bf3_red);
+        const int ex2 = BF3S2 ? bf3_operand_exponent(B2, p.b2_off, K2 * N2, tid, bf3_red) : 0;
         bf3_ex = ex1 + ex2;
         load_b_planes_bf3<true>(Q1, B1, p.b1_off, K1, N1, PACK1 ? 3 : 2, tid, VEC, pow2f(-ex1));
-        load_b_planes_bf3<false>(Q2, B2, p.b2_off, K2, N2, PACK2 ? 3 : 2, tid, false, pow2f(-ex2));
+        if constexpr (BF3S2) load_b_planes_bf3<false>(Q2, B2, p.b2_off, K2, N2, PACK2 ? 3 : 2, tid, false, pow2f(-ex2));
+        else load_b_planes<false>(P2, B2, p.b2_off, K2, N2, PACK2, tid);
     } else {
         load_b_planes<true>(P1, B1, p.b1_off, K1, N1, PACK1, tid, VEC);
         load_b_planes<false>(P2, B2, p.b2_off, K2, N2, PACK2, tid);
@@ -467,7 +473,7 @@ __global__ __launch_bounds__(SW * 64, 1) void stem2_kernel(StemArgs p) {
     // copy: the lanes of the second k-row hold -Im b instead, and the loop feeds A' = (Re a,
     // Im a) to both tiles
     f32x4 b1r[BR1 && !BF3 ? NCH * 2 : 1][2];
-    f32x4 b2r[K2Q > 0 && !BF3 ? K2Q : 1][PACK2 ? 1 : 2];
+    f32x4 b2r[K2Q > 0 && !BF3S2 ? K2Q : 1][PACK2 ? 1 : 2];
     bf16x8 b1r3[BR1 && BF3 ? NCH : 1][3][2];   // BF3: [chunk][split][b1p | b1q]
     if constexpr (BR1 && BF3) {
 #pragma unroll
@@ -826,7 +832,7 @@ __global__ __launch_bounds__(SW * 64, 1) void stem2_kernel(StemArgs p) {
     auto item2 = [&](int item, int64_t c_row, auto scaled_tag, auto drain_tag, auto defer_tag)
                      __attribute__((always_inline)) {
         constexpr bool DRAIN = decltype(drain_tag)::value;
-        if constexpr (DRAIN && (K2Q == 0 || BF3)) drain(0, NST, std::integral_constant<int, 0>{}, scaled_tag);   // (run-time trip count below: no slots to put them in)
+        if constexpr (DRAIN && (K2Q == 0 || BF3S2)) drain(0, NST, std::integral_constant<int, 0>{}, scaled_tag);   // (run-time trip count below: no slots to put them in)
         const int cg = item / n_rt2, rt2 = item - cg * n_rt2;
         f32x16 cx, cy;
 #pragma unroll
@@ -1089,6 +1095,14 @@ static size_t stem2_lds_bytes_ri2(const StemArgs& p, bool b2_in_regs) {
     return 4 * (b1 + (b2_in_regs ? (mid > b2 ? mid : b2) : b2 + mid)) + 8 * (size_t)p.N2;
 }
 
+// ... and of the mixed arithmetic (BF3 && RI2): B1 as bf16 x 3 planes, B2 / the intermediate as in RI2
+static size_t stem2_lds_bytes_mix(const StemArgs& p, bool b2_in_regs) {
+    const size_t q1 = (size_t)(p.N1 == 16 ? 3 : 2) * p.N1 * ((p.K1 >> 4) * 48 + 8);
+    const size_t b2 = (size_t)2 * p.N2 * (p.K2 + 4);
+    const size_t mid = (size_t)3 * p.rows2 * p.ld2;
+    return 2 * q1 + 4 * (b2_in_regs ? (mid > b2 ? mid : b2) : b2 + mid) + 8 * (size_t)p.N2 + 64;
+}
+
 template <bool PACK1, bool PACK2, int RT1, int CS1, int NCH, int IT2, bool BR1 = false, int K2Q = 0, bool VEC = false,
           bool BF3 = false, bool RI2 = false>
 static hipError_t launch_stem2_t(const StemArgs& p, hipStream_t stream) {
@@ -1098,7 +1112,8 @@ static hipError_t launch_stem2_t(const StemArgs& p, hipStream_t stream) {
         const hipError_t e = lds_opt_in((const void*)kern, 160 * 1024, &ready);
         if (e != hipSuccess) return e;
     }
-    const size_t smem = BF3 ? stem2_lds_bytes_bf3(p) : (RI2 ? stem2_lds_bytes_ri2(p, K2Q > 0) : stem2_lds_bytes(p));
+    const size_t smem = BF3 ? (RI2 ? stem2_lds_bytes_mix(p, K2Q > 0) : stem2_lds_bytes_bf3(p))
+                            : (RI2 ? stem2_lds_bytes_ri2(p, K2Q > 0) : stem2_lds_bytes(p));
     // persistent: one workgroup per CU (the tile owns most of the CU's LDS)
     int64_t blocks = p.n_tiles < 256 ? p.n_tiles : 256;
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks, 1), dim3(SW * 64), smem, stream, p);
@@ -1152,6 +1167,23 @@ bool stem2_supported(const StemArgs& p) {
     X(true, false, 2, 1, 1, 1, true, 16, false, true) X(false, true, 1, 1, 8, 2, false, 4, false, false) \
     X(false, false, 1, 1, 2, 4, true, 4, false, true) X(false, false, 1, 1, 2, 4, true, 8, false, true) \
     X(false, false, 1, 1, 2, 2, true, 4, false, true) X(true, true, 2, 1, 4, 1, true, 8, false, false)
+
+// the row-interleaved entries of CTG_STEM_INST once more: the instantiations of the MIXED arithmetic
+// (step 1 bf16 x 3 with B1 in registers up to two chunks, step 2 as in the fp32 entry)
+#define CTG_STEM_MIX(X) \
+    X(false, false, 1, 1, 2, 1, true, 8, false, true) X(false, false, 1, 2, 4, 1, true, 8, false, true) \
+    X(false, false, 1, 1, 2, 1, true, 16, false, true) X(true, false, 2, 1, 1, 1, true, 8, false, true) \
+    X(false, false, 1, 2, 4, 1, true, 8, true, true) X(false, false, 1, 2, 2, 1, true, 8, false, true) \
+    X(true, false, 2, 1, 1, 1, true, 8, true, true) X(false, false, 1, 1, 2, 2, true, 8, false, true) \
+    X(false, false, 1, 2, 2, 1, true, 16, false, true) X(true, false, 2, 1, 1, 2, true, 8, true, true) \
+    X(false, false, 1, 1, 8, 1, false, 8, false, true) X(false, false, 1, 1, 4, 1, true, 8, true, true) \
+    X(false, false, 1, 2, 1, 1, true, 8, false, true) X(false, false, 1, 1, 8, 2, false, 8, false, true) \
+    X(true, false, 2, 1, 1, 2, true, 8, false, true) X(false, false, 1, 2, 2, 4, true, 4, true, true) \
+    X(false, false, 1, 1, 2, 1, true, 8, true, true) X(true, false, 2, 1, 1, 2, true, 16, false, true) \
+    X(false, false, 1, 1, 1, 2, true, 8, false, true) X(false, false, 1, 1, 4, 1, true, 0, false, true) \
+    X(true, false, 2, 1, 2, 1, true, 8, false, true) X(true, false, 2, 1, 1, 2, true, 4, false, true) \
+    X(true, false, 2, 1, 1, 1, true, 16, false, true) X(false, false, 1, 1, 2, 4, true, 4, false, true) \
+    X(false, false, 1, 1, 2, 4, true, 8, false, true) X(false, false, 1, 1, 2, 2, true, 4, false, true)
 
 #define CTG_STEM_GEO(G) \
     G(false, false, 1, 1, 1, 2, false) G(false, false, 1, 1, 2, 1, false) G(false, false, 1, 1, 2, 1, true) \
@@ -1245,17 +1277,31 @@ static bool stem2_has_geo(const StemShape& s) {
 // option ctg_exec_set_stem_arithmetic(exec, 0) selects fp32 products on the fp32 matrix cores; the
 // environment variable CTG_STEM_BF16X3, when SET, overrides both ("0" / "" = fp32, anything else =
 // bf16 x 3) and is read at every launch (tests switch it within a process).
-static bool stem2_bf3(const StemArgs& p) {
+static bool stem2_want_bf3(const StemArgs& p) {
     const char* v = getenv("CTG_STEM_BF16X3");
-    const bool want = v != nullptr ? !(v[0] == '\0' || (v[0] == '0' && v[1] == '\0')) : p.bf3 != 0;
-    return want && stem2_has_geo(stem2_shape(p, true)) && (p.K2 & 7) == 0 && stem2_lds_bytes_bf3(p) <= 160 * 1024;
+    return v != nullptr ? !(v[0] == '\0' || (v[0] == '0' && v[1] == '\0')) : p.bf3 != 0;
+}
+static bool stem2_bf3(const StemArgs& p) {
+    return stem2_want_bf3(p) && stem2_has_geo(stem2_shape(p, true)) && (p.K2 & 7) == 0 &&
+           stem2_lds_bytes_bf3(p) <= 160 * 1024;
+}
+// MIXED arithmetic (experiment switch CTG_STEM_MIXED, off by default): step 1 on the bf16 matrix
+// cores, step 2 row-interleaved on the fp32 ones -- for the shapes whose fp32 form is a static
+// row-interleaved instantiation
+static bool stem2_mixed(const StemArgs& p) {
+    if (!env_on("CTG_STEM_MIXED") || !stem2_want_bf3(p)) return false;
+    const StemShape s = stem2_shape(p);
+    return s.ri2 && stem2_variant(p) && stem2_lds_bytes_mix(p, s.k2q > 0) <= 160 * 1024;
 }
 
 // the instantiation a step runs on, spelled like its symbol in a kernel trace
 void stem2_kernel_name(const StemArgs& p, char* buf, size_t n) {
     const StemShape s = stem2_shape(p);
     auto tf = [](bool b) { return b ? "true" : "false"; };
-    if (stem2_bf3(p))
+    if (stem2_mixed(p))
+        snprintf(buf, n, "stem2_kernel<%s,%s,%d,%d,%d,%d,%s,%d,%s,true,true>", tf(s.p1), tf(s.p2), s.rt1, s.cs1, s.nch,
+                 s.it2, tf(s.nch <= 2), s.k2q, tf(s.vec));
+    else if (stem2_bf3(p))
         snprintf(buf, n, "stem2_kernel<%s,%s,%d,%d,%d,%d,%s,0,%s,true,false>", tf(s.p1), tf(s.p2), s.rt1, s.cs1, s.nch,
                  s.it2, tf(s.nch <= 2), tf(s.vec));
     else if (stem2_variant(p))
@@ -1268,6 +1314,15 @@ void stem2_kernel_name(const StemArgs& p, char* buf, size_t n) {
 
 hipError_t launch_stem2(const StemArgs& p, hipStream_t stream) {
     if (!stem2_supported(p)) return hipErrorInvalidValue;
+    if (stem2_mixed(p)) {
+        const StemShape s = stem2_shape(p);
+#define CTG_STEM_GOM(P1, P2, R, CS, NC, IT, B1, KQ, V, RI)                                             \
+    if (s.p1 == P1 && s.p2 == P2 && s.rt1 == R && s.cs1 == CS && s.nch == NC && s.it2 == IT && s.br1 == B1 && \
+        s.k2q == KQ && s.vec == V)                                                                     \
+        return launch_stem2_t<P1, P2, R, CS, NC, IT, (NC <= 2), KQ, V, true, true>(p, stream);
+        CTG_STEM_MIX(CTG_STEM_GOM)
+#undef CTG_STEM_GOM
+    }
     if (stem2_bf3(p)) {
         const StemShape s = stem2_shape(p, true);
 #define CTG_STEM_GO3(P1, P2, R, CS, NC, IT, V)                                                          \
