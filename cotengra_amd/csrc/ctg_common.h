@@ -70,6 +70,8 @@ enum StemWord {
     SW_NTILES = 8, SW_GLO = 9, SW_LD2 = 10, SW_LDS = 11,
     SW_B2_SPACE = 12, SW_B2_OFF = 13, SW_B2_LEAF = 14, SW_B2_SIZE = 15, SW_B2_PROD = 16,
     SW_VEC = 17,    // 1: slots 2 q, 2 q + 1 of a task are adjacent in memory (one 16-byte load)
+    SW_ONE = 18,    // 1: the first half alone (ONE step: K2 = N2 = rows2 = 0, no B2; out_row over the
+                    //    tile rows of step 1, out_col over its columns) -- stem.py: build_stem_one
     SW_TABS = 20,   // 14 table offsets: gA_hi gA_lo gC_hi gC_lo kj_a lane_a rt_a chunk_a
                     //                   b1_off b2_off mid_row mid_col out_row out_col
     STEM_WORDS = 40
@@ -177,6 +179,7 @@ struct StemArgs {
     int32_t nz, z0;       // slice batching, as StepArgs
     int64_t zA, zB1, zB2, zC;
     int64_t zsA, zsB1, zsB2, zsC;
+    int32_t one;                // the first half alone (SW_ONE)
     int64_t a_elems, c_elems;   // extents of the big operand and of the result (the bounds-checked
                                 // experiment build -DCTG_STEM_BOUNDS tests every gather and store)
 };

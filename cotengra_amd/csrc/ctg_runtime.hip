@@ -94,14 +94,23 @@ int validate_stem(const ctg_plan* p, int64_t s) {
     a.K1 = (int)K1; a.N1 = (int)N1; a.K2 = (int)K2; a.N2 = (int)N2; a.nr1 = (int)nr1;
     a.rows2 = (int)rows2; a.ng2 = (int)h[SW_NG2]; a.ld2 = (int)h[SW_LD2];
     a.n_tiles = n_tiles;
-    if (K1 < 1 || K1 > 128 || N1 < 1 || N1 > 128 || K2 < 1 || K2 > 128 || N2 < 1 || N2 > 128 || nr1 < 5 ||
-        nr1 > 9 || rows2 < 1 || rows2 > (1 << 16) || !stem2_supported(a))
+    if (h[SW_ONE] != 0 && h[SW_ONE] != 1) return fail(CTG_E_INVALID, "step %lld: bad stem step count", sl);
+    const bool one = h[SW_ONE] == 1;
+    a.one = one ? 1 : 0;
+    if (one) {
+        // the first half alone: no second operand, no intermediate tile
+        if (K1 < 1 || K1 > 128 || N1 < 1 || N1 > 128 || K2 != 0 || N2 != 0 || rows2 != 0 || h[SW_NG2] != 0 ||
+            h[SW_LD2] != 0 || nr1 < 5 || nr1 > 9 || !stem2_supported(a))
+            return fail(CTG_E_INVALID, "step %lld: single stem step shape the kernel does not take", sl);
+    } else if (K1 < 1 || K1 > 128 || N1 < 1 || N1 > 128 || K2 < 1 || K2 > 128 || N2 < 1 || N2 > 128 || nr1 < 5 ||
+               nr1 > 9 || rows2 < 1 || rows2 > (1 << 16) || !stem2_supported(a))
         return fail(CTG_E_INVALID, "step %lld: stem pair shape the kernel does not take", sl);
     if (n_tiles < 1 || g_lo < 1 || log2_exact(g_lo) < 0 || n_tiles % g_lo != 0 || log2_exact(n_tiles) < 0)
         return fail(CTG_E_INVALID, "step %lld: bad stem grid", sl);
     const int64_t rows1 = 1ll << nr1;
     const int64_t len[ST_COUNT] = {n_tiles / g_lo, g_lo, n_tiles / g_lo, g_lo, 8, 64, rows1 / 32, K1 / 16,
-                                   K1 * N1, K2 * N2, rows1, N1, rows2, N2};
+                                   K1 * N1, one ? 1 : K2 * N2, one ? 1 : rows1, one ? 1 : N1,
+                                   one ? rows1 : rows2, one ? N1 : N2};
     int64_t mx[ST_COUNT], mn[ST_COUNT];
     for (int t = 0; t < ST_COUNT; ++t) {
         if (!tab_ok(p, h[SW_TABS + t], len[t]))
@@ -127,7 +136,7 @@ int validate_stem(const ctg_plan* p, int64_t s) {
         if ((r[W_A_OFF] & 1) || r[W_A_LEAF] >= 0)
             return fail(CTG_E_INVALID, "step %lld: stem operand not aligned for 16-byte gathers", sl);
     }
-    if (mx[ST_MID_ROW] + mx[ST_MID_COL] >= rows2 * (K2 + 4))
+    if (!one && mx[ST_MID_ROW] + mx[ST_MID_COL] >= rows2 * (K2 + 4))
         return fail(CTG_E_BOUNDS, "step %lld: intermediate tile overflows its LDS", sl);
     struct Op { int64_t space, off, leaf, size, top; char name; };
     const Op ops[4] = {
@@ -139,6 +148,7 @@ int validate_stem(const ctg_plan* p, int64_t s) {
          mx[ST_GC_HI] + mx[ST_GC_LO] + mx[ST_OUT_ROW] + mx[ST_OUT_COL], 'C'},
     };
     for (const Op& op : ops) {
+        if (one && op.name == 'b') continue;
         const int64_t cap = space_elems(p, op.space);
         if (cap < 0) return fail(CTG_E_INVALID, "step %lld: bad space", sl);
         if (op.leaf < -1 || op.leaf > p->n_inputs) return fail(CTG_E_INVALID, "step %lld: bad leaf", sl);
@@ -347,7 +357,8 @@ void resolve_args(ctg_exec* e) {
             q.A = a.A;
             q.B1 = a.B;
             q.C = a.C;
-            q.B2 = (char*)space_ptr(e, h[SW_B2_SPACE]) + h[SW_B2_OFF] * isz;
+            q.one = h[SW_ONE] == 1 ? 1 : 0;
+            q.B2 = q.one ? nullptr : (char*)space_ptr(e, h[SW_B2_SPACE]) + h[SW_B2_OFF] * isz;
             q.soffA = a.soffA;
             q.soffB1 = a.soffB;
             q.soffC = a.soffC;
@@ -378,7 +389,7 @@ void resolve_args(ctg_exec* e) {
                 };
                 q.facA = fac(r[W_A_PROD]);
                 q.facB1 = fac(r[W_B_PROD]);
-                q.facB2 = fac(h[SW_B2_PROD]);
+                q.facB2 = q.one ? e->d_fac + p->n_steps : fac(h[SW_B2_PROD]);   // (one step: the constant 1)
             }
         }
     }

@@ -277,17 +277,18 @@ __device__ __forceinline__ void settle(T& v) {
 // (csrc/tools/ctg_probe_loop.hip, profiles/r4_loop_probe.txt): K2 = 64 0.839 -> 0.872 of the
 // fp32 matrix peak, K2 = 32 0.728 -> 0.797.  A wave keeps ONE column group for all its items
 // (item = (row tile, column group) with the column group = wave % ng2).
+// ONE (round 4): the first half alone -- a large step no pair took (a chain of odd length leaves one
+// over): gather -> MFMA as in step 1, then the 32 x 32 accumulators of a unit go straight to the result
+// (8-byte stores, issued between the MFMAs of the wave's next unit like every deferred store here).  No
+// intermediate, no barrier in the tile loop, LDS for B1 only.  >= 32 columns.
 template <bool PACK1, bool PACK2, int RT1, int CS1, int NCH, int IT2, bool BR1 = false, int K2Q = 0, bool VEC = false,
-          bool BF3 = false, bool RI2 = false>
+          bool BF3 = false, bool RI2 = false, bool ONE = false>
 __global__ __launch_bounds__(SW * 64, 1) void stem2_kernel(StemArgs p) {
+    static_assert(!ONE || (!PACK1 && !PACK2 && !RI2 && IT2 == 0 && K2Q == 0), "one step: >= 32 columns, nothing of step 2");
     static_assert(!PACK1 || CS1 == 1, "16 columns are one group");
     static_assert(!BR1 || NCH > 0, "B1 in registers needs the chunk count at compile time");
     static_assert(K2Q == 0 || PACK2 || IT2 == 1 || RI2, "B2 in registers: one column group per wave");
-    static_assert(!RI2 || (!PACK2 && NCH > 0 && IT2 > 0), "row-interleaved step 2: fp32 products, >= 32 columns, static");
-    // BF3 && RI2: the MIXED arithmetic -- step 1 on the bf16 matrix cores (its splits work on gathered
-    // registers, its B1 fragments live in registers), step 2 row-interleaved on the fp32 matrix cores
-    // (no split of the intermediate per column group, no bf16 planes of B2 in LDS)
-    constexpr bool BF3S2 = BF3 && !RI2;   // step 2 on the bf16 matrix cores
+    static_assert(!RI2 || (!PACK2 && !BF3 && NCH > 0 && IT2 > 0), "row-interleaved step 2: fp32, >= 32 columns, static");
     constexpr int RTW = SW / CS1;   // row tiles the 8 waves cover at once
     constexpr bool STATIC = NCH > 0;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -298,11 +299,6 @@ __global__ __launch_bounds__(SW * 64, 1) void stem2_kernel(StemArgs p) {
     const int PLANE = p.rows2 * LD2;                       // floats per plane of the intermediate
     float* P1 = (float*)smem;                              // [2|3][N1][LDB1]
     float* P2 = P1 + (PACK1 ? 3 : 2) * N1 * LDB1;          // [2|3][N2][LDB2]
-    // (BF3: the small operands as bf16 x 3 planes instead -- mixed arithmetic: B1 only)
-    const int ROW1 = bf3_row(K1, true), ROW2 = bf3_row(K2, false);
-    unsigned short* Q1 = (unsigned short*)smem;            // [2|3][N1][ROW1]
-    unsigned short* Q2 = Q1 + (PACK1 ? 3 : 2) * N1 * ROW1; // [2|3][N2][ROW2]
-    if constexpr (BF3 && RI2) P2 = (float*)Q2;             // (a multiple of 16 bytes behind Q1)
     float* mid = P2 + (PACK2 ? 3 : 2) * N2 * LDB2;         // [2][rows2][LD2]
     // RI2: three planes (Re, Im, -Im) INTERLEAVED PER ROW -- [rows2][3][LD2], row pitch RP = 3 LD2:
     // the three values of an element are LD2 floats apart, an immediate offset of the scatter's
@@ -322,7 +318,11 @@ __global__ __launch_bounds__(SW * 64, 1) void stem2_kernel(StemArgs p) {
             mid_floats = mid_floats > p2f ? mid_floats : p2f;
         }
     }
-    if constexpr (BF3S2) mid = (float*)(Q2 + (PACK2 ? 3 : 2) * N2 * ROW2);
+    // (BF3: the small operands as bf16 x 3 planes instead)
+    const int ROW1 = bf3_row(K1, true), ROW2 = bf3_row(K2, false);
+    unsigned short* Q1 = (unsigned short*)smem;            // [2|3][N1][ROW1]
+    unsigned short* Q2 = Q1 + (PACK1 ? 3 : 2) * N1 * ROW1; // [2|3][N2][ROW2]
+    if constexpr (BF3) mid = (float*)(Q2 + (PACK2 ? 3 : 2) * N2 * ROW2);
     int64_t* oc_s = (int64_t*)(mid + mid_floats);          // [N2] column offsets of the result
 
     const int tid = threadIdx.x;
@@ -341,18 +341,18 @@ __global__ __launch_bounds__(SW * 64, 1) void stem2_kernel(StemArgs p) {
 
     int bf3_ex = 0;   // BF3: power of two taken out of the small operands (goes back in through alpha)
     if constexpr (BF3) {
-        float* bf3_red = (float*)(oc_s + N2);   // (64 bytes behind the column table: stem2_lds_bytes_bf3)
+        float* bf3_red = (float*)(oc_s + (ONE ? N1 : N2));   // (64 bytes behind the column table: stem2_lds_bytes_bf3)
         const int ex1 = bf3_operand_exponent(B1, p.b1_off, K1 * N1, tid, bf3_red);
-        const int ex2 = BF3S2 ? bf3_operand_exponent(B2, p.b2_off, K2 * N2, tid, bf3_red) : 0;
+        const int ex2 = ONE ? 0 : bf3_operand_exponent(B2, p.b2_off, K2 * N2, tid, bf3_red);
         bf3_ex = ex1 + ex2;
         load_b_planes_bf3<true>(Q1, B1, p.b1_off, K1, N1, PACK1 ? 3 : 2, tid, VEC, pow2f(-ex1));
-        if constexpr (BF3S2) load_b_planes_bf3<false>(Q2, B2, p.b2_off, K2, N2, PACK2 ? 3 : 2, tid, false, pow2f(-ex2));
-        else load_b_planes<false>(P2, B2, p.b2_off, K2, N2, PACK2, tid);
+        if constexpr (!ONE) load_b_planes_bf3<false>(Q2, B2, p.b2_off, K2, N2, PACK2 ? 3 : 2, tid, false, pow2f(-ex2));
     } else {
         load_b_planes<true>(P1, B1, p.b1_off, K1, N1, PACK1, tid, VEC);
-        load_b_planes<false>(P2, B2, p.b2_off, K2, N2, PACK2, tid);
+        if constexpr (!ONE) load_b_planes<false>(P2, B2, p.b2_off, K2, N2, PACK2, tid);
     }
-    for (int n = tid; n < N2; n += SW * 64) oc_s[n] = p.out_col[n];
+    const int NOUT = ONE ? N1 : N2;   // columns of the result
+    for (int n = tid; n < NOUT; n += SW * 64) oc_s[n] = p.out_col[n];
 
     // ---- per-lane constants ---------------------------------------------------
     // gather: this lane is (row l31, k parity kk) of every task; slot j = element k = 2 j + kk
@@ -414,21 +414,28 @@ __global__ __launch_bounds__(SW * 64, 1) void stem2_kernel(StemArgs p) {
     // scatter of the step-1 accumulators: lane part of mid_row[row] + mid_col[n]
     // (RI2 with 16 columns: the lanes of columns 16-31 hold imaginary parts -> plane Im, and
     // once more negated -> plane -Im)
-    int mid_lane;
-    if (PACK1) mid_lane = ri_off((int)p.mid_col[l31 & 15]) + (l31 >> 4) * (RI2 ? LD2 : PLANE) + ri_off((int)p.mid_row[4 * kk]);
-    else mid_lane = ri_off((int)p.mid_col[wcol + l31]) + ri_off((int)p.mid_row[4 * kk]);
+    int mid_lane = 0;
+    if constexpr (!ONE) {
+        if (PACK1) mid_lane = ri_off((int)p.mid_col[l31 & 15]) + (l31 >> 4) * (RI2 ? LD2 : PLANE) + ri_off((int)p.mid_row[4 * kk]);
+        else mid_lane = ri_off((int)p.mid_col[wcol + l31]) + ri_off((int)p.mid_row[4 * kk]);
+    }
     settle(mid_lane);
     // (accumulator register t is row rowmap(t) = bits 0, 1, 3, 4 of t's four bits: the tables are
     // additive over binary digits, so four entries each and a few scalar adds where they are
     // used replace 16-entry arrays that did not fit the scalar registers)
     int mid_o[4];
 #pragma unroll
-    for (int b = 0; b < 4; ++b) mid_o[b] = ri_off((int)sload64(p.mid_row + (b < 2 ? 1 << b : 2 << b)));
+    for (int b = 0; b < 4; ++b) mid_o[b] = ONE ? 0 : ri_off((int)sload64(p.mid_row + (b < 2 ? 1 << b : 2 << b)));
     // (the row tiles' parts, per unit of this wave: scalar, fixed for the whole kernel)
     int mid_rt[RT1];
+    int64_t one_rt[RT1];   // ONE: the result's offset of this wave's row tile, per unit
 #pragma unroll
-    for (int m = 0; m < RT1; ++m)
-        mid_rt[m] = __builtin_amdgcn_readfirstlane(ri_off((int)sload64(p.mid_row + 32 * (wrt + RTW * m))));
+    for (int m = 0; m < RT1; ++m) {
+        mid_rt[m] = ONE ? 0 : __builtin_amdgcn_readfirstlane(ri_off((int)sload64(p.mid_row + 32 * (wrt + RTW * m))));
+        one_rt[m] = ONE ? sload64(p.out_row + 32 * (wrt + RTW * m)) : 0;
+    }
+    // ONE: this lane's column of the result (its column of step 1)
+    const int64_t one_col = ONE ? p.out_col[wcol + l31] : 0;
     auto mid_t = [&](int t) __attribute__((always_inline)) {
         return ((t & 1) ? mid_o[0] : 0) + ((t & 2) ? mid_o[1] : 0) + ((t & 4) ? mid_o[2] : 0) + ((t & 8) ? mid_o[3] : 0);
     };
@@ -473,7 +480,7 @@ __global__ __launch_bounds__(SW * 64, 1) void stem2_kernel(StemArgs p) {
     // copy: the lanes of the second k-row hold -Im b instead, and the loop feeds A' = (Re a,
     // Im a) to both tiles
     f32x4 b1r[BR1 && !BF3 ? NCH * 2 : 1][2];
-    f32x4 b2r[K2Q > 0 && !BF3S2 ? K2Q : 1][PACK2 ? 1 : 2];
+    f32x4 b2r[K2Q > 0 && !BF3 ? K2Q : 1][PACK2 ? 1 : 2];
     bf16x8 b1r3[BR1 && BF3 ? NCH : 1][3][2];   // BF3: [chunk][split][b1p | b1q]
     if constexpr (BR1 && BF3) {
 #pragma unroll
@@ -832,7 +839,7 @@ __global__ __launch_bounds__(SW * 64, 1) void stem2_kernel(StemArgs p) {
     auto item2 = [&](int item, int64_t c_row, auto scaled_tag, auto drain_tag, auto defer_tag)
                      __attribute__((always_inline)) {
         constexpr bool DRAIN = decltype(drain_tag)::value;
-        if constexpr (DRAIN && (K2Q == 0 || BF3S2)) drain(0, NST, std::integral_constant<int, 0>{}, scaled_tag);   // (run-time trip count below: no slots to put them in)
+        if constexpr (DRAIN && (K2Q == 0 || BF3)) drain(0, NST, std::integral_constant<int, 0>{}, scaled_tag);   // (run-time trip count below: no slots to put them in)
         const int cg = item / n_rt2, rt2 = item - cg * n_rt2;
         f32x16 cx, cy;
 #pragma unroll
@@ -956,6 +963,19 @@ __global__ __launch_bounds__(SW * 64, 1) void stem2_kernel(StemArgs p) {
             if constexpr (!decltype(defer_tag)::value) drain(0, NST, std::integral_constant<int, 0>{}, scaled_tag);
         }
     };
+    // ONE: the accumulators of unit m become the pending stores (copied: the unit's registers
+    // are zeroed for its next tile before the stores are out)
+    auto emit_one = [&](int m, int64_t c_tile, auto scaled_tag) __attribute__((always_inline)) {
+        constexpr bool SC = decltype(scaled_tag)::value;
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+            float2 v;
+            v.x = SC ? ax[m][t] * alpha : ax[m][t];
+            v.y = SC ? ay[m][t] * alpha : ay[m][t];
+            pv[RI2 ? 0 : t] = v;
+        }
+        pdst = C + 2 * (c_tile + one_rt[m] + out_lane + one_col);
+    };
     auto tile_c = [&](int64_t g) __attribute__((always_inline)) -> int64_t {
         const int64_t gh = g >> p.g_lo_shift, gl = g & (p.g_lo - 1);
         return sload64(p.gC_hi + uniform64(gh)) + sload64(p.gC_lo + uniform64(gl));
@@ -976,6 +996,22 @@ __global__ __launch_bounds__(SW * 64, 1) void stem2_kernel(StemArgs p) {
         auto tile = [&](auto slot0_tag, auto first_tag) __attribute__((always_inline)) {
             constexpr int SLOT0 = decltype(slot0_tag)::value;
             constexpr bool FIRST = decltype(first_tag)::value;   // (no item before this tile: nothing pending)
+            if constexpr (ONE) {
+                const int64_t c_tile = tile_c(g);
+                static_for<0, RT1>([&](auto mi) __attribute__((always_inline)) {
+                    constexpr int M = decltype(mi)::value;
+                    zero_acc(M);
+                    static_for<0, NCH>([&](auto ci) __attribute__((always_inline)) {
+                        constexpr int CH = decltype(ci)::value;
+                        // (the first task of a unit issues the stores of the unit before)
+                        consume(regs[(SLOT0 + M * NCH + CH) & 1], M, CH, std::true_type{},
+                                std::integral_constant<int, (CH == 0 && !(FIRST && M == 0)) ? 0 : -1>{}, scaled_tag);
+                    });
+                    emit_one(M, c_tile, scaled_tag);
+                });
+                g += tile_step;
+                return;
+            }
             static_for<0, RT1>([&](auto mi) __attribute__((always_inline)) {
                 constexpr int M = decltype(mi)::value;
                 zero_acc(M);
@@ -1036,6 +1072,7 @@ __global__ __launch_bounds__(SW * 64, 1) void stem2_kernel(StemArgs p) {
         prep(std::false_type{});
         int slot = 0;
         for (int64_t g = tile0; g < n_tiles; g += tile_step) {
+            const int64_t c_tile1 = ONE ? tile_c(g) : 0;
 #pragma unroll
             for (int m = 0; m < RT1; ++m) {
                 zero_acc(m);
@@ -1044,7 +1081,12 @@ __global__ __launch_bounds__(SW * 64, 1) void stem2_kernel(StemArgs p) {
                     else consume(regs[1], m, ch, std::false_type{}, std::integral_constant<int, -1>{}, scaled_tag);
                     slot ^= 1;
                 }
+                if constexpr (ONE) {
+                    emit_one(m, c_tile1, scaled_tag);
+                    drain(0, NST, std::integral_constant<int, 0>{}, scaled_tag);
+                }
             }
+            if constexpr (ONE) continue;
             CTG_STEM_SYNC();
             scatter();
             CTG_STEM_SYNC();
@@ -1095,14 +1137,6 @@ static size_t stem2_lds_bytes_ri2(const StemArgs& p, bool b2_in_regs) {
     return 4 * (b1 + (b2_in_regs ? (mid > b2 ? mid : b2) : b2 + mid)) + 8 * (size_t)p.N2;
 }
 
-// ... and of the mixed arithmetic (BF3 && RI2): B1 as bf16 x 3 planes, B2 / the intermediate as in RI2
-static size_t stem2_lds_bytes_mix(const StemArgs& p, bool b2_in_regs) {
-    const size_t q1 = (size_t)(p.N1 == 16 ? 3 : 2) * p.N1 * ((p.K1 >> 4) * 48 + 8);
-    const size_t b2 = (size_t)2 * p.N2 * (p.K2 + 4);
-    const size_t mid = (size_t)3 * p.rows2 * p.ld2;
-    return 2 * q1 + 4 * (b2_in_regs ? (mid > b2 ? mid : b2) : b2 + mid) + 8 * (size_t)p.N2 + 64;
-}
-
 template <bool PACK1, bool PACK2, int RT1, int CS1, int NCH, int IT2, bool BR1 = false, int K2Q = 0, bool VEC = false,
           bool BF3 = false, bool RI2 = false>
 static hipError_t launch_stem2_t(const StemArgs& p, hipStream_t stream) {
@@ -1112,16 +1146,41 @@ static hipError_t launch_stem2_t(const StemArgs& p, hipStream_t stream) {
         const hipError_t e = lds_opt_in((const void*)kern, 160 * 1024, &ready);
         if (e != hipSuccess) return e;
     }
-    const size_t smem = BF3 ? (RI2 ? stem2_lds_bytes_mix(p, K2Q > 0) : stem2_lds_bytes_bf3(p))
-                            : (RI2 ? stem2_lds_bytes_ri2(p, K2Q > 0) : stem2_lds_bytes(p));
+    const size_t smem = BF3 ? stem2_lds_bytes_bf3(p) : (RI2 ? stem2_lds_bytes_ri2(p, K2Q > 0) : stem2_lds_bytes(p));
     // persistent: one workgroup per CU (the tile owns most of the CU's LDS)
     int64_t blocks = p.n_tiles < 256 ? p.n_tiles : 256;
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks, 1), dim3(SW * 64), smem, stream, p);
     return hipGetLastError();
 }
 
+// the first half alone (ONE): B1's planes and the column table
+static size_t stem2_lds_bytes_one(const StemArgs& p, bool bf3) {
+    if (bf3) return 2 * (size_t)2 * p.N1 * ((p.K1 >> 4) * 48 + 8) + 8 * (size_t)p.N1 + 64;
+    return 4 * (size_t)2 * p.N1 * (p.K1 + 4) + 8 * (size_t)p.N1;
+}
+
+template <int RT1, int CS1, int NCH, bool BR1, bool VEC, bool BF3>
+static hipError_t launch_stem1_t(const StemArgs& p, hipStream_t stream) {
+    auto kern = stem2_kernel<false, false, RT1, CS1, NCH, 0, BR1, 0, VEC, BF3, false, true>;
+    static unsigned long long ready = 0;   // (bit per device)
+    {
+        const hipError_t e = lds_opt_in((const void*)kern, 160 * 1024, &ready);
+        if (e != hipSuccess) return e;
+    }
+    // persistent; no LDS to speak of, one workgroup of 8 waves per CU (the register budget is the pair kernel's)
+    int64_t blocks = p.n_tiles < 256 ? p.n_tiles : 256;
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks, 1), dim3(SW * 64), stem2_lds_bytes_one(p, BF3), stream, p);
+    return hipGetLastError();
+}
+
 bool stem2_supported(const StemArgs& p) {
     auto k_ok = [](int k) { return k == 16 || k == 32 || k == 64 || k == 128; };
+    if (p.one) {
+        if (!k_ok(p.K1) || (p.N1 != 32 && p.N1 != 64 && p.N1 != 128) || p.K2 != 0 || p.N2 != 0) return false;
+        if (p.nr1 < 5 || p.nr1 > 9) return false;
+        const int units = (1 << (p.nr1 - 5)) * (p.N1 / 32);
+        return (units == 8 || units == 16) && stem2_lds_bytes_one(p, false) <= 160 * 1024;
+    }
     if (!k_ok(p.K1) || !k_ok(p.K2)) return false;
     if (p.N1 != 16 && p.N1 != 32 && p.N1 != 64 && p.N1 != 128) return false;
     if (p.N2 != 16 && p.N2 != 32 && p.N2 != 64 && p.N2 != 128) return false;
@@ -1138,7 +1197,7 @@ bool stem2_supported(const StemArgs& p) {
 }
 
 // static instantiations of the pairs the Sycamore m20 trees are made of (tools/stem_shapes.py
-// prints both lists from the tree fixtures with the rules of stem2_shape below); anything else
+// prints the lists from the tree fixtures, planned in both arithmetics, with the rules of stem2_shape below); anything else
 // runs on the run-time-count variant.
 //   CTG_STEM_INST: fp32 products -- (16 columns first, 16 columns last, units per wave, column
 //   groups of step 1, chunks of K1, items per wave, B1 in registers, K2 / 4 if B2 is (else 0),
@@ -1148,42 +1207,27 @@ bool stem2_supported(const StemArgs& p) {
 //   chunks, B2 from LDS, X / Y form)
 #define CTG_STEM_INST(X) \
     X(false, false, 1, 1, 2, 1, true, 8, false, true) X(false, true, 1, 1, 2, 2, true, 4, false, false) \
-    X(false, false, 1, 2, 4, 1, true, 8, false, true) X(true, true, 2, 1, 1, 2, true, 4, false, false) \
-    X(false, true, 1, 1, 2, 2, true, 4, true, false) X(false, false, 1, 1, 2, 1, true, 16, false, true) \
-    X(true, false, 2, 1, 1, 1, true, 8, false, true) X(false, false, 1, 2, 4, 1, true, 8, true, true) \
-    X(false, false, 1, 2, 2, 1, true, 8, false, true) X(true, true, 2, 1, 1, 2, true, 4, true, false) \
-    X(true, false, 2, 1, 1, 1, true, 8, true, true) X(false, false, 1, 1, 2, 2, true, 8, false, true) \
+    X(false, false, 1, 2, 4, 1, true, 8, false, true) X(false, false, 1, 1, 2, 1, true, 16, false, true) \
+    X(true, true, 2, 1, 1, 2, true, 4, false, false) X(false, true, 1, 1, 2, 2, true, 4, true, false) \
+    X(true, false, 2, 1, 1, 1, true, 8, false, true) X(false, false, 1, 2, 2, 1, true, 8, false, true) \
+    X(false, false, 1, 2, 4, 1, true, 8, true, true) X(false, false, 1, 1, 8, 1, false, 8, false, true) \
+    X(true, true, 2, 1, 1, 2, true, 4, true, false) X(true, false, 2, 1, 1, 1, true, 8, true, true) \
+    X(false, false, 1, 2, 4, 1, true, 0, false, false) X(false, false, 1, 1, 2, 2, true, 8, false, true) \
     X(false, true, 1, 1, 1, 2, true, 4, false, false) X(false, false, 1, 2, 2, 1, true, 16, false, true) \
     X(false, true, 1, 2, 2, 2, true, 4, false, false) X(true, false, 2, 1, 1, 2, true, 8, true, true) \
-    X(false, false, 1, 1, 8, 1, false, 8, false, true) X(false, true, 1, 2, 4, 2, true, 4, false, false) \
-    X(false, false, 1, 1, 4, 1, true, 8, true, true) X(false, false, 1, 2, 4, 2, true, 0, false, false) \
-    X(false, false, 1, 2, 1, 1, true, 8, false, true) X(false, false, 1, 1, 8, 2, false, 8, false, true) \
-    X(true, false, 2, 1, 1, 2, true, 8, false, true) X(false, false, 1, 2, 2, 4, true, 4, true, true) \
-    X(false, false, 1, 1, 2, 1, true, 8, true, true) X(true, false, 2, 1, 1, 2, true, 16, false, true) \
+    X(false, true, 1, 2, 4, 2, true, 4, false, false) X(false, false, 1, 2, 4, 2, true, 0, false, false) \
+    X(false, false, 1, 1, 4, 1, true, 8, true, true) X(false, false, 1, 2, 1, 1, true, 8, false, true) \
+    X(false, false, 1, 1, 8, 2, false, 8, false, true) X(true, false, 2, 1, 1, 2, true, 8, false, true) \
+    X(false, false, 1, 2, 2, 4, true, 4, true, true) X(false, false, 1, 1, 2, 1, true, 8, true, true) \
+    X(false, false, 1, 1, 2, 2, true, 0, false, false) X(true, false, 2, 1, 1, 2, true, 16, false, true) \
     X(false, false, 2, 1, 1, 2, true, 0, false, false) X(false, false, 1, 1, 1, 2, true, 8, false, true) \
-    X(false, false, 1, 1, 4, 1, true, 0, false, true) X(true, false, 2, 1, 2, 1, true, 8, false, true) \
-    X(false, true, 1, 2, 2, 1, true, 8, false, false) X(false, true, 1, 4, 4, 2, true, 4, true, false) \
-    X(false, true, 1, 1, 8, 2, false, 4, true, false) X(true, false, 2, 1, 1, 2, true, 4, false, true) \
-    X(true, false, 2, 1, 1, 1, true, 16, false, true) X(false, true, 1, 1, 8, 2, false, 4, false, false) \
-    X(false, false, 1, 1, 2, 4, true, 4, false, true) X(false, false, 1, 1, 2, 4, true, 8, false, true) \
-    X(false, false, 1, 1, 2, 2, true, 4, false, true) X(true, true, 2, 1, 4, 1, true, 8, false, false)
-
-// the row-interleaved entries of CTG_STEM_INST once more: the instantiations of the MIXED arithmetic
-// (step 1 bf16 x 3 with B1 in registers up to two chunks, step 2 as in the fp32 entry)
-#define CTG_STEM_MIX(X) \
-    X(false, false, 1, 1, 2, 1, true, 8, false, true) X(false, false, 1, 2, 4, 1, true, 8, false, true) \
-    X(false, false, 1, 1, 2, 1, true, 16, false, true) X(true, false, 2, 1, 1, 1, true, 8, false, true) \
-    X(false, false, 1, 2, 4, 1, true, 8, true, true) X(false, false, 1, 2, 2, 1, true, 8, false, true) \
-    X(true, false, 2, 1, 1, 1, true, 8, true, true) X(false, false, 1, 1, 2, 2, true, 8, false, true) \
-    X(false, false, 1, 2, 2, 1, true, 16, false, true) X(true, false, 2, 1, 1, 2, true, 8, true, true) \
-    X(false, false, 1, 1, 8, 1, false, 8, false, true) X(false, false, 1, 1, 4, 1, true, 8, true, true) \
-    X(false, false, 1, 2, 1, 1, true, 8, false, true) X(false, false, 1, 1, 8, 2, false, 8, false, true) \
-    X(true, false, 2, 1, 1, 2, true, 8, false, true) X(false, false, 1, 2, 2, 4, true, 4, true, true) \
-    X(false, false, 1, 1, 2, 1, true, 8, true, true) X(true, false, 2, 1, 1, 2, true, 16, false, true) \
-    X(false, false, 1, 1, 1, 2, true, 8, false, true) X(false, false, 1, 1, 4, 1, true, 0, false, true) \
-    X(true, false, 2, 1, 2, 1, true, 8, false, true) X(true, false, 2, 1, 1, 2, true, 4, false, true) \
-    X(true, false, 2, 1, 1, 1, true, 16, false, true) X(false, false, 1, 1, 2, 4, true, 4, false, true) \
-    X(false, false, 1, 1, 2, 4, true, 8, false, true) X(false, false, 1, 1, 2, 2, true, 4, false, true)
+    X(false, false, 1, 1, 4, 1, true, 0, false, true) X(false, true, 1, 2, 2, 1, true, 8, false, false) \
+    X(false, true, 1, 1, 2, 1, true, 8, false, false) X(false, true, 1, 4, 4, 2, true, 4, true, false) \
+    X(false, true, 1, 1, 8, 2, false, 4, true, false) X(true, false, 2, 1, 2, 1, true, 8, false, true) \
+    X(true, false, 2, 1, 1, 2, true, 4, false, true) X(true, false, 2, 1, 1, 1, true, 16, false, true) \
+    X(false, true, 1, 1, 8, 2, false, 4, false, false) X(false, false, 1, 1, 2, 4, true, 4, false, true) \
+    X(false, false, 1, 1, 2, 4, true, 8, false, true) X(false, false, 1, 1, 2, 2, true, 4, false, true) \
+    X(true, true, 2, 1, 4, 1, true, 8, false, false)
 
 #define CTG_STEM_GEO(G) \
     G(false, false, 1, 1, 1, 2, false) G(false, false, 1, 1, 2, 1, false) G(false, false, 1, 1, 2, 1, true) \
@@ -1191,12 +1235,13 @@ bool stem2_supported(const StemArgs& p) {
     G(false, false, 1, 1, 4, 1, true) G(false, false, 1, 1, 8, 1, false) G(false, false, 1, 1, 8, 2, false) \
     G(false, false, 1, 2, 1, 1, false) G(false, false, 1, 2, 2, 1, false) G(false, false, 1, 2, 2, 4, true) \
     G(false, false, 1, 2, 4, 1, false) G(false, false, 1, 2, 4, 1, true) G(false, false, 1, 2, 4, 2, false) \
-    G(false, false, 2, 1, 1, 2, false) G(false, true, 1, 1, 1, 2, false) G(false, true, 1, 1, 2, 2, false) \
-    G(false, true, 1, 1, 2, 2, true) G(false, true, 1, 1, 8, 2, false) G(false, true, 1, 1, 8, 2, true) \
-    G(false, true, 1, 2, 2, 1, false) G(false, true, 1, 2, 2, 2, false) G(false, true, 1, 2, 4, 2, false) \
-    G(false, true, 1, 4, 4, 2, true) G(true, false, 2, 1, 1, 1, false) G(true, false, 2, 1, 1, 1, true) \
-    G(true, false, 2, 1, 1, 2, false) G(true, false, 2, 1, 1, 2, true) G(true, false, 2, 1, 2, 1, false) \
-    G(true, true, 2, 1, 1, 2, false) G(true, true, 2, 1, 1, 2, true) G(true, true, 2, 1, 4, 1, false)
+    G(false, false, 2, 1, 1, 2, false) G(false, true, 1, 1, 1, 2, false) G(false, true, 1, 1, 2, 1, false) \
+    G(false, true, 1, 1, 2, 2, false) G(false, true, 1, 1, 2, 2, true) G(false, true, 1, 1, 8, 2, false) \
+    G(false, true, 1, 1, 8, 2, true) G(false, true, 1, 2, 2, 1, false) G(false, true, 1, 2, 2, 2, false) \
+    G(false, true, 1, 2, 4, 2, false) G(false, true, 1, 4, 4, 2, true) G(true, false, 2, 1, 1, 1, false) \
+    G(true, false, 2, 1, 1, 1, true) G(true, false, 2, 1, 1, 2, false) G(true, false, 2, 1, 1, 2, true) \
+    G(true, false, 2, 1, 2, 1, false) G(true, true, 2, 1, 1, 2, false) G(true, true, 2, 1, 1, 2, true) \
+    G(true, true, 2, 1, 4, 1, false)
 
 namespace {
 struct StemShape {
@@ -1249,8 +1294,24 @@ StemShape stem2_shape(const StemArgs& p, bool bf3 = false) {
 }
 }  // namespace
 
+// single steps (ONE): (units per wave, column groups, chunks of K1, 16-byte gathers) of the m20 trees
+// (B1 in registers up to K1 = 64; bf16 x 3: up to two chunks); anything else: run-time counts, fp32
+#define CTG_STEM_ONE(X) \
+    X(1, 4, 8, false) X(1, 1, 2, false) X(1, 2, 4, false) X(1, 1, 8, false) \
+    X(1, 1, 4, false) X(1, 4, 4, false) X(1, 1, 2, true) X(1, 2, 2, true) X(2, 1, 1, false)
+
+static bool stem1_static(const StemShape& s) {
+    if (env_on("CTG_STEM_GENERIC")) return false;
+#define CTG_STEM_HAS1(R, CS, NC, V) \
+    if (s.rt1 == R && s.cs1 == CS && s.nch == NC && s.vec == V) return true;
+    CTG_STEM_ONE(CTG_STEM_HAS1)
+#undef CTG_STEM_HAS1
+    return false;
+}
+
 // 1: static (counts known at compile time, fragments in registers where they fit), 0: run-time counts
 int stem2_variant(const StemArgs& p) {
+    if (p.one) return stem1_static(stem2_shape(p, true)) ? 1 : 0;
     const StemShape s = stem2_shape(p);
     if (env_on("CTG_STEM_GENERIC") || s.it2 == 0) return 0;
 #define CTG_STEM_HAS(P1, P2, R, CS, NC, IT, B1, KQ, V, RI)                                             \
@@ -1277,31 +1338,24 @@ static bool stem2_has_geo(const StemShape& s) {
 // option ctg_exec_set_stem_arithmetic(exec, 0) selects fp32 products on the fp32 matrix cores; the
 // environment variable CTG_STEM_BF16X3, when SET, overrides both ("0" / "" = fp32, anything else =
 // bf16 x 3) and is read at every launch (tests switch it within a process).
-static bool stem2_want_bf3(const StemArgs& p) {
-    const char* v = getenv("CTG_STEM_BF16X3");
-    return v != nullptr ? !(v[0] == '\0' || (v[0] == '0' && v[1] == '\0')) : p.bf3 != 0;
-}
 static bool stem2_bf3(const StemArgs& p) {
-    return stem2_want_bf3(p) && stem2_has_geo(stem2_shape(p, true)) && (p.K2 & 7) == 0 &&
-           stem2_lds_bytes_bf3(p) <= 160 * 1024;
-}
-// MIXED arithmetic (experiment switch CTG_STEM_MIXED, off by default): step 1 on the bf16 matrix
-// cores, step 2 row-interleaved on the fp32 ones -- for the shapes whose fp32 form is a static
-// row-interleaved instantiation
-static bool stem2_mixed(const StemArgs& p) {
-    if (!env_on("CTG_STEM_MIXED") || !stem2_want_bf3(p)) return false;
-    const StemShape s = stem2_shape(p);
-    return s.ri2 && stem2_variant(p) && stem2_lds_bytes_mix(p, s.k2q > 0) <= 160 * 1024;
+    const char* v = getenv("CTG_STEM_BF16X3");
+    const bool want = v != nullptr ? !(v[0] == '\0' || (v[0] == '0' && v[1] == '\0')) : p.bf3 != 0;
+    if (p.one) return want && stem1_static(stem2_shape(p, true)) && stem2_lds_bytes_one(p, true) <= 160 * 1024;
+    return want && stem2_has_geo(stem2_shape(p, true)) && (p.K2 & 7) == 0 && stem2_lds_bytes_bf3(p) <= 160 * 1024;
 }
 
 // the instantiation a step runs on, spelled like its symbol in a kernel trace
 void stem2_kernel_name(const StemArgs& p, char* buf, size_t n) {
     const StemShape s = stem2_shape(p);
     auto tf = [](bool b) { return b ? "true" : "false"; };
-    if (stem2_mixed(p))
-        snprintf(buf, n, "stem2_kernel<%s,%s,%d,%d,%d,%d,%s,%d,%s,true,true>", tf(s.p1), tf(s.p2), s.rt1, s.cs1, s.nch,
-                 s.it2, tf(s.nch <= 2), s.k2q, tf(s.vec));
-    else if (stem2_bf3(p))
+    if (p.one) {
+        const bool st = stem1_static(s), b3 = stem2_bf3(p);
+        snprintf(buf, n, "stem2_kernel<false,false,%d,%d,%d,0,%s,0,%s,%s,false,true>", s.rt1, s.cs1, st ? s.nch : 0,
+                 tf(st && (b3 ? s.nch <= 2 : p.K1 <= 64)), tf(s.vec), tf(b3));
+        return;
+    }
+    if (stem2_bf3(p))
         snprintf(buf, n, "stem2_kernel<%s,%s,%d,%d,%d,%d,%s,0,%s,true,false>", tf(s.p1), tf(s.p2), s.rt1, s.cs1, s.nch,
                  s.it2, tf(s.nch <= 2), tf(s.vec));
     else if (stem2_variant(p))
@@ -1314,14 +1368,25 @@ void stem2_kernel_name(const StemArgs& p, char* buf, size_t n) {
 
 hipError_t launch_stem2(const StemArgs& p, hipStream_t stream) {
     if (!stem2_supported(p)) return hipErrorInvalidValue;
-    if (stem2_mixed(p)) {
-        const StemShape s = stem2_shape(p);
-#define CTG_STEM_GOM(P1, P2, R, CS, NC, IT, B1, KQ, V, RI)                                             \
-    if (s.p1 == P1 && s.p2 == P2 && s.rt1 == R && s.cs1 == CS && s.nch == NC && s.it2 == IT && s.br1 == B1 && \
-        s.k2q == KQ && s.vec == V)                                                                     \
-        return launch_stem2_t<P1, P2, R, CS, NC, IT, (NC <= 2), KQ, V, true, true>(p, stream);
-        CTG_STEM_MIX(CTG_STEM_GOM)
-#undef CTG_STEM_GOM
+    if (p.one) {
+        const StemShape s = stem2_shape(p, true);
+        const bool b3 = stem2_bf3(p);
+        if (stem1_static(s)) {
+#define CTG_STEM_GO1(R, CS, NC, V)                                                           \
+    if (s.rt1 == R && s.cs1 == CS && s.nch == NC && s.vec == V)                              \
+        return b3 ? launch_stem1_t<R, CS, NC, (NC <= 2), V, true>(p, stream)                 \
+                  : launch_stem1_t<R, CS, NC, (NC <= 4), V, false>(p, stream);
+            CTG_STEM_ONE(CTG_STEM_GO1)
+#undef CTG_STEM_GO1
+        }
+#define CTG_STEM_CASE1(R, CS)                                                               \
+    if (s.rt1 == R && s.cs1 == CS)                                                          \
+        return s.vec ? launch_stem1_t<R, CS, 0, false, true, false>(p, stream)              \
+                     : launch_stem1_t<R, CS, 0, false, false, false>(p, stream);
+        CTG_STEM_CASE1(1, 1) CTG_STEM_CASE1(2, 1) CTG_STEM_CASE1(1, 2) CTG_STEM_CASE1(2, 2)
+        CTG_STEM_CASE1(1, 4) CTG_STEM_CASE1(2, 4)
+#undef CTG_STEM_CASE1
+        return hipErrorInvalidValue;
     }
     if (stem2_bf3(p)) {
         const StemShape s = stem2_shape(p, true);

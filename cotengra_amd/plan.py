@@ -660,7 +660,7 @@ def compile_tree(tree, dtype, order=None, force_kernel=None, fuse=None, fuse_min
             return base
         return compile_tree(tree, dtype, order, force_kernel, fuse=False, _pairs=pairs)
     pairs = _pairs or {}
-    pair_second = {v: k for k, v in pairs.items()}
+    pair_second = {v: k for k, v in pairs.items() if v != k}   # (k: k = a single step on the stem kernel)
     stem_pending = {}  # first node of a pair -> (A, B1, legs of the intermediate)
     plan = Plan(dtype)
     size_dict = tree.size_dict
@@ -768,7 +768,7 @@ def compile_tree(tree, dtype, order=None, force_kernel=None, fuse=None, fuse_min
         if step.kind == KIND_STEM2:
             step.a_prod = producer.get(id(step.a), -1)
             step.b_prod = producer.get(id(step.b), -1)
-            step.b2_prod = producer.get(id(step.b2), -1)
+            step.b2_prod = producer.get(id(step.b2), -1) if step.b2 is not None else -1
             producer[id(step.c)] = len(plan.steps)
         plan.steps.append(step)
         plan.macs_per_slice += step.macs
@@ -868,7 +868,16 @@ def compile_tree(tree, dtype, order=None, force_kernel=None, fuse=None, fuse_min
             )
             p_inds = root_order if is_root else tuple(tree.get_legs(p))
             tl, tr = tensors.pop(l), tensors.pop(r)
-            if p in pairs and not is_root:
+            steps_new = None
+            if pairs.get(p) == p:
+                # a large step no pair took: the stem kernel's first half alone (stem.build_stem_one)
+                from .stem import build_stem_one
+
+                A1, B1 = pick_rows_operand(size_dict, tl, tr, p_inds)
+                one = build_stem_one(size_dict, A1, B1, p_inds, factory, node=p)
+                if one is not None:
+                    steps_new = [one]
+            elif p in pairs and not is_root:
                 # first step of a fused pair: nothing is emitted, nothing allocated; the
                 # operands stay alive until the second step takes them
                 A1, B1 = pick_rows_operand(size_dict, tl, tr, p_inds)
@@ -876,7 +885,6 @@ def compile_tree(tree, dtype, order=None, force_kernel=None, fuse=None, fuse_min
                 stem_pending[id(virt)] = (A1, B1, p)
                 tensors[p] = virt
                 continue
-            steps_new = None
             if p in pair_second:
                 from .stem import build_stem_step
 
@@ -911,7 +919,7 @@ def compile_tree(tree, dtype, order=None, force_kernel=None, fuse=None, fuse_min
             for step in steps_new:
                 step.invariant = inv
                 add(step)
-                operands = [step.a, step.b] + ([step.b2] if step.kind == KIND_STEM2 else [])
+                operands = [step.a, step.b] + ([step.b2] if step.kind == KIND_STEM2 and step.b2 is not None else [])
                 if level is not None:
                     pending += operands
                 else:

@@ -255,6 +255,64 @@ def geometry(size_dict, A, B1, B2, c1_inds, c2_inds):
     return g
 
 
+def geometry_one(size_dict, A, B1, c_inds):
+    """Tile decomposition of ONE stem step  C[r, n] = sum_k A[r, k] B1[k, n]  run by the stem
+    kernel's first half alone (gather straight into matrix-core fragments -> MFMA -> stores from
+    the accumulators; no LDS for the big tensors, no barrier): the step a chain of odd length
+    leaves over.  ``None`` if the step does not fit (K in 16..128, N in 32..128, 256 or 512 tile
+    rows out of A's lowest-stride free digits)."""
+    o1 = set(c_inds)
+    a_bits = _bits_of(A.inds, size_dict)
+    k1 = _bits_of([ix for ix in A.inds if ix not in o1], size_dict)
+    n1 = _bits_of([ix for ix in B1.inds if ix in o1], size_dict)
+    if None in (a_bits, k1, n1):
+        return None
+    K1, N1 = 1 << len(k1), 1 << len(n1)
+    if K1 not in K_OK or N1 not in (32, 64, 128):
+        return None
+    k1_set = set(k1)
+
+    def sa(b):
+        return _stride(A, b)
+
+    free = sorted((b for b in a_bits if b not in k1_set), key=sa)
+    cs1 = N1 // 32
+    lds = b_lds_bytes(K1, N1) + LDS_SLACK
+    if lds > LDS_BYTES:
+        return None
+    # (a 16-deep contraction is ONE 4 KB task per unit: two units per wave keep two in flight)
+    units = 2 * WAVES if K1 == 16 else WAVES
+    nr1 = 5 + _log2(units // cs1) if units >= cs1 else None
+    if nr1 is None or nr1 < 5 or nr1 > len(free):
+        return None
+    g = Geometry()
+    g.K1, g.N1, g.K2, g.N2 = K1, N1, 0, 0
+    g.nr1, g.rows2_bits, g.ng2, g.items, g.lds = nr1, 0, 0, 0, lds
+    g.k1 = sorted(k1, key=sa)
+    g.n1 = sorted(n1, key=lambda b: _stride(B1, b))
+    g.r1 = free[:nr1]
+    r1_set = set(g.r1)
+    g.grid = sorted((b for b in free if b not in r1_set), key=sa)
+    g.row_a = _table(g.r1, [sa(b) for b in g.r1])
+    g.k_a = _table(g.k1, [sa(b) for b in g.k1])
+    g.vec = bool(g.k_a[1] == 1 and A.offset % 2 == 0)
+    hbit = 2 if g.vec else 1
+    if A.leaf >= 0 or 8 * int(g.row_a[31] + g.k_a[hbit]) >= 1 << 32:
+        return None
+    task = np.sort((g.row_a[:32, None] + g.k_a[None, :16]).reshape(-1))
+    runs = np.flatnonzero(np.diff(task) != 1)
+    g.run_bytes = 8 * int(runs[0] + 1 if len(runs) else len(task))
+    return g
+
+
+def single_seconds(macs, elems_a, elems_c, run_bytes=256, bf16x3=None):
+    """Modelled time of a single stem step (``geometry_one``): the pair model with one step."""
+    rate = FUSED_MFMA_RATE * (BF16X3_SPEEDUP if bf16x3_mode(bf16x3) else 1.0)
+    t_mfma = 8.0 * macs / rate
+    t_mem = 8.0 * elems_a / gather_rate(run_bytes) + 8.0 * elems_c / FUSED_STORE_RATE
+    return max(t_mfma, t_mem) + FUSED_OVERLAP_LOSS * min(t_mfma, t_mem)
+
+
 def pair_seconds(macs1, macs2, elems_a, elems_c2, items, run_bytes=256, bf16x3=None):
     """Modelled time of a fused pair in the arithmetic ``bf16x3_mode(bf16x3)`` says."""
     rate = FUSED_MFMA_RATE * (BF16X3_SPEEDUP if bf16x3_mode(bf16x3) else 1.0)
@@ -268,7 +326,12 @@ def find_pairs(plan, size_dict, min_elems=1 << 24, model=None, bf16x3=None):
     ``{node of the first step: node of the second}``.  Candidates are pairs
     (s1, s2) where s2's row operand is s1's result, both plain matrix-core steps
     over binary indices with shapes the kernel takes; a chain of candidates is
-    paired off by dynamic programming on the modelled time saved."""
+    paired off by dynamic programming on the modelled time saved.  Round 4: a large
+    step that ends up in no pair (chains of odd length, partners that pair better
+    elsewhere) may run on the stem kernel's first half alone -- ``{node: node}``, a
+    "pair" with itself (``geometry_one`` / ``build_stem_one``) -- when the model says
+    that beats the tiled kernel (it does in the bf16 x 3 arithmetic, where the step
+    becomes memory-bound; in fp32 arithmetic the two are equal and nothing is chosen)."""
     if plan.dtype != "complex64":
         return {}
     if model is None:
@@ -327,6 +390,21 @@ def find_pairs(plan, size_dict, min_elems=1 << 24, model=None, bf16x3=None):
             used.add(j)
             j = gain[j][0]
         used.add(j)
+    # large steps left alone: the stem kernel's first half, where the model prefers it
+    in_pair = {n for kv in chosen.items() for n in kv}
+    if os.environ.get("CTG_NO_STEM_ONE", "0") in ("", "0"):
+        for i, s1 in enumerate(steps):
+            if s1.kind != P.KIND_PAIR or s1.node in in_pair or s1.a.size < min_elems or s1.a.leaf >= 0:
+                continue
+            if classify(i) is None:
+                continue
+            geo = geometry_one(size_dict, s1.a, s1.b, s1.c.inds)
+            if geo is None:
+                continue
+            before = unfused_seconds(s1)
+            after = single_seconds(s1.macs, s1.a.size, s1.c.size, geo.run_bytes, bf16x3=bf16x3)
+            if before - after >= MIN_GAIN * before:
+                chosen[s1.node] = s1.node
     return chosen
 
 
@@ -419,6 +497,61 @@ def build_stem_step(size_dict, A, B1, B2, c1_inds, out_inds, out_ref_factory, no
     return step
 
 
+def build_stem_one(size_dict, A, B1, out_inds, out_ref_factory, node=-1):
+    """Lower ``A, B1 -> out_inds`` to a STEM2 step with the ``one`` flag: the stem kernel's first
+    half alone (``None`` if the step does not fit).  Same tables as a pair's first step; the result
+    goes from the accumulators straight to ``gC[tile] + out_row[tile row] + out_col[n]``."""
+    geo = geometry_one(size_dict, A, B1, out_inds)
+    if geo is None:
+        return None
+    o = set(out_inds)
+    natural = tuple(ix for ix in A.inds if ix in o) + tuple(ix for ix in B1.inds if ix in o)
+    C = out_ref_factory(tuple(out_inds), natural)
+
+    def sa(b):
+        return _stride(A, b)
+
+    def sc(b):
+        return _stride(C, b)
+
+    K1, N1 = geo.K1, geo.N1
+    row_a, k_a = geo.row_a, geo.k_a
+    lane, slot = np.arange(64), np.arange(8)
+    if geo.vec:
+        lane_a = row_a[lane & 31] + k_a[2 * (lane >> 5)]
+        kj_a = k_a[4 * (slot >> 1) + (slot & 1)]
+    else:
+        lane_a = row_a[lane & 31] + k_a[lane >> 5]
+        kj_a = k_a[2 * slot]
+    tk = _table(geo.k1, [_stride(B1, b) for b in geo.k1])
+    tn = _table(geo.n1, [_stride(B1, b) for b in geo.n1])
+    g_lo_bits = min(G_LO_BITS, len(geo.grid))
+    glo, ghi = geo.grid[:g_lo_bits], geo.grid[g_lo_bits:]
+    none = np.zeros(1, dtype=np.int64)
+    tabs = {
+        "gA_hi": _table(ghi, [sa(b) for b in ghi]), "gA_lo": _table(glo, [sa(b) for b in glo]),
+        "gC_hi": _table(ghi, [sc(b) for b in ghi]), "gC_lo": _table(glo, [sc(b) for b in glo]),
+        "kj_a": kj_a, "lane_a": lane_a, "rt_a": row_a[::32].copy(), "chunk_a": k_a[::16].copy(),
+        "b1_off": (tk[:, None] + tn[None, :]).reshape(-1), "b2_off": none, "mid_row": none, "mid_col": none,
+        "out_row": _table(geo.r1, [sc(b) for b in geo.r1]),       # [2^nr1] tile rows of C
+        "out_col": _table(geo.n1, [sc(b) for b in geo.n1]),       # [N1]
+    }
+    step = P.Step(kind=P.KIND_STEM2, kernel=P.KERNEL_MFMA, a=A, b=B1, c=C, node=node)
+    step.b2 = None
+    step.stem = {
+        "K1": K1, "N1": N1, "K2": 0, "N2": 0, "nr1": geo.nr1, "rows2": 0, "ng2": 0,
+        "n_tiles": 1 << len(geo.grid), "g_lo": 1 << g_lo_bits, "ld2": 0, "lds_bytes": geo.lds, "items": 0,
+        "run_bytes": geo.run_bytes, "vec": int(geo.vec), "one": 1, "tabs": tabs,
+    }
+    rows_total = A.size // K1
+    step.R, step.Bt, step.K, step.N = rows_total, 1, K1, N1
+    step.macs = rows_total * K1 * N1
+    step.elems_rw = A.size + K1 * N1 + rows_total * N1
+    step.elems_moved = step.elems_rw
+    step.label = f"stem1 k{K1} n{N1} rows {rows_total}"
+    return step
+
+
 TAB_ORDER = ("gA_hi", "gA_lo", "gC_hi", "gC_lo", "kj_a", "lane_a", "rt_a", "chunk_a",
              "b1_off", "b2_off", "mid_row", "mid_col", "out_row", "out_col")
 
@@ -428,15 +561,20 @@ def serialise_stem(step, put):
     word offset``); returns the offset of its header.  Header layout
     (csrc/ctg_common.h: StemWord): magic, K1, N1, K2, N2, nr1, rows2, ng2,
     n_tiles, g_lo, ld2, lds_bytes, B2 space / offset / leaf / size, B2 producer, 16-byte gathers,
+    the single-step flag (word 18: the record describes the first half alone, K2 = N2 = 0, no B2),
     then the 14 table offsets at words 20..33."""
     st = step.stem
     head = np.zeros(DESC_WORDS, dtype=np.int64)
     head[0] = DESC_MAGIC
     head[1:12] = (st["K1"], st["N1"], st["K2"], st["N2"], st["nr1"], st["rows2"], st["ng2"],
                   st["n_tiles"], st["g_lo"], st["ld2"], st["lds_bytes"])
-    head[12:16] = (step.b2.space, step.b2.offset, step.b2.leaf, step.b2.size)
+    if step.b2 is not None:
+        head[12:16] = (step.b2.space, step.b2.offset, step.b2.leaf, step.b2.size)
+    else:
+        head[12:16] = (0, 0, -1, 0)
     head[16] = getattr(step, "b2_prod", -1)
     head[17] = st["vec"]
+    head[18] = st.get("one", 0)
     for i, name in enumerate(TAB_ORDER):
         head[20 + i] = put(st["tabs"][name])
     return put(head)

@@ -57,7 +57,9 @@ def run_stem2(step, spaces, base, chunk=256):
     * second product with B2, stored at grid + ``out_row[row2] + out_col[n2]``.
     """
     st, T = step.stem, step.stem["tabs"]
-    A, B1, B2, C = (spaces[t.space] for t in (step.a, step.b, step.b2, step.c))
+    one = bool(st.get("one"))   # the first half alone: the product goes straight to the result
+    A, B1, C = (spaces[t.space] for t in (step.a, step.b, step.c))
+    B2 = None if one else spaces[step.b2.space]
     K1, N1, K2, N2, ld2, rows2 = st["K1"], st["N1"], st["K2"], st["N2"], st["ld2"], st["rows2"]
     rows1 = 1 << st["nr1"]
     # element (row r, k) of a tile: row tile + chunk of 16 k + slot + the constant of the
@@ -73,12 +75,15 @@ def run_stem2(step, spaces, base, chunk=256):
     in_tile = (T["rt_a"][r >> 5][:, None] + T["chunk_a"][k >> 4][None, :] + T["kj_a"][slot][None, :]
                + T["lane_a"][(r & 31)[:, None] + 32 * h[None, :]])
     b1 = B1[base(step.b) + T["b1_off"]].reshape(K1, N1)
-    b2 = B2[base(step.b2) + T["b2_off"]].reshape(K2, N2)
-    mid_at = (T["mid_row"][:, None] + T["mid_col"][None, :]).reshape(-1)
-    assert len(np.unique(mid_at)) == rows1 * N1 and mid_at.max() < rows2 * ld2
-    assert rows1 * N1 == rows2 * K2
-    take = (np.arange(rows2)[:, None] * ld2 + np.arange(K2)[None, :])
     out_at = T["out_row"][:, None] + T["out_col"][None, :]
+    if one:
+        assert out_at.shape == (rows1, N1) and len(np.unique(out_at)) == rows1 * N1
+    else:
+        b2 = B2[base(step.b2) + T["b2_off"]].reshape(K2, N2)
+        mid_at = (T["mid_row"][:, None] + T["mid_col"][None, :]).reshape(-1)
+        assert len(np.unique(mid_at)) == rows1 * N1 and mid_at.max() < rows2 * ld2
+        assert rows1 * N1 == rows2 * K2
+        take = (np.arange(rows2)[:, None] * ld2 + np.arange(K2)[None, :])
     g_lo = st["g_lo"]
     for g0 in range(0, st["n_tiles"], chunk):
         g = np.arange(g0, min(g0 + chunk, st["n_tiles"]))
@@ -86,6 +91,9 @@ def run_stem2(step, spaces, base, chunk=256):
         gc = base(step.c) + T["gC_hi"][g // g_lo] + T["gC_lo"][g % g_lo]
         a = A[ga[:, None, None] + in_tile[None]]                  # (g, rows1, K1)
         c1 = a @ b1                                               # (g, rows1, N1)
+        if one:
+            C[gc[:, None, None] + out_at[None]] = c1
+            continue
         mid = np.zeros((len(g), rows2 * ld2), dtype=c1.dtype)
         mid[:, mid_at] = c1.reshape(len(g), -1)
         a2 = mid[:, take]                                         # (g, rows2, K2)

@@ -287,6 +287,72 @@ def test_bf16x3_unrescaled_inputs_under_strip_exponent(case, log2_scale, underfl
 
 
 # ---------------------------------------------------------------------- #
+# single stem steps: the stem kernel's first half alone (csrc/ctg_stem.hip: ONE)
+# ---------------------------------------------------------------------- #
+
+from test_host_round4 import ONE_CASES  # noqa: E402
+
+
+@pytest.fixture
+def take_every_single(monkeypatch):
+    from cotengra_amd import stem
+    monkeypatch.setattr(stem, "gather_rate", lambda run_bytes: 5.4e12)
+    monkeypatch.setattr(stem, "MIN_GAIN", -1e9)
+
+
+@pytest.mark.parametrize("case", range(len(ONE_CASES)))
+@pytest.mark.parametrize("sliced", [0, 2])
+def test_single_stem_steps_on_the_device(case, sliced, take_every_single, monkeypatch):
+    """A large step no pair took runs on the stem kernel's first half: fp32 products (static
+    instantiation and the run-time-count variant: the same bits), bf16 x 3 (the default), with and
+    without ``strip_exponent``, slice by slice -- against the numpy complex128 oracle."""
+    nq, gates = ONE_CASES[case]
+    tree = G.stem_network(nq, gates, 300 + case, sliced=sliced)
+    arrays = ca.make_arrays_from_inputs(tree.inputs, tree.size_dict, seed=case, dtype="complex64")
+    ref = np.asarray(orc.contract(tree, [a.astype("complex128") for a in arrays]))
+    gate = G.single_gate(ref, orc.contract(tree, arrays))
+    fn = HipContractor(tree, fuse=True, fuse_min_elems=1 << 10)
+    ones = [s_ for s_ in fn.get_plan("complex64")[0].steps if s_.kind == KIND_STEM2 and s_.stem.get("one")]
+    if sliced and not ones:
+        pytest.skip("the sliced indices are contracted ones of the step")
+    assert len(ones) == 1
+    got = {}
+    got["default"] = np.asarray(fn(*arrays))
+    # (a single step's kernel name carries twelve template arguments: ..., BF3, RI2 = false, ONE = true)
+    one_names = [n for n in stem_names(fn, arrays) if n.count(",") == 11]
+    assert len(one_names) == 1 and one_names[0].endswith(",false,true>"), one_names
+    one_name = one_names[0]
+    monkeypatch.setenv("CTG_STEM_BF16X3", "0")
+    got["fp32"] = np.asarray(fn(*arrays))
+    m, e = fn(*arrays, strip_exponent=True)
+    got["fp32 strip"] = np.asarray(m).astype("complex128") * 10.0**e
+    monkeypatch.setenv("CTG_STEM_GENERIC", "1")
+    got["fp32 generic"] = np.asarray(fn(*arrays))
+    gnames = stem_names(fn, arrays)
+    monkeypatch.delenv("CTG_STEM_GENERIC")
+    monkeypatch.setenv("CTG_STEM_BF16X3", "1")
+    got["bf16x3"] = np.asarray(fn(*arrays))
+    bnames = stem_names(fn, arrays)
+    m, e = fn(*arrays, strip_exponent=True)
+    got["bf16x3 strip"] = np.asarray(m).astype("complex128") * 10.0**e
+    if tree.nslices > 1:
+        a128 = [a.astype("complex128") for a in arrays]
+        for i in range(tree.nslices):
+            ri = np.asarray(orc.contract_slice(tree, a128, i))
+            gi = max(gate, G.single_gate(ri, orc.contract_slice(tree, arrays, i)))
+            assert G.relerr(np.asarray(fn.contract_slice(arrays, i)), ri) <= gi
+    fn.close()
+    print(one_name, {k_: f"{G.relerr(v, ref):.2e}" for k_, v in got.items()})
+    for k_, v in got.items():
+        assert G.relerr(v, ref) <= gate, (k_, G.relerr(v, ref), gate)
+    assert np.array_equal(got["fp32"], got["fp32 generic"])
+    assert any(n.count(",") == 11 and ",0,0,false,0," in n and n.endswith(",false,false,true>") for n in gnames), gnames
+    assert np.array_equal(got["default"], got["bf16x3"])
+    if any(n.count(",") == 11 and n.endswith(",true,false,true>") for n in bnames):   # (static: it ran on the bf16 pipe)
+        assert not np.array_equal(got["bf16x3"], got["fp32"])
+
+
+# ---------------------------------------------------------------------- #
 # two GPUs, when the box has them (the driver's 8-GPU node; skipped on the one-GPU lease)
 # ---------------------------------------------------------------------- #
 

@@ -272,3 +272,98 @@ def test_boolean_switches_treat_zero_as_off(monkeypatch, value, on):
         monkeypatch.setenv("CTG_STEM_BF16X3", value)
         assert stem.bf16x3_mode(not on) is on      # the environment wins
     assert stem.bf16x3_mode() is on
+
+
+# ---- single stem steps (round 4): the stem kernel's first half alone ------------------------
+
+ONE_CASES = [
+    (17, [(3, 3), (5, 5)]),                       # k32 n32
+    (17, [(3, 3), (7, 5)]),                       # k128 n32
+    (17, [(3, 3), (6, 6)]),                       # k64 n64: two waves per row tile
+    (18, [(3, 3), (7, 7)]),                       # k128 n128: four waves per row tile
+    (17, [(3, 3), (4, 5)]),                       # k16 n32: 512-row tiles
+    (17, [(3, 3), (5, 6)]),                       # k32 n64
+    (17, [(3, 3), (5, 5), (6, 6), (5, 5)]),       # a chain of odd length: a pair and a step left over
+]
+
+
+@pytest.fixture
+def take_every_single(monkeypatch):
+    """(every single step the kernel can take, whatever the model thinks it gains)"""
+    from cotengra_amd import stem
+
+    monkeypatch.setattr(stem, "gather_rate", lambda run_bytes: 5.4e12)
+    monkeypatch.setattr(stem, "MIN_GAIN", -1e9)
+
+
+@pytest.mark.parametrize("case", range(len(ONE_CASES)))
+@pytest.mark.parametrize("sliced", [0, 2])
+def test_single_stem_steps_plan_semantics(case, sliced, take_every_single):
+    """A large step no pair took is planned as a STEM2 record with the ``one`` flag
+    (stem.build_stem_one); the numpy interpreter of the plan (oracle/plan_interp.py) executes it from
+    the very tables the kernel reads and lands on the oracle's result; the C ABI accepts the
+    descriptor and refuses corrupted ones."""
+    import golden_util as G
+    from cotengra_amd import plan as P, runtime
+    from oracle import plan_interp
+
+    nq, gates = ONE_CASES[case]
+    tree = G.stem_network(nq, gates, 300 + case, sliced=sliced)
+    plan = P.compile_tree(tree, "complex64", fuse=True, fuse_min_elems=1 << 10)
+    ones = [s for s in plan.steps if s.kind == P.KIND_STEM2 and s.stem.get("one")]
+    if sliced and not ones:
+        pytest.skip("the sliced indices are contracted ones of the step: no longer a shape the kernel takes")
+    assert len(ones) == 1, [s.label for s in plan.steps]
+    s1 = ones[0]
+    assert s1.b2 is None and s1.stem["K2"] == 0 and s1.elems_moved == s1.elems_rw
+    arrays = ca.make_arrays_from_inputs(tree.inputs, tree.size_dict, seed=case, dtype="complex128")
+    ref = orc.contract(tree, arrays)
+    plan128 = P.compile_tree(tree, "complex64", fuse=True, fuse_min_elems=1 << 10)
+    plan128.dtype = "complex128"   # (the interpreter only needs the tables)
+    got = plan_interp.run_plan(plan128, arrays)
+    assert np.allclose(got, ref, rtol=1e-10, atol=1e-13 * np.abs(ref).max())
+    # the library validates the descriptor (host-only) ...
+    runtime.DevicePlan(plan).close()
+    # ... and refuses corrupted ones: the flag out of range, a second step smuggled in, tables
+    # that reach outside the result / the operand
+    st = s1.stem
+    for key, value in (("one", 2), ("K2", 32), ("rows2", 32)):
+        keep = st[key]
+        st[key] = value
+        with pytest.raises((runtime.CtgError, ValueError)):
+            runtime.DevicePlan(plan)
+        st[key] = keep
+    for name, how in (("out_row", lambda t: t + (1 << 40)), ("out_col", lambda t: t + (1 << 40)),
+                      ("gA_hi", lambda t: t + (1 << 40)), ("lane_a", lambda t: t + (1 << 29))):
+        keep = st["tabs"][name]
+        st["tabs"][name] = how(keep.copy())
+        with pytest.raises((runtime.CtgError, ValueError)):
+            runtime.DevicePlan(plan)
+        st["tabs"][name] = keep
+    runtime.DevicePlan(plan).close()
+
+
+def test_singles_are_chosen_by_the_model(monkeypatch):
+    """On the m20 headline tree the large steps the pairing leaves alone (chains of odd length) go to
+    the stem kernel's first half in the bf16 x 3 arithmetic -- there a lone K = 32 ... 128 step is
+    memory-bound and the tiled fp32 kernel is not -- and stay on the tiled kernel in fp32 arithmetic,
+    where the model sees nothing to gain; CTG_NO_STEM_ONE=1 switches them off."""
+    import os
+
+    from cotengra_amd import plan as P
+
+    tree = ca.tree_from_record(ca.load_network(os.path.join(ROOT, "tests", "golden", "trees", "sycamore_m20_native.json")))
+    monkeypatch.delenv("CTG_STEM_BF16X3", raising=False)
+    plan = P.compile_tree(tree, "complex64")
+    ones = [s for s in plan.steps if s.kind == P.KIND_STEM2 and s.stem.get("one")]
+    assert len(ones) >= 3 and any(s.a.size == 2**32 for s in ones)
+    left = [s for s in plan.steps if s.kind == P.KIND_PAIR and not s.invariant and s.a.size >= 2**28 and s.K >= 16]
+    assert not left, [s.label for s in left]
+    fp32 = P.compile_tree(tree, "complex64", stem_bf16x3=False)
+    assert not [s for s in fp32.steps if s.kind == P.KIND_STEM2 and s.stem.get("one")]
+    monkeypatch.setenv("CTG_NO_STEM_ONE", "1")
+    off = P.compile_tree(tree, "complex64")
+    assert not [s for s in off.steps if s.kind == P.KIND_STEM2 and s.stem.get("one")]
+    assert plan.macs_per_slice == fp32.macs_per_slice == off.macs_per_slice
+
+

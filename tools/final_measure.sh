@@ -35,8 +35,11 @@ for tree in sycamore_m20_native sycamore_m20_fused sycamore_m20_w32_c512; do
   F=$(find $O/pmc_fetch_$tree -name "*.db" | head -1); W=$(find $O/pmc_write_$tree -name "*.db" | head -1)
   # (2 timed + 1 warm-up + 1 profiled slice = 4 slices in the run)
   python tools/pmc_traffic.py $F $W 4 $O/pmc_summary_$tree.json $tree.json | tail -8
-  timeout 600 python bench.py --steps 1 --warmup 1 --no-cpu-baseline --tree tests/golden/trees/$tree.json --dump-steps $O/steps_$tree.json > /dev/null 2>&1
+  timeout 600 python bench.py --steps 1 --warmup 1 --no-cpu-baseline --headline-only --tree tests/golden/trees/$tree.json --dump-steps $O/steps_$tree.json > /dev/null 2>&1
   python tools/steps_report.py $O/steps_$tree.json 40 > $O/steps_$tree.txt 2>&1
+  # the same slice with fp32 products in the fused pairs (CTG_STEM_BF16X3=0; the plan is priced for it and differs)
+  CTG_STEM_BF16X3=0 timeout 600 python bench.py --steps 1 --warmup 1 --no-cpu-baseline --headline-only --tree tests/golden/trees/$tree.json --dump-steps $O/steps_${tree}_fp32.json > /dev/null 2>&1
+  python tools/steps_report.py $O/steps_${tree}_fp32.json 40 > $O/steps_${tree}_fp32.txt 2>&1
 done
 # the small configurations: kernel timeline of one contraction / slice batch, per-kernel
 # summary, per-step times with the slices batched

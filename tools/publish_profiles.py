@@ -9,7 +9,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "gpurun_out", "final")
 DST = os.path.join(ROOT, "profiles")
-tag = sys.argv[1] if len(sys.argv) > 1 else "r3"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r4"
 
 pairs = {
     "kernels_kernels.json": f"{tag}_bench_kernels.json",
@@ -21,6 +21,7 @@ pairs = {
 for tree in ("sycamore_m20_w32_c512", "sycamore_m20_native", "sycamore_m20_fused"):
     pairs[f"pmc_summary_{tree}.json"] = f"pmc_summary_{tree}.json"   # (read by bench.py: roofline.traffic)
     pairs[f"steps_{tree}.txt"] = f"{tag}_steps_{tree}.txt"
+    pairs[f"steps_{tree}_fp32.txt"] = f"{tag}_steps_{tree}_fp32.txt"
 for w in ("C2", "C3", "C5"):
     pairs[f"timeline_{w}.txt"] = f"{tag}_timeline_{w}.txt"
     pairs[f"kernels_{w}.txt"] = f"{tag}_kernels_{w}.txt"

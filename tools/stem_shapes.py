@@ -45,20 +45,29 @@ def shape(st):
     return (p1, p2, rt1, cs1, nch, it2, bool(r1), st["K2"] // 4 if r2 else 0, bool(st["vec"]), False)
 
 
-need = {}
+need, ones = {}, {}
 for f in sorted(glob.glob(os.path.join(ROOT, "tests", "golden", "trees", "sycamore_m20*.json"))):
     tree = ca.tree_from_record(json.load(open(f)))
-    plan = compile_tree(tree, "complex64")
-    for s in plan.steps:
-        if s.kind != KIND_STEM2:
-            continue
-        st = s.stem
-        key = shape(st)
-        if key[5] == 0:
-            continue   # (item count not a multiple of the waves: the run-time-count variant)
-        d = need.setdefault(key, [0, set()])
-        d[0] += s.macs
-        d[1].add((os.path.basename(f)[13:-5], st["K1"], st["N1"], st["K2"], st["N2"]))
+    # (the pairing is priced in the arithmetic the pairs will run in: the plans of the two modes differ)
+    for mode in (True, False):
+        plan = compile_tree(tree, "complex64", stem_bf16x3=mode)
+        for s in plan.steps:
+            if s.kind != KIND_STEM2:
+                continue
+            st = s.stem
+            if st.get("one"):
+                cs1 = st["N1"] // 32
+                key = ((1 << (st["nr1"] - 5)) * cs1 // SW, cs1, st["K1"] // 16, bool(st["vec"]))
+                d = ones.setdefault(key, [0, set()])
+                d[0] += s.macs
+                d[1].add((os.path.basename(f)[13:-5], st["K1"], st["N1"]))
+                continue
+            key = shape(st)
+            if key[5] == 0:
+                continue   # (item count not a multiple of the waves: the run-time-count variant)
+            d = need.setdefault(key, [0, set()])
+            d[0] += s.macs
+            d[1].add((os.path.basename(f)[13:-5], st["K1"], st["N1"], st["K2"], st["N2"]))
 lo = lambda b: str(b).lower()   # noqa: E731
 print("// fp32 instantiations (P1, P2, RT1, CS1, NCH, IT2, BR1, K2Q, VEC, RI2), by share of the work")
 for key, (macs, where) in sorted(need.items(), key=lambda kv: -kv[1][0]):
@@ -68,3 +77,6 @@ geo = sorted({(k[0], k[1], k[2], k[3], k[4], k[5], k[8]) for k in need})
 print("// geometries (P1, P2, RT1, CS1, NCH, IT2, VEC): the bf16 x 3 instantiations")
 for g in geo:
     print("G(%s, %s, %d, %d, %d, %d, %s)" % (lo(g[0]), lo(g[1]), *g[2:6], lo(g[6])))
+print("// single steps (RT1, CS1, NCH, VEC)")
+for key, (macs, where) in sorted(ones.items(), key=lambda kv: -kv[1][0]):
+    print("O(%d, %d, %d, %s)" % (*key[:3], lo(key[3])), "// %.2e" % macs, sorted(where)[:3])

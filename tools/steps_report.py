@@ -7,8 +7,10 @@ also the intermediate it never writes) and ``moved`` = what the plan really move
 big operand in, result out).  THE BOUND of a step is max(flops / matrix peak, moved bytes / 8 TB/s)
 -- a fused pair is priced on the bytes it moves, so no efficiency exceeds 100 %; the unfused
 figure is kept as a second column ("unf": what the reference's step-by-step execution would be
-bound by).  --bf16x3: fused pairs are priced against the bf16 matrix pipe with six products per
-fp32 product (2500 / 6 = 416.7 TFLOP/s fp32-equivalent) instead of the fp32 pipe's 157.3."""
+bound by).  A stem kernel that multiplies on the bf16 matrix cores (the tenth template argument of
+its name; the default arithmetic since round 4) is priced against bf16 peak / 6 products = 416.7
+TFLOP/s fp32-equivalent instead of the fp32 pipe's 157.3 (--bf16x3: every stem step, for dumps
+without kernel names)."""
 import json
 import sys
 
@@ -20,6 +22,10 @@ P32, PBF3, BW = 157.3e12, 2500e12 / 6, 8e12
 
 
 def peak(r):
+    name = r.get("kernel_name") or ""
+    if name.startswith("stem2_kernel<"):
+        a = name[len("stem2_kernel<"):].rstrip(">").split(",")
+        return PBF3 if len(a) >= 10 and a[9].strip() == "true" else P32
     return PBF3 if (BF3 and r.get("kind") == "stem2") else P32
 
 
@@ -35,7 +41,8 @@ print("total ms %.3f" % tot)
 roof = sum(bound_ms(r) for r in rows)
 unf = sum(unfused_ms(r) for r in rows)
 fl = sum(8 * r["macs"] for r in rows)
-print("flops-only floor (all flops at 157.3 TFLOP/s) ms %.2f -> %.1f%% of the fp32 matrix peak" % (fl / P32 * 1e3, 100 * fl / P32 * 1e3 / tot))
+print("all flops at the fp32 matrix peak (157.3 TFLOP/s) would take %.2f ms: the slice runs at %.1f%% of that rate "
+      "(a fraction of a bound only where every step multiplies on the fp32 pipe)" % (fl / P32 * 1e3, 100 * fl / P32 * 1e3 / tot))
 print("mixed per-step BOUND (moved bytes) ms %.2f -> the slice runs at %.1f%% of it" % (roof, 100 * roof / tot))
 print("mixed per-step roofline of the UNFUSED steps (SURVEY 8d bytes) ms %.2f (the reference's execution model; "
       "a fused pair may finish below it)" % unf)
