@@ -97,7 +97,7 @@ def test_fused_stem_pairs_on_the_bf16_matrix_cores(case, fuse_whatever_fits, mon
     default = np.asarray(fn(*arrays))
     monkeypatch.setenv("CTG_STEM_BF16X3", "0")
     fp32 = np.asarray(fn(*arrays))
-    assert not any(n.endswith(",true,false>") for n in fn.setup(*arrays)["exec"].step_kernels())
+    assert not any(n.endswith(",true,false,false>") for n in fn.setup(*arrays)["exec"].step_kernels())
     monkeypatch.setenv("CTG_STEM_BF16X3", "1")
     got = np.asarray(fn(*arrays))
     assert np.array_equal(got, default)     # (bf16 x 3 is what runs when nothing is said)
@@ -105,7 +105,7 @@ def test_fused_stem_pairs_on_the_bf16_matrix_cores(case, fuse_whatever_fits, mon
     m, e = fn(*arrays, strip_exponent=True)
     fn.close()
     assert names
-    if any(n.endswith(",true,false>") for n in names):   # (the tenth template argument: BF3)
+    if any(n.endswith(",true,false,false>") for n in names):   # (the tenth template argument: BF3)
         assert not np.array_equal(got, fp32)   # (it really ran)
     assert G.relerr(got, ref) <= gate, (G.relerr(got, ref), gate, G.relerr(fp32, ref))
     assert G.relerr(np.asarray(m).astype("complex128") * 10.0**e, ref) <= gate
@@ -161,7 +161,7 @@ def test_fused_stem_pairs_run_time_count_variant(case, fuse_whatever_fits, monke
     monkeypatch.setenv("CTG_STEM_NO_RI2", "1")
     static = np.asarray(fn(*arrays))
     xnames = [n for n in fn.setup(*arrays)["exec"].step_kernels() if n.startswith("stem2_kernel")]
-    assert all(n.endswith(",false>") for n in xnames), xnames
+    assert all(n.endswith(",false,false,false>") for n in xnames), xnames   # (fp32, X / Y form, a pair)
     monkeypatch.setenv("CTG_STEM_GENERIC", "1")
     generic = np.asarray(fn(*arrays))
     gnames = [n for n in fn.setup(*arrays)["exec"].step_kernels() if n.startswith("stem2_kernel")]
@@ -169,7 +169,7 @@ def test_fused_stem_pairs_run_time_count_variant(case, fuse_whatever_fits, monke
     fn.close()
     assert np.array_equal(static, generic)
     assert G.relerr(default, ref) <= gate and G.relerr(static, ref) <= gate
-    if any(n.endswith(",true>") for n in names):   # (the eleventh template argument: RI2)
+    if any(n.endswith(",true,false>") for n in names):   # (the eleventh template argument: RI2)
         assert G.relerr(default, static) <= 4e-6
 
 
