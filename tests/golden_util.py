@@ -93,6 +93,18 @@ def single_gate(ref, numpy_single):
     return max(NORTH_STAR, 8.0 * relerr(np.asarray(numpy_single), ref))
 
 
+def stem_flags(name):
+    """Template arguments of a ``stem2_kernel<...>`` instantiation as the executor spells them
+    (csrc/ctg_stem.hip: stem2_kernel_name): chunks and items known at compile time (0: the
+    run-time-count variant), B2 in registers, bf16 x 3 products, row-interleaved step 2, single step,
+    B2 with a -Im limb plane."""
+    a = [x.strip() for x in name[name.index("<") + 1 : name.rindex(">")].split(",")]
+    t = [x == "true" for x in a]
+    return {"pack1": t[0], "pack2": t[1], "rt1": int(a[2]), "cs1": int(a[3]), "nch": int(a[4]), "it2": int(a[5]),
+            "br1": t[6], "k2q": int(a[7]), "vec": t[8], "bf3": t[9], "ri2": t[10], "one": t[11],
+            "b2n": t[12] if len(t) > 12 else False}
+
+
 def stem_network(nq, gates, seed, sliced=0):
     """A small 'stem': one tensor of ``nq`` binary indices to which tensors are
     applied one after the other, gate ``(k, n)`` contracting ``k`` randomly chosen
@@ -119,6 +131,18 @@ def stem_network(nq, gates, seed, sliced=0):
     for ix in inputs[0][:sliced]:
         tree.remove_ind_(ix)
     return tree
+
+
+# (nq, gates): single stem steps -- a large step no pair takes runs on the stem kernel's first half
+ONE_CASES = [
+    (17, [(3, 3), (5, 5)]),                       # k32 n32
+    (17, [(3, 3), (7, 5)]),                       # k128 n32
+    (17, [(3, 3), (6, 6)]),                       # k64 n64: two waves per row tile
+    (18, [(3, 3), (7, 7)]),                       # k128 n128: four waves per row tile
+    (17, [(3, 3), (4, 5)]),                       # k16 n32: 512-row tiles
+    (17, [(3, 3), (5, 6)]),                       # k32 n64
+    (17, [(3, 3), (5, 5), (6, 6), (5, 5)]),       # a chain of odd length: a pair and a step left over
+]
 
 
 def random_stem(seed):

@@ -97,7 +97,7 @@ def test_fused_stem_pairs_on_the_bf16_matrix_cores(case, fuse_whatever_fits, mon
     default = np.asarray(fn(*arrays))
     monkeypatch.setenv("CTG_STEM_BF16X3", "0")
     fp32 = np.asarray(fn(*arrays))
-    assert not any(n.endswith(",true,false,false>") for n in fn.setup(*arrays)["exec"].step_kernels())
+    assert not any(n.startswith("stem2_kernel") and G.stem_flags(n)["bf3"] for n in fn.setup(*arrays)["exec"].step_kernels())
     monkeypatch.setenv("CTG_STEM_BF16X3", "1")
     got = np.asarray(fn(*arrays))
     assert np.array_equal(got, default)     # (bf16 x 3 is what runs when nothing is said)
@@ -105,7 +105,7 @@ def test_fused_stem_pairs_on_the_bf16_matrix_cores(case, fuse_whatever_fits, mon
     m, e = fn(*arrays, strip_exponent=True)
     fn.close()
     assert names
-    if any(n.endswith(",true,false,false>") for n in names):   # (the tenth template argument: BF3)
+    if any(G.stem_flags(n)["bf3"] for n in names):   # (the tenth template argument: BF3)
         assert not np.array_equal(got, fp32)   # (it really ran)
     assert G.relerr(got, ref) <= gate, (G.relerr(got, ref), gate, G.relerr(fp32, ref))
     assert G.relerr(np.asarray(m).astype("complex128") * 10.0**e, ref) <= gate
@@ -161,15 +161,15 @@ def test_fused_stem_pairs_run_time_count_variant(case, fuse_whatever_fits, monke
     monkeypatch.setenv("CTG_STEM_NO_RI2", "1")
     static = np.asarray(fn(*arrays))
     xnames = [n for n in fn.setup(*arrays)["exec"].step_kernels() if n.startswith("stem2_kernel")]
-    assert all(n.endswith(",false,false,false>") for n in xnames), xnames   # (fp32, X / Y form, a pair)
+    assert all(not (f["bf3"] or f["ri2"] or f["one"]) for f in map(G.stem_flags, xnames)), xnames   # (fp32, X / Y form, a pair)
     monkeypatch.setenv("CTG_STEM_GENERIC", "1")
     generic = np.asarray(fn(*arrays))
     gnames = [n for n in fn.setup(*arrays)["exec"].step_kernels() if n.startswith("stem2_kernel")]
-    assert all(",0,0,false,0," in n for n in gnames), gnames
+    assert all(G.stem_flags(n)["nch"] == 0 for n in gnames), gnames
     fn.close()
     assert np.array_equal(static, generic)
     assert G.relerr(default, ref) <= gate and G.relerr(static, ref) <= gate
-    if any(n.endswith(",true,false>") for n in names):   # (the eleventh template argument: RI2)
+    if any(G.stem_flags(n)["ri2"] for n in names):   # (the eleventh template argument: RI2)
         assert G.relerr(default, static) <= 4e-6
 
 

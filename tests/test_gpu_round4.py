@@ -128,18 +128,19 @@ def test_intermediate_of_a_pair_element_by_element(k, fuse_whatever_fits, monkey
         assert sum(s_.kind == KIND_STEM2 for s_ in fn.get_plan("complex64")[0].steps) == 1
         res = {"ri2": np.asarray(fn(*arrays))}
         names = stem_names(fn, arrays)
-        if names and names[0].endswith(",false,true,false>"):
+        if names and G.stem_flags(names[0])["ri2"]:
             break
         fn.close()
-    assert names and names[0].endswith(",false,true,false>"), names       # fp32, row-interleaved
+    assert names and G.stem_flags(names[0])["ri2"] and not G.stem_flags(names[0])["bf3"], names       # fp32, row-interleaved
     ref = np.asarray(orc.contract(tree, [a.astype("complex128") for a in arrays]))
     monkeypatch.setenv("CTG_STEM_NO_RI2", "1")
     res["xy"] = np.asarray(fn(*arrays))
-    assert stem_names(fn, arrays)[0].endswith(",false,false,false>")
+    f_ = G.stem_flags(stem_names(fn, arrays)[0])
+    assert not (f_["bf3"] or f_["ri2"] or f_["one"])
     monkeypatch.delenv("CTG_STEM_NO_RI2")
     monkeypatch.delenv("CTG_STEM_BF16X3")          # the default arithmetic: bf16 x 3
     res["bf3"] = np.asarray(fn(*arrays))
-    assert stem_names(fn, arrays)[0].endswith(",true,false,false>")
+    assert G.stem_flags(stem_names(fn, arrays)[0])["bf3"]
     fn.close()
     scale = np.abs(ref).max()
     err = {m: (np.abs(v - ref).max() / scale, np.sqrt((np.abs(v - ref) ** 2).mean()) / scale) for m, v in res.items()}
@@ -171,7 +172,7 @@ def test_bf16x3_wide_dynamic_range_inside_one_operand(fuse_whatever_fits, monkey
     fp32 = np.asarray(fn(*arrays))
     monkeypatch.setenv("CTG_STEM_BF16X3", "1")
     bf3 = np.asarray(fn(*arrays))
-    assert any(n.endswith(",true,false,false>") for n in stem_names(fn, arrays))
+    assert any(G.stem_flags(n)["bf3"] for n in stem_names(fn, arrays))
     fn.close()
     assert np.isfinite(fp32).all() and np.isfinite(bf3).all()
     c32, c3 = class_errors(fp32, ref), class_errors(bf3, ref)
@@ -208,7 +209,7 @@ def test_bf16x3_hard_cancelling_pair(fuse_whatever_fits, monkeypatch):
     fp32 = np.asarray(fn(*arrays))
     monkeypatch.setenv("CTG_STEM_BF16X3", "1")
     bf3 = np.asarray(fn(*arrays))
-    assert any(n.endswith(",true,false,false>") for n in stem_names(fn, arrays))
+    assert any(G.stem_flags(n)["bf3"] for n in stem_names(fn, arrays))
     fn.close()
     cancel = np.abs(ref).max() / terms
     e32, e3 = np.abs(fp32 - ref).max() / terms, np.abs(bf3 - ref).max() / terms
@@ -279,7 +280,7 @@ def test_bf16x3_unrescaled_inputs_under_strip_exponent(case, log2_scale, underfl
     monkeypatch.setenv("CTG_STEM_BF16X3", "1")
     m, e = fn(*arrays, strip_exponent=True)
     out["bf16x3"] = np.asarray(m).astype("complex128") * 10.0**e
-    assert any(n.endswith(",true,false,false>") for n in stem_names(fn, arrays))
+    assert any(G.stem_flags(n)["bf3"] for n in stem_names(fn, arrays))
     fn.close()
     err = {k_: G.relerr(v, ref) for k_, v in out.items()}
     print(err)
@@ -319,7 +320,7 @@ def test_single_stem_steps_on_the_device(case, sliced, take_every_single, monkey
     got = {}
     got["default"] = np.asarray(fn(*arrays))
     # (a single step's kernel: the last three template arguments are BF3, RI2 = false, ONE = true)
-    one_names = [n for n in stem_names(fn, arrays) if n.endswith(",false,true>")]
+    one_names = [n for n in stem_names(fn, arrays) if G.stem_flags(n)["one"]]
     assert len(one_names) == 1, stem_names(fn, arrays)
     one_name = one_names[0]
     monkeypatch.setenv("CTG_STEM_BF16X3", "0")
@@ -346,9 +347,9 @@ def test_single_stem_steps_on_the_device(case, sliced, take_every_single, monkey
     for k_, v in got.items():
         assert G.relerr(v, ref) <= gate, (k_, G.relerr(v, ref), gate)
     assert np.array_equal(got["fp32"], got["fp32 generic"])
-    assert any(",0,0,false,0," in n and n.endswith(",false,false,true>") for n in gnames), gnames
+    assert any(f["one"] and f["nch"] == 0 and not f["bf3"] for f in map(G.stem_flags, gnames)), gnames
     assert np.array_equal(got["default"], got["bf16x3"])
-    if any(n.endswith(",true,false,true>") for n in bnames):   # (static: it ran on the bf16 pipe)
+    if any(f["one"] and f["bf3"] for f in map(G.stem_flags, bnames)):   # (static: it ran on the bf16 pipe)
         assert not np.array_equal(got["bf16x3"], got["fp32"])
 
 

@@ -276,15 +276,9 @@ def test_boolean_switches_treat_zero_as_off(monkeypatch, value, on):
 
 # ---- single stem steps (round 4): the stem kernel's first half alone ------------------------
 
-ONE_CASES = [
-    (17, [(3, 3), (5, 5)]),                       # k32 n32
-    (17, [(3, 3), (7, 5)]),                       # k128 n32
-    (17, [(3, 3), (6, 6)]),                       # k64 n64: two waves per row tile
-    (18, [(3, 3), (7, 7)]),                       # k128 n128: four waves per row tile
-    (17, [(3, 3), (4, 5)]),                       # k16 n32: 512-row tiles
-    (17, [(3, 3), (5, 6)]),                       # k32 n64
-    (17, [(3, 3), (5, 5), (6, 6), (5, 5)]),       # a chain of odd length: a pair and a step left over
-]
+import golden_util as _G  # noqa: E402
+
+ONE_CASES = _G.ONE_CASES
 
 
 @pytest.fixture

@@ -71,8 +71,28 @@ for mode in ("fp32", "bf16x3"):
                 launches += n_stem * tree.nslices
                 say(f"{mode} case {ci} seed {seed} sliced {sliced}: {n_stem} fused pairs x {tree.nslices} slices, "
                     f"out-of-bounds gathers {g} stores {s}, err vs oracle {err:.1e} {'ok' if ok else 'BAD'}  {names}")
+    # single steps (the kernel's first half alone), every one the kernel can take
+    keep_gain, stem.MIN_GAIN = stem.MIN_GAIN, -1e9
+    for ci, (nq, gates) in enumerate(G.ONE_CASES):
+        for sliced in (0, 2):
+            tree = G.stem_network(nq, gates, 300 + ci, sliced=sliced)
+            arrays = ca.make_arrays_from_inputs(tree.inputs, tree.size_dict, seed=ci, dtype="complex64")
+            ref = np.asarray(orc.contract(tree, [a.astype("complex128") for a in arrays]))
+            fn = HipContractor(tree, fuse=True, fuse_min_elems=1 << 10)
+            n_one = sum(1 for s in fn.get_plan("complex64")[0].steps if s.kind == KIND_STEM2 and s.stem.get("one"))
+            got = np.asarray(fn(*arrays))
+            names = sorted({k for k in fn.setup(*arrays)["exec"].step_kernels() if k.startswith("stem2")})
+            fn.close()
+            g, s = oob()
+            err = np.abs(got - ref).max() / np.abs(ref).max()
+            ok = g == 0 and s == 0 and err <= 1e-4
+            bad += not ok
+            launches += n_one * tree.nslices
+            say(f"{mode} single-step case {ci} sliced {sliced}: {n_one} single steps x {tree.nslices} slices, out-of-bounds "
+                f"gathers {g} stores {s}, err vs oracle {err:.1e} {'ok' if ok else 'BAD'}  {names}")
+    stem.MIN_GAIN = keep_gain
     os.environ.pop("CTG_STEM_BF16X3", None)
-say(f"stem networks: {launches} fused launches checked, {bad} bad")
+say(f"stem networks: {launches} stem launches checked, {bad} bad")
 
 # one full-width slice of the headline tree: 2^32-element tensors
 try:
