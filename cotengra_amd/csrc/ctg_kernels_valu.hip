@@ -138,6 +138,73 @@ __global__ __launch_bounds__(256) void pair_kred_kernel(StepArgs p, int64_t G, i
     }
 }
 
+// Two to four outputs (the closing dot products of a tree: R x N = 3 x 1 in the 200-tensor hyper
+// network, K = 1.1e6): one wave per k-chunk computes ALL of them -- the k offsets of both operands
+// are looked up once per k instead of once per k and output (two-level tables: four dependent loads),
+// and an operand that does not depend on the output (a zero row stride) is loaded once.  Every output
+// sees the same lanes take the same k in the same order as in pair_kred_kernel: the same bits.
+template <typename T, int NO>
+__global__ __launch_bounds__(256) void pair_kred_multi_kernel(StepArgs p, int64_t G, int64_t chunk,
+                                                              T* __restrict__ partial) {
+    const T* __restrict__ A = (const T*)p.A + zoffA(p);
+    const T* __restrict__ B = (const T*)p.B + zoffB(p);
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int64_t n_waves = (int64_t)gridDim.x * 4;
+    const T* a[NO];
+    const T* b[NO];
+    bool same_a = true, same_b = true;
+#pragma unroll
+    for (int o = 0; o < NO; ++o) {
+        const int64_t row = o / p.N, n = o - row * p.N;
+        int64_t hi, lo;
+        split_row(p, row, hi, lo);
+        a[o] = A + p.rowA.hi[hi] + p.rowA.lo[lo];
+        b[o] = B + p.rowB.hi[hi] + p.rowB.lo[lo] + p.nB[n];
+        same_a = same_a && a[o] == a[0];
+        same_b = same_b && b[o] == b[0];
+    }
+    for (int64_t g = wave; g < G; g += n_waves) {
+        const int64_t k0 = g * chunk;
+        const int64_t k1 = (k0 + chunk < p.K) ? k0 + chunk : p.K;
+        T acc[NO];
+#pragma unroll
+        for (int o = 0; o < NO; ++o) acc[o] = zero_of(T{});
+        constexpr int U = 4;
+        for (int64_t k = k0 + lane; k < k1; k += 64 * U) {
+            int64_t ia[U], ib[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int64_t ku = k + 64 * u < k1 ? k + 64 * u : k;   // (clamped: a valid address)
+                int64_t kh, kl;
+                split_k(p, ku, kh, kl);
+                ia[u] = p.kA.hi[kh] + p.kA.lo[kl];
+                ib[u] = p.kB.hi[kh] + p.kB.lo[kl];
+            }
+            T av[NO][U], bv[NO][U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+#pragma unroll
+                for (int o = 0; o < NO; ++o) {
+                    av[o][u] = (o > 0 && same_a) ? av[0][u] : a[o][ia[u]];
+                    bv[o][u] = (o > 0 && same_b) ? bv[0][u] : b[o][ib[u]];
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+                if (k + 64 * u < k1) {
+#pragma unroll
+                    for (int o = 0; o < NO; ++o) fma_acc(acc[o], av[o][u], bv[o][u]);
+                }
+        }
+#pragma unroll
+        for (int o = 0; o < NO; ++o) {
+            const T r = wave_sum(acc[o]);
+            if (lane == 0) partial[((int64_t)blockIdx.y * NO + o) * G + g] = r;   // (the layout pair_kred_finish_kernel reads)
+        }
+    }
+}
+
 // WAVE: few outputs, many partials -- one wavefront per output adds the partials
 // (lane l takes l, l + 64, ... in order, then a butterfly: a fixed tree), instead
 // of one thread walking up to 256 of them.
@@ -200,6 +267,15 @@ static hipError_t launch_pair_valu_t(const StepArgs& p, void* scratch, int64_t s
                 });
             int64_t blocks = (items + 3) / 4;
             if (blocks > 8192) blocks = 8192;
+            if (outs >= 2 && outs <= 4) {
+                // (a handful of outputs: every wave takes a k-chunk of all of them)
+                int64_t mb = (G + 3) / 4;
+                if (mb > 8192) mb = 8192;
+                const dim3 mg((unsigned)mb, (unsigned)p.nz);
+                if (outs == 2) hipLaunchKernelGGL((pair_kred_multi_kernel<T, 2>), mg, dim3(256), 0, stream, p, G, chunk, (T*)scratch);
+                else if (outs == 3) hipLaunchKernelGGL((pair_kred_multi_kernel<T, 3>), mg, dim3(256), 0, stream, p, G, chunk, (T*)scratch);
+                else hipLaunchKernelGGL((pair_kred_multi_kernel<T, 4>), mg, dim3(256), 0, stream, p, G, chunk, (T*)scratch);
+            } else
             hipLaunchKernelGGL(pair_kred_kernel<T>, dim3((unsigned)blocks, (unsigned)p.nz), dim3(256), 0, stream, p,
                                G, chunk, (T*)scratch);
             if (outs <= 4096 && G >= 16) {

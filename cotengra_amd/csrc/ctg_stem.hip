@@ -120,8 +120,11 @@ __device__ __forceinline__ void load_b_planes(float* P, const c64* __restrict__ 
 // operands, so the k order inside the instruction does not matter.
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ constexpr int bf3_ta(int t) { return t == 2 || t == 3 ? 1 : (t == 5 ? 2 : 0); }
-__device__ __forceinline__ constexpr int bf3_tb(int t) { return t == 1 || t == 3 ? 1 : (t == 4 ? 2 : 0); }
+// the six products kept, (limb of a, limb of b): those that need only the FIRST limb of the operand
+// being split come first -- it is a byte permute of the words as they arrive, the MFMAs can start while
+// the other two limbs are still being subtracted out
+__device__ __forceinline__ constexpr int bf3_ta(int t) { return t < 3 ? 0 : (t == 5 ? 2 : 1); }
+__device__ __forceinline__ constexpr int bf3_tb(int t) { return t == 1 || t == 4 ? 1 : (t == 2 ? 2 : 0); }
 
 __device__ __forceinline__ void split3(const float (&x)[8], bf16x8 (&o)[3]) {
     // Per value: two ANDs and two subtractions.  A limb's bf16 pattern is the HIGH half of an fp32
