@@ -259,7 +259,7 @@ def modelled_seconds(tree, model=None, dtype="complex64"):
     it: the device plan's steps (their real K, N, MACs and bytes, slice-invariant
     steps included) priced by ``model`` (default :data:`MI355X_C64`)."""
     from .plan import KIND_STEM2, compile_tree
-    from .stem import pair_seconds
+    from .stem import pair_seconds, single_seconds
 
     model = MI355X_C64 if model is None else model
     plan = compile_tree(tree, dtype)
@@ -271,6 +271,9 @@ def modelled_seconds(tree, model=None, dtype="complex64"):
         if s.kind == KIND_STEM2:
             # a fused stem pair (stem.py): its own model -- the big tensor moves once
             st = s.stem
+            if st.get("one"):   # (a single step on the stem kernel's first half)
+                t += single_seconds(s.macs, s.a.size, s.c.size, st["run_bytes"])
+                continue
             macs1 = (s.a.size // st["K1"]) * st["K1"] * st["N1"]
             t += pair_seconds(macs1, s.macs - macs1, s.a.size, s.c.size, st["items"], st["run_bytes"])
         else:

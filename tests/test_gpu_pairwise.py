@@ -57,6 +57,12 @@ CASES = [
     # largest (66 KB of dynamic LDS: the kernel opts in); odd row count so that it IS this kernel
     ("abkc,knm->abcnm", dict(a=27, b=32, c=12, k=6, n=4, m=8)),       # K = 6, N = 32
     ("xabk,xkn->xabn", dict(x=3, a=96, b=96, k=8, n=32)),             # the same with a batch index
+    # two to four outputs under a long contraction: one wave per k-chunk computes all of them
+    # (pair_kred_multi_kernel, round 4) -- shared and per-output operands, odd K, k slowest
+    ("ak,k->a", dict(a=3, k=99999)),                                  # the second operand is shared
+    ("xk,xk->x", dict(x=3, k=70001)),                                 # both operands depend on the output
+    ("ka,kb->ab", dict(a=2, k=65537, b=2)),                           # k slowest in both, 2 x 2 outputs
+    ("akl,lk->a", dict(a=2, k=300, l=301)),                           # two contracted indices, transposed
 ]
 
 
