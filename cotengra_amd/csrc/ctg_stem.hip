@@ -1307,7 +1307,7 @@ StemShape stem2_shape(const StemArgs& p, bool bf3 = false) {
 // (B1 in registers up to K1 = 64; bf16 x 3: up to two chunks); anything else: run-time counts, fp32
 #define CTG_STEM_ONE(X) \
     X(1, 4, 8, false) X(1, 1, 2, false) X(1, 2, 4, false) X(1, 1, 8, false) \
-    X(1, 1, 4, false) X(1, 4, 4, false) X(1, 1, 2, true) X(1, 2, 2, true) X(2, 1, 1, false)
+    X(1, 1, 4, false) X(1, 4, 4, false) X(1, 1, 2, true) X(1, 2, 2, true) X(2, 1, 1, false) X(1, 2, 8, false)
 
 static bool stem1_static(const StemShape& s) {
     if (env_on("CTG_STEM_GENERIC")) return false;

@@ -272,10 +272,11 @@ def modelled_seconds(tree, model=None, dtype="complex64"):
             # a fused stem pair (stem.py): its own model -- the big tensor moves once
             st = s.stem
             if st.get("one"):   # (a single step on the stem kernel's first half)
-                t += single_seconds(s.macs, s.a.size, s.c.size, st["run_bytes"])
+                t += single_seconds(s.macs, s.a.size, s.c.size, st["run_bytes"], bf3_fits=st.get("bf3_fits", True))
                 continue
             macs1 = (s.a.size // st["K1"]) * st["K1"] * st["N1"]
-            t += pair_seconds(macs1, s.macs - macs1, s.a.size, s.c.size, st["items"], st["run_bytes"])
+            t += pair_seconds(macs1, s.macs - macs1, s.a.size, s.c.size, st["items"], st["run_bytes"],
+                              bf3_fits=st.get("bf3_fits", True))
         else:
             t += model.step_seconds(s.macs, s.elems_rw, s.K, s.N)
     return t, plan.arena_elems * itemsize

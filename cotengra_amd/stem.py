@@ -135,6 +135,15 @@ def b_lds_bytes(K, N):
     return (3 if N == 16 else 2) * N * (K + 4) * 4
 
 
+def bf16x3_fits(K1, N1, K2, N2, rows2):
+    """Does the pair's tile fit the LDS in the bf16 x 3 arithmetic (the small operands as three
+    bfloat16 limb planes: csrc/ctg_stem.hip ``stem2_lds_bytes_bf3``)?  A pair that does not runs
+    fp32 products whatever the mode (``stem2_bf3``), and is priced so."""
+    q1 = (3 if N1 == 16 else 2) * N1 * ((K1 >> 4) * 48 + 8)
+    q2 = (3 if N2 == 16 else 2) * N2 * ((K2 >> 3) * 24 + 8)
+    return 2 * (q1 + q2) + 8 * rows2 * (K2 + 4) + 8 * N2 + 64 <= LDS_BYTES
+
+
 class Geometry:
     """Tile decomposition of one fused pair (all fields are plain data)."""
 
@@ -224,6 +233,8 @@ def geometry(size_dict, A, B1, B2, c1_inds, c2_inds):
     g = Geometry()
     g.K1, g.N1, g.K2, g.N2 = K1, N1, K2, N2
     g.nr1, g.rows2_bits, g.ng2, g.items, g.lds = nr1, rows2_bits, ng2, items, lds
+    # (the bf16 x 3 instantiations are static ones: item counts that are multiples of the waves)
+    g.bf3_fits = bf16x3_fits(K1, N1, K2, N2, 1 << rows2_bits) and items % WAVES == 0
     g.k1 = sorted(k1, key=sa)                      # k index: digit 0 = lowest stride in A
     g.n1 = sorted(n1, key=lambda b: _stride(B1, b))
     x = free[:nx]
@@ -288,6 +299,8 @@ def geometry_one(size_dict, A, B1, c_inds):
     g = Geometry()
     g.K1, g.N1, g.K2, g.N2 = K1, N1, 0, 0
     g.nr1, g.rows2_bits, g.ng2, g.items, g.lds = nr1, 0, 0, 0, lds
+    # (B1's limb planes: csrc/ctg_stem.hip stem2_lds_bytes_one; K = N = 128 has no room and multiplies in fp32)
+    g.bf3_fits = 2 * 2 * N1 * ((K1 >> 4) * 48 + 8) + 8 * N1 + 64 <= LDS_BYTES
     g.k1 = sorted(k1, key=sa)
     g.n1 = sorted(n1, key=lambda b: _stride(B1, b))
     g.r1 = free[:nr1]
@@ -305,17 +318,18 @@ def geometry_one(size_dict, A, B1, c_inds):
     return g
 
 
-def single_seconds(macs, elems_a, elems_c, run_bytes=256, bf16x3=None):
+def single_seconds(macs, elems_a, elems_c, run_bytes=256, bf16x3=None, bf3_fits=True):
     """Modelled time of a single stem step (``geometry_one``): the pair model with one step."""
-    rate = FUSED_MFMA_RATE * (BF16X3_SPEEDUP if bf16x3_mode(bf16x3) else 1.0)
+    rate = FUSED_MFMA_RATE * (BF16X3_SPEEDUP if (bf3_fits and bf16x3_mode(bf16x3)) else 1.0)
     t_mfma = 8.0 * macs / rate
     t_mem = 8.0 * elems_a / gather_rate(run_bytes) + 8.0 * elems_c / FUSED_STORE_RATE
     return max(t_mfma, t_mem) + FUSED_OVERLAP_LOSS * min(t_mfma, t_mem)
 
 
-def pair_seconds(macs1, macs2, elems_a, elems_c2, items, run_bytes=256, bf16x3=None):
-    """Modelled time of a fused pair in the arithmetic ``bf16x3_mode(bf16x3)`` says."""
-    rate = FUSED_MFMA_RATE * (BF16X3_SPEEDUP if bf16x3_mode(bf16x3) else 1.0)
+def pair_seconds(macs1, macs2, elems_a, elems_c2, items, run_bytes=256, bf16x3=None, bf3_fits=True):
+    """Modelled time of a fused pair in the arithmetic ``bf16x3_mode(bf16x3)`` says
+    (``bf3_fits``: ``Geometry.bf3_fits`` -- a tile too large for the limb planes multiplies in fp32)."""
+    rate = FUSED_MFMA_RATE * (BF16X3_SPEEDUP if (bf3_fits and bf16x3_mode(bf16x3)) else 1.0)
     t_mfma = 8.0 * macs1 / rate + 8.0 * macs2 / (rate * min(1.0, items / WAVES))
     t_mem = 8.0 * elems_a / gather_rate(run_bytes) + 8.0 * elems_c2 / FUSED_STORE_RATE
     return max(t_mfma, t_mem) + FUSED_OVERLAP_LOSS * min(t_mfma, t_mem)
@@ -362,7 +376,8 @@ def find_pairs(plan, size_dict, min_elems=1 << 24, model=None, bf16x3=None):
         if geo is None:
             continue
         before = unfused_seconds(s1) + unfused_seconds(s2)
-        after = pair_seconds(s1.macs, s2.macs, s1.a.size, s2.c.size, geo.items, geo.run_bytes, bf16x3=bf16x3)
+        after = pair_seconds(s1.macs, s2.macs, s1.a.size, s2.c.size, geo.items, geo.run_bytes, bf16x3=bf16x3,
+                             bf3_fits=geo.bf3_fits)
         if before - after >= MIN_GAIN * before:
             gain[i2] = (i1, before - after)
     # chains: i1 -> i2 -> i3 ...; a step can be in one pair only
@@ -402,7 +417,7 @@ def find_pairs(plan, size_dict, min_elems=1 << 24, model=None, bf16x3=None):
             if geo is None:
                 continue
             before = unfused_seconds(s1)
-            after = single_seconds(s1.macs, s1.a.size, s1.c.size, geo.run_bytes, bf16x3=bf16x3)
+            after = single_seconds(s1.macs, s1.a.size, s1.c.size, geo.run_bytes, bf16x3=bf16x3, bf3_fits=geo.bf3_fits)
             if before - after >= MIN_GAIN * before:
                 chosen[s1.node] = s1.node
     return chosen
@@ -482,6 +497,7 @@ def build_stem_step(size_dict, A, B1, B2, c1_inds, out_inds, out_ref_factory, no
         "K1": K1, "N1": N1, "K2": K2, "N2": N2, "nr1": geo.nr1, "rows2": 1 << geo.rows2_bits,
         "ng2": geo.ng2, "n_tiles": 1 << len(geo.grid), "g_lo": 1 << g_lo_bits, "ld2": ld2,
         "lds_bytes": geo.lds, "items": geo.items, "run_bytes": geo.run_bytes, "vec": int(geo.vec), "tabs": tabs,
+        "bf3_fits": bool(geo.bf3_fits),
     }
     # reporting fields: the second step's shape; work and traffic of BOTH steps as if unfused
     rows_total = A.size // K1
@@ -541,7 +557,7 @@ def build_stem_one(size_dict, A, B1, out_inds, out_ref_factory, node=-1):
     step.stem = {
         "K1": K1, "N1": N1, "K2": 0, "N2": 0, "nr1": geo.nr1, "rows2": 0, "ng2": 0,
         "n_tiles": 1 << len(geo.grid), "g_lo": 1 << g_lo_bits, "ld2": 0, "lds_bytes": geo.lds, "items": 0,
-        "run_bytes": geo.run_bytes, "vec": int(geo.vec), "one": 1, "tabs": tabs,
+        "run_bytes": geo.run_bytes, "vec": int(geo.vec), "one": 1, "bf3_fits": bool(geo.bf3_fits), "tabs": tabs,
     }
     rows_total = A.size // K1
     step.R, step.Bt, step.K, step.N = rows_total, 1, K1, N1

@@ -350,9 +350,13 @@ def test_singles_are_chosen_by_the_model(monkeypatch):
     monkeypatch.delenv("CTG_STEM_BF16X3", raising=False)
     plan = P.compile_tree(tree, "complex64")
     ones = [s for s in plan.steps if s.kind == P.KIND_STEM2 and s.stem.get("one")]
-    assert len(ones) >= 3 and any(s.a.size == 2**32 for s in ones)
-    left = [s for s in plan.steps if s.kind == P.KIND_PAIR and not s.invariant and s.a.size >= 2**28 and s.K >= 16]
+    assert len(ones) >= 3 and any(s.a.size >= 2**30 for s in ones)
+    # (a single step needs >= 32 output columns: a lone 16 x 16 step stays on the streaming kernel, memory-bound there too)
+    left = [s for s in plan.steps if s.kind == P.KIND_PAIR and not s.invariant and s.a.size >= 2**28 and s.K >= 16 and s.N >= 32]
     assert not left, [s.label for s in left]
+    # a pair whose tile has no room for the bf16 limb planes would multiply in fp32: priced so, and not chosen here
+    pairs = [s for s in plan.steps if s.kind == P.KIND_STEM2 and not s.stem.get("one")]
+    assert pairs and all(s.stem["bf3_fits"] for s in pairs)
     fp32 = P.compile_tree(tree, "complex64", stem_bf16x3=False)
     assert not [s for s in fp32.steps if s.kind == P.KIND_STEM2 and s.stem.get("one")]
     monkeypatch.setenv("CTG_NO_STEM_ONE", "1")
@@ -361,3 +365,14 @@ def test_singles_are_chosen_by_the_model(monkeypatch):
     assert plan.macs_per_slice == fp32.macs_per_slice == off.macs_per_slice
 
 
+def test_bf16x3_tile_fit_is_part_of_the_pair_model():
+    """``stem.bf16x3_fits`` restates the C side's LDS sizing of the limb planes (csrc/ctg_stem.hip
+    stem2_lds_bytes_bf3, the condition of stem2_bf3): 32 32 | 64 128 on 128 rows needs 185 KB and
+    multiplies in fp32 whatever the mode; the model prices it at the fp32 rate."""
+    from cotengra_amd import stem
+
+    assert stem.bf16x3_fits(32, 32, 64, 64, 128) and stem.bf16x3_fits(16, 16, 128, 64, 32)
+    assert not stem.bf16x3_fits(32, 32, 64, 128, 128) and not stem.bf16x3_fits(16, 16, 128, 64, 64)
+    args = (2**25 * 32 * 32, 2**24 * 64 * 128, 2**30, 2**31, 16)
+    fits, not_fits = stem.pair_seconds(*args, bf16x3=True), stem.pair_seconds(*args, bf16x3=True, bf3_fits=False)
+    assert not_fits == stem.pair_seconds(*args, bf16x3=False) > fits

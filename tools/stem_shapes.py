@@ -80,3 +80,23 @@ for g in geo:
 print("// single steps (RT1, CS1, NCH, VEC)")
 for key, (macs, where) in sorted(ones.items(), key=lambda kv: -kv[1][0]):
     print("O(%d, %d, %d, %s)" % (*key[:3], lo(key[3])), "// %.2e" % macs, sorted(where)[:3])
+
+# what csrc/ctg_stem.hip has: anything printed below runs the run-time-count variant (fp32) until it is added
+import re  # noqa: E402
+
+src = open(os.path.join(ROOT, "cotengra_amd", "csrc", "ctg_stem.hip")).read()
+
+
+def have(macro, letter):
+    body = src.split("#define %s(%s)" % (macro, letter))[1].split("\n\n")[0]
+    return {tuple(a.strip() for a in m.split(",")) for m in re.findall(r"%s\(([^)]*)\)" % letter, body)}
+
+
+def fmt(key):
+    return tuple(lo(v) if isinstance(v, bool) else str(v) for v in key)
+
+
+missing = [("X", fmt(k)) for k in need if fmt(k) not in have("CTG_STEM_INST", "X")]
+missing += [("G", fmt(g)) for g in geo if fmt(g) not in have("CTG_STEM_GEO", "G")]
+missing += [("O", fmt(k)) for k in ones if fmt(k) not in have("CTG_STEM_ONE", "X")]
+print("// not in csrc/ctg_stem.hip:", ", ".join("%s(%s)" % (l, ", ".join(k)) for l, k in missing) or "nothing")
