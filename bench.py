@@ -53,10 +53,11 @@ PEAK_HBM_GBS = 8000.0
 TREES = os.path.join(ROOT, "tests", "golden", "trees")
 TREE = os.path.join(TREES, "sycamore_m20_native.json")        # reaches the amplitude first
 PEAK_TREE = os.path.join(TREES, "sycamore_m20_w32_c512.json")  # highest FLOP/s per slice (r1 / r2 headline)
-# the headline tree refined once more for an executor that fuses stem pairs (tests/golden/gen/
-# refine_fused.py): a quarter less work in smaller, memory-bound steps -- fewer FLOP/s, but the
-# amplitude 12 % sooner
-TTS_TREE = os.path.join(TREES, "sycamore_m20_fused.json")
+# the headline tree refined for an executor that fuses stem pairs (tests/golden/gen/refine_fused.py,
+# round 3) and once more under the model of the executor as it is since round 4 (single stem steps,
+# bf16 x 3 products: gen/refine_r4.py): a quarter less work in smaller, memory-bound steps -- fewer
+# FLOP/s, but the amplitude 14 % sooner
+TTS_TREE = os.path.join(TREES, "sycamore_m20_w32_r4.json")
 # the same with one index less sliced: 2^19 slices of width 2^33 (68 GB tensors, a 161 GiB arena --
 # what 288 GB of HBM are for); the amplitude another 6 % sooner
 TTS33_TREE = os.path.join(TREES, "sycamore_m20_w33_bf3.json")   # (refined once more: gen/refine_bf3.py)

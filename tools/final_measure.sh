@@ -26,7 +26,7 @@ cd /tmp
 timeout 600 rocprofv3 --kernel-trace --stats -d $O/trace_headline -- python $R/bench.py --headline-only --no-cpu-baseline --steps 4 --warmup 1 > $O/trace_headline.log 2>&1
 cd $R
 python tools/rocprof_summary.py $(find $O/trace_headline -name "*.db" | head -1) $O/kernels_headline > /dev/null 2>&1; head -4 $O/kernels_headline_kernels.txt | cut -c1-190
-for tree in sycamore_m20_native sycamore_m20_fused sycamore_m20_w32_c512; do
+for tree in sycamore_m20_native sycamore_m20_w32_r4 sycamore_m20_w32_c512; do
   CMD="python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --tree $R/tests/golden/trees/$tree.json"
   cd /tmp
   timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/pmc_fetch_$tree -- $CMD > $O/pmc_fetch_$tree.log 2>&1

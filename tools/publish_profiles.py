@@ -18,7 +18,7 @@ pairs = {
     "kernels_headline_kernels.json": f"{tag}_bench_kernels_headline.json",
     "kernels_headline_kernels.txt": f"{tag}_bench_kernels_headline.txt",
 }
-for tree in ("sycamore_m20_w32_c512", "sycamore_m20_native", "sycamore_m20_fused"):
+for tree in ("sycamore_m20_w32_c512", "sycamore_m20_native", "sycamore_m20_w32_r4"):
     pairs[f"pmc_summary_{tree}.json"] = f"pmc_summary_{tree}.json"   # (read by bench.py: roofline.traffic)
     pairs[f"steps_{tree}.txt"] = f"{tag}_steps_{tree}.txt"
     pairs[f"steps_{tree}_fp32.txt"] = f"{tag}_steps_{tree}_fp32.txt"
