@@ -74,7 +74,13 @@ enum StemWord {
                     //    tile rows of step 1, out_col over its columns) -- stem.py: build_stem_one
     SW_TABS = 20,   // 14 table offsets: gA_hi gA_lo gC_hi gC_lo kj_a lane_a rt_a chunk_a
                     //                   b1_off b2_off mid_row mid_col out_row out_col
-    STEM_WORDS = 40
+    // a MIDDLE stage (three-step tile, stem.py: build_stem_triple; round 4): the fields above that
+    // speak of "step 2" then describe the LAST step, these the one between -- its shape, its small
+    // operand, its tables (bm_off, mid2_row, mid2_col: its result -> the second intermediate)
+    SW_KM = 34, SW_NM = 35, SW_ROWSM = 36, SW_NGM = 37, SW_LDM = 38, SW_TRI = 39,
+    SW_BM_SPACE = 40, SW_BM_OFF = 41, SW_BM_LEAF = 42, SW_BM_SIZE = 43, SW_BM_PROD = 44,
+    SW_TABS_M = 45,
+    STEM_WORDS = 56
 };
 constexpr int64_t STEM_MAGIC = 0x53544D33;
 enum StemTab {
@@ -180,6 +186,15 @@ struct StemArgs {
     int64_t zA, zB1, zB2, zC;
     int64_t zsA, zsB1, zsB2, zsC;
     int32_t one;                // the first half alone (SW_ONE)
+    // three-step tile (SW_TRI): the middle step
+    int32_t tri, KM, NM, rowsM, ngM, ldM;
+    const void* BM;
+    const int64_t* soffBM;
+    const int64_t* bm_off;
+    const int64_t* mid2_row;    // [rowsM] + mid2_col [NM]: the middle step's result in the second intermediate
+    const int64_t* mid2_col;
+    const double* facBM;
+    int64_t zBM, zsBM;
     int64_t a_elems, c_elems;   // extents of the big operand and of the result (the bounds-checked
                                 // experiment build -DCTG_STEM_BOUNDS tests every gather and store)
 };
@@ -487,6 +502,7 @@ hipError_t launch_pair_mfma_c128(const StepArgs& p, int flags, hipStream_t strea
 hipError_t launch_pair_mfma_real(int dtype, const StepArgs& p, int flags, hipStream_t stream);
 // fused stem pair (ctg_stem.hip)
 bool stem2_supported(const StemArgs& p);
+bool stem3_supported(const StemArgs& p);   // (a three-step tile: shape, instantiation, LDS)
 size_t stem2_lds_bytes(const StemArgs& p);
 hipError_t launch_stem2(const StemArgs& p, hipStream_t stream);
 void stem2_kernel_name(const StemArgs& p, char* buf, size_t n);

@@ -103,7 +103,7 @@ int validate_stem(const ctg_plan* p, int64_t s) {
             h[SW_LD2] != 0 || nr1 < 5 || nr1 > 9 || !stem2_supported(a))
             return fail(CTG_E_INVALID, "step %lld: single stem step shape the kernel does not take", sl);
     } else if (K1 < 1 || K1 > 128 || N1 < 1 || N1 > 128 || K2 < 1 || K2 > 128 || N2 < 1 || N2 > 128 || nr1 < 5 ||
-               nr1 > 9 || rows2 < 1 || rows2 > (1 << 16) || !stem2_supported(a))
+               nr1 > 9 || rows2 < 1 || rows2 > (1 << 16) || (h[SW_TRI] != 1 && !stem2_supported(a)))
         return fail(CTG_E_INVALID, "step %lld: stem pair shape the kernel does not take", sl);
     if (n_tiles < 1 || g_lo < 1 || log2_exact(g_lo) < 0 || n_tiles % g_lo != 0 || log2_exact(n_tiles) < 0)
         return fail(CTG_E_INVALID, "step %lld: bad stem grid", sl);
@@ -136,7 +136,40 @@ int validate_stem(const ctg_plan* p, int64_t s) {
         if ((r[W_A_OFF] & 1) || r[W_A_LEAF] >= 0)
             return fail(CTG_E_INVALID, "step %lld: stem operand not aligned for 16-byte gathers", sl);
     }
-    if (!one && mx[ST_MID_ROW] + mx[ST_MID_COL] >= rows2 * (K2 + 4))
+    if (h[SW_TRI] != 0 && h[SW_TRI] != 1) return fail(CTG_E_INVALID, "step %lld: bad stem stage count", sl);
+    const bool tri = h[SW_TRI] == 1;
+    int64_t bm_top = 0;
+    if (tri) {
+        // a middle stage: its shape one the kernel is instantiated for, its tables inside the blob,
+        // both intermediates inside the LDS region they share
+        const int64_t KM = h[SW_KM], NM = h[SW_NM], rowsM = h[SW_ROWSM];
+        if (one || KM < 16 || KM > 128 || NM < 16 || NM > 128 || rowsM < 32 || rowsM > (1 << 16) ||
+            h[SW_LDM] != KM + 4 || rows1 * N1 != rowsM * KM || rowsM * NM != rows2 * K2)
+            return fail(CTG_E_INVALID, "step %lld: three-step tile shape the kernel does not take", sl);
+        a.tri = 1; a.KM = (int)KM; a.NM = (int)NM; a.rowsM = (int)rowsM; a.ngM = (int)h[SW_NGM]; a.ldM = (int)h[SW_LDM];
+        a.vec = (int)h[SW_VEC];
+        if (!stem3_supported(a))
+            return fail(CTG_E_INVALID, "step %lld: three-step tile shape the kernel does not take", sl);
+        const int64_t lenm[3] = {KM * NM, rowsM, NM};
+        int64_t mxm[3], mnm[3];
+        for (int t = 0; t < 3; ++t) {
+            if (!tab_ok(p, h[SW_TABS_M + t], lenm[t]))
+                return fail(CTG_E_BOUNDS, "step %lld: stem table outside the blob", sl);
+            mxm[t] = tab_max(p, h[SW_TABS_M + t], lenm[t], &mnm[t]);
+            if (mnm[t] < 0) return fail(CTG_E_BOUNDS, "step %lld: negative stem offset", sl);
+        }
+        bm_top = mxm[0];
+        if (mx[ST_MID_ROW] + mx[ST_MID_COL] >= rowsM * (KM + 4) || mxm[1] + mxm[2] >= rows2 * (K2 + 4))
+            return fail(CTG_E_BOUNDS, "step %lld: intermediate tile overflows its LDS", sl);
+        const int64_t cap = space_elems(p, h[SW_BM_SPACE]);
+        if (cap < 0) return fail(CTG_E_INVALID, "step %lld: bad space", sl);
+        if (h[SW_BM_LEAF] < -1 || h[SW_BM_LEAF] > p->n_inputs) return fail(CTG_E_INVALID, "step %lld: bad leaf", sl);
+        const int64_t hi = h[SW_BM_OFF] + (h[SW_BM_LEAF] >= 0 ? p->max_soff[h[SW_BM_LEAF]] : 0) + bm_top;
+        if (h[SW_BM_OFF] < 0 || hi >= cap)
+            return fail(CTG_E_BOUNDS, "step %lld: stem operand m reaches element %lld of a space of %lld", sl,
+                        (long long)hi, (long long)cap);
+    }
+    if (!one && !tri && mx[ST_MID_ROW] + mx[ST_MID_COL] >= rows2 * (K2 + 4))
         return fail(CTG_E_BOUNDS, "step %lld: intermediate tile overflows its LDS", sl);
     struct Op { int64_t space, off, leaf, size, top; char name; };
     const Op ops[4] = {
@@ -390,6 +423,19 @@ void resolve_args(ctg_exec* e) {
                 q.facA = fac(r[W_A_PROD]);
                 q.facB1 = fac(r[W_B_PROD]);
                 q.facB2 = q.one ? e->d_fac + p->n_steps : fac(h[SW_B2_PROD]);   // (one step: the constant 1)
+                q.facBM = h[SW_TRI] == 1 ? fac(h[SW_BM_PROD]) : e->d_fac + p->n_steps;
+            }
+            if (h[SW_TRI] == 1) {
+                q.tri = 1;
+                q.KM = (int)h[SW_KM]; q.NM = (int)h[SW_NM]; q.rowsM = (int)h[SW_ROWSM]; q.ngM = (int)h[SW_NGM];
+                q.ldM = (int)h[SW_LDM];
+                q.BM = (char*)space_ptr(e, h[SW_BM_SPACE]) + h[SW_BM_OFF] * isz;
+                q.soffBM = h[SW_BM_LEAF] >= 0 ? e->d_soff + h[SW_BM_LEAF] : e->d_zero;
+                q.bm_off = T + h[SW_TABS_M];
+                q.mid2_row = T + h[SW_TABS_M + 1];
+                q.mid2_col = T + h[SW_TABS_M + 2];
+                q.zBM = per_slice(h[SW_BM_SPACE], h[SW_BM_OFF]);
+                q.zsBM = h[SW_BM_LEAF] >= 0 ? p->n_inputs + 1 : 0;
             }
         }
     }

@@ -290,9 +290,17 @@ __device__ __forceinline__ void settle(T& v) {
 // over): gather -> MFMA as in step 1, then the 32 x 32 accumulators of a unit go straight to the result
 // (8-byte stores, issued between the MFMAs of the wave's next unit like every deferred store here).  No
 // intermediate, no barrier in the tile loop, LDS for B1 only.  >= 32 columns.
+// ITM > 0 (round 4, opt-in: CTG_STEM_TRIPLES): a MIDDLE stage between the two -- a three-step tile.  The
+// fields and code of "step 2" then are the LAST step's; the middle step reads the first intermediate
+// ([rowsM][ldM], written by the scatter of step 1), multiplies by BM (ITM work items per wave, accumulators
+// kept in registers), and after a barrier scatters its result over it as the second intermediate
+// ([rows2][ld2], mid2_row[rowM] + mid2_col[nM]) which the last step reads.  PACKM: its 16 columns.  Static
+// shapes, X / Y form; four barriers per tile instead of two.
 template <bool PACK1, bool PACK2, int RT1, int CS1, int NCH, int IT2, bool BR1 = false, int K2Q = 0, bool VEC = false,
-          bool BF3 = false, bool RI2 = false, bool ONE = false>
+          bool BF3 = false, bool RI2 = false, bool ONE = false, int ITM = 0, bool PACKM = false>
 __global__ __launch_bounds__(SW * 64, 1) void stem2_kernel(StemArgs p) {
+    constexpr bool TRI = ITM > 0;
+    static_assert(!TRI || (NCH > 0 && IT2 > 0 && !RI2 && !ONE && K2Q == 0), "three-step tile: static, X / Y form");
     static_assert(!ONE || (!PACK1 && !PACK2 && !RI2 && IT2 == 0 && K2Q == 0), "one step: >= 32 columns, nothing of step 2");
     static_assert(!PACK1 || CS1 == 1, "16 columns are one group");
     static_assert(!BR1 || NCH > 0, "B1 in registers needs the chunk count at compile time");
@@ -306,8 +314,13 @@ __global__ __launch_bounds__(SW * 64, 1) void stem2_kernel(StemArgs p) {
     const int K1 = p.K1, N1 = p.N1, K2 = K2Q > 0 ? 4 * K2Q : p.K2, N2 = p.N2;
     const int LDB1 = K1 + 4, LDB2 = K2 + 4, LD2 = K2Q > 0 ? 4 * K2Q + 4 : p.ld2;
     const int PLANE = p.rows2 * LD2;                       // floats per plane of the intermediate
+    // (three-step tile: the middle step's operand, and the FIRST intermediate [rowsM][LDM])
+    const int KM = TRI ? p.KM : 0, NM = TRI ? p.NM : 0, LDM = TRI ? p.ldM : 0, LDBM = KM + 4;
+    const int PLANEM = TRI ? p.rowsM * LDM : 0;
+    const int PLANE1 = TRI ? PLANEM : PLANE;               // plane of the intermediate step 1 scatters into
     float* P1 = (float*)smem;                              // [2|3][N1][LDB1]
-    float* P2 = P1 + (PACK1 ? 3 : 2) * N1 * LDB1;          // [2|3][N2][LDB2]
+    float* PM = P1 + (PACK1 ? 3 : 2) * N1 * LDB1;          // [2|3][NM][LDBM] (three-step tile)
+    float* P2 = PM + (TRI ? (PACKM ? 3 : 2) * NM * LDBM : 0);   // [2|3][N2][LDB2]
     float* mid = P2 + (PACK2 ? 3 : 2) * N2 * LDB2;         // [2][rows2][LD2]
     // RI2: three planes (Re, Im, -Im) INTERLEAVED PER ROW -- [rows2][3][LD2], row pitch RP = 3 LD2:
     // the three values of an element are LD2 floats apart, an immediate offset of the scatter's
@@ -318,7 +331,7 @@ __global__ __launch_bounds__(SW * 64, 1) void stem2_kernel(StemArgs p) {
     const int RP = 3 * LD2;
     // an offset row2 * LD2 + k2 of the planner's tables in that layout: row2 * RP + k2
     auto ri_off = [&](int e) __attribute__((always_inline)) { return RI2 ? (e / LD2) * RP + e % LD2 : e; };
-    int mid_floats = 2 * PLANE;
+    int mid_floats = 2 * (PLANE > PLANEM ? PLANE : PLANEM);   // (the two intermediates of a three-step tile share it)
     if constexpr (RI2) {
         mid_floats = 3 * PLANE;
         if constexpr (K2Q > 0) {
@@ -328,9 +341,10 @@ __global__ __launch_bounds__(SW * 64, 1) void stem2_kernel(StemArgs p) {
         }
     }
     // (BF3: the small operands as bf16 x 3 planes instead)
-    const int ROW1 = bf3_row(K1, true), ROW2 = bf3_row(K2, false);
+    const int ROW1 = bf3_row(K1, true), ROW2 = bf3_row(K2, false), ROWM = TRI ? bf3_row(KM, false) : 0;
     unsigned short* Q1 = (unsigned short*)smem;            // [2|3][N1][ROW1]
-    unsigned short* Q2 = Q1 + (PACK1 ? 3 : 2) * N1 * ROW1; // [2|3][N2][ROW2]
+    unsigned short* QM = Q1 + (PACK1 ? 3 : 2) * N1 * ROW1; // [2|3][NM][ROWM] (three-step tile)
+    unsigned short* Q2 = QM + (TRI ? (PACKM ? 3 : 2) * NM * ROWM : 0);   // [2|3][N2][ROW2]
     if constexpr (BF3) mid = (float*)(Q2 + (PACK2 ? 3 : 2) * N2 * ROW2);
     int64_t* oc_s = (int64_t*)(mid + mid_floats);          // [N2] column offsets of the result
 
@@ -347,18 +361,25 @@ __global__ __launch_bounds__(SW * 64, 1) void stem2_kernel(StemArgs p) {
     const c64* __restrict__ B1 = (const c64*)p.B1 + (sload64(p.soffB1 + z * p.zsB1) + z * p.zB1);
     const c64* __restrict__ B2 = (const c64*)p.B2 + (sload64(p.soffB2 + z * p.zsB2) + z * p.zB2);
     float* __restrict__ C = (float*)((c64*)p.C + (sload64(p.soffC + z * p.zsC) + z * p.zC));
+    const c64* __restrict__ BM = TRI ? (const c64*)p.BM + (sload64(p.soffBM + z * p.zsBM) + z * p.zBM) : nullptr;
 
     int bf3_ex = 0;   // BF3: power of two taken out of the small operands (goes back in through alpha)
     if constexpr (BF3) {
         float* bf3_red = (float*)(oc_s + (ONE ? N1 : N2));   // (64 bytes behind the column table: stem2_lds_bytes_bf3)
         const int ex1 = bf3_operand_exponent(B1, p.b1_off, K1 * N1, tid, bf3_red);
         const int ex2 = ONE ? 0 : bf3_operand_exponent(B2, p.b2_off, K2 * N2, tid, bf3_red);
-        bf3_ex = ex1 + ex2;
+        int exm = 0;
+        if constexpr (TRI) {
+            exm = bf3_operand_exponent(BM, p.bm_off, KM * NM, tid, bf3_red);
+            load_b_planes_bf3<false>(QM, BM, p.bm_off, KM, NM, PACKM ? 3 : 2, tid, false, pow2f(-exm));
+        }
+        bf3_ex = ex1 + ex2 + exm;
         load_b_planes_bf3<true>(Q1, B1, p.b1_off, K1, N1, PACK1 ? 3 : 2, tid, VEC, pow2f(-ex1));
         if constexpr (!ONE) load_b_planes_bf3<false>(Q2, B2, p.b2_off, K2, N2, PACK2 ? 3 : 2, tid, false, pow2f(-ex2));
     } else {
         load_b_planes<true>(P1, B1, p.b1_off, K1, N1, PACK1, tid, VEC);
         if constexpr (!ONE) load_b_planes<false>(P2, B2, p.b2_off, K2, N2, PACK2, tid);
+        if constexpr (TRI) load_b_planes<false>(PM, BM, p.bm_off, KM, NM, PACKM, tid);
     }
     const int NOUT = ONE ? N1 : N2;   // columns of the result
     for (int n = tid; n < NOUT; n += SW * 64) oc_s[n] = p.out_col[n];
@@ -425,7 +446,7 @@ __global__ __launch_bounds__(SW * 64, 1) void stem2_kernel(StemArgs p) {
     // once more negated -> plane -Im)
     int mid_lane = 0;
     if constexpr (!ONE) {
-        if (PACK1) mid_lane = ri_off((int)p.mid_col[l31 & 15]) + (l31 >> 4) * (RI2 ? LD2 : PLANE) + ri_off((int)p.mid_row[4 * kk]);
+        if (PACK1) mid_lane = ri_off((int)p.mid_col[l31 & 15]) + (l31 >> 4) * (RI2 ? LD2 : PLANE1) + ri_off((int)p.mid_row[4 * kk]);
         else mid_lane = ri_off((int)p.mid_col[wcol + l31]) + ri_off((int)p.mid_row[4 * kk]);
     }
     settle(mid_lane);
@@ -462,6 +483,46 @@ __global__ __launch_bounds__(SW * 64, 1) void stem2_kernel(StemArgs p) {
     auto out_t = [&](int t) __attribute__((always_inline)) {
         return ((t & 1) ? out_o[0] : 0) + ((t & 2) ? out_o[1] : 0) + ((t & 4) ? out_o[2] : 0) + ((t & 8) ? out_o[3] : 0);
     };
+    // three-step tile, middle stage: this wave's items (item = wave + SW i -> column group item / n_rtM,
+    // row tile item % n_rtM) are the same for every tile -- their B fragments' bases and the scatter
+    // addresses of their results in the second intermediate are kernel constants
+    const int n_rtM = TRI ? p.rowsM >> 5 : 1;
+    const unsigned short* qmx[TRI ? ITM : 1];
+    const unsigned short* qmy[TRI ? ITM : 1];
+    const float* bmx[TRI ? ITM : 1];
+    const float* bmy[TRI ? ITM : 1];
+    int m2_lane[TRI ? ITM : 1], m2_rt[TRI ? ITM : 1], am_row[TRI ? ITM : 1];
+    int m2_o[4] = {0, 0, 0, 0};
+    if constexpr (TRI) {
+        const int h16 = l31 >> 4;
+#pragma unroll
+        for (int i = 0; i < ITM; ++i) {
+            const int item = wave + SW * i;
+            const int cg = item / n_rtM, rtm = item - cg * n_rtM;
+            am_row[i] = (rtm * 32 + l31) * LDM;
+            if (PACKM) {
+                const int plane = kk == 0 ? (h16 ? 1 : 0) : (h16 ? 0 : 2);
+                qmx[i] = QM + (plane * NM + (l31 & 15)) * ROWM;
+                qmy[i] = nullptr;
+                bmx[i] = PM + (plane * NM + (l31 & 15)) * LDBM;
+                bmy[i] = nullptr;
+                m2_lane[i] = (int)p.mid2_col[l31 & 15] + h16 * PLANE + (int)p.mid2_row[4 * kk];
+            } else {
+                qmx[i] = QM + ((kk ? 1 : 0) * NM + cg * 32 + l31) * ROWM;
+                qmy[i] = QM + ((kk ? 0 : 1) * NM + cg * 32 + l31) * ROWM;
+                bmx[i] = PM + ((kk ? 1 : 0) * NM + cg * 32 + l31) * LDBM;
+                bmy[i] = PM + ((kk ? 0 : 1) * NM + cg * 32 + l31) * LDBM;
+                m2_lane[i] = (int)p.mid2_col[cg * 32 + l31] + (int)p.mid2_row[4 * kk];
+            }
+            settle(m2_lane[i]);
+            m2_rt[i] = __builtin_amdgcn_readfirstlane((int)sload64(p.mid2_row + 32 * rtm));
+        }
+#pragma unroll
+        for (int b = 0; b < 4; ++b) m2_o[b] = (int)sload64(p.mid2_row + (b < 2 ? 1 << b : 2 << b));
+    }
+    auto m2_t = [&](int t) __attribute__((always_inline)) {
+        return ((t & 1) ? m2_o[0] : 0) + ((t & 2) ? m2_o[1] : 0) + ((t & 4) ? m2_o[2] : 0) + ((t & 8) ? m2_o[3] : 0);
+    };
     // RI2, step 2: this lane's A' plane -- (row parity, k-row) -> Re, -Im, Im, Re -- and B' plane
     const int ri_par = l31 & 1;
     const int ri_plane = (ri_par == kk ? 0 : (ri_par ? 1 : 2)) * LD2;
@@ -472,7 +533,7 @@ __global__ __launch_bounds__(SW * 64, 1) void stem2_kernel(StemArgs p) {
 
     float alpha = 1.f;
     if (p.facA != nullptr) {
-        const double f = (*p.facA) * (*p.facB1) * (*p.facB2);
+        const double f = (*p.facA) * (*p.facB1) * (*p.facB2) * (TRI ? *p.facBM : 1.0);
         alpha = (f == 0.0 && p.check_zero) ? 0.f : (float)(1.0 / f * (BF3 ? exp2((double)bf3_ex) : 1.0));
     } else if (BF3 && bf3_ex != 0) {
         alpha = (float)exp2((double)bf3_ex);
@@ -769,7 +830,7 @@ __global__ __launch_bounds__(SW * 64, 1) void stem2_kernel(StemArgs p) {
                         dst[2 * LD2 + mid_t(t)] = -ay[m][t];
                     }
                 } else {
-                    if (!PACK1) dst[PLANE + mid_t(t)] = ay[m][t];
+                    if (!PACK1) dst[PLANE1 + mid_t(t)] = ay[m][t];
                 }
             }
         }
@@ -972,6 +1033,77 @@ __global__ __launch_bounds__(SW * 64, 1) void stem2_kernel(StemArgs p) {
             if constexpr (!decltype(defer_tag)::value) drain(0, NST, std::integral_constant<int, 0>{}, scaled_tag);
         }
     };
+    // three-step tile: work item i of the middle stage -- (32 rows of the first intermediate) x BM's
+    // column group into mx / my (the loops of item2, with the middle step's operand) ...
+    f32x16 mx[TRI ? ITM : 1], my[TRI ? ITM : 1];
+    auto item_mid = [&](auto ii) __attribute__((always_inline)) {
+        constexpr int I = decltype(ii)::value;
+        f32x16 cx, cy;
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+            cx[t] = 0.f;
+            cy[t] = 0.f;
+        }
+        const float* a_base = mid + kk * PLANEM + am_row[I];
+        if constexpr (BF3) {
+            for (int kb = 0; kb < (KM >> 3); ++kb) {
+                const f32x4 lo = *(const f32x4*)(a_base + 8 * kb), hi = *(const f32x4*)(a_base + 8 * kb + 4);
+                const float a8[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                bf16x8 a3[3], ax3[3], bx3[3], by3[3];
+                split3(a8, a3);
+#pragma unroll
+                for (int q = 0; q < 3; ++q) {
+                    ax3[q] = PACKM ? a3[q]
+                                   : __builtin_bit_cast(bf16x8, __builtin_bit_cast(u32x4, a3[q]) ^ (sgn2 | (sgn2 >> 16)));
+                    bx3[q] = *(const bf16x8*)(qmx[I] + kb * 24 + q * 8);
+                    if (!PACKM) by3[q] = *(const bf16x8*)(qmy[I] + kb * 24 + q * 8);
+                }
+#pragma unroll
+                for (int t = 0; t < 6; ++t) {
+                    cx = mfma_bf(ax3[bf3_ta(t)], bx3[bf3_tb(t)], cx);
+                    if (!PACKM) cy = mfma_bf(a3[bf3_ta(t)], by3[bf3_tb(t)], cy);
+                }
+            }
+        } else {
+            const int nq = KM >> 2;   // >= 4, even
+            f32x4 af[2], bx[2], by[2];
+            af[0] = *(const f32x4*)(a_base);
+            bx[0] = *(const f32x4*)(bmx[I]);
+            if (!PACKM) by[0] = *(const f32x4*)(bmy[I]);
+            for (int kq = 0; kq < nq; kq += 2) {
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int nx = (kq + h + 1 < nq ? kq + h + 1 : nq - 1) * 4;
+                    af[(h + 1) & 1] = *(const f32x4*)(a_base + nx);
+                    bx[(h + 1) & 1] = *(const f32x4*)(bmx[I] + nx);
+                    if (!PACKM) by[(h + 1) & 1] = *(const f32x4*)(bmy[I] + nx);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        if (PACKM) {
+                            cx = mfma(af[h][t], bx[h][t], cx);
+                        } else {
+                            cx = mfma(flip(af[h][t], sgn2), bx[h][t], cx);
+                            cy = mfma(af[h][t], by[h][t], cy);
+                        }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        }
+        mx[I] = cx;
+        my[I] = cy;
+    };
+    // ... and its accumulators -> the second intermediate, laid out as the last step's operand
+    auto scatter_mid = [&](auto ii) __attribute__((always_inline)) {
+        constexpr int I = decltype(ii)::value;
+        float* dst = mid + (m2_lane[I] + m2_rt[I]);
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+            dst[m2_t(t)] = mx[I][t];
+            if (!PACKM) dst[PLANE + m2_t(t)] = my[I][t];
+        }
+    };
     // ONE: the accumulators of unit m become the pending stores (copied: the unit's registers
     // are zeroed for its next tile before the stores are out)
     auto emit_one = [&](int m, int64_t c_tile, auto scaled_tag) __attribute__((always_inline)) {
@@ -1047,6 +1179,12 @@ __global__ __launch_bounds__(SW * 64, 1) void stem2_kernel(StemArgs p) {
                 }
             });
             CTG_STEM_SYNC();
+            if constexpr (TRI) {
+                static_for<0, ITM>([&](auto ii) __attribute__((always_inline)) { item_mid(ii); });
+                CTG_STEM_SYNC();   // every wave has read the first intermediate: the second goes over it
+                static_for<0, ITM>([&](auto ii) __attribute__((always_inline)) { scatter_mid(ii); });
+                CTG_STEM_SYNC();
+            }
             static_for<0, IT2>([&](auto ii) __attribute__((always_inline)) {
                 constexpr int I = decltype(ii)::value;
                 if constexpr (RI2)
@@ -1182,8 +1320,102 @@ static hipError_t launch_stem1_t(const StemArgs& p, hipStream_t stream) {
     return hipGetLastError();
 }
 
+// three-step tile (round 4): the three small operands' planes, the two intermediates in one region
+static size_t stem3_lds_bytes(const StemArgs& p, bool bf3) {
+    const size_t m1 = (size_t)p.rowsM * p.ldM, m2 = (size_t)p.rows2 * p.ld2;
+    const size_t mid = 8 * (m1 > m2 ? m1 : m2);
+    auto planes = [](int n) { return (size_t)(n == 16 ? 3 : 2); };
+    if (bf3) {
+        const size_t q = planes(p.N1) * p.N1 * ((p.K1 >> 4) * 48 + 8) + planes(p.NM) * p.NM * ((p.KM >> 3) * 24 + 8) +
+                         planes(p.N2) * p.N2 * ((p.K2 >> 3) * 24 + 8);
+        return 2 * q + mid + 8 * (size_t)p.N2 + 64;
+    }
+    const size_t b = planes(p.N1) * p.N1 * (p.K1 + 4) + planes(p.NM) * p.NM * (p.KM + 4) + planes(p.N2) * p.N2 * (p.K2 + 4);
+    return 4 * b + mid + 8 * (size_t)p.N2;
+}
+
+template <bool P1, bool PM, bool P2, int RT1, int CS1, int NCH, int ITM, int IT2, bool VEC, bool BF3>
+static hipError_t launch_stem3_t(const StemArgs& p, hipStream_t stream) {
+    auto kern = stem2_kernel<P1, P2, RT1, CS1, NCH, IT2, (NCH <= 2), 0, VEC, BF3, false, false, ITM, PM>;
+    static unsigned long long ready = 0;   // (bit per device)
+    {
+        const hipError_t e = lds_opt_in((const void*)kern, 160 * 1024, &ready);
+        if (e != hipSuccess) return e;
+    }
+    int64_t blocks = p.n_tiles < 256 ? p.n_tiles : 256;
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks, 1), dim3(SW * 64), stem3_lds_bytes(p, BF3), stream, p);
+    return hipGetLastError();
+}
+
+// static instantiations of the three-step tiles (16 columns in step 1 / middle / last, units per wave,
+// column groups of step 1, chunks of K1, items per wave of the middle and of the last step, 16-byte
+// gathers): the shapes the m20 tree fixtures and the test stems need (tools/stem_shapes.py); there is
+// no run-time-count variant -- the planner asks ctg_stem_triple_instantiated before it emits one
+#ifdef CTG_STEM_TRI_DEV
+#define CTG_STEM_TRI(X) \
+    X(true, true, true, 2, 1, 1, 2, 2, false) X(false, false, false, 1, 1, 2, 1, 1, false) \
+    X(true, false, true, 2, 1, 1, 1, 1, false) X(true, false, false, 1, 1, 1, 1, 1, true)
+#else
+#define CTG_STEM_TRI(X) \
+    X(true, true, false, 2, 1, 1, 2, 1, true) X(true, true, true, 2, 1, 1, 2, 2, false) \
+    X(false, false, false, 1, 1, 2, 1, 1, true) X(true, true, false, 2, 1, 1, 2, 1, false) \
+    X(true, false, true, 2, 1, 1, 1, 2, true) X(false, false, true, 1, 1, 2, 1, 2, false) \
+    X(false, true, false, 1, 2, 4, 2, 1, true) X(false, true, false, 1, 2, 1, 2, 2, false) \
+    X(true, false, true, 2, 1, 1, 1, 2, false) X(false, true, true, 1, 1, 2, 2, 2, false) \
+    X(false, false, true, 1, 1, 4, 1, 1, true) X(false, false, false, 1, 1, 2, 1, 1, false) \
+    X(false, false, false, 1, 2, 2, 1, 2, true) \
+    X(true, false, true, 2, 1, 1, 1, 1, false) X(true, false, true, 2, 1, 1, 1, 1, true) \
+    X(false, true, true, 1, 4, 2, 2, 2, true) X(false, true, false, 1, 1, 1, 2, 1, false) \
+    X(false, false, false, 1, 1, 2, 1, 4, false) X(true, true, false, 2, 1, 1, 2, 2, false) \
+    X(true, true, false, 2, 1, 2, 1, 2, false) X(true, false, false, 1, 1, 1, 1, 1, true)
+#endif
+
+static bool stem3_instantiated(bool p1, bool pm, bool p2, int rt1, int cs1, int nch, int itm, int it2, bool vec) {
+#define CTG_STEM_HAS3(A, M, B, R, CS, NC, IM, IT, V) \
+    if (p1 == A && pm == M && p2 == B && rt1 == R && cs1 == CS && nch == NC && itm == IM && it2 == IT && vec == V) return true;
+    CTG_STEM_TRI(CTG_STEM_HAS3)
+#undef CTG_STEM_HAS3
+    return false;
+}
+
+struct Stem3Shape { bool p1, pm, p2; int rt1, cs1, nch, itm, it2; bool vec; };
+static Stem3Shape stem3_shape(const StemArgs& p) {
+    Stem3Shape s;
+    s.p1 = p.N1 == 16; s.pm = p.NM == 16; s.p2 = p.N2 == 16;
+    s.cs1 = p.N1 >= 32 ? p.N1 / 32 : 1;
+    s.rt1 = ((1 << (p.nr1 - 5)) * s.cs1) / SW;
+    s.nch = p.K1 / 16;
+    const int im = (p.rowsM / 32) * p.ngM, i2 = (p.rows2 / 32) * p.ng2;
+    s.itm = im % SW == 0 ? im / SW : 0;
+    s.it2 = i2 % SW == 0 ? i2 / SW : 0;
+    s.vec = p.vec != 0;
+    return s;
+}
+
+bool stem3_instantiated_c(bool p1, bool pm, bool p2, int rt1, int cs1, int nch, int itm, int it2, bool vec) {
+    return stem3_instantiated(p1, pm, p2, rt1, cs1, nch, itm, it2, vec);
+}
+
+bool stem3_supported(const StemArgs& p) {
+    auto k_ok = [](int k) { return k == 16 || k == 32 || k == 64 || k == 128; };
+    auto n_ok = [](int n) { return n == 16 || n == 32 || n == 64 || n == 128; };
+    if (!p.tri || p.one || !k_ok(p.K1) || !k_ok(p.KM) || !k_ok(p.K2) || !n_ok(p.N1) || !n_ok(p.NM) || !n_ok(p.N2)) return false;
+    const int cs1 = p.N1 >= 32 ? p.N1 / 32 : 1;
+    if (p.nr1 < 5 || p.nr1 > 9) return false;
+    const int units = (1 << (p.nr1 - 5)) * cs1;
+    if (units != 8 && units != 16) return false;
+    if (p.rowsM < 32 || (p.rowsM & 31) || p.ldM != p.KM + 4 || p.rows2 < 32 || (p.rows2 & 31) || p.ld2 != p.K2 + 4) return false;
+    if ((int64_t)(1 << p.nr1) * p.N1 != (int64_t)p.rowsM * p.KM || (int64_t)p.rowsM * p.NM != (int64_t)p.rows2 * p.K2) return false;
+    if (p.ngM != (p.NM >= 32 ? p.NM / 32 : 1) || p.ng2 != (p.N2 >= 32 ? p.N2 / 32 : 1)) return false;
+    const Stem3Shape s = stem3_shape(p);
+    if (s.itm < 1 || s.itm > 2 || s.it2 < 1 || s.it2 > 4) return false;
+    if (!stem3_instantiated(s.p1, s.pm, s.p2, s.rt1, s.cs1, s.nch, s.itm, s.it2, s.vec)) return false;
+    return stem3_lds_bytes(p, true) <= 160 * 1024 && stem3_lds_bytes(p, false) <= 160 * 1024;
+}
+
 bool stem2_supported(const StemArgs& p) {
     auto k_ok = [](int k) { return k == 16 || k == 32 || k == 64 || k == 128; };
+    if (p.tri) return stem3_supported(p);
     if (p.one) {
         if (!k_ok(p.K1) || (p.N1 != 32 && p.N1 != 64 && p.N1 != 128) || p.K2 != 0 || p.N2 != 0) return false;
         if (p.nr1 < 5 || p.nr1 > 9) return false;
@@ -1214,6 +1446,10 @@ bool stem2_supported(const StemArgs& p) {
 //   CTG_STEM_GEO: the geometries (16 columns first, last, units per wave, column groups, chunks,
 //   items per wave, 16-byte gathers) -- the bf16 x 3 instantiations (B1 in registers up to two
 //   chunks, B2 from LDS, X / Y form)
+#ifdef CTG_STEM_DEV_MIN   // (development builds: one instantiation of each kind, a minute to compile)
+#define CTG_STEM_INST(X) X(false, false, 1, 1, 2, 1, true, 8, false, true)
+#define CTG_STEM_GEO(G) G(false, false, 1, 1, 2, 1, false)
+#else
 #define CTG_STEM_INST(X) \
     X(false, false, 1, 1, 2, 1, true, 8, false, true) X(false, true, 1, 1, 2, 2, true, 4, false, false) \
     X(false, false, 1, 2, 4, 1, true, 8, false, true) X(false, false, 1, 1, 2, 1, true, 16, false, true) \
@@ -1253,6 +1489,7 @@ bool stem2_supported(const StemArgs& p) {
     G(true, false, 2, 1, 2, 1, false) G(true, true, 2, 1, 1, 2, false) G(true, true, 2, 1, 1, 2, true) \
     G(true, true, 2, 1, 4, 1, false) G(false, false, 1, 2, 2, 2, true) G(false, true, 1, 2, 1, 2, false) \
     G(true, false, 2, 1, 4, 1, false)
+#endif
 
 namespace {
 struct StemShape {
@@ -1307,9 +1544,13 @@ StemShape stem2_shape(const StemArgs& p, bool bf3 = false) {
 
 // single steps (ONE): (units per wave, column groups, chunks of K1, 16-byte gathers) of the m20 trees
 // (B1 in registers up to K1 = 64; bf16 x 3: up to two chunks); anything else: run-time counts, fp32
+#ifdef CTG_STEM_DEV_MIN
+#define CTG_STEM_ONE(X) X(1, 1, 2, false)
+#else
 #define CTG_STEM_ONE(X) \
     X(1, 4, 8, false) X(1, 1, 2, false) X(1, 2, 4, false) X(1, 1, 8, false) \
     X(1, 1, 4, false) X(1, 4, 4, false) X(1, 1, 2, true) X(1, 2, 2, true) X(2, 1, 1, false) X(1, 2, 8, false)
+#endif
 
 static bool stem1_static(const StemShape& s) {
     if (env_on("CTG_STEM_GENERIC")) return false;
@@ -1349,6 +1590,11 @@ static bool stem2_has_geo(const StemShape& s) {
 // option ctg_exec_set_stem_arithmetic(exec, 0) selects fp32 products on the fp32 matrix cores; the
 // environment variable CTG_STEM_BF16X3, when SET, overrides both ("0" / "" = fp32, anything else =
 // bf16 x 3) and is read at every launch (tests switch it within a process).
+static bool stem3_bf3(const StemArgs& p) {   // (three-step tiles: every listed shape exists in both arithmetics)
+    const char* v = getenv("CTG_STEM_BF16X3");
+    return v != nullptr ? !(v[0] == '\0' || (v[0] == '0' && v[1] == '\0')) : p.bf3 != 0;
+}
+
 static bool stem2_bf3(const StemArgs& p) {
     const char* v = getenv("CTG_STEM_BF16X3");
     const bool want = v != nullptr ? !(v[0] == '\0' || (v[0] == '0' && v[1] == '\0')) : p.bf3 != 0;
@@ -1360,6 +1606,12 @@ static bool stem2_bf3(const StemArgs& p) {
 void stem2_kernel_name(const StemArgs& p, char* buf, size_t n) {
     const StemShape s = stem2_shape(p);
     auto tf = [](bool b) { return b ? "true" : "false"; };
+    if (p.tri) {
+        const Stem3Shape t = stem3_shape(p);
+        snprintf(buf, n, "stem2_kernel<%s,%s,%d,%d,%d,%d,%s,0,%s,%s,false,false,%d,%s>", tf(t.p1), tf(t.p2), t.rt1, t.cs1,
+                 t.nch, t.it2, tf(t.nch <= 2), tf(t.vec), tf(stem3_bf3(p)), t.itm, tf(t.pm));
+        return;
+    }
     if (p.one) {
         const bool st = stem1_static(s), b3 = stem2_bf3(p);
         snprintf(buf, n, "stem2_kernel<false,false,%d,%d,%d,0,%s,0,%s,%s,false,true>", s.rt1, s.cs1, st ? s.nch : 0,
@@ -1379,6 +1631,18 @@ void stem2_kernel_name(const StemArgs& p, char* buf, size_t n) {
 
 hipError_t launch_stem2(const StemArgs& p, hipStream_t stream) {
     if (!stem2_supported(p)) return hipErrorInvalidValue;
+    if (p.tri) {
+        const Stem3Shape t = stem3_shape(p);
+        const bool b3 = stem3_bf3(p);
+#define CTG_STEM_GO3T(A, M, B, R, CS, NC, IM, IT, V)                                                                  \
+    if (t.p1 == A && t.pm == M && t.p2 == B && t.rt1 == R && t.cs1 == CS && t.nch == NC && t.itm == IM && t.it2 == IT && \
+        t.vec == V)                                                                                                   \
+        return b3 ? launch_stem3_t<A, M, B, R, CS, NC, IM, IT, V, true>(p, stream)                                    \
+                  : launch_stem3_t<A, M, B, R, CS, NC, IM, IT, V, false>(p, stream);
+        CTG_STEM_TRI(CTG_STEM_GO3T)
+#undef CTG_STEM_GO3T
+        return hipErrorInvalidValue;
+    }
     if (p.one) {
         const StemShape s = stem2_shape(p, true);
         const bool b3 = stem2_bf3(p);
@@ -1437,3 +1701,8 @@ hipError_t launch_stem2(const StemArgs& p, hipStream_t stream) {
 }
 
 }  // namespace ctg
+
+// (include/ctg_hip.h) is there a three-step tile kernel for this shape?  A pure function of the shape.
+extern "C" int ctg_stem_triple_instantiated(int p1, int pm, int p2, int rt1, int cs1, int nch, int itm, int it2, int vec) {
+    return ctg::stem3_instantiated_c(p1 != 0, pm != 0, p2 != 0, rt1, cs1, nch, itm, it2, vec != 0) ? 1 : 0;
+}

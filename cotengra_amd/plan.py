@@ -769,6 +769,8 @@ def compile_tree(tree, dtype, order=None, force_kernel=None, fuse=None, fuse_min
             step.a_prod = producer.get(id(step.a), -1)
             step.b_prod = producer.get(id(step.b), -1)
             step.b2_prod = producer.get(id(step.b2), -1) if step.b2 is not None else -1
+            if getattr(step, "bm", None) is not None:
+                step.bm_prod = producer.get(id(step.bm), -1)
             producer[id(step.c)] = len(plan.steps)
         plan.steps.append(step)
         plan.macs_per_slice += step.macs
@@ -877,6 +879,33 @@ def compile_tree(tree, dtype, order=None, force_kernel=None, fuse=None, fuse_min
                 one = build_stem_one(size_dict, A1, B1, p_inds, factory, node=p)
                 if one is not None:
                     steps_new = [one]
+            elif p in pairs and p in pair_second and not is_root and (
+                    id(tl) in stem_pending or id(tr) in stem_pending):
+                # middle step of a three-step tile (stem.build_stem_triple): still nothing emitted;
+                # the chain (A, B1, first node, BM, legs of the first intermediate) waits for the last
+                virt, other = (tl, tr) if id(tl) in stem_pending else (tr, tl)
+                chain = stem_pending.pop(id(virt))
+                if len(chain) == 3 and pick_rows_operand(size_dict, virt, other, p_inds)[0] is virt:
+                    virt2 = TensorRef(-2, 0, -1, p_inds, (0,) * len(p_inds), prod(size_dict[ix] for ix in p_inds))
+                    stem_pending[id(virt2)] = chain + (other, virt.inds, p)
+                    tensors[p] = virt2
+                    continue
+                # (does not chain after all: the first step as usual, this one starts a pair)
+                A1, B1, p1 = chain[:3]
+                first = build_pair_step(dtype, size_dict, A1, B1, virt.inds, arena_factory(invariant=inv), node=p1)
+                first.invariant = inv
+                add(first)
+                for ref in (first.a, first.b):
+                    release(ref) if level is None else pending.append(ref)
+                if virt is tl:
+                    tl = first.c
+                else:
+                    tr = first.c
+                A1, B1 = pick_rows_operand(size_dict, tl, tr, p_inds)
+                virt = TensorRef(-2, 0, -1, p_inds, (0,) * len(p_inds), prod(size_dict[ix] for ix in p_inds))
+                stem_pending[id(virt)] = (A1, B1, p)
+                tensors[p] = virt
+                continue
             elif p in pairs and not is_root:
                 # first step of a fused pair: nothing is emitted, nothing allocated; the
                 # operands stay alive until the second step takes them
@@ -889,13 +918,50 @@ def compile_tree(tree, dtype, order=None, force_kernel=None, fuse=None, fuse_min
                 from .stem import build_stem_step
 
                 virt, other = (tl, tr) if id(tl) in stem_pending else (tr, tl)
-                A1, B1, p1 = stem_pending.pop(id(virt))
+                chain = stem_pending.pop(id(virt))
+                if len(chain) == 6:
+                    # last step of a three-step tile
+                    from .stem import build_stem_triple
+
+                    A1, B1, p1, BM, c1_inds, pm = chain
+                    triple = None
+                    if pick_rows_operand(size_dict, virt, other, p_inds)[0] is virt:
+                        triple = build_stem_triple(size_dict, A1, B1, BM, other, c1_inds, virt.inds, p_inds, factory, node=p)
+                    if triple is not None:
+                        triple.invariant = inv
+                        add(triple)
+                        for ref in (triple.a, triple.b, triple.bm, triple.b2):
+                            release(ref) if level is None else pending.append(ref)
+                        tensors[p] = triple.c
+                        final = triple.c
+                        continue
+                    # (no tile after all: the first two as a pair -- or one by one -- then this step)
+                    two = build_stem_step(size_dict, A1, B1, BM, c1_inds, virt.inds, arena_factory(invariant=inv), node=pm)
+                    if two is None:
+                        one_ = build_pair_step(dtype, size_dict, A1, B1, c1_inds, arena_factory(invariant=inv), node=p1)
+                        two_ = build_pair_step(dtype, size_dict, one_.c, BM, virt.inds, arena_factory(invariant=inv), node=pm)
+                        emitted = [one_, two_]
+                    else:
+                        emitted = [two]
+                    for st_ in emitted:
+                        st_.invariant = inv
+                        add(st_)
+                        ops_ = [st_.a, st_.b] + ([st_.b2] if st_.kind == KIND_STEM2 and st_.b2 is not None else [])
+                        for ref in ops_:
+                            release(ref) if level is None else pending.append(ref)
+                    if virt is tl:
+                        tl = emitted[-1].c
+                    else:
+                        tr = emitted[-1].c
+                    chain = None
                 fused = None
-                if pick_rows_operand(size_dict, virt, other, p_inds)[0] is virt:
+                if chain is not None:
+                    A1, B1, p1 = chain
+                if chain is not None and pick_rows_operand(size_dict, virt, other, p_inds)[0] is virt:
                     fused = build_stem_step(size_dict, A1, B1, other, virt.inds, p_inds, factory, node=p)
                 if fused is not None:
                     steps_new = [fused]
-                else:
+                elif chain is not None:
                     # the pair does not fit after all: both steps as usual, one after the other
                     first = build_pair_step(
                         dtype, size_dict, A1, B1, virt.inds, arena_factory(invariant=inv), node=p1,

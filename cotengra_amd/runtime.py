@@ -12,7 +12,7 @@ import os
 import numpy as np
 
 _LIB_PATH = os.environ.get("CTG_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libctg_hip.so")
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 # every symbol include/ctg_hip.h declares
 SYMBOLS = (
@@ -34,6 +34,7 @@ SYMBOLS = (
     "ctg_exec_run_slices",
     "ctg_exec_slice_batch",
     "ctg_exec_device_bytes",
+    "ctg_stem_triple_instantiated",
     "ctg_exec_launch_count",
     "ctg_exec_profile_slice",
     "ctg_exec_step_kernel",
@@ -133,6 +134,7 @@ def load():
         "ctg_exec_run_slices": [vp, C.c_int64, C.c_int64, C.c_int64],
         "ctg_exec_slice_batch": [vp, i64p],
         "ctg_exec_device_bytes": [vp, i64p],
+        "ctg_stem_triple_instantiated": [C.c_int] * 9,
         "ctg_exec_launch_count": [vp, i64p, i64p],
         "ctg_exec_profile_slice": [vp, C.c_int64, C.POINTER(C.c_float)],
         "ctg_exec_step_kernel": [vp, C.c_int64, C.c_char_p, C.c_int64],

@@ -44,7 +44,7 @@ LDS_BYTES = 160 * 1024       # per CU (one workgroup per CU)
 LDS_SLACK = 256
 G_LO_BITS = 12               # fast level of the two-level grid tables
 
-DESC_WORDS = 40              # header of the serialised descriptor (int64 words)
+DESC_WORDS = 56              # header of the serialised descriptor (int64 words; 40 until ABI 4)
 DESC_MAGIC = 0x53544D33      # "STM3"
 
 # what the kernel is instantiated for (csrc/ctg_stem.hip: launch_stem2)
@@ -380,6 +380,8 @@ def find_pairs(plan, size_dict, min_elems=1 << 24, model=None, bf16x3=None):
                              bf3_fits=geo.bf3_fits)
         if before - after >= MIN_GAIN * before:
             gain[i2] = (i1, before - after)
+    if triples_enabled() and bf16x3_mode(bf16x3):
+        return _find_chains(steps, size_dict, by_out, classify, unfused_seconds, gain, min_elems, bf16x3)
     # chains: i1 -> i2 -> i3 ...; a step can be in one pair only
     best = {}   # step -> (total gain of the chain ending here, pairs chosen)
     order = sorted(gain)
@@ -421,6 +423,94 @@ def find_pairs(plan, size_dict, min_elems=1 << 24, model=None, bf16x3=None):
             if before - after >= MIN_GAIN * before:
                 chosen[s1.node] = s1.node
     return chosen
+
+
+def _find_chains(steps, size_dict, by_out, classify, unfused_seconds, gain2, min_elems, bf16x3):
+    """``find_pairs`` with three-step tiles among the choices (``CTG_STEM_TRIPLES``): a dynamic
+    programme along every chain of stem steps over "alone", "second of a pair" and "last of a
+    triple".  A triple ``n1 -> n2 -> n3`` comes back as the two links ``{n1: n2, n2: n3}``."""
+    def ok(i):
+        s = steps[i]
+        return s.kind == P.KIND_PAIR and classify(i) is not None
+
+    pred = {}
+    for i, s in enumerate(steps):
+        j = by_out.get(id(s.a)) if s.kind == P.KIND_PAIR else None
+        if j is not None and ok(i) and ok(j) and steps[j].invariant == s.invariant:
+            pred[i] = j
+    gain3 = {}
+    for i3, i2 in pred.items():
+        i1 = pred.get(i2)
+        if i1 is None:
+            continue
+        s1, s2, s3 = steps[i1], steps[i2], steps[i3]
+        if s1.a.size < min_elems or s1.a.leaf >= 0:
+            continue
+        geo = geometry3(size_dict, s1.a, s1.b, s2.b, s3.b, s1.c.inds, s2.c.inds, s3.c.inds)
+        if geo is None or not _triple_instantiated(geo):
+            continue
+        before = unfused_seconds(s1) + unfused_seconds(s2) + unfused_seconds(s3)
+        after = triple_seconds(s1.macs, s2.macs, s3.macs, s1.a.size, s3.c.size, geo.run_bytes, bf16x3=bf16x3)
+        if before - after >= MIN_GAIN * before:
+            gain3[i3] = (i1, i2, before - after)
+    best = {}   # step -> (gain of the chain up to and including it, links chosen)
+    zero = (0.0, ())
+    for i in sorted(set(pred) | set(pred.values())):
+        cands = [best.get(pred.get(i), zero)]
+        if i in gain2 and gain2[i][0] == pred.get(i):
+            i1, g = gain2[i]
+            b = best.get(pred.get(i1), zero)
+            cands.append((b[0] + g, b[1] + ((i1, i),)))
+        if i in gain3:
+            i1, i2, g = gain3[i]
+            b = best.get(pred.get(i1), zero)
+            cands.append((b[0] + g, b[1] + ((i1, i2, i),)))
+        best[i] = max(cands, key=lambda c: c[0])
+    chosen = {}
+    ends = set(best) - set(pred.values())
+    for i in sorted(ends):
+        for link in best[i][1]:
+            for a, b in zip(link, link[1:]):
+                chosen[steps[a].node] = steps[b].node
+    in_chain = {n for kv in chosen.items() for n in kv}
+    if os.environ.get("CTG_NO_STEM_ONE", "0") in ("", "0"):
+        for i, s1 in enumerate(steps):
+            if s1.kind != P.KIND_PAIR or s1.node in in_chain or s1.a.size < min_elems or s1.a.leaf >= 0:
+                continue
+            if classify(i) is None:
+                continue
+            geo = geometry_one(size_dict, s1.a, s1.b, s1.c.inds)
+            if geo is None:
+                continue
+            before = unfused_seconds(s1)
+            after = single_seconds(s1.macs, s1.a.size, s1.c.size, geo.run_bytes, bf16x3=bf16x3, bf3_fits=geo.bf3_fits)
+            if before - after >= MIN_GAIN * before:
+                chosen[s1.node] = s1.node
+    return chosen
+
+
+def triple_shape(geo):
+    """The template arguments of ``stem2_kernel`` a three-step tile needs
+    (csrc/ctg_stem.hip: CTG_STEM_TRI): 16 columns in step 1 / middle / last, units per wave, column
+    groups of step 1, chunks of K1, items per wave of the middle and the last step, 16-byte gathers."""
+    cs1 = max(1, geo.N1 // 32)
+    return (geo.N1 == 16, geo.NM == 16, geo.N2 == 16, ((1 << (geo.nr1 - 5)) * cs1) // WAVES, cs1, geo.K1 // 16,
+            geo.items_m // WAVES, geo.items // WAVES, bool(geo.vec))
+
+
+def _triple_instantiated(geo):
+    """Three-step tiles run on static instantiations only: ask the library (a pure function of the
+    shape, no device needed) -- the planner must not emit a record the kernel list does not hold."""
+    from . import runtime
+
+    if os.environ.get("CTG_STEM_TRIPLES") == "any":   # (planner tests: every tile that fits)
+        return True
+    lib = runtime.load()
+    fn = getattr(lib, "ctg_stem_triple_instantiated", None)
+    if fn is None:
+        return False
+    p1, pm, p2, rt1, cs1, nch, itm, it2, vec = triple_shape(geo)
+    return bool(fn(int(p1), int(pm), int(p2), rt1, cs1, nch, itm, it2, int(vec)))
 
 
 def build_stem_step(size_dict, A, B1, B2, c1_inds, out_inds, out_ref_factory, node=-1):
@@ -568,6 +658,218 @@ def build_stem_one(size_dict, A, B1, out_inds, out_ref_factory, node=-1):
     return step
 
 
+def triples_enabled():
+    """Three-step tiles (``geometry3`` / ``build_stem_triple``) are chosen by ``find_pairs`` only
+    when ``CTG_STEM_TRIPLES`` is set to something other than "" / "0" (round 4: the path is new)."""
+    return os.environ.get("CTG_STEM_TRIPLES", "0") not in ("", "0")
+
+
+def triple_lds_bytes(K1, N1, KM, NM, K2, N2, rowsM, rows2, bf16x3=True):
+    """LDS of a three-step tile: the three small operands' planes, the two intermediates in ONE
+    region (the second is written over the first between two barriers), the column table
+    (csrc/ctg_stem.hip: stem3_lds_bytes)."""
+    mid = 8 * max(rowsM * (KM + 4), rows2 * (K2 + 4))
+    if bf16x3:
+        q = ((3 if N1 == 16 else 2) * N1 * ((K1 >> 4) * 48 + 8) + (3 if NM == 16 else 2) * NM * ((KM >> 3) * 24 + 8)
+             + (3 if N2 == 16 else 2) * N2 * ((K2 >> 3) * 24 + 8))
+        return 2 * q + mid + 8 * N2 + 64
+    return b_lds_bytes(K1, N1) + b_lds_bytes(KM, NM) + b_lds_bytes(K2, N2) + mid + 8 * N2
+
+
+def geometry3(size_dict, A, B1, BM, B2, c1_inds, cm_inds, out_inds):
+    """Tile decomposition of THREE consecutive stem steps
+
+        C1[r1, n1] = sum_k1 A[r1, k1] B1[k1, n1]
+        CM[rM, nM] = sum_kM C1[rM, kM] BM[kM, nM]       (the middle step; rM u kM = r1 u n1)
+        C2[r2, n2] = sum_k2 CM[r2, k2] B2[k2, n2]       (the last one;   r2 u k2 = rM u nM)
+
+    as one tile: the row digits of a tile of ``A`` hold the contracted digits of BOTH later steps
+    that live on ``A`` (``kMr``, ``k2a``) plus the lowest-stride free digits; the first intermediate
+    is laid out ``[rM][kM]`` in LDS, the second ``[r2][k2]`` over it.  ``None`` if the three do not
+    fit (shapes, tile rows, LDS, item counts that are multiples of the eight waves)."""
+    o1, om, o2 = set(c1_inds), set(cm_inds), set(out_inds)
+    a_bits = _bits_of(A.inds, size_dict)
+    k1 = _bits_of([ix for ix in A.inds if ix not in o1], size_dict)
+    n1 = _bits_of([ix for ix in B1.inds if ix in o1], size_dict)
+    km = _bits_of([ix for ix in c1_inds if ix not in om], size_dict)
+    nm = _bits_of([ix for ix in BM.inds if ix in om], size_dict)
+    k2 = _bits_of([ix for ix in cm_inds if ix not in o2], size_dict)
+    n2 = _bits_of([ix for ix in B2.inds if ix in o2], size_dict)
+    if None in (a_bits, k1, n1, km, nm, k2, n2):
+        return None
+    K1, N1, KM, NM, K2, N2 = (1 << len(g) for g in (k1, n1, km, nm, k2, n2))
+    if any(k not in K_OK for k in (K1, KM, K2)) or N1 not in N1_OK or NM not in N2_OK or N2 not in N2_OK:
+        return None
+    a_set, k1_set, n1_set, nm_set, km_set = set(a_bits), set(k1), set(n1), set(nm), set(km)
+    kmr = [b for b in km if b not in n1_set]
+    if any(b not in a_set or b in k1_set for b in kmr):
+        return None
+    k2a = [b for b in k2 if b in a_set]                      # contracted by the last step, still on A's rows
+    if any(b in k1_set or b in km_set for b in k2a):
+        return None
+    if any(b not in a_set and b not in n1_set and b not in nm_set for b in k2):
+        return None
+    if any(b in n1_set and b in km_set for b in k2):          # (gone after the middle step)
+        return None
+
+    def sa(b):
+        return _stride(A, b)
+
+    taken = set(kmr) | set(k2a)
+    free = sorted((b for b in a_bits if b not in k1_set and b not in taken), key=sa)
+    cs1 = max(1, N1 // 32)
+    best = None
+    for units in (WAVES, 2 * WAVES):
+        if units < cs1:
+            continue
+        nr1 = 5 + _log2(units // cs1)
+        nx = nr1 - len(kmr) - len(k2a)
+        if nx < 0 or nx > len(free):
+            continue
+        rm_bits = nr1 + len(n1) - len(km)
+        r2_bits = rm_bits + len(nm) - len(k2)
+        if rm_bits < 5 or r2_bits < 5:
+            continue
+        rows_m, rows2 = 1 << rm_bits, 1 << r2_bits
+        lds = triple_lds_bytes(K1, N1, KM, NM, K2, N2, rows_m, rows2) + LDS_SLACK
+        if lds > LDS_BYTES:
+            continue
+        ngm, ng2 = max(1, NM // 32), max(1, N2 // 32)
+        items_m, items2 = (rows_m // 32) * ngm, (rows2 // 32) * ng2
+        if items_m % WAVES or items2 % WAVES or items_m // WAVES > 2 or items2 // WAVES > 4:
+            continue
+        deep = 1 if (K1 == 16 and units == 2 * WAVES) else 0
+        cand = (deep, -nr1, nr1, nx, rm_bits, r2_bits, ngm, ng2, items_m, items2, lds)
+        if best is None or cand > best:
+            best = cand
+    if best is None:
+        return None
+    _, _, nr1, nx, rm_bits, r2_bits, ngm, ng2, items_m, items2, lds = best
+    g = Geometry()
+    g.K1, g.N1, g.KM, g.NM, g.K2, g.N2 = K1, N1, KM, NM, K2, N2
+    g.nr1, g.rowsm_bits, g.rows2_bits, g.ngm, g.ng2, g.items_m, g.items, g.lds = nr1, rm_bits, r2_bits, ngm, ng2, items_m, items2, lds
+    g.bf3_fits = True
+    g.k1 = sorted(k1, key=sa)
+    g.n1 = sorted(n1, key=lambda b: _stride(B1, b))
+    x = free[:nx]
+    g.r1 = sorted(kmr + k2a + x, key=sa)
+    r1_set = set(g.r1)
+    g.grid = sorted((b for b in a_bits if b not in k1_set and b not in r1_set), key=sa)
+    g.km = [b for b in km if b in n1_set] + sorted(kmr, key=sa)      # kM index: the fresh columns first
+    g.nm = sorted(nm, key=lambda b: _stride(BM, b))
+    g.rm_members = [b for b in g.r1 if b not in km_set] + [b for b in g.n1 if b not in km_set]
+    k2_set = set(k2)
+    g.k2 = [b for b in k2 if b in nm_set] + [b for b in k2 if b in n1_set] + sorted(k2a, key=sa)
+    g.r2_members = [b for b in g.rm_members if b not in k2_set] + [b for b in g.nm if b not in k2_set]
+    g.n2 = n2
+    g.row_a = _table(g.r1, [sa(b) for b in g.r1])
+    g.k_a = _table(g.k1, [sa(b) for b in g.k1])
+    g.vec = bool(g.k_a[1] == 1 and A.offset % 2 == 0)
+    hbit = 2 if g.vec else 1
+    if A.leaf >= 0 or 8 * int(g.row_a[31] + g.k_a[hbit]) >= 1 << 32:
+        return None
+    task = np.sort((g.row_a[:32, None] + g.k_a[None, :16]).reshape(-1))
+    runs = np.flatnonzero(np.diff(task) != 1)
+    g.run_bytes = 8 * int(runs[0] + 1 if len(runs) else len(task))
+    return g
+
+
+def triple_seconds(macs1, macs_m, macs2, elems_a, elems_c2, run_bytes=256, bf16x3=None):
+    """Modelled time of a three-step tile: the pair model with one more step's matrix work and the
+    same traffic (the big operand in, the LAST result out)."""
+    rate = FUSED_MFMA_RATE * (BF16X3_SPEEDUP if bf16x3_mode(bf16x3) else 1.0)
+    t_mfma = 8.0 * (macs1 + macs_m + macs2) / rate
+    t_mem = 8.0 * elems_a / gather_rate(run_bytes) + 8.0 * elems_c2 / FUSED_STORE_RATE
+    return max(t_mfma, t_mem) + FUSED_OVERLAP_LOSS * min(t_mfma, t_mem)
+
+
+def build_stem_triple(size_dict, A, B1, BM, B2, c1_inds, cm_inds, out_inds, out_ref_factory, node=-1):
+    """Lower three consecutive stem steps (``geometry3``) to one STEM2 step with a MIDDLE stage:
+    the record of a pair (whose "second step" fields describe the LAST step) plus the middle
+    step's shape, small operand and tables.  ``None`` if the three do not fit."""
+    geo = geometry3(size_dict, A, B1, BM, B2, c1_inds, cm_inds, out_inds)
+    if geo is None:
+        return None
+    o2 = set(out_inds)
+    seen = set()
+    natural = []
+    for ref in (A, B1, BM, B2):
+        for ix in ref.inds:
+            if ix in o2 and ix not in seen:
+                seen.add(ix)
+                natural.append(ix)
+    C = out_ref_factory(tuple(out_inds), tuple(natural))
+
+    def sa(b):
+        return _stride(A, b)
+
+    def sc(b):
+        return _stride(C, b)
+
+    K1, N1, KM, NM, K2, N2 = geo.K1, geo.N1, geo.KM, geo.NM, geo.K2, geo.N2
+    rm = list(geo.rm_members)                      # rows of the middle step: any fixed order (LDS only)
+    r2 = sorted(geo.r2_members, key=sc)            # rows of the last step, digit 0 = lowest stride in C2
+    n2 = sorted(geo.n2, key=sc)
+    ldm, ld2 = KM + 4, K2 + 4
+    row_a, k_a = geo.row_a, geo.k_a
+    lane, slot = np.arange(64), np.arange(8)
+    if geo.vec:
+        lane_a = row_a[lane & 31] + k_a[2 * (lane >> 5)]
+        kj_a = k_a[4 * (slot >> 1) + (slot & 1)]
+    else:
+        lane_a = row_a[lane & 31] + k_a[lane >> 5]
+        kj_a = k_a[2 * slot]
+
+    def b_off(ref, kbits, nbits):
+        tk = _table(kbits, [_stride(ref, b) for b in kbits])
+        tn = _table(nbits, [_stride(ref, b) for b in nbits])
+        return (tk[:, None] + tn[None, :]).reshape(-1)
+
+    def layout(kbits, rbits, ld):
+        pos_k = {b: p for p, b in enumerate(kbits)}
+        pos_r = {b: p for p, b in enumerate(rbits)}
+        return lambda b: (1 << pos_k[b]) if b in pos_k else (1 << pos_r[b]) * ld
+
+    at_m = layout(geo.km, rm, ldm)                 # first intermediate: element -> rowM * ldM + kM
+    at_2 = layout(geo.k2, r2, ld2)                 # second: row2 * ld2 + k2
+    g_lo_bits = min(G_LO_BITS, len(geo.grid))
+    glo, ghi = geo.grid[:g_lo_bits], geo.grid[g_lo_bits:]
+    tabs = {
+        "gA_hi": _table(ghi, [sa(b) for b in ghi]), "gA_lo": _table(glo, [sa(b) for b in glo]),
+        "gC_hi": _table(ghi, [sc(b) for b in ghi]), "gC_lo": _table(glo, [sc(b) for b in glo]),
+        "kj_a": kj_a, "lane_a": lane_a, "rt_a": row_a[::32].copy(), "chunk_a": k_a[::16].copy(),
+        "b1_off": b_off(B1, geo.k1, geo.n1), "b2_off": b_off(B2, geo.k2, n2),
+        "mid_row": _table(geo.r1, [at_m(b) for b in geo.r1]), "mid_col": _table(geo.n1, [at_m(b) for b in geo.n1]),
+        "out_row": _table(r2, [sc(b) for b in r2]), "out_col": _table(n2, [sc(b) for b in n2]),
+        # the middle stage: BM[kM * NM + nM]; its result (rowM, nM) -> the second intermediate
+        "bm_off": b_off(BM, geo.km, geo.nm),
+        "mid2_row": _table(rm, [at_2(b) for b in rm]), "mid2_col": _table(geo.nm, [at_2(b) for b in geo.nm]),
+    }
+    step = P.Step(kind=P.KIND_STEM2, kernel=P.KERNEL_MFMA, a=A, b=B1, c=C, node=node)
+    step.b2 = B2
+    step.bm = BM
+    rows_total = A.size // K1
+    rows_m_total = (rows_total * N1) // KM
+    step.R = (rows_m_total * NM) // K2
+    step.stem = {
+        "K1": K1, "N1": N1, "K2": K2, "N2": N2, "nr1": geo.nr1, "rows2": 1 << geo.rows2_bits,
+        "ng2": geo.ng2, "n_tiles": 1 << len(geo.grid), "g_lo": 1 << g_lo_bits, "ld2": ld2,
+        "lds_bytes": geo.lds, "items": geo.items, "run_bytes": geo.run_bytes, "vec": int(geo.vec), "tabs": tabs,
+        "bf3_fits": True, "KM": KM, "NM": NM, "rowsM": 1 << geo.rowsm_bits, "ngM": geo.ngm, "ldM": ldm,
+        "itemsM": geo.items_m,
+    }
+    step.Bt, step.K, step.N = 1, K2, N2
+    macs1, macs_m, macs2 = rows_total * K1 * N1, rows_m_total * KM * NM, step.R * K2 * N2
+    c1_size, cm_size = rows_total * N1, rows_m_total * NM
+    step.macs = macs1 + macs_m + macs2
+    step.stem["macs3"] = (macs1, macs_m, macs2)
+    b1e, bme, b2e = K1 * N1, KM * NM, K2 * N2
+    step.elems_rw = (A.size + b1e + c1_size) + (c1_size + bme + cm_size) + (cm_size + b2e + step.R * N2)
+    step.elems_moved = A.size + b1e + bme + b2e + step.R * N2
+    step.label = f"stem3 k{K1} n{N1} | k{KM} n{NM} | k{K2} n{N2} rows {rows_total}"
+    return step
+
+
 TAB_ORDER = ("gA_hi", "gA_lo", "gC_hi", "gC_lo", "kj_a", "lane_a", "rt_a", "chunk_a",
              "b1_off", "b2_off", "mid_row", "mid_col", "out_row", "out_col")
 
@@ -593,4 +895,12 @@ def serialise_stem(step, put):
     head[18] = st.get("one", 0)
     for i, name in enumerate(TAB_ORDER):
         head[20 + i] = put(st["tabs"][name])
+    if st.get("KM"):
+        # a middle stage (three-step tile): its shape at words 34..39, its small operand at 40..44,
+        # its tables (bm_off, mid2_row, mid2_col) at 45..47
+        bm = step.bm
+        head[34:40] = (st["KM"], st["NM"], st["rowsM"], st["ngM"], st["ldM"], 1)
+        head[40:45] = (bm.space, bm.offset, bm.leaf, bm.size, getattr(step, "bm_prod", -1))
+        for i, name in enumerate(("bm_off", "mid2_row", "mid2_col")):
+            head[45 + i] = put(st["tabs"][name])
     return put(head)

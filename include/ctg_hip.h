@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define CTG_ABI_VERSION 4
+#define CTG_ABI_VERSION 5
 
 /* element types of the tensors (reference tests cover all four:
  * tests/test_compute.py:102-115) */
@@ -177,6 +177,15 @@ int ctg_exec_slice_batch(ctg_exec* exec, int64_t* batch);
  * (allocated by ctg_exec_create).  What a cache of contractors -- the reference keeps them
  * on the tree, core.py:3708-3722 -- has to count against its budget. */
 int ctg_exec_device_bytes(ctg_exec* exec, int64_t* bytes);
+/* ABI 5.  Is there a kernel instantiation for a three-step tile of this shape (stem steps fused
+ * three at a time, cotengra_amd/stem.py: build_stem_triple; opt-in, CTG_STEM_TRIPLES)?  A pure
+ * function of the shape -- 16 output columns in the first / middle / last step (0 / 1), units of
+ * step 1 per wave, its column groups, 16-deep chunks of its contraction, work items per wave of the
+ * middle and of the last step, 16-byte gathers (0 / 1) -- that needs no device: the planner asks
+ * before it emits such a record (there is no run-time-count variant; ctg_plan_create rejects a
+ * record without one).  Returns 1 or 0.  (The reference has no counterpart: it contracts step by
+ * step, contract.py:788-832.) */
+int ctg_stem_triple_instantiated(int p1, int pm, int p2, int rt1, int cs1, int nch, int itm, int it2, int vec);
 
 /* Steps of one slice and the kernel launches they take.  Independent small steps
  * (the leaves-upward wave fronts of a tree; the reference contracts them one

@@ -58,6 +58,7 @@ def run_stem2(step, spaces, base, chunk=256):
     """
     st, T = step.stem, step.stem["tabs"]
     one = bool(st.get("one"))   # the first half alone: the product goes straight to the result
+    tri = bool(st.get("KM"))    # a middle stage between the two (three-step tile)
     A, B1, C = (spaces[t.space] for t in (step.a, step.b, step.c))
     B2 = None if one else spaces[step.b2.space]
     K1, N1, K2, N2, ld2, rows2 = st["K1"], st["N1"], st["K2"], st["N2"], st["ld2"], st["rows2"]
@@ -81,9 +82,18 @@ def run_stem2(step, spaces, base, chunk=256):
     else:
         b2 = B2[base(step.b2) + T["b2_off"]].reshape(K2, N2)
         mid_at = (T["mid_row"][:, None] + T["mid_col"][None, :]).reshape(-1)
-        assert len(np.unique(mid_at)) == rows1 * N1 and mid_at.max() < rows2 * ld2
-        assert rows1 * N1 == rows2 * K2
         take = (np.arange(rows2)[:, None] * ld2 + np.arange(K2)[None, :])
+        if tri:
+            KM, NM, rows_m, ld_m = st["KM"], st["NM"], st["rowsM"], st["ldM"]
+            bm = spaces[step.bm.space][base(step.bm) + T["bm_off"]].reshape(KM, NM)
+            assert len(np.unique(mid_at)) == rows1 * N1 and mid_at.max() < rows_m * ld_m
+            assert rows1 * N1 == rows_m * KM and rows_m * NM == rows2 * K2
+            take_m = (np.arange(rows_m)[:, None] * ld_m + np.arange(KM)[None, :])
+            mid2_at = (T["mid2_row"][:, None] + T["mid2_col"][None, :]).reshape(-1)
+            assert len(np.unique(mid2_at)) == rows_m * NM and mid2_at.max() < rows2 * ld2
+        else:
+            assert len(np.unique(mid_at)) == rows1 * N1 and mid_at.max() < rows2 * ld2
+            assert rows1 * N1 == rows2 * K2
     g_lo = st["g_lo"]
     for g0 in range(0, st["n_tiles"], chunk):
         g = np.arange(g0, min(g0 + chunk, st["n_tiles"]))
@@ -94,8 +104,17 @@ def run_stem2(step, spaces, base, chunk=256):
         if one:
             C[gc[:, None, None] + out_at[None]] = c1
             continue
-        mid = np.zeros((len(g), rows2 * ld2), dtype=c1.dtype)
-        mid[:, mid_at] = c1.reshape(len(g), -1)
+        if tri:
+            # three-step tile: the first intermediate [rowsM][ldM] x BM, its result laid out as the
+            # second intermediate [rows2][ld2] through mid2_row[rowM] + mid2_col[nM]
+            mid = np.zeros((len(g), rows_m * ld_m), dtype=c1.dtype)
+            mid[:, mid_at] = c1.reshape(len(g), -1)
+            cm = mid[:, take_m] @ bm                                  # (g, rowsM, NM)
+            mid = np.zeros((len(g), rows2 * ld2), dtype=c1.dtype)
+            mid[:, mid2_at] = cm.reshape(len(g), -1)
+        else:
+            mid = np.zeros((len(g), rows2 * ld2), dtype=c1.dtype)
+            mid[:, mid_at] = c1.reshape(len(g), -1)
         a2 = mid[:, take]                                         # (g, rows2, K2)
         C[gc[:, None, None] + out_at[None]] = a2 @ b2
 
