@@ -1349,25 +1349,22 @@ static hipError_t launch_stem3_t(const StemArgs& p, hipStream_t stream) {
 
 // static instantiations of the three-step tiles (16 columns in step 1 / middle / last, units per wave,
 // column groups of step 1, chunks of K1, items per wave of the middle and of the last step, 16-byte
-// gathers): the shapes the m20 tree fixtures and the test stems need (tools/stem_shapes.py); there is
-// no run-time-count variant -- the planner asks ctg_stem_triple_instantiated before it emits one
+// gathers): the shapes the time-to-solution trees (sycamore_m20_w32_r4 / w33_bf3, first seven) and the
+// test stems (last five) take when every tile that fits is chosen; there is no run-time-count variant --
+// the planner asks ctg_stem_triple_instantiated before it emits one
 #ifdef CTG_STEM_TRI_DEV
 #define CTG_STEM_TRI(X) \
     X(true, true, true, 2, 1, 1, 2, 2, false) X(false, false, false, 1, 1, 2, 1, 1, false) \
     X(true, false, true, 2, 1, 1, 1, 1, false) X(true, false, false, 1, 1, 1, 1, 1, true)
 #else
 #define CTG_STEM_TRI(X) \
-    X(true, true, false, 2, 1, 1, 2, 1, true) X(true, true, true, 2, 1, 1, 2, 2, false) \
-    X(false, false, false, 1, 1, 2, 1, 1, true) X(true, true, false, 2, 1, 1, 2, 1, false) \
-    X(true, false, true, 2, 1, 1, 1, 2, true) X(false, false, true, 1, 1, 2, 1, 2, false) \
-    X(false, true, false, 1, 2, 4, 2, 1, true) X(false, true, false, 1, 2, 1, 2, 2, false) \
+    X(true, true, false, 2, 1, 1, 2, 1, true) X(true, true, false, 2, 1, 1, 2, 1, false) \
     X(true, false, true, 2, 1, 1, 1, 2, false) X(false, true, true, 1, 1, 2, 2, 2, false) \
-    X(false, false, true, 1, 1, 4, 1, 1, true) X(false, false, false, 1, 1, 2, 1, 1, false) \
-    X(false, false, false, 1, 2, 2, 1, 2, true) \
+    X(false, true, false, 1, 2, 1, 2, 2, false) X(false, false, true, 1, 1, 2, 1, 2, false) \
+    X(false, false, true, 1, 1, 4, 1, 1, true) \
     X(true, false, true, 2, 1, 1, 1, 1, false) X(true, false, true, 2, 1, 1, 1, 1, true) \
-    X(false, true, true, 1, 4, 2, 2, 2, true) X(false, true, false, 1, 1, 1, 2, 1, false) \
-    X(false, false, false, 1, 1, 2, 1, 4, false) X(true, true, false, 2, 1, 1, 2, 2, false) \
-    X(true, true, false, 2, 1, 2, 1, 2, false) X(true, false, false, 1, 1, 1, 1, 1, true)
+    X(false, true, true, 1, 4, 2, 2, 2, true) X(false, false, false, 1, 1, 2, 1, 4, false) \
+    X(true, false, false, 1, 1, 1, 1, 1, true)
 #endif
 
 static bool stem3_instantiated(bool p1, bool pm, bool p2, int rt1, int cs1, int nch, int itm, int it2, bool vec) {

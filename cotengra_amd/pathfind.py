@@ -274,6 +274,11 @@ def modelled_seconds(tree, model=None, dtype="complex64"):
             if st.get("one"):   # (a single step on the stem kernel's first half)
                 t += single_seconds(s.macs, s.a.size, s.c.size, st["run_bytes"], bf3_fits=st.get("bf3_fits", True))
                 continue
+            if st.get("KM"):    # (a three-step tile: opt-in, stem.triples_enabled)
+                from .stem import triple_seconds
+
+                t += triple_seconds(st["macs3"], (st["N1"], st["NM"], st["N2"]), s.a.size, s.c.size, st["run_bytes"])
+                continue
             macs1 = (s.a.size // st["K1"]) * st["K1"] * st["N1"]
             t += pair_seconds(macs1, s.macs - macs1, s.a.size, s.c.size, st["items"], st["run_bytes"],
                               bf3_fits=st.get("bf3_fits", True))

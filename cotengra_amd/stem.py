@@ -450,7 +450,7 @@ def _find_chains(steps, size_dict, by_out, classify, unfused_seconds, gain2, min
         if geo is None or not _triple_instantiated(geo):
             continue
         before = unfused_seconds(s1) + unfused_seconds(s2) + unfused_seconds(s3)
-        after = triple_seconds(s1.macs, s2.macs, s3.macs, s1.a.size, s3.c.size, geo.run_bytes, bf16x3=bf16x3)
+        after = triple_seconds((s1.macs, s2.macs, s3.macs), (geo.N1, geo.NM, geo.N2), s1.a.size, s3.c.size, geo.run_bytes)
         if before - after >= MIN_GAIN * before:
             gain3[i3] = (i1, i2, before - after)
     best = {}   # step -> (gain of the chain up to and including it, links chosen)
@@ -659,8 +659,14 @@ def build_stem_one(size_dict, A, B1, out_inds, out_ref_factory, node=-1):
 
 
 def triples_enabled():
-    """Three-step tiles (``geometry3`` / ``build_stem_triple``) are chosen by ``find_pairs`` only
-    when ``CTG_STEM_TRIPLES`` is set to something other than "" / "0" (round 4: the path is new)."""
+    """Three-step tiles (``geometry3`` / ``build_stem_triple``) are among ``find_pairs``' choices only
+    when ``CTG_STEM_TRIPLES`` is set to something other than "" / "0".  Round 4 built and measured
+    them: parity with the oracle in both arithmetics, and SLOWER than a pair
+    plus a single step on every m20 tree -- in the bf16 x 3 arithmetic a pair of 16- or 32-column
+    steps is already balanced between its traffic and its arithmetic, so taking the third step's
+    traffic out leaves the tile bound by three steps' arithmetic (``TRIPLE_STAGE_RATE``).  Kept as an
+    experiment switch for the day a stage's arithmetic gets cheaper; priced with the measured rates
+    the dynamic programme rarely takes one."""
     return os.environ.get("CTG_STEM_TRIPLES", "0") not in ("", "0")
 
 
@@ -774,11 +780,21 @@ def geometry3(size_dict, A, B1, BM, B2, c1_inds, cm_inds, out_inds):
     return g
 
 
-def triple_seconds(macs1, macs_m, macs2, elems_a, elems_c2, run_bytes=256, bf16x3=None):
-    """Modelled time of a three-step tile: the pair model with one more step's matrix work and the
-    same traffic (the big operand in, the LAST result out)."""
-    rate = FUSED_MFMA_RATE * (BF16X3_SPEEDUP if bf16x3_mode(bf16x3) else 1.0)
-    t_mfma = 8.0 * (macs1 + macs_m + macs2) / rate
+# Matrix-side rate of ONE stage of a three-step tile by its output columns, bf16 x 3 arithmetic, as
+# measured on the m20 trees (profiles/r4_triples.txt): a stage splits every value of its row operand
+# into limbs whatever the number of columns it is then multiplied with -- 7.3 vector instructions per
+# MFMA with 16 columns, 3.7 with 32 -- so a 16-column stage runs at 81-86 TFLOP/s and a 32-column one
+# at 135-146.  (The pair model needs no such table: a pair of 16-column steps is bound by its traffic
+# and its arithmetic alike, and the one rate it uses reproduces measured pairs to 3-7 %.  It is the
+# third step that has no traffic of its own to hide behind.)
+TRIPLE_STAGE_RATE = {16: 85e12, 32: 140e12, 64: 165e12, 128: 165e12}
+
+
+def triple_seconds(macs, cols, elems_a, elems_c2, run_bytes=256):
+    """Modelled time of a three-step tile (bf16 x 3 arithmetic): the matrix time of its stages at
+    ``TRIPLE_STAGE_RATE`` (``macs`` and ``cols`` per stage), the traffic of the big operand in and
+    the LAST result out, the longer of the two plus a fifth of the shorter."""
+    t_mfma = sum(8.0 * m / TRIPLE_STAGE_RATE[n] for m, n in zip(macs, cols))
     t_mem = 8.0 * elems_a / gather_rate(run_bytes) + 8.0 * elems_c2 / FUSED_STORE_RATE
     return max(t_mfma, t_mem) + FUSED_OVERLAP_LOSS * min(t_mfma, t_mem)
 

@@ -97,12 +97,12 @@ def stem_flags(name):
     """Template arguments of a ``stem2_kernel<...>`` instantiation as the executor spells them
     (csrc/ctg_stem.hip: stem2_kernel_name): chunks and items known at compile time (0: the
     run-time-count variant), B2 in registers, bf16 x 3 products, row-interleaved step 2, single step,
-    B2 with a -Im limb plane."""
+    and -- three-step tiles only -- the middle stage's items per wave and whether it has 16 columns."""
     a = [x.strip() for x in name[name.index("<") + 1 : name.rindex(">")].split(",")]
     t = [x == "true" for x in a]
     return {"pack1": t[0], "pack2": t[1], "rt1": int(a[2]), "cs1": int(a[3]), "nch": int(a[4]), "it2": int(a[5]),
             "br1": t[6], "k2q": int(a[7]), "vec": t[8], "bf3": t[9], "ri2": t[10], "one": t[11],
-            "b2n": t[12] if len(t) > 12 else False}
+            "itm": int(a[12]) if len(a) > 12 else 0, "packm": t[13] if len(t) > 13 else False}
 
 
 def stem_network(nq, gates, seed, sliced=0):

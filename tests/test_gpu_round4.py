@@ -407,3 +407,38 @@ def test_two_ranks_plain_c_driver_and_bench_line(tmp_path):
     a1 = complex(*json.loads(r1.stdout.strip().splitlines()[-1])["config"]["partial_amplitude"])
     a2 = complex(*two["config"]["partial_amplitude"])
     assert abs(a2 - a1) <= 1e-4 * abs(a1), (a1, a2)
+
+
+# ---- three-step tiles (opt-in: CTG_STEM_TRIPLES) -----------------------------------------------------------
+
+@pytest.mark.parametrize("bf16x3", [True, False])
+@pytest.mark.parametrize("seed", (0, 27, 34, 41, 45))
+def test_three_step_tiles_on_device(seed, bf16x3, monkeypatch):
+    """Random stems planned with a three-step tile (the shapes csrc/ctg_stem.hip: CTG_STEM_TRI holds for
+    them), run in both arithmetics -- the plan is made for bf16 x 3, the fp32 kernels of the same shapes
+    serve an executor whose arithmetic is switched afterwards -- against the complex128 oracle within the
+    gate of the unfused HIP path; the kernel that ran carries a middle stage (its last two template
+    arguments)."""
+    from cotengra_amd import stem
+
+    monkeypatch.setenv("CTG_STEM_TRIPLES", "1")
+    monkeypatch.delenv("CTG_STEM_BF16X3", raising=False)
+    monkeypatch.setattr(stem, "gather_rate", lambda run_bytes: 5.4e12)
+    monkeypatch.setattr(stem, "TRIPLE_STAGE_RATE", {n: 1e15 for n in stem.TRIPLE_STAGE_RATE})
+    tree = G.random_stem(seed)
+    arrays = ca.make_arrays_from_inputs(tree.inputs, tree.size_dict, seed=seed, dtype="complex64")
+    ref = np.asarray(orc.contract(tree, [a.astype("complex128") for a in arrays]))
+    plain = HipContractor(tree, fuse=False)
+    base = np.asarray(plain(*arrays))
+    plain.close()
+    fn = HipContractor(tree, fuse=True, fuse_min_elems=1 << 9, stem_bf16x3=True)
+    plan = fn.get_plan("complex64")[0]
+    assert [s for s in plan.steps if s.kind == KIND_STEM2 and s.stem.get("KM")]
+    fn.stem_bf16x3 = bf16x3          # (the executor's arithmetic; the plan stays)
+    got = np.asarray(fn(*arrays))
+    names = [n for n in fn.setup(*arrays)["exec"].step_kernels() if n.startswith("stem2_kernel<") and n.count(",") == 13]
+    fn.close()
+    assert names and all(n.split(",")[9] == ("true" if bf16x3 else "false") and int(n.split(",")[12]) >= 1 for n in names), names
+    scale = np.abs(ref).max()
+    gate = max(1e-5, 8 * np.abs(base - ref).max() / scale)
+    assert np.abs(got - ref).max() / scale <= gate

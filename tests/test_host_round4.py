@@ -376,3 +376,96 @@ def test_bf16x3_tile_fit_is_part_of_the_pair_model():
     args = (2**25 * 32 * 32, 2**24 * 64 * 128, 2**30, 2**31, 16)
     fits, not_fits = stem.pair_seconds(*args, bf16x3=True), stem.pair_seconds(*args, bf16x3=True, bf3_fits=False)
     assert not_fits == stem.pair_seconds(*args, bf16x3=False) > fits
+
+
+# ---- three-step tiles (opt-in: CTG_STEM_TRIPLES; stem.geometry3 / build_stem_triple) -------------------
+
+TRIPLE_SEEDS = (0, 27, 34, 36, 41, 42, 43, 45)   # random stems (golden_util.random_stem) with a chain of three that fits
+
+
+@pytest.fixture
+def take_every_triple(monkeypatch):
+    """(every three-step tile that fits, whatever the model thinks it gains -- measured: nothing)"""
+    from cotengra_amd import stem
+
+    monkeypatch.setattr(stem, "gather_rate", lambda run_bytes: 5.4e12)
+    monkeypatch.setattr(stem, "TRIPLE_STAGE_RATE", {n: 1e15 for n in stem.TRIPLE_STAGE_RATE})
+
+
+def test_three_step_tiles_are_opt_in(monkeypatch, take_every_triple):
+    """Without CTG_STEM_TRIPLES no plan holds a middle stage, however cheap the model finds one."""
+    import golden_util as G
+    from cotengra_amd import plan as P
+
+    monkeypatch.delenv("CTG_STEM_TRIPLES", raising=False)
+    for seed in TRIPLE_SEEDS[:4]:
+        plan = P.compile_tree(G.random_stem(seed), "complex64", fuse=True, fuse_min_elems=1 << 9)
+        assert not [s for s in plan.steps if s.kind == P.KIND_STEM2 and s.stem.get("KM")]
+
+
+@pytest.mark.parametrize("seed", TRIPLE_SEEDS)
+def test_three_step_tile_plan_semantics(seed, monkeypatch, take_every_triple):
+    """Three consecutive stem steps as ONE record with a middle stage: the numpy interpreter of the
+    plan executes it from the very tables the kernel reads (first intermediate, middle product, second
+    intermediate written through mid2_row / mid2_col, last product) and lands on the oracle's result;
+    work and algorithmic bytes are those of the unfused plan, the moved bytes fewer."""
+    import golden_util as G
+    from cotengra_amd import plan as P
+    from oracle import plan_interp
+
+    monkeypatch.setenv("CTG_STEM_TRIPLES", "any")   # (every tile that fits; the library's kernel list is not asked)
+    tree = G.random_stem(seed)
+    arrays = ca.make_arrays_from_inputs(tree.inputs, tree.size_dict, seed=seed, dtype="complex128")
+    fused = P.compile_tree(tree, "complex64", fuse=True, fuse_min_elems=1 << 9)
+    plain = P.compile_tree(tree, "complex64", fuse=False)
+    tri = [s for s in fused.steps if s.kind == P.KIND_STEM2 and s.stem.get("KM")]
+    assert len(tri) == 1, [s.label for s in fused.steps]
+    st = tri[0].stem
+    assert (1 << st["nr1"]) * st["N1"] == st["rowsM"] * st["KM"] and st["rowsM"] * st["NM"] == st["rows2"] * st["K2"]
+    assert st["lds_bytes"] <= 160 * 1024 and st["itemsM"] % 8 == 0 and st["items"] % 8 == 0
+    assert fused.macs_per_slice == plain.macs_per_slice and sum(st["macs3"]) == tri[0].macs
+    assert fused.elems_rw_per_slice == plain.elems_rw_per_slice
+    assert fused.elems_moved_per_slice < plain.elems_rw_per_slice
+    fused.dtype = "complex128"
+    got = plan_interp.run_plan(fused, arrays)
+    ref = orc.contract(tree, arrays)
+    assert np.allclose(got, ref, rtol=1e-12, atol=1e-12 * np.abs(ref).max())
+
+
+@pytest.mark.parametrize("seed", (0, 34, 41, 45))
+def test_three_step_tile_records_validate(seed, monkeypatch, take_every_triple):
+    """CTG_STEM_TRIPLES=1: the planner asks the library which shapes it has kernels for
+    (ctg_stem_triple_instantiated, ABI 5) and the C ABI accepts exactly such records -- and refuses a
+    middle stage whose shape, tables or operand do not fit."""
+    import golden_util as G
+    from cotengra_amd import plan as P, runtime
+
+    monkeypatch.setenv("CTG_STEM_TRIPLES", "1")
+    plan = P.compile_tree(G.random_stem(seed), "complex64", fuse=True, fuse_min_elems=1 << 9)
+    tri = [s for s in plan.steps if s.kind == P.KIND_STEM2 and s.stem.get("KM")]
+    assert len(tri) == 1
+    runtime.DevicePlan(plan).close()
+    st = tri[0].stem
+    for key, value in (("KM", 48), ("NM", 8), ("rowsM", st["rowsM"] * 2), ("ldM", st["KM"]), ("ngM", 3)):
+        keep = st[key]
+        st[key] = value
+        with pytest.raises((runtime.CtgError, ValueError)):
+            runtime.DevicePlan(plan)
+        st[key] = keep
+    for name, how in (("mid2_row", lambda t: t + (1 << 20)), ("mid2_col", lambda t: t + (1 << 20)),
+                      ("mid_row", lambda t: t + (1 << 20)), ("bm_off", lambda t: t + (1 << 40))):
+        keep = st["tabs"][name]
+        st["tabs"][name] = how(keep.copy())
+        with pytest.raises((runtime.CtgError, ValueError)):
+            runtime.DevicePlan(plan)
+        st["tabs"][name] = keep
+    runtime.DevicePlan(plan).close()
+    lib = runtime.load()
+    from cotengra_amd import stem
+
+    class Geo:   # (the fields triple_shape reads)
+        pass
+
+    assert lib.ctg_stem_triple_instantiated(1, 0, 1, 2, 1, 1, 1, 1, 0) == 1       # seed 0's
+    assert lib.ctg_stem_triple_instantiated(1, 1, 1, 7, 3, 5, 2, 2, 0) == 0
+    assert stem.triples_enabled()

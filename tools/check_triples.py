@@ -23,7 +23,8 @@ from oracle import contract_ref as orc  # noqa: E402
 import golden_util as G  # noqa: E402
 from cotengra_amd import stem  # noqa: E402
 
-stem.gather_rate = lambda run_bytes: 5.4e12   # everything the kernel can take, whatever the model thinks of its gathers
+stem.gather_rate = lambda run_bytes: 5.4e12   # everything the kernel can take, whatever the model thinks of it
+stem.TRIPLE_STAGE_RATE = {n: 1e15 for n in stem.TRIPLE_STAGE_RATE}
 first = int(sys.argv[1]) if len(sys.argv) > 1 else 0
 count = int(sys.argv[2]) if len(sys.argv) > 2 else 48
 bad = n_tri = 0

@@ -12,7 +12,11 @@ shorter), make of it.  A dynamic programme over the chain then chooses among pai
 Round 4, bf16 x 3 pricing: fused tree 33 feasible triples, 7 chosen, 21 ms less than pairs alone (of 217);
 width-2^33 tree 3 chosen, -28 ms (of 379); headline tree 2 chosen, -8 ms (of 240) -- on trees that were refined
 for PAIRS.  (Round 3 priced the same with fp32 products: -11.5 ms on the fused tree; with the cheaper products
-the pairs are bound by their traffic, so taking one more round trip out is worth twice as much.)"""
+the pairs are bound by their traffic, so taking one more round trip out is worth twice as much.)
+
+MEASURED afterwards (the tiles were built: CTG_STEM_TRIPLES, profiles/r4_triples.txt): slower than pairs -- this pricing takes
+one matrix rate for all shapes, and a 16-column stage runs at less than half of it (stem.TRIPLE_STAGE_RATE is what the planner
+uses since).  The script is kept as the record of the estimate."""
 import math
 import os
 import sys
