@@ -88,7 +88,7 @@ src = open(os.path.join(ROOT, "cotengra_amd", "csrc", "ctg_stem.hip")).read()
 
 
 def have(macro, letter):
-    body = src.split("#define %s(%s)" % (macro, letter))[1].split("\n\n")[0]
+    body = src.split("#define %s(%s)" % (macro, letter))[-1].split("#endif")[0]   # (the full list: behind the development one)
     return {tuple(a.strip() for a in m.split(",")) for m in re.findall(r"%s\(([^)]*)\)" % letter, body)}
 
 
