@@ -200,9 +200,17 @@ def step_table(ex, plan, slice_id=0):
     stream, ``ctg_exec_profile_slice``) and kernel names."""
     ms = ex.profile_slice(slice_id)
     rows = plan.describe_steps()
-    for r, m, nm in zip(rows, ms, ex.step_kernels()):
+    share = 1.0 / plan.group_size
+    for r, m, nm, st in zip(rows, ms, ex.step_kernels(), plan.steps):
         r["ms"] = float(m)
         r["kernel_name"] = nm
+        if st.group and plan.group_size > 1:
+            # a step the slices of a group share: a slice is charged its share of the time, the work
+            # and the bytes (the profiled slice computed it in full: ms_full)
+            r["shared"], r["ms_full"] = True, r["ms"]
+            for key in ("ms", "macs", "bytes", "bytes_moved"):
+                if key in r:
+                    r[key] = r[key] * share
     return rows
 
 
@@ -316,6 +324,43 @@ def time_slices(ex, first, count, stride=1):
     return time.perf_counter() - t0
 
 
+def slice_ids_from_groups(plan, first_group, count, rank=0, world=1):
+    """``count`` slice ids for ``rank``: the members of the slice groups ``first_group + rank``,
+    ``+ world``, ... one after the other (cotengra_amd/plan.py: Plan.group_ids; without groups in the
+    plan a group is a single slice) -- whole groups, so that what a group shares is computed once per
+    group INSIDE the timed region, as it is over the whole job."""
+    n_groups = max(1, plan.nslices // plan.group_size)
+    ids, g = [], first_group + rank
+    while len(ids) < count:
+        ids += plan.group_ids(g % n_groups)
+        g += world
+    return ids[:count]
+
+
+def slice_groups_note(plan, ids):
+    """What the line says about slice groups (cotengra_amd/plan.py: choose_slice_group)."""
+    if plan.group_size <= 1:
+        return None
+    return {
+        "group_indices": len(plan.group_inds),
+        "slices_per_group": int(plan.group_size),
+        "shared_steps": sum(1 for s in plan.steps if s.group),
+        "shared_macs_fraction": plan.macs_shared_per_group / max(plan.macs_per_slice, 1),
+        "timed": "%d slices in %d groups" % (len(ids), len({plan.group_of(i) for i in ids})),
+        "note": "slices that differ only in the group indices share every step that depends on none of them: "
+                "computed for the first slice of a group, kept for the others (CTG_SLICE_GROUPS=0: off)",
+    }
+
+
+def executed_flops(plan, ids, flops_per_mac=8.0):
+    """Flops the executor really does for the slices ``ids`` in one call: every step for the first slice
+    of each group among them, everything but the steps the group shares for the others."""
+    groups = len({plan.group_of(i) for i in ids}) if plan.group_size > 1 else len(ids)
+    shared = plan.macs_shared_per_group if plan.group_size > 1 else 0
+    return flops_per_mac / 8.0 * (8.0 if plan.is_complex else 2.0) * (
+        plan.macs_per_slice * len(ids) - shared * (len(ids) - groups))
+
+
 # ---------------------------------------------------------------------- #
 # the other workloads of the line (rank 0, N = 1)
 # ---------------------------------------------------------------------- #
@@ -341,11 +386,20 @@ def tree_report(tree_file, dev, steps=5, warmup=1, mode=None):
     st = fn.setup(*[torch.as_tensor(a, device=dev) for a in arrays])
     ex, plan = st["exec"], st["plan"]
     ex.zero_result()
-    ex.run_slices(0, warmup, 1)
-    dt = time_slices(ex, warmup, steps) / steps
+    # (whole slice groups: warm up on the last groups, time the first ones)
+    gs = plan.group_size
+    steps = gs * max(1, -(-steps // gs))
+    n_groups = max(1, plan.nslices // gs)
+    ex.run_slice_list(slice_ids_from_groups(plan, n_groups - 1 - (warmup - 1) // gs, warmup))
+    ids = slice_ids_from_groups(plan, 0, steps)
+    ex.sync()
+    t0 = time.perf_counter()
+    ex.run_slice_list(ids)
+    ex.sync()
+    dt = (time.perf_counter() - t0) / steps
     rows = step_table(ex, plan)
     name, dom, _ = dominant_kernel(rows, 8.0)
-    flops = plan.flops_per_slice()
+    flops = executed_flops(plan, ids) / steps
     bound_ms = mixed_roofline_ms(rows, 8.0, moved=True, bf16x3=bf16x3)
     unfused_ms = mixed_roofline_ms(rows, 8.0, moved=False)
     mf = dom["flops"] / max(dom["ms"] * 1e-3, 1e-12) / 1e12
@@ -357,6 +411,7 @@ def tree_report(tree_file, dev, steps=5, warmup=1, mode=None):
         "nslices_log2": float(np.log2(tree.nslices)),
         "width_log2": float(np.log2(tree.max_size())),
         "macs_per_slice": int(plan.macs_per_slice),
+        "slice_groups": slice_groups_note(plan, ids),
         "ms_per_slice": dt * 1e3,
         "tflops": flops / dt / 1e12,
         "mixed_bound_ms": bound_ms,
@@ -637,8 +692,11 @@ def main():
 
     # warmup (untimed)
     ex.zero_result()
-    if args.warmup:
-        ex.run_slices(rank % nsl, args.warmup, world)
+    n_groups = max(1, plan.nslices // plan.group_size)
+    if args.warmup:   # (on the last slice groups; the timed slices are whole groups from the first on)
+        ex.run_slice_list(slice_ids_from_groups(plan, n_groups - world * (1 + (args.warmup - 1) // plan.group_size),
+                                                args.warmup, rank, world))
+    timed_ids = slice_ids_from_groups(plan, 0, args.steps, rank, world)
     reduce_partials()
     barrier()
 
@@ -648,7 +706,7 @@ def main():
     barrier()
     t0 = time.perf_counter()
     ev[0].record()
-    ex.run_slices((args.warmup * world + rank) % nsl, args.steps, world)
+    ex.run_slice_list(timed_ids)
     ev[1].record()
     reduce_partials()
     ev[2].record()
@@ -693,7 +751,9 @@ def main():
                         "shards is the amplitude, not the slice",
             }
 
-    flops_slice = plan.flops_per_slice()
+    # (flops really executed: the steps a slice group shares count once per group -- every rank times the
+    # same number of whole groups, so rank 0's count x world is the job's)
+    flops_slice = executed_flops(plan, timed_ids) / args.steps
     total_slices = args.steps * world
     value = flops_slice * total_slices / dt
 
@@ -792,6 +852,9 @@ def main():
                 "nslices_log2": float(np.log2(nsl)),
                 "macs_per_slice": int(plan.macs_per_slice),
                 "flops_per_slice": float(flops_slice),
+                "flops_per_slice_is": "flops executed per slice in the timed region: the steps a slice group shares "
+                                      "count once per group (nominal, every step for every slice: %.6g)" % plan.flops_per_slice(),
+                "slice_groups": slice_groups_note(plan, timed_ids),
                 "algorithmic_bytes_per_slice": float(plan.bytes_per_slice()),
                 "bytes_moved_per_slice": float(plan.elems_moved_per_slice * plan.itemsize),
                 "fused_stem_pairs": sum(1 for s_ in plan.steps if s_.kind == 3),

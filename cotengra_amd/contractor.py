@@ -349,18 +349,31 @@ class HipContractor:
         multiple of the executor's slice batch, sized for a few updates per second) with a
         synchronisation in between, so that the counter shows slices that are DONE."""
         prog = _Progress(progbar, count) if progbar and count > 1 else None
+        plan = ex.plan
+        ids = None
+        if plan.group_size > 1 and count > 1:
+            # slice groups: the slices asked for, group by group (what a group shares is computed once
+            # per group among them) -- in one call, or in chunks of whole groups under a progress bar
+            ids = np.arange(first, first + count * stride, stride, dtype=np.int64)
+            ids = ids[np.lexsort((ids, plan.group_of(ids)))]
         if prog is None or not prog.active:
-            ex.run_slices(first, count, stride)
+            if ids is None:
+                ex.run_slices(first, count, stride)
+            else:
+                ex.run_slice_list(ids)
             return
         import time
 
-        chunk = max(int(ex.batch), 1)
+        chunk = max(int(ex.batch), 1) if ids is None else int(plan.group_size)
         done = 0
         try:
             while done < count:
                 n = min(chunk, count - done)
                 t0 = time.perf_counter()
-                ex.run_slices(first + done * stride, n, stride)
+                if ids is not None:
+                    ex.run_slice_list(ids[done:done + n])
+                else:
+                    ex.run_slices(first + done * stride, n, stride)
                 ex.sync()
                 dt = time.perf_counter() - t0
                 done += n

@@ -19,6 +19,8 @@ struct ctg_plan {
     std::vector<int64_t> tables;
     int64_t n_sliced = 0;
     std::vector<int64_t> slice_sizes, slice_fixed, slice_strides;
+    std::vector<int64_t> slice_group;   // [n_sliced] 1: a group index (ctg_plan_desc.slice_group)
+    bool has_groups = false;            // some step is shared by the slices of a group (word 42 = 2)
     int64_t nslices = 1;
     // per-leaf maximum slice offset (for bounds validation)
     std::vector<int64_t> max_soff;
@@ -65,6 +67,7 @@ struct ctg_exec {
         uint32_t blocks;
     };
     std::vector<Issue> issue;
+    std::vector<Issue> issue_reuse;   // ... of a slice that finds the shared steps of its group done
     ctg::ValuGroupItem* d_group_items = nullptr;
     ctg::FastGroupItem* d_fast_items = nullptr;
     std::vector<hipEvent_t> events;
@@ -84,6 +87,9 @@ struct ctg_exec {
     // slice-invariant steps: executed once per upload / option change
     std::vector<char> invariant;
     bool invariants_ready = false;
+    // steps shared by the slices of a group: executed when the group key changes
+    std::vector<char> grouped;
+    int64_t group_key = -1;
     ctg::StripState* d_strip = nullptr;
     int64_t root_step = -1;
 };

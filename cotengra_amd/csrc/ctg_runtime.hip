@@ -218,11 +218,23 @@ int validate_plan(ctg_plan* p) {
             p->max_soff[l] += st * (f >= 0 ? f : d - 1);
         }
     }
+    // slice groups: flags 0 / 1 on sliced indices that are not projected
+    bool any_group = false;
+    for (int64_t j = 0; j < p->n_sliced; ++j) {
+        const int64_t g = p->slice_group[j];
+        if (g != 0 && g != 1) return fail(CTG_E_INVALID, "bad slice group flag");
+        if (g == 1 && p->slice_fixed[j] >= 0) return fail(CTG_E_INVALID, "a projected index cannot be a group index");
+        any_group = any_group || g == 1;
+    }
+    p->has_groups = false;
     // steps
     for (int64_t s = 0; s < p->n_steps; ++s) {
         const int64_t* r = &p->steps[s * STEP_WORDS];
         const int64_t kind = r[W_KIND];
         if (kind < 0 || kind > 3) return fail(CTG_E_INVALID, "step %lld: bad kind", (long long)s);
+        if (r[W_INVARIANT] < 0 || r[W_INVARIANT] > 2 || (r[W_INVARIANT] == 2 && !any_group))
+            return fail(CTG_E_INVALID, "step %lld: bad sharing class", (long long)s);
+        p->has_groups = p->has_groups || (r[W_INVARIANT] == 2 && kind != KIND_ACCUM);
         if (kind == KIND_STEM2) {
             const int rc = validate_stem(p, s);
             if (rc != CTG_OK) return rc;
@@ -283,6 +295,55 @@ int validate_plan(ctg_plan* p) {
                             (long long)s, "ABC"[o], (long long)lo_addr, (long long)hi_addr, (long long)cap);
         }
     }
+    if (p->has_groups) {
+        // What a per-slice step reads of a step that its group shares must survive the group: no
+        // per-slice step may write into that range of the arena (element ranges of the records; the
+        // planner keeps such results out of the recycled part, cotengra_amd/plan.py: kept_for_group).
+        struct Range { int64_t lo, hi; };
+        auto out_of = [&](int64_t s) {
+            const int64_t* r = &p->steps[s * STEP_WORDS];
+            return Range{r[W_C_OFF], r[W_C_OFF] + r[W_C_SIZE]};
+        };
+        auto reads = [&](int64_t s, const Range& x) {
+            const int64_t* r = &p->steps[s * STEP_WORDS];
+            auto hit = [&](int64_t space, int64_t off, int64_t size) {
+                return space == SPACE_ARENA && off < x.hi && x.lo < off + size;
+            };
+            if (hit(r[W_A_SPACE], r[W_A_OFF], r[W_A_SIZE]) || hit(r[W_B_SPACE], r[W_B_OFF], r[W_B_SIZE])) return true;
+            if (r[W_KIND] == KIND_STEM2) {
+                const int64_t* h = &p->tables[r[W_STEM]];
+                if (h[SW_ONE] != 1 && hit(h[SW_B2_SPACE], h[SW_B2_OFF], h[SW_B2_SIZE])) return true;
+                if (h[SW_TRI] == 1 && hit(h[SW_BM_SPACE], h[SW_BM_OFF], h[SW_BM_SIZE])) return true;
+            }
+            return false;
+        };
+        auto shared = [&](int64_t s) { return p->steps[s * STEP_WORDS + W_INVARIANT] == 2; };
+        for (int64_t g = 0; g < p->n_steps; ++g) {
+            const int64_t* rg = &p->steps[g * STEP_WORDS];
+            if (!shared(g) || rg[W_KIND] == KIND_ACCUM || rg[W_C_SPACE] != SPACE_ARENA) continue;
+            const Range x = out_of(g);
+            // (the value lives until the next step that writes into its range: ranges are recycled)
+            int64_t until = p->n_steps;
+            for (int64_t s = g + 1; s < p->n_steps && until == p->n_steps; ++s) {
+                const int64_t* r = &p->steps[s * STEP_WORDS];
+                if (r[W_KIND] == KIND_ACCUM || r[W_C_SPACE] != SPACE_ARENA) continue;
+                const Range y = out_of(s);
+                if (y.lo < x.hi && x.lo < y.hi) until = s;
+            }
+            bool kept = false;
+            for (int64_t s = g + 1; s < until && !kept; ++s)
+                kept = p->steps[s * STEP_WORDS + W_INVARIANT] == 0 && reads(s, x);
+            if (!kept) continue;
+            for (int64_t s = 0; s < p->n_steps; ++s) {
+                const int64_t* r = &p->steps[s * STEP_WORDS];
+                if (s == g || r[W_INVARIANT] == 1 || r[W_KIND] == KIND_ACCUM || r[W_C_SPACE] != SPACE_ARENA) continue;
+                const Range y = out_of(s);
+                if (y.lo < x.hi && x.lo < y.hi)
+                    return fail(CTG_E_INVALID, "step %lld writes into what step %lld keeps for its slice group",
+                                (long long)s, (long long)g);
+            }
+        }
+    }
     return CTG_OK;
 }
 
@@ -309,7 +370,7 @@ void resolve_args(ctg_exec* e) {
     std::vector<std::pair<int64_t, int64_t>> persistent;
     for (int64_t s = 0; s < p->n_steps; ++s) {
         const int64_t* r = &p->steps[s * STEP_WORDS];
-        if (r[W_INVARIANT] != 0 && r[W_KIND] != KIND_ACCUM && r[W_C_SPACE] == SPACE_ARENA)
+        if (r[W_INVARIANT] == 1 && r[W_KIND] != KIND_ACCUM && r[W_C_SPACE] == SPACE_ARENA)
             persistent.emplace_back(r[W_C_OFF], r[W_C_OFF] + r[W_C_SIZE]);
     }
     auto per_slice = [&](int64_t space, int64_t off) -> int64_t {
@@ -939,7 +1000,7 @@ int build_groups(ctg_exec* e) {
     // class of a step: -1 launches alone, 0 thread-per-output, 1 + key tiled fast kernel
     auto class_of = [&](int64_t s) -> int {
         const int64_t* r = &p->steps[s * STEP_WORDS];
-        if (off || r[W_KIND] != KIND_PAIR || e->invariant[s]) return -1;
+        if (off || r[W_KIND] != KIND_PAIR || e->invariant[s] || e->grouped[s]) return -1;   // (shared steps launch alone)
         if (r[W_KERNEL] != KERNEL_MFMA) {
             if (!valu_thread_per_output(e->args[s])) return -1;
             ValuGroupItem it;
@@ -1011,6 +1072,11 @@ int build_groups(ctg_exec* e) {
         }
         s = j;
     }
+    // slice groups: the launch list of a slice whose group's shared steps are done (they launch alone)
+    e->issue_reuse.clear();
+    for (const ctg_exec::Issue& q : e->issue)
+        if (!(q.cls < 0 && e->grouped[q.step])) e->issue_reuse.push_back(q);
+    e->group_key = -1;
     if (!vitems.empty()) {
         HIP_TRY(hipMalloc((void**)&e->d_group_items, vitems.size() * sizeof(ValuGroupItem)));
         HIP_TRY(hipMemcpy(e->d_group_items, vitems.data(), vitems.size() * sizeof(ValuGroupItem),
@@ -1038,6 +1104,43 @@ int launch_issue(ctg_exec* e, const ctg_exec::Issue& q, int nb, hipStream_t stre
     if (err != hipSuccess)
         return fail(CTG_E_HIP, "launch of the %d steps grouped at step %lld failed: %s", (int)q.n,
                     (long long)q.step, hipGetErrorString(err));
+    return CTG_OK;
+}
+
+// the slice id with the digits of the group indices set to zero: what the slices of a group share
+int64_t slice_group_key(const ctg_plan* p, int64_t sid) {
+    int64_t key = 0, rem = sid, stride = 1;
+    for (int64_t j = p->n_sliced - 1; j >= 0; --j) {
+        if (p->slice_fixed[j] >= 0) continue;
+        const int64_t d = rem % p->slice_sizes[j];
+        rem /= p->slice_sizes[j];
+        if (!p->slice_group[j]) key += d * stride;
+        stride *= p->slice_sizes[j];
+    }
+    return key;
+}
+
+// Slice groups: the given slices group by group -- same key (= all sliced indices but the group ones)
+// one after the other, in slice order within a group --, the steps the slices of a group share launched
+// when the key changes.  (Under strip_exponent every step keeps a scale per slice: the callers then take
+// the ordinary path, on which the shared steps are simply computed for every slice.)
+int run_grouped(ctg_exec* e, const std::vector<int64_t>& ids) {
+    const ctg_plan* p = e->plan;
+    std::vector<std::pair<int64_t, int64_t>> order(ids.size());
+    for (size_t k = 0; k < ids.size(); ++k) order[k] = {slice_group_key(p, ids[k]), ids[k]};
+    std::sort(order.begin(), order.end());
+    for (const auto& ks : order) {
+        const bool fresh = ks.first != e->group_key;
+        hipError_t err = launch_prologue(e->meta, e->d_state, e->d_soff, ks.second, e->stream, 1, 1);
+        if (err != hipSuccess) return fail(CTG_E_HIP, "prologue launch failed: %s", hipGetErrorString(err));
+        e->group_key = -1;   // (until the shared steps of this key are all launched)
+        for (const ctg_exec::Issue& q : fresh ? e->issue : e->issue_reuse) {
+            const int rc = launch_issue(e, q, 1, e->stream);
+            if (rc != CTG_OK) return rc;
+        }
+        e->group_key = ks.first;
+    }
+    e->warm = true;
     return CTG_OK;
 }
 
@@ -1101,7 +1204,9 @@ int ctg_plan_create(const ctg_plan_desc* d, ctg_plan** out) {
         p->slice_fixed.assign(d->slice_fixed, d->slice_fixed + d->n_sliced);
         p->slice_strides.assign(d->slice_strides,
                                 d->slice_strides + (d->n_inputs + 1) * d->n_sliced);
+        if (d->slice_group) p->slice_group.assign(d->slice_group, d->slice_group + d->n_sliced);
     }
+    p->slice_group.resize(p->n_sliced, 0);
     if (p->inputs_elems < 1 || p->arena_elems < 1 || p->result_elems < 1) {
         delete p;
         return fail(CTG_E_INVALID, "empty buffer in plan");
@@ -1213,6 +1318,7 @@ int ctg_exec_create(const ctg_plan* p, int device, void* stream, void* ext_resul
         const int64_t per = std::max<int64_t>(p->arena_elems * isz, 1);
         b = std::min<int64_t>(b, (mib << 20) / per);
         e->batch = (int)std::max<int64_t>(b, 1);
+        if (p->has_groups) e->batch = 1;   // (what a group shares lives once, not once per slice of a launch)
         // what the plan alone says about batching (no environment, no free-memory
         // query): the k-splits of its steps are chosen for launches of this many
         // slices, so that they are a function of the plan and a result never depends
@@ -1270,9 +1376,13 @@ int ctg_exec_create(const ctg_plan* p, int device, void* stream, void* ext_resul
         std::vector<int32_t> counted(std::max<int64_t>(p->n_steps, 1), 0);
         std::vector<int32_t> fac_zero(std::max<int64_t>(p->n_steps, 1), 0);
         e->invariant.assign(p->n_steps, 0);
+        e->grouped.assign(p->n_steps, 0);
+        for (int64_t st = 0; st < p->n_steps; ++st)
+            e->grouped[st] = p->has_groups && p->steps[st * STEP_WORDS + W_INVARIANT] == 2 &&
+                             p->steps[st * STEP_WORDS + W_KIND] != KIND_ACCUM;
         for (int64_t st = 0; st < p->n_steps; ++st) {
             const int64_t* r = &p->steps[st * STEP_WORDS];
-            e->invariant[st] = r[W_INVARIANT] != 0 && r[W_KIND] != KIND_ACCUM;
+            e->invariant[st] = r[W_INVARIANT] == 1 && r[W_KIND] != KIND_ACCUM;
             if (r[W_KIND] == KIND_PAIR || r[W_KIND] == KIND_STEM2) {
                 counted[st] = 1;
                 fac_zero[st] = e->invariant[st] ? 0 : 1;
@@ -1342,6 +1452,7 @@ int ctg_exec_upload_inputs_host(ctg_exec* e, const void* const* ptrs) {
     HIP_TRY(hipStreamSynchronize(e->stream));
     HIP_TRY(hipMemcpy(e->d_inputs, staging.data(), staging.size(), hipMemcpyHostToDevice));
     e->invariants_ready = false;
+    e->group_key = -1;
     return CTG_OK;
 }
 
@@ -1356,6 +1467,7 @@ int ctg_exec_upload_inputs_device(ctg_exec* e, const void* const* ptrs) {
                                p->input_sizes[i] * isz, hipMemcpyDeviceToDevice, e->stream));
     }
     e->invariants_ready = false;
+    e->group_key = -1;
     return CTG_OK;
 }
 
@@ -1398,6 +1510,7 @@ int ctg_exec_set_strip_exponent(ctg_exec* e, int strip, int check_zero) {
     e->meta.fac_zero = e->d_fac_zero;
     e->meta.n_fac = strip ? e->plan->n_steps : 0;
     e->invariants_ready = false;  // their stored scale changes with the option
+    e->group_key = -1;
     resolve_args(e);
     {
         const int rc = build_groups(e);
@@ -1450,6 +1563,11 @@ int ctg_exec_run_slices(ctg_exec* e, int64_t first, int64_t count, int64_t strid
         }
         return CTG_OK;
     };
+    if (p->has_groups && !e->strip) {
+        std::vector<int64_t> ids((size_t)count);
+        for (int64_t k = 0; k < count; ++k) ids[(size_t)k] = first + k * stride;
+        return run_grouped(e, ids);
+    }
     int64_t i = 0;
     // (strip_exponent keeps one scale per step and slice: no batching there)
     const int64_t batch = e->strip ? 1 : e->batch;
@@ -1509,6 +1627,27 @@ int ctg_exec_run_slices(ctg_exec* e, int64_t first, int64_t count, int64_t strid
     return CTG_OK;
 }
 
+int ctg_exec_run_slice_list(ctg_exec* e, const int64_t* ids, int64_t n) {
+    if (!e || (n > 0 && !ids)) return fail(CTG_E_INVALID, "null argument");
+    const ctg_plan* p = e->plan;
+    if (n < 0) return fail(CTG_E_INVALID, "negative slice count");
+    for (int64_t k = 0; k < n; ++k)
+        if (ids[k] < 0 || ids[k] >= p->nslices)
+            return fail(CTG_E_INVALID, "slice id %lld outside [0, %lld)", (long long)ids[k], (long long)p->nslices);
+    if (n == 0) return CTG_OK;
+    if (p->has_groups && !e->strip) {
+        HIP_TRY(hipSetDevice(e->device));
+        const int rc = run_invariants(e);
+        if (rc != CTG_OK) return rc;
+        return run_grouped(e, std::vector<int64_t>(ids, ids + n));
+    }
+    for (int64_t k = 0; k < n; ++k) {
+        const int rc = ctg_exec_run_slices(e, ids[k], 1, 1);
+        if (rc != CTG_OK) return rc;
+    }
+    return CTG_OK;
+}
+
 int ctg_exec_launch_count(ctg_exec* e, int64_t* steps, int64_t* launches) {
     if (!e || !steps || !launches) return fail(CTG_E_INVALID, "null argument");
     int64_t ns = 0, nl = 0;
@@ -1542,6 +1681,7 @@ int ctg_exec_profile_slice(ctg_exec* e, int64_t slice_id, float* ms) {
     if (!e || !ms) return fail(CTG_E_INVALID, "null argument");
     const ctg_plan* p = e->plan;
     if (slice_id < 0 || slice_id >= p->nslices) return fail(CTG_E_INVALID, "slice id out of range");
+    e->group_key = -1;   // (every step of this slice is launched: whatever a group shared before is overwritten)
     HIP_TRY(hipSetDevice(e->device));
     while ((int64_t)e->events.size() < p->n_steps + 1) {
         hipEvent_t ev;

@@ -265,9 +265,24 @@ def modelled_seconds(tree, model=None, dtype="complex64"):
     plan = compile_tree(tree, dtype)
     itemsize = plan.itemsize
     t = 0.0
+    share = 0.5 ** len(plan.group_inds)   # (a step shared by a group of slices costs a slice its share)
     for s in plan.steps:
         if not s.macs:
             continue
+        t += step_seconds(s, model) * (share if s.group else 1.0)
+    return t, plan.arena_elems * itemsize
+
+
+def step_seconds(s, model=None):
+    """Modelled time of one step of a device plan (what ``modelled_seconds`` adds up)."""
+    from .plan import KIND_STEM2
+    from .stem import pair_seconds, single_seconds
+
+    model = MI355X_C64 if model is None else model
+    t = 0.0
+    if not s.macs:
+        return t
+    for _ in (0,):
         if s.kind == KIND_STEM2:
             # a fused stem pair (stem.py): its own model -- the big tensor moves once
             st = s.stem
@@ -284,7 +299,7 @@ def modelled_seconds(tree, model=None, dtype="complex64"):
                               bf3_fits=st.get("bf3_fits", True))
         else:
             t += model.step_seconds(s.macs, s.elems_rw, s.K, s.N)
-    return t, plan.arena_elems * itemsize
+    return t
 
 
 def unslice(tree, model=None, max_width=2**32, max_arena_bytes=160 * 2**30):

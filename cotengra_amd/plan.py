@@ -156,6 +156,9 @@ class Step:
     # True if the step does not depend on any sliced input: it is executed once
     # per upload instead of once per slice and its output is never recycled
     invariant: bool = False
+    # (round 4) does not depend on the GROUP indices of the plan (Plan.group_inds): computed once per group of
+    # slices that differ only in those, its result kept where per-slice steps do not recycle it
+    group: bool = False
     # STEM2 (stem.py): the second step's small operand, its producer, the tile
     # geometry + tables; elems_rw counts BOTH steps as if unfused (the roofline's
     # algorithmic bytes), elems_moved what the fused launch really moves
@@ -226,6 +229,10 @@ class Plan:
         self.slice_sizes = []  # extent per sliced index (1 if projected)
         self.slice_fixed = []  # projected value or -1
         self.slice_strides = None  # (n_inputs + 1, n_sliced) element strides
+        # slice groups (round 4): slices that differ only in these sliced indices share every step that does
+        # not depend on them (Step.group); one flag per sliced index, in the order of slice_sizes
+        self.group_inds = ()
+        self.slice_group = []
         self.nslices = 1
         # accounting
         self.macs_per_slice = 0
@@ -239,6 +246,59 @@ class Plan:
     @property
     def itemsize(self):
         return DTYPE_ITEMSIZE[self.dtype]
+
+    # ---- slice groups: which slices share the steps marked ``group`` ---------------------------------
+    def _slice_digits(self):
+        """``(stride in the slice id, size, is a group index)`` of every sliced index that is not
+        projected, least significant first (the last sliced index varies fastest: tree.get_slice_strides)."""
+        flags = list(self.slice_group) if len(self.slice_group) == len(self.slice_sizes) else [0] * len(self.slice_sizes)
+        out, stride = [], 1
+        for j in range(len(self.slice_sizes) - 1, -1, -1):
+            if self.slice_fixed[j] >= 0:
+                continue
+            out.append((stride, int(self.slice_sizes[j]), bool(flags[j])))
+            stride *= int(self.slice_sizes[j])
+        return out
+
+    @property
+    def group_size(self):
+        """Slices per group (1: the plan shares nothing between slices but the invariant steps)."""
+        return prod(size for _, size, g in self._slice_digits() if g)
+
+    def group_ids(self, g):
+        """Slice ids of the ``g``-th group, ascending (``g`` in ``range(nslices // group_size)``: the digits
+        of ``g`` are the values of the sliced indices that are not group indices)."""
+        digits = self._slice_digits()
+        base, rem = 0, int(g)
+        for stride, size, is_group in digits:
+            if not is_group:
+                base += (rem % size) * stride
+                rem //= size
+        ids = [base]
+        for stride, size, is_group in digits:
+            if is_group:
+                ids = [i + d * stride for i in ids for d in range(size)]
+        return sorted(ids)
+
+    def group_of(self, slice_id):
+        """The group number (argument of ``group_ids``) ``slice_id`` belongs to."""
+        # (a Python int of any size -- trees narrowed for tests have more than 2^63 slices -- or an
+        # int64 array of slice ids)
+        scalar = isinstance(slice_id, (int, np.integer))
+        rem = int(slice_id) if scalar else np.asarray(slice_id, dtype=np.int64)
+        g, mult = (0 if scalar else np.zeros_like(rem)), 1
+        for stride, size, is_group in self._slice_digits():
+            d = rem % size
+            rem = rem // size
+            if not is_group:
+                g = g + d * mult
+                mult *= size
+        return g
+
+    @property
+    def macs_shared_per_group(self):
+        """Multiply-adds of the steps a group computes once."""
+        return sum(s.macs for s in self.steps if s.group)
 
     @property
     def is_complex(self):
@@ -307,7 +367,7 @@ class Plan:
                 r[33], r[34], r[35] = s.macs, s.elems_rw, s.node
                 r[37] = r[38] = -1
                 r[40], r[41] = s.a_prod, s.b_prod
-                r[42] = 1 if s.invariant else 0
+                r[42] = 1 if s.invariant else (2 if s.group else 0)
                 r[W_STEM] = serialise_stem(s, put)
                 continue
             for base, t in ((2, s.a), (5, s.b), (8, s.c)):
@@ -344,7 +404,7 @@ class Plan:
             r[32] = s.c.size if s.c is not None else 0
             r[33], r[34], r[35] = s.macs, s.elems_rw, s.node
             r[40], r[41] = s.a_prod, s.b_prod
-            r[42] = 1 if s.invariant else 0
+            r[42] = 1 if s.invariant else (2 if s.group else 0)
 
         tables = np.concatenate(blobs) if blobs else np.zeros(1, np.int64)
         n_in = len(self.input_sizes)
@@ -366,6 +426,7 @@ class Plan:
             "slice_sizes": np.asarray(self.slice_sizes, dtype=np.int64),
             "slice_fixed": np.asarray(self.slice_fixed, dtype=np.int64),
             "slice_strides": slice_strides.reshape(-1),
+            "slice_group": np.asarray(self.slice_group if len(self.slice_group) == n_sl else [0] * n_sl, dtype=np.int64),
         }
 
     def describe_steps(self):
@@ -626,9 +687,77 @@ def build_single_step(size_dict, src, out_inds, out_ref_factory, node=-1):
 
 FUSE_MIN_ELEMS = 1 << 24  # stem pairs are fused when the big operand has at least this many elements
 
+# Slice groups (round 4).  The reference contracts every slice from the leaves (core.py:3802-3834); steps that
+# depend on no sliced index at all were already computed once (slice-invariant subtrees).  The same holds one
+# level down: two slices that differ only in the values of a FEW sliced indices share every step below which
+# none of those indices occurs.  With such "group indices" g_1 .. g_k chosen, the executor visits the slices
+# group by group (2^k slices that agree on all other sliced indices), computes the shared steps for the first
+# slice of a group and keeps what the other steps read of them in memory that per-slice steps do not recycle
+# -- 288 GB of HBM hold a 34 GB tensor more than the arena needs.
+GROUP_MIN_WIDTH = 1 << 28      # only trees whose slices are launch sequences of large steps
+GROUP_MAX_INDS = 3
+GROUP_MIN_SAVING = 0.02        # of a slice's modelled time
+GROUP_MAX_KEPT_BYTES = 96 * 2**30
+GROUP_MAX_TOTAL_BYTES = 250 * 2**30
+
+
+def slice_groups_enabled():
+    """On unless ``CTG_SLICE_GROUPS`` is "0" / "" (the plan then shares nothing between slices but the
+    slice-invariant steps, as in rounds 1-3)."""
+    return os.environ.get("CTG_SLICE_GROUPS", "1") not in ("", "0")
+
+
+def choose_slice_group(tree, plan):
+    """Which sliced indices to make the group indices of ``plan`` (compiled for ``tree`` without groups):
+    greedily the index whose addition saves most modelled time per slice -- a step that depends on none
+    of them costs a slice 2^-k of its time -- while the tensors to be kept for a group fit; ``()`` if
+    nothing saves ``GROUP_MIN_SAVING``."""
+    if not slice_groups_enabled() or tree.N < 3 or tree.multiplicity < 4 or tree.max_size() < GROUP_MIN_WIDTH:
+        return ()
+    from .pathfind import step_seconds
+
+    sliced = [si.ind for si in tree.sliced_inds.values() if si.project is None]
+    below = {i: frozenset(ix for ix in term if ix in tree.sliced_inds) for i, term in enumerate(tree.inputs)}
+    kids = {}
+    for p, l, r in tree.traverse():
+        below[p] = below[l] | below[r]
+        kids[p] = (l, r)
+    rows = [(s, step_seconds(s), below.get(s.node, frozenset())) for s in plan.steps if s.node >= 0 and not s.invariant]
+    total = sum(t for _, t, _ in rows)
+    if total <= 0:
+        return ()
+    itemsize = plan.itemsize
+    chosen, best_saving = [], 0.0
+    while len(chosen) < GROUP_MAX_INDS:
+        cands = []
+        for ix in sliced:
+            if ix in chosen:
+                continue
+            g = set(chosen) | {ix}
+            shared = [s for s, _, d in rows if d and not (g & d)]
+            saving = sum(t for _, t, d in rows if d and not (g & d)) * (1.0 - 0.5 ** len(g))
+            ids = {id(s.c) for s in shared}
+            kept = sum(op.size for s, _, d in rows if (g & d)
+                       for op in (s.a, s.b, getattr(s, "b2", None), getattr(s, "bm", None))
+                       if op is not None and id(op) in ids)
+            if kept * itemsize > GROUP_MAX_KEPT_BYTES or (plan.arena_elems + kept) * itemsize > GROUP_MAX_TOTAL_BYTES:
+                continue
+            cands.append((saving, ix))
+        if not cands:
+            break
+        saving, ix = max(cands, key=lambda c: (c[0], str(c[1])))
+        if saving <= best_saving * 1.02:
+            break
+        chosen.append(ix)
+        best_saving = saving
+    if best_saving < GROUP_MIN_SAVING * total:
+        return ()
+    return tuple(chosen)
+
+
 
 def compile_tree(tree, dtype, order=None, force_kernel=None, fuse=None, fuse_min_elems=None, _pairs=None,
-                 stem_bf16x3=None):
+                 stem_bf16x3=None, _group=None):
     """Compile ``tree`` (possibly sliced) into a :class:`Plan` that computes
     ONE slice and accumulates it into the full result tensor.
 
@@ -644,22 +773,31 @@ def compile_tree(tree, dtype, order=None, force_kernel=None, fuse=None, fuse_min
     """
     if fuse is None:
         fuse = os.environ.get("CTG_NO_FUSE", "0") in ("", "0")
-    if _pairs is None and fuse and dtype == "complex64" and force_kernel is None and tree.N > 2:
-        from .stem import find_pairs
+    if _pairs is None and _group is None:
+        # top level: compile without fusion, choose the pairs on that plan's steps, compile with them,
+        # choose the group indices on THAT plan's steps, compile once more with both
+        pairs = {}
+        plan = None
+        if fuse and dtype == "complex64" and force_kernel is None and tree.N > 2:
+            from .stem import find_pairs
 
-        base = compile_tree(tree, dtype, order, force_kernel, fuse=False)
-        pairs = find_pairs(
-            base, tree.size_dict,
-            min_elems=(
-                int(os.environ.get("CTG_FUSE_MIN_ELEMS", FUSE_MIN_ELEMS))
-                if fuse_min_elems is None else fuse_min_elems
-            ),
-            bf16x3=stem_bf16x3,   # (the pairs are priced in the arithmetic they will run in)
-        )
-        if not pairs:
-            return base
-        return compile_tree(tree, dtype, order, force_kernel, fuse=False, _pairs=pairs)
+            plan = compile_tree(tree, dtype, order, force_kernel, fuse=False, _pairs={}, _group=())
+            pairs = find_pairs(
+                plan, tree.size_dict,
+                min_elems=(
+                    int(os.environ.get("CTG_FUSE_MIN_ELEMS", FUSE_MIN_ELEMS))
+                    if fuse_min_elems is None else fuse_min_elems
+                ),
+                bf16x3=stem_bf16x3,   # (the pairs are priced in the arithmetic they will run in)
+            )
+        if plan is None or pairs:
+            plan = compile_tree(tree, dtype, order, force_kernel, fuse=False, _pairs=pairs, _group=())
+        group = choose_slice_group(tree, plan)
+        if group:
+            plan = compile_tree(tree, dtype, order, force_kernel, fuse=False, _pairs=pairs, _group=frozenset(group))
+        return plan
     pairs = _pairs or {}
+    group = frozenset(_group or ())
     pair_second = {v: k for k, v in pairs.items() if v != k}   # (k: k = a single step on the stem kernel)
     stem_pending = {}  # first node of a pair -> (A, B1, legs of the intermediate)
     plan = Plan(dtype)
@@ -760,7 +898,10 @@ def compile_tree(tree, dtype, order=None, force_kernel=None, fuse=None, fuse_min
 
     producer = {}  # id(TensorRef) -> index of the pair step that wrote it
 
+    cur = {"group": False}
+
     def add(step):
+        step.group = bool(cur["group"]) and not step.invariant
         if step.kind == KIND_PAIR:
             step.a_prod = producer.get(id(step.a), -1)
             step.b_prod = producer.get(id(step.b), -1)
@@ -780,6 +921,29 @@ def compile_tree(tree, dtype, order=None, force_kernel=None, fuse=None, fuse_min
     # -- leaves: strided views of the resident inputs
     tensors = {}
     depends = {}  # node -> does it depend on a sliced input?
+    # slice groups: does a node depend on one of the group indices?  Known for every node up front,
+    # because what matters at a node is its CONSUMER: a result that does not depend on the group but feeds
+    # a step that does is kept where per-slice steps never recycle it (like the invariant ones)
+    dep_g, parent_of = {}, {}
+    if group:
+        for i, term in enumerate(tree.inputs):
+            dep_g[i] = any(ix in group for ix in term)
+        for p_, l_, r_ in tree.traverse():
+            dep_g[p_] = dep_g[l_] or dep_g[r_]
+            parent_of[l_] = parent_of[r_] = p_
+        plan.group_inds = tuple(ix for ix in tree.sliced_inds if ix in group)
+        plan.slice_group = [1 if si.ind in group else 0 for si in tree.sliced_inds.values()]
+
+    def last_of(node):   # the node whose step consumes / emits a fused chain starting at ``node``
+        while node in pairs and pairs[node] != node:
+            node = pairs[node]
+        return node
+
+    def kept_for_group(node):
+        """``node``'s result is per-group work consumed by per-slice work."""
+        if not group or dep_g[node] or not depends[node] or node not in parent_of:
+            return False
+        return dep_g[last_of(parent_of[node])]
     for i, term in enumerate(tree.inputs):
         full_shape = [size_dict[ix] for ix in term]
         st = _row_major_strides(full_shape)
@@ -796,8 +960,9 @@ def compile_tree(tree, dtype, order=None, force_kernel=None, fuse=None, fuse_min
         depends[i] = (i in tree.sliced_inputs) or not use_invariants
         if i in tree.preprocessing and N > 1:
             inv = not depends[i]
+            cur["group"] = bool(group) and depends[i] and not dep_g[i]
             step = build_single_step(
-                size_dict, view, tuple(legs), arena_factory(invariant=inv), node=i
+                size_dict, view, tuple(legs), arena_factory(invariant=inv or kept_for_group(i)), node=i
             )
             step.invariant = inv
             add(step)
@@ -863,9 +1028,10 @@ def compile_tree(tree, dtype, order=None, force_kernel=None, fuse=None, fuse_min
             is_root = p == tree.root
             depends[p] = depends[l] or depends[r] or is_root
             inv = not depends[p]
+            cur["group"] = bool(group) and depends[p] and not dep_g[p] and not is_root
             factory = arena_factory(
                 root_order if is_root else None,
-                invariant=inv,
+                invariant=inv or kept_for_group(p),
                 reorder=consumer_order(p) if consumer_order is not None else None,
             )
             p_inds = root_order if is_root else tuple(tree.get_legs(p))

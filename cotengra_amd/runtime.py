@@ -32,6 +32,7 @@ SYMBOLS = (
     "ctg_exec_set_stem_arithmetic",
     "ctg_exec_get_exponent",
     "ctg_exec_run_slices",
+    "ctg_exec_run_slice_list",
     "ctg_exec_slice_batch",
     "ctg_exec_device_bytes",
     "ctg_stem_triple_instantiated",
@@ -83,6 +84,7 @@ class PlanDesc(C.Structure):
         ("slice_sizes", C.POINTER(C.c_int64)),
         ("slice_fixed", C.POINTER(C.c_int64)),
         ("slice_strides", C.POINTER(C.c_int64)),
+        ("slice_group", C.POINTER(C.c_int64)),
     ]
 
 
@@ -132,6 +134,7 @@ def load():
         "ctg_exec_set_stem_arithmetic": [vp, C.c_int],
         "ctg_exec_get_exponent": [vp, C.POINTER(C.c_double), C.POINTER(C.c_int)],
         "ctg_exec_run_slices": [vp, C.c_int64, C.c_int64, C.c_int64],
+        "ctg_exec_run_slice_list": [vp, i64p, C.c_int64],
         "ctg_exec_slice_batch": [vp, i64p],
         "ctg_exec_device_bytes": [vp, i64p],
         "ctg_stem_triple_instantiated": [C.c_int] * 9,
@@ -211,6 +214,7 @@ class DevicePlan:
         d.slice_sizes = _i64p(s["slice_sizes"])
         d.slice_fixed = _i64p(s["slice_fixed"])
         d.slice_strides = _i64p(s["slice_strides"])
+        d.slice_group = _i64p(s["slice_group"])
         handle = C.c_void_p()
         _check(lib.ctg_plan_create(C.byref(d), C.byref(handle)))
         self.handle = handle
@@ -303,6 +307,12 @@ class Executor:
         e, z = C.c_double(), C.c_int()
         _check(load().ctg_exec_get_exponent(self.handle, C.byref(e), C.byref(z)))
         return e.value, bool(z.value)
+
+    def run_slice_list(self, ids):
+        """Contract the slices ``ids`` (any order, any subset) and add them to the result; with slice
+        groups in the plan, group by group (``ctg_exec_run_slice_list``)."""
+        arr = np.ascontiguousarray(ids, dtype=np.int64)
+        _check(load().ctg_exec_run_slice_list(self.handle, arr.ctypes.data_as(C.POINTER(C.c_int64)), arr.size))
 
     def run_slices(self, first=0, count=None, stride=1):
         if count is None:

@@ -81,6 +81,13 @@ typedef struct ctg_plan_desc {
     const int64_t* slice_fixed;   /* [n_sliced] projected value or -1 */
     const int64_t* slice_strides; /* [(n_inputs+1) * n_sliced] element strides; row
                                      n_inputs is the output tensor (outer slices) */
+    /* ABI 5 (may be NULL = none).  [n_sliced] 1: a GROUP index.  Slices that differ only in the group
+     * indices form a group; a step whose record says so (word 42 = 2) depends on none of them and is
+     * computed for the first slice of a group only, what later steps read of it living in arena ranges
+     * no per-slice step writes (the planner's job, cotengra_amd/plan.py: choose_slice_group).
+     * ctg_exec_run_slices visits the slices it is given group by group.  The reference recomputes every
+     * slice from the leaves (core.py:3802-3834). */
+    const int64_t* slice_group;
 } ctg_plan_desc;
 
 typedef struct ctg_plan ctg_plan;
@@ -172,6 +179,12 @@ int ctg_exec_run_slices(ctg_exec* exec, int64_t first, int64_t count, int64_t st
  * and the order in which slices are added are those of one launch sequence per
  * slice. */
 int ctg_exec_slice_batch(ctg_exec* exec, int64_t* batch);
+/* ABI 5.  The same for an arbitrary list of slice ids (each in [0, nslices); repetitions allowed: a slice
+ * given twice is added twice).  With slice groups in the plan (ctg_plan_desc.slice_group) the slices are
+ * visited group by group and the steps a group shares are computed once per group among the ids given --
+ * pass whole groups to get the saving; the sum does not depend on the grouping beyond the order of
+ * its floating-point additions. */
+int ctg_exec_run_slice_list(ctg_exec* exec, const int64_t* ids, int64_t n);
 /* ABI 4.  Device memory this executor holds right now: inputs space, arena x slice batch,
  * tables, the result if it owns it, the scratch buffer if the plan has a step that needs one
  * (allocated by ctg_exec_create).  What a cache of contractors -- the reference keeps them

@@ -45,6 +45,41 @@ def slice_offsets(plan, slice_id):
     return plan.slice_strides @ np.asarray(digits, dtype=np.int64)
 
 
+def group_key(plan, slice_id):
+    """``slice_id`` with the digits of the plan's group indices (``plan.slice_group``) set to zero: slices
+    with the same key differ only in those and share every step marked ``group`` (the executor's
+    ``slice_group_key``, csrc/ctg_runtime.hip)."""
+    n_sl = len(plan.slice_sizes)
+    flags = list(plan.slice_group) if len(plan.slice_group) == n_sl else [0] * n_sl
+    key, rem, stride = 0, slice_id, 1
+    for j in range(n_sl - 1, -1, -1):
+        if plan.slice_fixed[j] >= 0:
+            continue
+        d = rem % plan.slice_sizes[j]
+        rem //= plan.slice_sizes[j]
+        if not flags[j]:
+            key += d * stride
+        stride *= plan.slice_sizes[j]
+    return key
+
+
+def group_members(plan, slice_id):
+    """All slice ids that share ``slice_id``'s group (every value of the group indices)."""
+    n_sl = len(plan.slice_sizes)
+    flags = list(plan.slice_group) if len(plan.slice_group) == n_sl else [0] * n_sl
+    strides, stride = [0] * n_sl, 1
+    for j in range(n_sl - 1, -1, -1):
+        if plan.slice_fixed[j] >= 0:
+            continue
+        strides[j] = stride
+        stride *= plan.slice_sizes[j]
+    ids = [group_key(plan, slice_id)]
+    for j in range(n_sl):
+        if flags[j] and plan.slice_fixed[j] < 0:
+            ids = [i + d * strides[j] for i in ids for d in range(plan.slice_sizes[j])]
+    return sorted(ids)
+
+
 def run_stem2(step, spaces, base, chunk=256):
     """A fused stem pair (cotengra_amd/stem.py, csrc/ctg_stem.hip) executed from
     the very tables the kernel reads, tile by tile:
@@ -134,8 +169,15 @@ def run_plan(plan, arrays, slice_ids=None, result=None):
         slice_ids = range(plan.nslices)
 
     first = True
+    # (slice groups: same-key slices one after the other, the shared steps once per key -- the executor's order)
+    grouped = any(getattr(st, "group", False) for st in plan.steps)
+    if grouped:
+        slice_ids = sorted(slice_ids, key=lambda i: (group_key(plan, i), i))
+    last_key = None
     for sid in slice_ids:
         soff = slice_offsets(plan, sid)
+        key = group_key(plan, sid) if grouped else None
+        fresh, last_key = key != last_key, key
 
         def base(t):
             b = t.offset
@@ -146,6 +188,8 @@ def run_plan(plan, arrays, slice_ids=None, result=None):
         for step in plan.steps:
             if step.invariant and not first:
                 continue  # computed once, output persistent (like the executor)
+            if grouped and getattr(step, "group", False) and not fresh:
+                continue  # computed for the first slice of this group, what is read of it kept
             if step.kind == P.KIND_SINGLE:
                 src, dst = spaces[step.a.space], spaces[step.c.space]
                 ia = base(step.a) + _rows(step, "A")[:, None] + _ks(step, "A")[None, :]

@@ -442,3 +442,64 @@ def test_three_step_tiles_on_device(seed, bf16x3, monkeypatch):
     scale = np.abs(ref).max()
     gate = max(1e-5, 8 * np.abs(base - ref).max() / scale)
     assert np.abs(got - ref).max() / scale <= gate
+
+
+# ---- slice groups ------------------------------------------------------------------------------------------
+
+@pytest.mark.parametrize("fixture", ["sycamore_m20_w32_r4.json", "sycamore_m20_native.json"])
+def test_slice_groups_narrowed_against_oracle(fixture, monkeypatch):
+    """m20 trees narrowed to width 2^20 with slice groups in the plan: whole groups, a partial group and
+    lone slices in one ``run_slice_list`` call (in descending order: the executor sorts them group by
+    group) against the complex128 oracle, within the gate numpy's own single precision sets."""
+    from cotengra_amd import plan as P
+    from oracle.plan_interp import group_members
+
+    monkeypatch.delenv("CTG_SLICE_GROUPS", raising=False)
+    monkeypatch.setattr(P, "GROUP_MIN_WIDTH", 1)
+    monkeypatch.setattr(P, "GROUP_MIN_SAVING", 0.0)
+    tree = ca.tree_from_record(ca.load_network(os.path.join(os.path.dirname(__file__), "golden", "trees", fixture)))
+    arrays = ca.make_arrays_from_inputs(tree.inputs, tree.size_dict, seed=42, dtype="complex64", rescale=True)
+    small = tree.slice(target_size=2**20)
+    fn = HipContractor(small)
+    plan = fn.get_plan("complex64")[0]
+    assert plan.group_size >= 2 and any(s.group for s in plan.steps)
+    ids = group_members(plan, 3) + group_members(plan, 77777)[:3] + [12345, 5]
+    a128 = [a.astype("complex128") for a in arrays]
+    ref = sum(complex(orc.contract_slice(small, a128, i)) for i in ids)
+    np64 = sum(complex(orc.contract_slice(small, arrays, i)) for i in ids)
+    ex = fn.setup(*arrays)["exec"]
+    ex.zero_result()
+    ex.run_slice_list(ids[::-1])
+    got = complex(ex.download_result())
+    # ... and the same slices one call each (nothing shared between calls but what the key says is there)
+    ex.zero_result()
+    for i in sorted(ids, key=lambda i: (plan.group_of(i), i)):
+        ex.run_slice_list([i])
+    again = complex(ex.download_result())
+    fn.close()
+    assert abs(got - ref) / abs(ref) <= max(1e-5, 8.0 * abs(np64 - ref) / abs(ref))
+    assert again == got
+
+
+def test_slice_groups_full_width_bit_identical(monkeypatch):
+    """One group of the time-to-solution tree at full width: the shared steps computed once == every step
+    computed for every slice, bit for bit (same kernels, same order of additions)."""
+    tree = ca.tree_from_record(ca.load_network(os.path.join(os.path.dirname(__file__), "golden", "trees",
+                                                            "sycamore_m20_w32_r4.json")))
+    arrays = ca.make_arrays_from_inputs(tree.inputs, tree.size_dict, seed=42, dtype="complex64", rescale=True)
+    res = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("CTG_SLICE_GROUPS", mode)
+        fn = HipContractor(tree)
+        plan = fn.get_plan("complex64")[0]
+        if mode == "1":
+            assert plan.group_size == 4
+            members = plan.group_ids(plan.group_of(5))
+        else:
+            assert plan.group_size == 1
+        ex = fn.setup(*arrays)["exec"]
+        ex.zero_result()
+        ex.run_slice_list(members)
+        res[mode] = complex(ex.download_result())
+        fn.close()
+    assert res["1"] == res["0"] and res["1"] != 0

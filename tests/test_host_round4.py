@@ -469,3 +469,93 @@ def test_three_step_tile_records_validate(seed, monkeypatch, take_every_triple):
     assert lib.ctg_stem_triple_instantiated(1, 0, 1, 2, 1, 1, 1, 1, 0) == 1       # seed 0's
     assert lib.ctg_stem_triple_instantiated(1, 1, 1, 7, 3, 5, 2, 2, 0) == 0
     assert stem.triples_enabled()
+
+
+# ---- slice groups (plan.choose_slice_group; ctg_plan_desc.slice_group, ctg_exec_run_slice_list) ---------
+
+@pytest.fixture
+def groups_on_small_trees(monkeypatch):
+    """(the planner keeps slice groups to trees whose slices are long launch sequences; the narrowed
+    fixtures the oracle can run are not)"""
+    from cotengra_amd import plan as P
+
+    monkeypatch.delenv("CTG_SLICE_GROUPS", raising=False)
+    monkeypatch.setattr(P, "GROUP_MIN_WIDTH", 1)
+    monkeypatch.setattr(P, "GROUP_MIN_SAVING", 0.0)
+
+
+@pytest.mark.parametrize("fixture", ["sycamore_m20_w32_r4.json", "sycamore_m20_native.json", "sycamore_m20_w33_bf3.json"])
+def test_slice_groups_plan_semantics(fixture, groups_on_small_trees):
+    """Slices that differ only in the plan's group indices share every step that depends on none of
+    them.  The numpy interpreter of the plan visits the slices group by group, skips the shared steps
+    for all but the first slice of a group -- reading what they left in the arena, at the offsets the
+    kernels would -- and lands on the sum of the oracle's slices: whole groups, partial groups and lone
+    slices in one list.  The C ABI validates the plan, and rejects one whose kept tensors are not safe."""
+    import copy
+
+    from cotengra_amd import plan as P, runtime
+    from oracle import plan_interp
+    from test_tree_fixtures import narrowed
+
+    tree = ca.tree_from_record(ca.load_network(os.path.join(ROOT, "tests", "golden", "trees", fixture)))
+    small = narrowed(tree, 10)
+    arrays = ca.make_arrays_from_inputs(small.inputs, small.size_dict, seed=42, dtype="complex128", rescale=True)
+    plan = P.compile_tree(small, "complex64", fuse_min_elems=1 << 6)
+    shared = [s for s in plan.steps if s.group]
+    assert plan.group_inds and shared and plan.group_size == 2 ** len(plan.group_inds)
+    assert not any(s.group and s.invariant for s in plan.steps)
+    # the helpers of the plan and of the interpreter agree on who shares with whom
+    for sid in (0, 37, 12345, 999999):
+        members = plan_interp.group_members(plan, sid)
+        assert members == plan.group_ids(plan.group_of(sid)) and sid in members
+        assert len({plan_interp.group_key(plan, i) for i in members}) == 1
+    ids = (plan_interp.group_members(plan, 37) + plan_interp.group_members(plan, 12345)[:5]
+           + plan_interp.group_members(plan, 999999) + [5, 900])
+    assert len({plan.group_of(i) for i in ids}) < len(ids)
+    runtime.DevicePlan(plan).close()
+    plan128 = copy.copy(plan)
+    plan128.dtype = "complex128"
+    got = complex(np.asarray(plan_interp.run_plan(plan128, arrays, slice_ids=ids[::-1])))
+    ref = sum(complex(orc.contract_slice(small, arrays, i)) for i in ids)
+    assert abs(got - ref) <= 1e-10 * abs(ref)
+    # without groups: the same plan but for the sharing classes and where the kept tensors live
+    os.environ["CTG_SLICE_GROUPS"] = "0"
+    try:
+        flat = P.compile_tree(small, "complex64", fuse_min_elems=1 << 6)
+    finally:
+        del os.environ["CTG_SLICE_GROUPS"]
+    assert flat.group_size == 1 and not [s for s in flat.steps if s.group]
+    assert flat.macs_per_slice == plan.macs_per_slice and len(flat.steps) == len(plan.steps)
+    # corrupted: group flags gone while steps still claim to be shared; a kept tensor moved into the
+    # recycled part of the arena (another step writes there)
+    keep = plan.slice_group
+    plan.slice_group = [0] * len(keep)
+    with pytest.raises((runtime.CtgError, ValueError)):
+        runtime.DevicePlan(plan)
+    plan.slice_group = keep
+    kept = next(s for s in shared if any(not t.group and not t.invariant and t.kind != P.KIND_ACCUM and
+                                         any(op is s.c for op in (t.a, t.b, getattr(t, "b2", None)))
+                                         for t in plan.steps))
+    victim = next(t for t in plan.steps if not t.group and not t.invariant and t.kind in (P.KIND_PAIR, P.KIND_STEM2)
+                  and t.c.space == P.SPACE_ARENA and t.c.size >= kept.c.size and t.c is not kept.c)
+    old = kept.c.offset
+    kept.c.offset = victim.c.offset
+    with pytest.raises((runtime.CtgError, ValueError)):
+        runtime.DevicePlan(plan)
+    kept.c.offset = old
+    runtime.DevicePlan(plan).close()
+
+
+def test_slice_groups_only_on_wide_trees(monkeypatch):
+    """By default the planner groups slices on trees whose slices are sequences of large launches (width
+    >= 2^28); the small configurations keep their slice batching."""
+    from cotengra_amd import plan as P
+    from test_tree_fixtures import narrowed
+
+    monkeypatch.delenv("CTG_SLICE_GROUPS", raising=False)
+    tree = ca.tree_from_record(ca.load_network(os.path.join(ROOT, "tests", "golden", "trees", "sycamore_m20_w32_r4.json")))
+    assert P.compile_tree(narrowed(tree, 10), "complex64").group_size == 1
+    wide = P.compile_tree(tree, "complex64")
+    assert wide.group_size == 4 and 0.05 < wide.macs_shared_per_group / wide.macs_per_slice < 0.5
+    monkeypatch.setenv("CTG_SLICE_GROUPS", "0")
+    assert P.compile_tree(tree, "complex64").group_size == 1
