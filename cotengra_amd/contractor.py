@@ -816,7 +816,7 @@ def benchmark_tree(
 
 
 def tree_signature(tree, dtype, rank=0, world=1, strip_exponent=False, check_zero=False, order=None,
-                   arrays=None):
+                   arrays=None, groups=None):
     """Digest of everything a partial sum depends on: network, schedule,
     slicing, element type, which share of the slices, stripping options -- and,
     with ``arrays``, the input tensors themselves (``inputs_digest``): the same
@@ -835,6 +835,8 @@ def tree_signature(tree, dtype, rank=0, world=1, strip_exponent=False, check_zer
         "strip": [bool(strip_exponent), bool(check_zero)],
         "arrays": inputs_digest(arrays) if arrays is not None else None,
     }
+    if groups:   # (the order in which a rank's slices are summed follows the slice groups)
+        doc["groups"] = [str(ix) for ix in groups]
     return hashlib.sha256(json.dumps(doc, sort_keys=True).encode()).hexdigest()
 
 
@@ -915,8 +917,23 @@ def _contract_resumable_locked(fn, tree, arrays, checkpoint, every, order, strip
     ex = st["exec"]
     ex.set_strip_exponent(strip_exponent, check_zero)
     total = len(range(rank, tree.multiplicity, world))
+    plan = st["plan"]
+    # slice groups (plan.choose_slice_group): this rank's share is whole groups -- groups rank, rank + world, ...
+    # --, the count of the checkpoint runs along that order, chunks are whole groups
+    grouped = plan.group_size > 1 and not strip_exponent
+    if grouped:
+        gs = int(plan.group_size)
+        my_groups = range(rank, plan.nslices // gs, world)
+        total = len(my_groups) * gs
+        every = gs * max(1, -(-int(every) // gs))
+
+        def ids_at(start, n):
+            out = []
+            for k in range(start // gs, -(-(start + n) // gs)):
+                out += plan.group_ids(my_groups[k])
+            return out[start % gs: start % gs + n]
     sig = tree_signature(tree, st["plan"].dtype, rank, world, strip_exponent, check_zero, order,
-                         arrays=arrays)
+                         arrays=arrays, groups=plan.group_inds if grouped else None)
     saved = load_checkpoint(checkpoint, sig)
     if saved is None:
         done = 0
@@ -933,7 +950,10 @@ def _contract_resumable_locked(fn, tree, arrays, checkpoint, every, order, strip
     try:
         while budget > 0:
             n = min(int(every), budget)
-            ex.run_slices(rank + done * world, n, world)
+            if grouped:
+                ex.run_slice_list(ids_at(done, n))
+            else:
+                ex.run_slices(rank + done * world, n, world)
             done += n
             budget -= n
             result, exponent, zero = ex.get_state()

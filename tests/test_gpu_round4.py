@@ -503,3 +503,74 @@ def test_slice_groups_full_width_bit_identical(monkeypatch):
         res[mode] = complex(ex.download_result())
         fn.close()
     assert res["1"] == res["0"] and res["1"] != 0
+
+
+GROUP_CASES = [c["name"] for c in G.cases("tree")
+               if c["name"] in ("lattice4x4_sliced", "lattice8x8_sliced", "preproc_s0_ac", "preproc_s1_ac")
+               or (c["name"].startswith("rand_") and c["name"].endswith("sliced"))]
+
+
+@pytest.fixture
+def groups_everywhere(monkeypatch):
+    from cotengra_amd import plan as P
+
+    monkeypatch.delenv("CTG_SLICE_GROUPS", raising=False)
+    monkeypatch.setattr(P, "GROUP_MIN_WIDTH", 1)
+    monkeypatch.setattr(P, "GROUP_MIN_SAVING", 0.0)
+
+
+@pytest.mark.parametrize("name", GROUP_CASES)
+def test_slice_groups_on_golden_trees(name, groups_everywhere):
+    """Every sliced golden tree (hyper and output indices sliced, extents 2 and 3, single-term
+    preprocessing) contracted with slice groups forced on: the whole contraction against the oracle."""
+    case = next(c for c in G.cases("tree") if c["name"] == name)
+    tree = G.tree_of(case)
+    if tree.multiplicity < 4:
+        pytest.skip("fewer than four slices")
+    arrays = [a.astype("complex64") for a in G.arrays_of(case, "complex128", tree)]
+    ref = np.asarray(orc.contract(tree, [a.astype("complex128") for a in arrays]))
+    fn = HipContractor(tree)
+    if fn.get_plan("complex64")[0].group_size < 2:
+        fn.close()
+        pytest.skip("no step is independent of a sliced index")
+    got = np.asarray(fn(*arrays))
+    fn.close()
+    tol = G.single_gate(ref, orc.contract(tree, arrays)) * np.abs(ref).max()
+    assert np.abs(got - ref).max() <= tol
+
+
+def test_slice_groups_resumable_and_list_api(tmp_path, groups_everywhere):
+    """With slice groups in the plan the resumable contraction sums this rank's slices group by group, in
+    chunks of whole groups, and a run killed in between resumes to the same bits; run_slice_list takes
+    repetitions (a slice given twice is added twice) and refuses ids outside the tree."""
+    from cotengra_amd import runtime
+    from cotengra_amd.contractor import contract_resumable
+
+    case = next(c for c in G.cases("tree") if c["name"] == "rand_s42_r3_o1_hi0_ho0_outsliced")
+    tree = G.tree_of(case)
+    arrays = [a.astype("complex64") for a in G.arrays_of(case, "complex128", tree)]
+    fn = HipContractor(tree)
+    plan = fn.get_plan("complex64")[0]
+    assert plan.group_size >= 2 and tree.multiplicity >= 4 * plan.group_size
+    ref = np.asarray(orc.contract(tree, [a.astype("complex128") for a in arrays]))
+    ck = str(tmp_path / "ck.npz")
+    assert contract_resumable(tree, arrays, ck, every=3, stop_after=2 * plan.group_size) is None
+    assert os.path.exists(ck)
+    out = np.asarray(contract_resumable(tree, arrays, ck, every=3))
+    whole = np.asarray(contract_resumable(tree, arrays, str(tmp_path / "ck2.npz"), every=3))
+    assert np.array_equal(out, whole)
+    scale = np.abs(ref).max()
+    assert np.abs(out - ref).max() <= G.single_gate(ref, orc.contract(tree, arrays)) * scale
+    ex = fn.setup(*arrays)["exec"]
+    ex.zero_result()
+    ex.run_slice_list([1, 1, 0])
+    twice = np.asarray(ex.download_result()).copy()
+    ex.zero_result()
+    ex.run_slice_list([0])
+    ex.run_slice_list([1])
+    ex.run_slice_list([1])
+    assert np.allclose(twice, np.asarray(ex.download_result()), rtol=1e-5, atol=1e-6 * scale)
+    ex.run_slice_list([])
+    with pytest.raises((runtime.CtgError, ValueError)):
+        ex.run_slice_list([tree.multiplicity])
+    fn.close()

@@ -559,3 +559,29 @@ def test_slice_groups_only_on_wide_trees(monkeypatch):
     assert wide.group_size == 4 and 0.05 < wide.macs_shared_per_group / wide.macs_per_slice < 0.5
     monkeypatch.setenv("CTG_SLICE_GROUPS", "0")
     assert P.compile_tree(tree, "complex64").group_size == 1
+
+
+def test_slice_groups_on_every_small_sliced_golden_tree(groups_on_small_trees):
+    """All sliced golden trees the interpreter can run in full (hyper and output indices sliced, extents 2
+    and 3, single-term preprocessing; 77 of them have a step that is independent of some sliced index):
+    with slice groups forced on, the plan passes the C ABI's validation and the interpreter -- group by
+    group, shared steps once per group -- lands on the oracle's contraction."""
+    import golden_util as G
+    from cotengra_amd import plan as P, runtime
+    from oracle import plan_interp
+
+    n = 0
+    for case in G.cases("tree"):
+        tree = G.tree_of(case)
+        if tree.multiplicity < 4 or tree.multiplicity > 4096 or tree.max_size() > 2**16:
+            continue
+        plan = P.compile_tree(tree, "complex128")
+        if plan.group_size < 2:
+            continue
+        runtime.DevicePlan(plan).close()
+        arrays = G.arrays_of(case, "complex128", tree)
+        got = plan_interp.run_plan(plan, arrays)
+        ref = np.asarray(orc.contract(tree, arrays))
+        assert np.allclose(got, ref, rtol=1e-10, atol=1e-12 * np.abs(ref).max()), case["name"]
+        n += 1
+    assert n >= 60
