@@ -458,8 +458,21 @@ def small_config(name, tree, arrays, dev, slices, reps, cpu_slices, note, dtype=
     st = fn.setup(*[torch.as_tensor(a, device=dev) for a in arrays])
     ex, plan = st["exec"], st["plan"]
     ex.zero_result()
+    # (slice groups: whole groups -- over the whole job every group is complete; a slice count that is not a
+    # multiple of the group size is rounded down to one and says so in "slices_timed")
+    ids = None
+    if plan.group_size > 1 and slices < tree.nslices:
+        slices = int(plan.group_size) * max(1, slices // int(plan.group_size))
+        ids = slice_ids_from_groups(plan, 0, slices)
+
+    def run_all():
+        if ids is None:
+            ex.run_slices(0, slices, 1)
+        else:
+            ex.run_slice_list(ids)
+
     for _ in range(2):   # warm-up touches every arena replica of the slice batch
-        ex.run_slices(0, slices, 1)
+        run_all()
     ex.sync()
     # repetitions in groups, the median group counts: the first passes after an
     # allocation of this size are occasionally several times slower (first touch)
@@ -468,7 +481,7 @@ def small_config(name, tree, arrays, dev, slices, reps, cpu_slices, note, dtype=
     for _ in range(groups):
         t0 = time.perf_counter()
         for _ in range(per):
-            ex.run_slices(0, slices, 1)
+            run_all()
         ex.sync()
         times.append((time.perf_counter() - t0) / per)
     dt = sorted(times)[len(times) // 2]
@@ -476,7 +489,8 @@ def small_config(name, tree, arrays, dev, slices, reps, cpu_slices, note, dtype=
     batch = ex.batch
     launches = ex.launch_count()[1]   # independent small steps share launches
     roof_ms = mixed_roofline_ms(rows, 8.0) * slices   # (no fused pairs here: moved = algorithmic bytes)
-    flops = plan.flops_per_slice() * slices
+    flops = (executed_flops(plan, ids) if ids is not None else
+             executed_flops(plan, list(range(slices))) if plan.group_size > 1 else plan.flops_per_slice() * slices)
     # the oracle (numpy, the reference's executor restated) on this node's cores
     ops = orc.extract_contractions(tree)
     t0 = time.perf_counter()
@@ -500,6 +514,7 @@ def small_config(name, tree, arrays, dev, slices, reps, cpu_slices, note, dtype=
         "cpu_sample": f"{cpu_slices} slice(s) with numpy {dtype}, scaled to {slices}",
         "slices_per_launch": int(min(slices, batch)),
         "speedup_vs_cpu_oracle": cpu / dt,
+        "slice_groups": slice_groups_note(plan, ids if ids is not None else list(range(slices))),
     }
 
 

@@ -143,6 +143,9 @@ struct StepArgs {
                             // heuristics are computed with): how many slices fit one launch
     int64_t zA, zB, zC;     // arena replica strides (elements)
     int64_t zsA, zsB, zsC;  // strides of the soff arrays (entries)
+    // slice groups in a batched launch (round 4): operand A / B was written by a step the zq slices of a
+    // group share -- it lives with the group's first slice: slice-in-batch z reads it at z / zq * zq (0, 1: off)
+    int32_t zqA, zqB;
 };
 
 // Kernel arguments of a STEM2 step.
@@ -201,8 +204,9 @@ struct StemArgs {
 
 // element offset of an operand for the slice-in-batch this block works on
 __device__ __forceinline__ int64_t zid(const StepArgs& p) { return (int64_t)p.z0 + blockIdx.y; }
-__device__ __forceinline__ int64_t zoffA(const StepArgs& p) { const int64_t z = zid(p); return p.soffA[z * p.zsA] + z * p.zA; }
-__device__ __forceinline__ int64_t zoffB(const StepArgs& p) { const int64_t z = zid(p); return p.soffB[z * p.zsB] + z * p.zB; }
+__device__ __forceinline__ int64_t zgroup(int64_t z, int32_t q) { return q > 1 ? z / q * q : z; }
+__device__ __forceinline__ int64_t zoffA(const StepArgs& p) { const int64_t z = zgroup(zid(p), p.zqA); return p.soffA[z * p.zsA] + z * p.zA; }
+__device__ __forceinline__ int64_t zoffB(const StepArgs& p) { const int64_t z = zgroup(zid(p), p.zqB); return p.soffB[z * p.zsB] + z * p.zB; }
 __device__ __forceinline__ int64_t zoffC(const StepArgs& p) { const int64_t z = zid(p); return p.soffC[z * p.zsC] + z * p.zC; }
 
 __device__ __forceinline__ double step_alpha(const StepArgs& p) {
@@ -266,8 +270,8 @@ __device__ __forceinline__ int64_t sload64(const int64_t* p) {
 }
 
 // the same through scalar loads (z is uniform over the block)
-__device__ __forceinline__ int64_t zoffA_s(const StepArgs& p) { const int64_t z = zid(p); return sload64(p.soffA + z * p.zsA) + z * p.zA; }
-__device__ __forceinline__ int64_t zoffB_s(const StepArgs& p) { const int64_t z = zid(p); return sload64(p.soffB + z * p.zsB) + z * p.zB; }
+__device__ __forceinline__ int64_t zoffA_s(const StepArgs& p) { const int64_t z = zgroup(zid(p), p.zqA); return sload64(p.soffA + z * p.zsA) + z * p.zA; }
+__device__ __forceinline__ int64_t zoffB_s(const StepArgs& p) { const int64_t z = zgroup(zid(p), p.zqB); return sload64(p.soffB + z * p.zsB) + z * p.zB; }
 __device__ __forceinline__ int64_t zoffC_s(const StepArgs& p) { const int64_t z = zid(p); return sload64(p.soffC + z * p.zsC) + z * p.zC; }
 
 __device__ __forceinline__ void split_k(const StepArgs& p, int64_t k, int64_t& hi, int64_t& lo) {
@@ -529,8 +533,9 @@ struct SliceMeta {
 // the id is taken from the device counter state[0], which is then advanced by
 // state[1] (lets a captured graph walk over slices without host involvement)
 // (nz > 1: the offsets of slices sid, sid + stride, ... in soff[z * n_leaves + leaf])
+// (ids != nullptr: the nz slices are ids[0 .. nz) -- device memory -- instead of sid + z * stride)
 hipError_t launch_prologue(const SliceMeta& m, int64_t* state, int64_t* soff, int64_t sid,
-                           hipStream_t stream, int nz = 1, int64_t stride = 1);
+                           hipStream_t stream, int nz = 1, int64_t stride = 1, const int64_t* ids = nullptr);
 // state[0] = next, state[1] = stride (device-side slice counter of a graph replay)
 hipError_t launch_set_state(int64_t* state, int64_t next, int64_t stride, hipStream_t stream);
 

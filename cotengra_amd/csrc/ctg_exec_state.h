@@ -55,6 +55,10 @@ struct ctg_exec {
     // slice batching: up to `batch` slices of a run share every launch (gridDim.y);
     // the arena holds `batch` replicas of itself, d_soff `batch` rows of leaf offsets
     int batch = 1;
+    // slice groups in batched launches: slices per group (0: the plan has no groups or slices go one by
+    // one), the ids of the slices of the launch at hand (device, `batch` entries)
+    int group_d = 0;
+    int64_t* d_batch_ids = nullptr;
     int batch_nominal = 1;         // min(64, nslices, 8 GiB / arena): what the k-splits are chosen for
     int64_t scratch_total = 0;     // bytes of d_scratch (64 MiB x up to 8 for batching executors)
     // the launch list of one slice: steps that launch alone (cls < 0) and wave-front

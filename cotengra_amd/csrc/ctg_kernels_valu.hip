@@ -570,7 +570,7 @@ hipError_t launch_rescale(int dtype, void* result, int64_t n, const StripState* 
 // ------------------------------------------------------------------------- //
 
 __global__ __launch_bounds__(256) void prologue_kernel(SliceMeta m, int64_t* state, int64_t* soff,
-                                                       int64_t sid_arg, int nz, int64_t stride) {
+                                                       int64_t sid_arg, int nz, int64_t stride, const int64_t* ids) {
     // slices sid, sid + stride, ... (nz of them): soff[z * n_leaves + leaf]
     // (several workgroups when the slice id comes from the host: 64 slices x hundreds of
     // leaves x dozens of sliced indices is 0.4 ms of dependent divisions for one of them)
@@ -578,7 +578,7 @@ __global__ __launch_bounds__(256) void prologue_kernel(SliceMeta m, int64_t* sta
     for (int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; w < m.n_leaves * nz;
          w += (int64_t)gridDim.x * blockDim.x) {
         const int64_t z = w / m.n_leaves, leaf = w - z * m.n_leaves;
-        int64_t rem = sid0 + z * stride;
+        int64_t rem = ids ? ids[z] : sid0 + z * stride;
         int64_t off = 0;
         const int64_t* st = m.strides + leaf * m.n_sliced;
         for (int64_t j = m.n_sliced - 1; j >= 0; --j) {
@@ -614,11 +614,11 @@ hipError_t launch_set_state(int64_t* state, int64_t next, int64_t stride, hipStr
 }
 
 hipError_t launch_prologue(const SliceMeta& m, int64_t* state, int64_t* soff, int64_t sid,
-                           hipStream_t stream, int nz, int64_t stride) {
+                           hipStream_t stream, int nz, int64_t stride, const int64_t* ids) {
     int64_t blocks = sid < 0 ? 1 : (m.n_leaves * nz + 255) / 256;
     if (blocks > 1024) blocks = 1024;
     hipLaunchKernelGGL(prologue_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, m, state, soff, sid, nz,
-                       stride);
+                       stride, ids);
     return hipGetLastError();
 }
 

@@ -435,6 +435,21 @@ void resolve_args(ctg_exec* e) {
         a.zsA = r[W_A_LEAF] >= 0 ? p->n_inputs + 1 : 0;
         a.zsB = r[W_B_LEAF] >= 0 ? p->n_inputs + 1 : 0;
         a.zsC = r[W_C_LEAF] >= 0 ? p->n_inputs + 1 : 0;
+        if (e->group_d > 1) {
+            auto shared = [&](int64_t st) {
+                return st >= 0 && st < p->n_steps && p->steps[st * STEP_WORDS + W_INVARIANT] == 2 &&
+                       p->steps[st * STEP_WORDS + W_KIND] != KIND_ACCUM;
+            };
+            const int64_t d = e->group_d;
+            if (shared(s)) {
+                // launched once per group: group g of the launch is slice-in-batch g * d
+                a.zA *= d; a.zB *= d; a.zC *= d;
+                a.zsA *= d; a.zsB *= d; a.zsC *= d;
+            } else if (r[W_KIND] == KIND_PAIR || r[W_KIND] == KIND_SINGLE) {
+                if (shared(r[W_A_PROD])) a.zqA = (int32_t)d;
+                if (r[W_KIND] == KIND_PAIR && shared(r[W_B_PROD])) a.zqB = (int32_t)d;
+            }
+        }
         a.facA = a.facB = nullptr;
         a.check_zero = e->check_zero;
         if (e->strip && r[W_KIND] == KIND_PAIR) {
@@ -1093,7 +1108,7 @@ int build_groups(ctg_exec* e) {
 // one entry of the per-slice launch list, for a batch of nb slices
 int launch_issue(ctg_exec* e, const ctg_exec::Issue& q, int nb, hipStream_t stream) {
     if (q.cls < 0) {
-        e->args[q.step].nz = nb;
+        e->args[q.step].nz = (e->group_d > 1 && e->grouped[q.step] && nb > 1) ? nb / e->group_d : nb;
         const int rc = launch_step(e, q.step, stream);
         e->args[q.step].nz = 1;
         return rc;
@@ -1129,6 +1144,45 @@ int run_grouped(ctg_exec* e, const std::vector<int64_t>& ids) {
     std::vector<std::pair<int64_t, int64_t>> order(ids.size());
     for (size_t k = 0; k < ids.size(); ++k) order[k] = {slice_group_key(p, ids[k]), ids[k]};
     std::sort(order.begin(), order.end());
+    if (e->group_d > 1) {
+        // Batched launches of whole groups: slice-in-batch z = group * d + member.  A group that is not
+        // complete among the ids (or has a slice twice) goes slice by slice -- a launch of one slice is
+        // consistent as it is (z = 0: every quantum and multiplier drops out), its shared steps are
+        // computed for it alone.
+        const size_t d = (size_t)e->group_d;
+        std::vector<int64_t> full, rest;
+        for (size_t k = 0; k < order.size();) {
+            size_t j = k;
+            while (j < order.size() && order[j].first == order[k].first) ++j;
+            bool whole = j - k == d;
+            for (size_t i = k + 1; whole && i < j; ++i) whole = order[i].second != order[i - 1].second;
+            for (size_t i = k; i < j; ++i) (whole ? full : rest).push_back(order[i].second);
+            k = j;
+        }
+        e->group_key = -1;
+        for (size_t k = 0; k < full.size(); k += (size_t)e->batch) {
+            const int nb = (int)std::min<size_t>((size_t)e->batch, full.size() - k);
+            HIP_TRY(hipMemcpyAsync(e->d_batch_ids, full.data() + k, nb * sizeof(int64_t), hipMemcpyHostToDevice, e->stream));
+            hipError_t err = launch_prologue(e->meta, e->d_state, e->d_soff, 0, e->stream, nb, 1, e->d_batch_ids);
+            if (err != hipSuccess) return fail(CTG_E_HIP, "prologue launch failed: %s", hipGetErrorString(err));
+            for (const ctg_exec::Issue& q : e->issue) {
+                const int rc = launch_issue(e, q, nb, e->stream);
+                if (rc != CTG_OK) return rc;
+            }
+        }
+        // (the host buffer `full` must outlive the asynchronous copies)
+        if (!full.empty()) HIP_TRY(hipStreamSynchronize(e->stream));
+        for (int64_t sid : rest) {
+            hipError_t err = launch_prologue(e->meta, e->d_state, e->d_soff, sid, e->stream, 1, 1);
+            if (err != hipSuccess) return fail(CTG_E_HIP, "prologue launch failed: %s", hipGetErrorString(err));
+            for (const ctg_exec::Issue& q : e->issue) {
+                const int rc = launch_issue(e, q, 1, e->stream);
+                if (rc != CTG_OK) return rc;
+            }
+        }
+        e->warm = true;
+        return CTG_OK;
+    }
     for (const auto& ks : order) {
         const bool fresh = ks.first != e->group_key;
         hipError_t err = launch_prologue(e->meta, e->d_state, e->d_soff, ks.second, e->stream, 1, 1);
@@ -1318,7 +1372,25 @@ int ctg_exec_create(const ctg_plan* p, int device, void* stream, void* ext_resul
         const int64_t per = std::max<int64_t>(p->arena_elems * isz, 1);
         b = std::min<int64_t>(b, (mib << 20) / per);
         e->batch = (int)std::max<int64_t>(b, 1);
-        if (p->has_groups) e->batch = 1;   // (what a group shares lives once, not once per slice of a launch)
+        e->group_d = 0;
+        if (p->has_groups) {
+            // Slice groups in batched launches: a launch carries whole groups, z = group * d + member;
+            // the shared steps go out once per group (nz / d), what the others read of them sits with
+            // the group's first slice (StepArgs.zqA / zqB).  Fused stem steps do not take part (their
+            // kernel has no z quantum): such plans contract slice by slice, and so does one whose group
+            // does not fit a launch.
+            int64_t d = 1;
+            for (int64_t j = 0; j < p->n_sliced; ++j)
+                if (p->slice_group[j] && p->slice_fixed[j] < 0) d *= p->slice_sizes[j];
+            bool stems = false;
+            for (int64_t s = 0; s < p->n_steps; ++s) stems = stems || p->steps[s * STEP_WORDS + W_KIND] == KIND_STEM2;
+            if (stems || d > e->batch || d < 2 || env_on("CTG_NO_BATCHED_GROUPS")) {
+                e->batch = 1;
+            } else {
+                e->batch = (int)(e->batch / d * d);
+                e->group_d = (int)d;
+            }
+        }
         // what the plan alone says about batching (no environment, no free-memory
         // query): the k-splits of its steps are chosen for launches of this many
         // slices, so that they are a function of the plan and a result never depends
@@ -1343,7 +1415,7 @@ int ctg_exec_create(const ctg_plan* p, int device, void* stream, void* ext_resul
     // those in the expression cache would pin 4 GiB of scratch for nothing)
     e->scratch_total = kScratchBytes * std::min<int64_t>(std::max(e->batch, 1), 8);
     const int64_t n_leaves = p->n_inputs + 1;
-    const int64_t misc_words = 3 + n_leaves * e->batch + 2 * p->n_sliced + n_leaves * p->n_sliced;
+    const int64_t misc_words = 3 + n_leaves * e->batch + 2 * p->n_sliced + n_leaves * p->n_sliced + e->batch;
     HIP_TRY_E(hipMalloc((void**)&e->d_misc, misc_words * 8));
     std::vector<int64_t> misc(misc_words, 0);
     int64_t* cur = e->d_misc;
@@ -1358,6 +1430,7 @@ int ctg_exec_create(const ctg_plan* p, int device, void* stream, void* ext_resul
     int64_t* d_fixed = cur;
     cur += p->n_sliced;
     int64_t* d_strides = cur;
+    e->d_batch_ids = d_strides + n_leaves * p->n_sliced;   // (the last `batch` words)
     for (int64_t j = 0; j < p->n_sliced; ++j) {
         misc[(d_sizes - e->d_misc) + j] = p->slice_sizes[j];
         misc[(d_fixed - e->d_misc) + j] = p->slice_fixed[j];

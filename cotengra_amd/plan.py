@@ -697,6 +697,7 @@ FUSE_MIN_ELEMS = 1 << 24  # stem pairs are fused when the big operand has at lea
 GROUP_MIN_WIDTH = 1 << 28      # only trees whose slices are launch sequences of large steps
 GROUP_MAX_INDS = 3
 GROUP_MIN_SAVING = 0.02        # of a slice's modelled time
+GROUP_MIN_SAVING_SMALL = 0.15  # ... for trees below GROUP_MIN_WIDTH (slices batched into launches)
 GROUP_MAX_KEPT_BYTES = 96 * 2**30
 GROUP_MAX_TOTAL_BYTES = 250 * 2**30
 
@@ -712,8 +713,15 @@ def choose_slice_group(tree, plan):
     greedily the index whose addition saves most modelled time per slice -- a step that depends on none
     of them costs a slice 2^-k of its time -- while the tensors to be kept for a group fit; ``()`` if
     nothing saves ``GROUP_MIN_SAVING``."""
-    if not slice_groups_enabled() or tree.N < 3 or tree.multiplicity < 4 or tree.max_size() < GROUP_MIN_WIDTH:
+    if not slice_groups_enabled() or tree.N < 3 or tree.multiplicity < 4:
         return ()
+    # trees whose slices go out many per launch (small ones): the executor batches whole groups -- the
+    # shared steps once per group of a launch -- which pays only when a good part of a slice is shared,
+    # and not at all next to fused stem steps (their kernel does not take part: slice by slice then)
+    small = tree.max_size() < GROUP_MIN_WIDTH
+    if small and any(s.kind == KIND_STEM2 for s in plan.steps):
+        return ()
+    min_saving = GROUP_MIN_SAVING_SMALL if small else GROUP_MIN_SAVING
     from .pathfind import step_seconds
 
     sliced = [si.ind for si in tree.sliced_inds.values() if si.project is None]
@@ -750,7 +758,7 @@ def choose_slice_group(tree, plan):
             break
         chosen.append(ix)
         best_saving = saving
-    if best_saving < GROUP_MIN_SAVING * total:
+    if best_saving < min_saving * total:
         return ()
     return tuple(chosen)
 

@@ -34,7 +34,7 @@ def build():
     case = next(c for c in G.cases("tree") if c["name"] == "lattice4x4_sliced")
     tree = G.tree_of(case)
     arrays = G.arrays_of(case, "complex128", tree)
-    plan = compile_tree(tree, "complex128")
+    plan = compile_tree(tree, "complex128", _group=())   # (the driver passes no slice_group array: no slice groups)
     ser = plan.serialise()
     n_in, n_sl = len(plan.input_sizes), len(plan.slice_sizes)
     head = np.array([MAGIC, ser["dtype"], n_in, plan.inputs_elems, ser["arena_elems"], ser["result_elems"],

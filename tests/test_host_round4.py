@@ -546,15 +546,23 @@ def test_slice_groups_plan_semantics(fixture, groups_on_small_trees):
     runtime.DevicePlan(plan).close()
 
 
-def test_slice_groups_only_on_wide_trees(monkeypatch):
+def test_slice_groups_thresholds(monkeypatch):
     """By default the planner groups slices on trees whose slices are sequences of large launches (width
-    >= 2^28); the small configurations keep their slice batching."""
+    >= 2^28) as soon as 2 % of a slice is shared; on small trees -- whose slices go out many per launch,
+    whole groups per launch then -- only when at least 15 % is, and never next to fused stem steps."""
+    import golden_util as G
     from cotengra_amd import plan as P
     from test_tree_fixtures import narrowed
 
     monkeypatch.delenv("CTG_SLICE_GROUPS", raising=False)
     tree = ca.tree_from_record(ca.load_network(os.path.join(ROOT, "tests", "golden", "trees", "sycamore_m20_w32_r4.json")))
-    assert P.compile_tree(narrowed(tree, 10), "complex64").group_size == 1
+    small = narrowed(tree, 10)
+    monkeypatch.setattr(P, "GROUP_MIN_SAVING_SMALL", 0.99)
+    assert P.compile_tree(small, "complex64").group_size == 1
+    monkeypatch.setattr(P, "GROUP_MIN_SAVING_SMALL", 0.15)
+    c5 = G.tree_of(next(c for c in G.cases("tree") if c["name"] == "C5_hyper200"))
+    p5 = P.compile_tree(c5, "complex64")
+    assert p5.group_size == 3 and not any(s.kind == P.KIND_STEM2 for s in p5.steps)
     wide = P.compile_tree(tree, "complex64")
     assert wide.group_size == 4 and 0.05 < wide.macs_shared_per_group / wide.macs_per_slice < 0.5
     monkeypatch.setenv("CTG_SLICE_GROUPS", "0")

@@ -79,4 +79,39 @@ for fx in fixtures:
           f"slice (arena {res['1'][2]:.0f} GiB) vs {res['0'][1] * 1e3 / len(members):.1f} ms without sharing (arena {res['0'][2]:.0f} GiB); "
           f"bit-identical {same} {'ok' if same else 'WRONG'}")
     bad += not same
+# ---- (3) a small, batched configuration: the 200-tensor hyper network (C5), whole groups per launch
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import golden_util as G  # noqa: E402
+
+case = next(c for c in G.cases("tree") if c["name"] == "C5_hyper200")
+tree = G.tree_of(case)
+arrays = [np.asarray(a).astype("complex64") for a in G.arrays_of(case, "complex128", tree)]
+res = {}
+for mode in ("1", "0"):
+    os.environ["CTG_SLICE_GROUPS"] = mode
+    fn = HipContractor(tree, handle_slicing=True)
+    plan = fn.get_plan("complex64")[0]
+    if mode == "1":
+        gs = int(plan.group_size)
+        ids = [i for g in range(22) for i in plan.group_ids(g)]
+    ex = fn.setup(*arrays)["exec"]
+    for _ in range(3):
+        ex.run_slice_list(ids)
+    ex.sync()
+    ex.zero_result()
+    t0 = time.perf_counter()
+    for _ in range(10):
+        ex.run_slice_list(ids)
+    ex.sync()
+    dt = (time.perf_counter() - t0) / 10
+    res[mode] = (np.asarray(ex.download_result()).copy(), dt, ex.batch, sum(s.group for s in plan.steps))
+    fn.close()
+os.environ["CTG_SLICE_GROUPS"] = "1"
+scale = np.abs(res["0"][0]).max()
+err = np.abs(res["1"][0] - res["0"][0]).max() / scale
+ok = err <= 1e-5 and gs > 1
+print(f"C5 hyper network: {len(ids)} slices in groups of {gs} ({res['1'][3]} shared steps, {res['1'][2]} slices per launch): "
+      f"{res['1'][1] * 1e3:.2f} ms vs {res['0'][1] * 1e3:.2f} ms without groups ({res['0'][2]} per launch); sums agree to {err:.1e} "
+      f"{'ok' if ok else 'WRONG'}")
+bad += not ok
 print("FAILED" if bad else "ALL OK", bad)
