@@ -74,6 +74,17 @@ def _rank_main(rank, world, port, q):
             return real(self, first, count, stride)
 
         rt.Executor.run_slices = spy
+        real_list = rt.Executor.run_slice_list
+
+        def spy_list(self, ids):
+            # (slice groups, round 4: the same share, visited group by group -- recorded as the range it is)
+            ids = sorted(int(i) for i in ids)
+            step = ids[1] - ids[0] if len(ids) > 1 else world
+            assert ids == list(range(ids[0], ids[0] + step * len(ids), step))
+            calls.append((ids[0], len(ids), step))
+            return real_list(self, ids)
+
+        rt.Executor.run_slice_list = spy_list
         cases = {c["name"]: c for c in G2.cases("tree")}
         # inner-sliced lattice: numpy inputs and device inputs, all-reduce and rooted
         c = cases["lattice8x8_sliced"]
