@@ -69,6 +69,7 @@ struct ctg_exec {
         int cls;
         int32_t item0, n;
         uint32_t blocks;
+        bool shared = false;   // steps the slices of a group share (all members of a wave-front group alike)
     };
     std::vector<Issue> issue;
     std::vector<Issue> issue_reuse;   // ... of a slice that finds the shared steps of its group done

@@ -1015,7 +1015,7 @@ int build_groups(ctg_exec* e) {
     // class of a step: -1 launches alone, 0 thread-per-output, 1 + key tiled fast kernel
     auto class_of = [&](int64_t s) -> int {
         const int64_t* r = &p->steps[s * STEP_WORDS];
-        if (off || r[W_KIND] != KIND_PAIR || e->invariant[s] || e->grouped[s]) return -1;   // (shared steps launch alone)
+        if (off || r[W_KIND] != KIND_PAIR || e->invariant[s]) return -1;
         if (r[W_KERNEL] != KERNEL_MFMA) {
             if (!valu_thread_per_output(e->args[s])) return -1;
             ValuGroupItem it;
@@ -1048,12 +1048,13 @@ int build_groups(ctg_exec* e) {
             continue;
         }
         if (class_of(s) < 0) {
-            e->issue.push_back(ctg_exec::Issue{s, -1, 0, 1, 0});
+            e->issue.push_back(ctg_exec::Issue{s, -1, 0, 1, 0, e->grouped[s] != 0});
             ++s;
             continue;
         }
         int64_t j = s + 1;
-        for (; j < n && j - s < 64 && !e->invariant[j] && class_of(j) >= 0; ++j) {
+        // (a wave front holds steps the slices of a group share, or steps they do not: never both)
+        for (; j < n && j - s < 64 && !e->invariant[j] && class_of(j) >= 0 && e->grouped[j] == e->grouped[s]; ++j) {
             bool ok = true;
             for (int64_t i = s; i < j && ok; ++i) ok = independent(j, i);
             if (!ok) break;
@@ -1069,7 +1070,7 @@ int build_groups(ctg_exec* e) {
                     done[b - s] = 1;
                 }
             if (members.size() == 1) {
-                e->issue.push_back(ctg_exec::Issue{a, -1, 0, 1, 0});
+                e->issue.push_back(ctg_exec::Issue{a, -1, 0, 1, 0, e->grouped[a] != 0});
                 continue;
             }
             uint32_t blocks = 0;
@@ -1083,14 +1084,14 @@ int build_groups(ctg_exec* e) {
                     blocks += fast_group_fill(e->args[m], e->hints[m], &fitems.back(), blocks);
                 }
             }
-            e->issue.push_back(ctg_exec::Issue{a, cls, item0, (int32_t)members.size(), blocks});
+            e->issue.push_back(ctg_exec::Issue{a, cls, item0, (int32_t)members.size(), blocks, e->grouped[a] != 0});
         }
         s = j;
     }
     // slice groups: the launch list of a slice whose group's shared steps are done (they launch alone)
     e->issue_reuse.clear();
     for (const ctg_exec::Issue& q : e->issue)
-        if (!(q.cls < 0 && e->grouped[q.step])) e->issue_reuse.push_back(q);
+        if (!q.shared) e->issue_reuse.push_back(q);
     e->group_key = -1;
     if (!vitems.empty()) {
         HIP_TRY(hipMalloc((void**)&e->d_group_items, vitems.size() * sizeof(ValuGroupItem)));
@@ -1107,8 +1108,10 @@ int build_groups(ctg_exec* e) {
 
 // one entry of the per-slice launch list, for a batch of nb slices
 int launch_issue(ctg_exec* e, const ctg_exec::Issue& q, int nb, hipStream_t stream) {
+    // (batched slice groups: what a group shares goes out once per group of the launch)
+    if (e->group_d > 1 && q.shared && nb > 1) nb /= e->group_d;
     if (q.cls < 0) {
-        e->args[q.step].nz = (e->group_d > 1 && e->grouped[q.step] && nb > 1) ? nb / e->group_d : nb;
+        e->args[q.step].nz = nb;
         const int rc = launch_step(e, q.step, stream);
         e->args[q.step].nz = 1;
         return rc;
