@@ -593,3 +593,33 @@ def test_slice_groups_on_every_small_sliced_golden_tree(groups_on_small_trees):
         assert np.allclose(got, ref, rtol=1e-10, atol=1e-12 * np.abs(ref).max()), case["name"]
         n += 1
     assert n >= 60
+
+
+def test_bench_deals_whole_slice_groups_to_ranks():
+    """bench.py's timed slices are whole slice groups, dealt round-robin to the ranks; the flops it counts
+    are the ones executed (a shared step once per group)."""
+    import importlib.util
+
+    from cotengra_amd import plan as P
+
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    tree = ca.tree_from_record(ca.load_network(os.path.join(ROOT, "tests", "golden", "trees", "sycamore_m20_w32_r4.json")))
+    os.environ.pop("CTG_SLICE_GROUPS", None)
+    plan = P.compile_tree(tree, "complex64")
+    gs, world = plan.group_size, 8
+    assert gs == 4
+    seen = []
+    for rank in range(world):
+        ids = bench.slice_ids_from_groups(plan, 0, 2 * gs, rank, world)
+        assert len(ids) == 2 * gs and [plan.group_of(i) for i in ids] == [rank] * gs + [rank + world] * gs
+        seen += ids
+    assert len(set(seen)) == len(seen) and all(0 <= i < plan.nslices for i in seen)
+    ids = bench.slice_ids_from_groups(plan, 0, gs + 1)
+    full, part = bench.executed_flops(plan, ids[:gs]), bench.executed_flops(plan, ids)
+    nominal = 8.0 * plan.macs_per_slice
+    assert full == pytest.approx(gs * nominal - 8.0 * plan.macs_shared_per_group * (gs - 1))
+    assert part - full == pytest.approx(nominal)            # (the lone slice of the next group pays for everything)
+    note = bench.slice_groups_note(plan, ids)
+    assert note["slices_per_group"] == gs and note["timed"] == "%d slices in 2 groups" % (gs + 1)
