@@ -54,7 +54,9 @@ enum StepWord {
     W_MACS = 33, W_ELEMS = 34, W_NODE = 35,
     W_K_LO = 36, W_KA_HI = 37, W_KB_HI = 38, W_K_HI_LEN = 39,
     W_A_PROD = 40, W_B_PROD = 41,  // step that produced the operand (-1: input / preprocessing)
-    W_INVARIANT = 42,              // 1: does not depend on sliced inputs, run once per upload
+    W_INVARIANT = 42,              // 1: does not depend on sliced inputs, run once per upload;
+                                   // 2 (round 4): does not depend on the plan's GROUP indices -- run once per
+                                   // group of slices (ctg_plan_desc.slice_group)
     W_STEM = 43,                   // KIND_STEM2: word offset of the descriptor in the table blob
     STEP_WORDS = 48
 };

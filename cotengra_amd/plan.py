@@ -335,7 +335,8 @@ class Plan:
          33 macs    34 elems_rw   35 node
          36 k_lo  37 kA_hi  38 kB_hi  39 k_hi_len   (23/24 hold the lo level)
          40 a.producer step  41 b.producer step   (-1: scale factor 1)
-         42 slice-invariant (run once per upload, output persistent)
+         42 sharing class: 1 slice-invariant (run once per upload, output persistent), 2 shared by the
+            slices of a group (Plan.group_inds: run once per group, what per-slice steps read of it kept)
          43.. reserved (0)
         """
         blobs = []
