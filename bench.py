@@ -61,6 +61,10 @@ TTS_TREE = os.path.join(TREES, "sycamore_m20_w32_r4.json")
 # the same with one index less sliced: 2^19 slices of width 2^33 (68 GB tensors, a 161 GiB arena --
 # what 288 GB of HBM are for); the amplitude another 6 % sooner
 TTS33_TREE = os.path.join(TREES, "sycamore_m20_w33_bf3.json")   # (refined once more: gen/refine_bf3.py)
+# `fused` refined under the model WITH slice groups (gen/refine_r4.py at the very end of round 4, after the
+# round's GPU budget was spent): modelled 177.5 ms per slice against 189.0 for w32_r4 (which measures 185-192);
+# reported as its own leg until it has been measured next to it
+TTS_GROUPS_TREE = os.path.join(TREES, "sycamore_m20_w32_g.json")
 
 
 # ---------------------------------------------------------------------- #
@@ -894,6 +898,8 @@ def main():
                 out["time_to_solution_tree"] = tree_report(TTS_TREE, dev)
             if os.path.abspath(args.tree) != os.path.abspath(TTS33_TREE) and os.path.exists(TTS33_TREE):
                 out["time_to_solution_tree_w33"] = tree_report(TTS33_TREE, dev, steps=3)
+            if os.path.exists(TTS_GROUPS_TREE):
+                out["time_to_solution_tree_groups"] = tree_report(TTS_GROUPS_TREE, dev)
             if os.path.abspath(args.tree) != os.path.abspath(PEAK_TREE) and os.path.exists(PEAK_TREE):
                 out["peak_rate_tree"] = tree_report(PEAK_TREE, dev)
             # the other arithmetic of the fused pairs on the same trees (each entry with its own

@@ -1470,7 +1470,8 @@ bool stem2_supported(const StemArgs& p) {
     X(false, true, 1, 1, 8, 2, false, 4, false, false) X(false, false, 1, 1, 2, 4, true, 4, false, true) \
     X(false, false, 1, 1, 2, 4, true, 8, false, true) X(false, false, 1, 1, 2, 2, true, 4, false, true) \
     X(true, true, 2, 1, 4, 1, true, 8, false, false) X(false, false, 1, 2, 2, 2, true, 8, true, true) \
-    X(false, true, 1, 2, 1, 2, true, 4, false, false) X(true, false, 2, 1, 4, 1, true, 8, false, true)
+    X(false, true, 1, 2, 1, 2, true, 4, false, false) X(true, false, 2, 1, 4, 1, true, 8, false, true) \
+    X(false, false, 1, 2, 2, 4, true, 4, false, true)
 
 #define CTG_STEM_GEO(G) \
     G(false, false, 1, 1, 1, 2, false) G(false, false, 1, 1, 2, 1, false) G(false, false, 1, 1, 2, 1, true) \
@@ -1485,7 +1486,7 @@ bool stem2_supported(const StemArgs& p) {
     G(true, false, 2, 1, 1, 1, true) G(true, false, 2, 1, 1, 2, false) G(true, false, 2, 1, 1, 2, true) \
     G(true, false, 2, 1, 2, 1, false) G(true, true, 2, 1, 1, 2, false) G(true, true, 2, 1, 1, 2, true) \
     G(true, true, 2, 1, 4, 1, false) G(false, false, 1, 2, 2, 2, true) G(false, true, 1, 2, 1, 2, false) \
-    G(true, false, 2, 1, 4, 1, false)
+    G(true, false, 2, 1, 4, 1, false) G(false, false, 1, 2, 2, 4, false)
 #endif
 
 namespace {

@@ -57,7 +57,7 @@ def rel(a, b):
 
 
 @pytest.mark.parametrize("fixture", ["sycamore_m20_w32_c512.json", "sycamore_m20_native.json", "sycamore_m20_fused.json",
-                                     "sycamore_m20_w33_bf3.json", "sycamore_m20_w32_r4.json"])
+                                     "sycamore_m20_w33_bf3.json", "sycamore_m20_w32_r4.json", "sycamore_m20_w32_g.json"])
 @pytest.mark.parametrize("log2_width", [20, 24])
 def test_narrowed_trees_against_oracle(fixture, log2_width):
     """(i): both precisions of the HIP path vs the oracle on the bench tree and
@@ -81,7 +81,7 @@ def test_narrowed_trees_against_oracle(fixture, log2_width):
 
 
 @pytest.mark.parametrize("fixture", ["sycamore_m20_w32_c512.json", "sycamore_m20_native.json", "sycamore_m20_fused.json",
-                                     "sycamore_m20_w33_bf3.json", "sycamore_m20_w32_r4.json"])
+                                     "sycamore_m20_w33_bf3.json", "sycamore_m20_w32_r4.json", "sycamore_m20_w32_g.json"])
 def test_full_width_slice_is_sum_of_double_precision_sub_slices(fixture, monkeypatch):
     """(ii): complex64 at width 2^32 -- and 2^33, the configuration BASELINE calls "sliced to fit
     288 GB HBM" (68 GB tensors in a 153 GiB arena; round 4) -- vs complex128 at width 2^28, in BOTH

@@ -182,7 +182,7 @@ def test_check_zero():
     "fixture",
     ["sycamore_m20_w30.json", "sycamore_m20_w32.json", "sycamore_m20_w32_c512.json", "sycamore_m20_w32_c128.json",
      "sycamore_m20_w32_time.json", "sycamore_m20_native.json", "sycamore_m20_fused.json",
-     "sycamore_m20_w33_bf3.json", "sycamore_m20_w32_r4.json"],
+     "sycamore_m20_w33_bf3.json", "sycamore_m20_w32_r4.json", "sycamore_m20_w32_g.json"],
 )
 def test_full_size_properties_m20(fixture):
     """Size-independent checks at full slice width (2^30 first-search tree;

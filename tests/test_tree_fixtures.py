@@ -16,7 +16,7 @@ from oracle.plan_interp import run_plan
 HERE = os.path.dirname(os.path.abspath(__file__))
 FIXTURES = ["sycamore_m20_w30.json", "sycamore_m20_w32.json", "sycamore_m20_w32_c512.json", "sycamore_m20_w32_c128.json",
      "sycamore_m20_w32_time.json", "sycamore_m20_native.json", "sycamore_m20_fused.json",
-     "sycamore_m20_w33_fused.json", "sycamore_m20_w33_bf3.json", "sycamore_m20_w32_r4.json"]
+     "sycamore_m20_w33_fused.json", "sycamore_m20_w33_bf3.json", "sycamore_m20_w32_r4.json", "sycamore_m20_w32_g.json"]
 
 
 def narrowed(tree, log2_width):
