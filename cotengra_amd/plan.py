@@ -29,6 +29,13 @@ Intermediates live in one arena whose offsets are assigned here from the
 traversal's liveness (the reference frees operands by ``temps.pop``,
 contract.py:806-807; its peak model is core.py:1299-1316).
 
+Steps come in three sharing classes: per slice; slice-invariant (below which no
+sliced index occurs: once per upload); and, round 4, shared by a *slice group*
+(``choose_slice_group``: below which none of a few chosen "group indices"
+occurs -- once per group of slices that differ only in those, what per-slice
+steps read of them kept outside the recycled part of the arena).  Consecutive
+steps of a contraction stem are emitted as one fused step (``stem.py``).
+
 The plan is serialised to flat int64 arrays (see ``Plan.serialise``) and
 handed through the C ABI in ``include/ctg_hip.h``.
 """

@@ -21,6 +21,11 @@ one row and one of the two k-rows of the instruction) and multiplies by ``B1``; 
 out as the second step's operand ``[r2][k2]``; the second step reads its
 fragments from there and stores ``C2``.  HBM sees ``A`` once and ``C2`` once.
 
+A large step no pair took runs on the same kernel's first half alone (round 4:
+``geometry_one`` / ``build_stem_one``); three consecutive steps as one tile exist
+behind ``CTG_STEM_TRIPLES`` (``geometry3`` / ``build_stem_triple``: parity green,
+measured slower than pair + single step on every m20 tree -- DESIGN.md section 8).
+
 This module is host-side planning only: which pairs to fuse (``find_pairs``)
 and the offset tables of a fused step (``build_stem_step``); the kernel is
 ``csrc/ctg_stem.hip``, the numpy restatement of its addressing
