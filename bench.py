@@ -270,17 +270,38 @@ def dominant_kernel(rows, flops_per_mac):
     return name, dom, by_name
 
 
+STEM2_TEMPLATE_DEFAULTS = ("false", "false", "0", "false")   # RI2, ONE, ITM, PACKM of stem2_kernel (arguments 11-14)
+
+
+def norm_kernel_name(name):
+    """One spelling per kernel instantiation: no blanks, and a ``stem2_kernel<...>`` name written
+    with its trailing template arguments left at their defaults (the executor's step names,
+    csrc/ctg_stem.hip: ctg_stem_kernel_name) padded to the full list rocprof prints."""
+    if not name:
+        return name
+    name = name.replace(" ", "")
+    if name.startswith("stem2_kernel<") and name.endswith(">"):
+        targs = name[len("stem2_kernel<"):-1].split(",")
+        full = 10 + len(STEM2_TEMPLATE_DEFAULTS)
+        if 10 <= len(targs) < full:
+            targs += list(STEM2_TEMPLATE_DEFAULTS[len(targs) - 10:])
+        name = "stem2_kernel<" + ",".join(targs) + ">"
+    return name
+
+
 def pmc_traffic_for(tree_file, kernel):
     """HBM bytes per launch of ``kernel`` from the PMC passes taken on THIS tree
     (profiles/pmc_summary_<tree>.json, written by tools/pmc_traffic.py); None
-    when no such pass exists."""
+    when no such pass exists.  Names are compared through ``norm_kernel_name``."""
     tag = os.path.splitext(os.path.basename(tree_file))[0]
     path = os.path.join(ROOT, "profiles", f"pmc_summary_{tag}.json")
     if not os.path.exists(path):
         return None, None
     try:
         pm = json.load(open(path))
-        kv = pm.get("kernels", {}).get(kernel)
+        want = norm_kernel_name(kernel)
+        kv = next((v for k, v in pm.get("kernels", {}).items()
+                   if want in (norm_kernel_name(k), norm_kernel_name(v.get("rocprof_name")))), None)
         return (kv["hbm_bytes_per_launch"] if kv else None), pm.get("hbm_bytes_per_launch")
     except Exception:
         return None, None
@@ -603,6 +624,117 @@ def m10_amplitudes(dev, seconds=2.0):
 
 
 # ---------------------------------------------------------------------- #
+# what goes to stdout: ONE compact line (the driver parses the last stdout line and keeps an 8 KB
+# tail); the full record -- every leg, every kernel -- goes to bench_full.json
+# ---------------------------------------------------------------------- #
+
+COMPACT_LIMIT = 4096
+
+
+def _pick(d, *keys):
+    return {k: d[k] for k in keys if isinstance(d, dict) and k in d}
+
+
+def _sig(x, digits=6):
+    """Floats to ``digits`` significant digits (the compact line only)."""
+    if isinstance(x, float):
+        return float(f"{x:.{digits}g}")
+    if isinstance(x, dict):
+        return {k: _sig(v, digits) for k, v in x.items()}
+    if isinstance(x, (list, tuple)):
+        return [_sig(v, digits) for v in x]
+    return x
+
+
+def compact_record(out, full_path="bench_full.json"):
+    """The line the driver reads: the contract's keys, ``roofline`` and ``cpu_baseline`` of the
+    headline, and ONE number per extra leg.  Everything else lives in ``full_path``."""
+    roof = out.get("roofline") or {}
+    cfg = out.get("config") or {}
+    rec = _pick(out, "metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
+                "scaling", "vs_baseline")
+    rec["dtype"] = out.get("dtype_short", "complex64")
+    rec["data"] = out.get("data", "synthetic")
+    rec.update(_pick(out, "slices_per_sec", "tflops", "est_time_total_s"))
+    rec["config"] = _pick(cfg, "workload", "tree", "nslices_log2", "macs_per_slice", "flops_per_slice",
+                          "bytes_moved_per_slice", "algorithmic_bytes_per_slice", "steps_per_slice", "parallelism",
+                          "reduce_via", "arithmetic")
+    sg = cfg.get("slice_groups")
+    if sg:
+        rec["config"]["slice_groups"] = _pick(sg, "slices_per_group", "shared_steps", "timed")
+    rec["roofline"] = _pick(roof, "bound", "kernel", "achieved", "peak", "unit", "frac", "avg_launch_ms",
+                            "launches_per_slice", "moved_bytes_per_launch", "algorithmic_bytes_per_launch",
+                            "flops_per_launch", "traffic", "share_of_slice_time")
+    if "matrix_side" in roof:
+        rec["roofline"]["matrix_frac"] = roof["matrix_side"].get("frac")
+    if "mixed_per_step" in roof:
+        rec["roofline"]["mixed_per_step"] = _pick(roof["mixed_per_step"], "bound_ms", "frac")
+    if out.get("precision"):
+        rec["precision"] = _pick(out["precision"], "rel_err", "gate", "numpy_complex64_rel_err",
+                                 "rel_err_complex128_path")
+    if out.get("cpu_baseline"):
+        rec["cpu_baseline"] = _pick(out["cpu_baseline"], "value", "unit", "cores", "kind", "sample")
+    # one number per extra leg
+    legs = {}
+    for key, leg in (("tts_ms", "time_to_solution_tree"), ("w33_ms", "time_to_solution_tree_w33"),
+                     ("tts_g_ms", "time_to_solution_tree_groups"), ("peak_tree_ms", "peak_rate_tree")):
+        if isinstance(out.get(leg), dict):
+            legs[key] = out[leg].get("ms_per_slice")
+            legs[key.replace("_ms", "_total_s")] = out[leg].get("est_time_total_s")
+    for name, leg in out.items():
+        if name.endswith("_arithmetic") and isinstance(leg, dict):
+            short = name[: -len("_arithmetic")]
+            for tree_name, rep in leg.items():
+                if tree_name == cfg.get("tree"):
+                    legs[short + "_ms"] = rep.get("ms_per_slice")
+                    legs[short + "_rel_err"] = (rep.get("precision") or {}).get("rel_err")
+    for name, c in (out.get("configs") or {}).items():
+        if "mixed_roofline_frac" in c:
+            legs[name + "_ms"] = c.get("ms")
+            legs[name + "_frac"] = c.get("mixed_roofline_frac")
+        elif "amplitudes_per_sec" in c:
+            legs[name + "_per_sec"] = c.get("amplitudes_per_sec")
+        elif "ms" in c:
+            legs[name + "_ms"] = c.get("ms")
+            if "speedup_vs_one_rank" in c:
+                legs[name + "_speedup"] = c.get("speedup_vs_one_rank")
+    if legs:
+        rec["legs"] = legs
+    if out.get("per_rank"):
+        rec["distinct_gpus"] = out.get("distinct_gpus")
+        rec["slowest_rank_ms"] = max(r["wall_ms"] for r in out["per_rank"])
+        rec["reduce_wait_ms_max"] = max(r["reduce_wait_ms"] for r in out["per_rank"])
+    rec["full_record"] = full_path
+    rec = _sig(rec)
+    # never over the limit: drop the least important keys first (none of them is part of the contract)
+    for drop in ("legs", "precision", ("config", "slice_groups"), ("roofline", "mixed_per_step"),
+                 ("config", "workload")):
+        if len(json.dumps(rec, separators=(",", ":"))) < COMPACT_LIMIT:
+            break
+        if isinstance(drop, tuple):
+            rec.get(drop[0], {}).pop(drop[1], None)
+        else:
+            rec.pop(drop, None)
+    return rec
+
+
+def emit(out):
+    """Write the full record next to the script (and under gpurun_out/ when that exists on this
+    box), then print the compact record as the LAST stdout line."""
+    name = "bench_full.json" if out.get("n_gpus", 1) == 1 else "bench_full_n%d.json" % out["n_gpus"]
+    written = None
+    for d in (os.path.join(ROOT, "gpurun_out"), ROOT):
+        if os.path.isdir(d):
+            try:
+                with open(os.path.join(d, name), "w") as f:
+                    json.dump(out, f)
+                written = written or os.path.relpath(os.path.join(d, name), ROOT)
+            except OSError:
+                pass
+    line = json.dumps(compact_record(out, written or name), separators=(",", ":"))
+    assert len(line) < COMPACT_LIMIT and "\n" not in line
+    sys.stdout.flush()
+    print(line, flush=True)
 
 
 def respawn(args):
@@ -854,6 +986,7 @@ def main():
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": ("complex64, 8 real flops per complex MAC -- " + (BF16X3_NOTE if bf3_run else FP32_NOTE)),
+            "dtype_short": "complex64",
             "data": "synthetic",
             "slices_per_sec": total_slices / dt,
             "tflops": value / 1e12,
@@ -879,6 +1012,7 @@ def main():
                 "fused_stem_pairs": sum(1 for s_ in plan.steps if s_.kind == 3),
                 "steps_per_slice": len(plan.steps),
                 "parallelism": f"slice-parallel x{world}, 1 RCCL reduce",
+                "arithmetic": "bf16x3 stem pairs + fp32 MFMA" if bf3_run else "fp32 MFMA",
                 "reduce_via": reduce_via,
                 "partial_amplitude": [float(result.real.item()), float(result.imag.item())]
                 if result.numel() == 1
@@ -913,7 +1047,7 @@ def main():
             out["configs"] = other_configs(dev)
         if c3_amp is not None:
             out.setdefault("configs", {})["C3_amplitudes"] = c3_amp
-        print(json.dumps(out))
+        emit(out)
     else:
         fn.close()
     if comm is not None:

@@ -1,0 +1,65 @@
+"""The line bench.py prints must stay machine-readable: ONE compact JSON record under 4 KB with the
+contract's keys, ``roofline`` and ``cpu_baseline`` (the round-4 line had grown to 21 KB and the
+driver could no longer parse it).  CPU-only: the compaction is exercised on a committed full record."""
+import json
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+import bench  # noqa: E402
+
+FULL = os.path.join(ROOT, "profiles", "r4_bench_line.json")
+
+
+@pytest.fixture()
+def full():
+    return json.load(open(FULL))
+
+
+def test_compact_line_is_small_and_complete(full):
+    rec = bench.compact_record(full)
+    line = json.dumps(rec, separators=(",", ":"))
+    assert len(line) < 4096 and "\n" not in line
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in rec, key
+    assert rec["value"] == pytest.approx(full["value"], rel=1e-5)
+    assert rec["ms_per_step"] == pytest.approx(full["ms_per_step"], rel=1e-5)
+    assert 0.0 < rec["roofline"]["frac"] <= 1.0
+    assert rec["roofline"]["bound"] in ("hbm", "mfma") and rec["roofline"]["unit"] in ("GB/s", "TFLOP/s")
+    assert rec["roofline"]["achieved"] / rec["roofline"]["peak"] == pytest.approx(rec["roofline"]["frac"], rel=1e-4)
+    assert rec["cpu_baseline"]["value"] > 0 and rec["cpu_baseline"]["cores"] >= 1
+    assert rec["config"]["workload"] and "model" not in rec["config"]
+    # one number per extra leg
+    assert {"tts_ms", "w33_ms", "fp32_ms", "C2_frac", "C3_frac", "C5_frac"} <= set(rec["legs"])
+
+
+def test_compact_line_never_outgrows_the_limit(full):
+    # a record with absurdly many legs still compacts below the limit, keeping the contract's keys
+    full["configs"].update({"X%03d" % i: {"ms": 1.0, "mixed_roofline_frac": 0.5} for i in range(400)})
+    rec = bench.compact_record(full)
+    assert len(json.dumps(rec, separators=(",", ":"))) < bench.COMPACT_LIMIT
+    assert "roofline" in rec and "cpu_baseline" in rec and "value" in rec
+
+
+def test_emit_prints_one_last_line(full, capsys, tmp_path, monkeypatch):
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    bench.emit(full)
+    out = capsys.readouterr().out.strip().splitlines()
+    assert len(out) == 1 and len(out[0]) < 4096
+    rec = json.loads(out[0])
+    assert rec["roofline"]["frac"] > 0 and rec["cpu_baseline"]["value"] > 0
+    assert json.load(open(tmp_path / rec["full_record"]))["value"] == full["value"]
+
+
+def test_pmc_traffic_lookup_normalises_template_arguments():
+    # the executor names a stem kernel with its trailing template arguments at their defaults (12 of 14)
+    short = "stem2_kernel<false,false,1,1,2,1,true,0,false,true,false,false>"
+    long_ = "stem2_kernel<false, false, 1, 1, 2, 1, true, 0, false, true, false, false, 0, false>"
+    assert bench.norm_kernel_name(short) == bench.norm_kernel_name(long_)
+    traffic, _ = bench.pmc_traffic_for(bench.TREE, short)
+    assert traffic == pytest.approx(68.7e9, rel=0.01)
