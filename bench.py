@@ -21,15 +21,19 @@ each contracts its own slices (round-robin, no data-path traffic) and the
 partial amplitudes are combined by ONE RCCL reduce on the executors' streams
 (``ctg_exec_reduce`` of the C ABI) inside the timed region -- weak scaling.
 
-Prints ONE JSON line (rank 0): whole-node contracted FLOP/s, the dominant
+Reports (rank 0): whole-node contracted FLOP/s, the dominant
 kernel's roofline numbers measured live with HIP events, the numpy-oracle CPU
 baseline on this node's host cores (rank 0, every N; the launcher's
 OMP_NUM_THREADS=1 is lifted for it) and -- at N = 1 -- ``peak_rate_tree`` and the
 other BASELINE.json configurations (``configs``: C2 8x8 lattice, C3 Sycamore m10,
 C5 hyper network), each with its own mixed per-step roofline and CPU-oracle time;
 at N > 1 ``configs.C3_amplitudes``: Sycamore m10 amplitudes of different
-bitstrings per second, the unit of that configuration that shards (one 3 ms
-amplitude of 64 slices does not strong-scale over 8 GPUs).
+bitstrings per second, the unit of that configuration that shards, and
+``configs.C3_strong``: the ONE 64-slice amplitude dealt over the N ranks + reduce, as
+BASELINE.json words the configuration (a 3 ms job does not strong-scale; it is printed
+anyway).  The LAST stdout line is a compact record (< 4 KB: the contract's keys, ``roofline``,
+``cpu_baseline``, one number per extra leg); the full record is written to
+``bench_full.json`` (``bench_full_n<N>.json`` at N > 1; also under gpurun_out/).
 """
 import argparse
 import json
@@ -350,15 +354,19 @@ def time_slices(ex, first, count, stride=1):
 
 
 def slice_ids_from_groups(plan, first_group, count, rank=0, world=1):
-    """``count`` slice ids for ``rank``: the members of the slice groups ``first_group + rank``,
-    ``+ world``, ... one after the other (cotengra_amd/plan.py: Plan.group_ids; without groups in the
-    plan a group is a single slice) -- whole groups, so that what a group shares is computed once per
-    group INSIDE the timed region, as it is over the whole job."""
-    n_groups = max(1, plan.nslices // plan.group_size)
-    ids, g = [], first_group + rank
+    """``count`` slice ids for ``rank`` out of ITS SHARE as the library deals it (``Plan.rank_slice_ids`` =
+    ``ctg_exec_run_share``: the whole slice groups ``rank, rank + world, ...``; without groups in the plan a
+    unit is a single slice), starting at the unit that holds group ``first_group + rank`` -- whole groups, so
+    that what a group shares is computed once per group INSIDE the timed region, as it is over the whole job."""
+    units, gs = plan.share_units(rank, world)
+    u0 = (first_group // world) % max(units, 1)
+    need = -(-count // gs)
+    ids = []
     while len(ids) < count:
-        ids += plan.group_ids(g % n_groups)
-        g += world
+        n = min(need, units - u0)
+        ids += plan.rank_slice_ids(rank, world, u0, n).tolist()
+        need -= n
+        u0 = 0
     return ids[:count]
 
 
@@ -621,6 +629,71 @@ def m10_amplitudes(dev, seconds=2.0):
     dt = time.perf_counter() - t0
     fn.close()
     return {"amplitudes": n, "seconds": dt, "nslices": int(tree.nslices), "amplitude": complex(amp.item())}
+
+
+def m10_strong(dev, rank, world, comm, dist, reps=20):
+    """BASELINE config 3 as worded: ONE Sycamore m10 amplitude, its 64 slices dealt over the N ranks
+    (``ctg_exec_run_share``) + the RCCL reduce to rank 0, against the same amplitude on one rank.  Strong
+    scaling of a 3 ms job: printed because the configuration names it, not because it scales."""
+    import torch
+
+    import cotengra_amd as ca
+    from cotengra_amd.contractor import HipContractor
+
+    m10 = os.path.join(TREES, "sycamore_m10.json")
+    arr = os.path.join(ROOT, "tests", "golden", "sycamore_m10_arrays.npz")
+    if not (os.path.exists(m10) and os.path.exists(arr)):
+        return None
+    tree = ca.tree_from_record(ca.load_network(m10))
+    z = np.load(arr)
+    xs = [torch.as_tensor(z[f"t{i}"].astype("complex64"), device=dev) for i in range(tree.N)]
+    fn = HipContractor(tree, handle_slicing=True)
+    st = fn.setup(*xs)
+    ex, result = st["exec"], st["result"]
+
+    def sync_all():
+        ex.sync()
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize(dev)
+
+    def timed(r, w, reduce_):
+        for _ in range(3):
+            ex.zero_result()
+            ex.run_share(r, w)
+            if reduce_:
+                reduce_()
+        sync_all()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            ex.zero_result()
+            ex.run_share(r, w)
+            if reduce_:
+                reduce_()
+        sync_all()
+        return (time.perf_counter() - t0) / reps
+
+    def reduce_():
+        if comm is not None:
+            ex.reduce(comm, 0)
+        elif dist is not None:
+            dist.reduce(torch.view_as_real(result), dst=0)
+
+    one = timed(0, 1, None)                       # every rank computes the whole amplitude alone
+    amp1 = complex(result.item())
+    many = timed(rank, world, reduce_ if world > 1 else None)
+    ampn = complex(result.item())
+    if dist is not None:
+        t = torch.tensor([one, many], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        one, many = float(t[0].item()), float(t[1].item())
+    fn.close()
+    return {
+        "workload": "Sycamore circuit_n53_m10 amplitude, %d slices dealt over %d rank(s) + 1 RCCL reduce to rank 0"
+                    % (tree.nslices, world),
+        "ms": many * 1e3, "ms_one_rank": one * 1e3, "speedup_vs_one_rank": one / many, "nslices": int(tree.nslices),
+        "amplitude_rel_diff": abs(ampn - amp1) / abs(amp1) if rank == 0 else None,
+    }
 
 
 # ---------------------------------------------------------------------- #
@@ -902,6 +975,11 @@ def main():
                         "shards is the amplitude, not the slice",
             }
 
+    # BASELINE config 3 as worded: the one 64-slice amplitude over the N ranks (strong scaling)
+    c3_strong = None
+    if (world > 1 or os.environ.get("CTG_BENCH_C3_AMPLITUDES")) and not args.headline_only:
+        c3_strong = m10_strong(dev, rank, world, comm, dist)
+
     # (flops really executed: the steps a slice group shares count once per group -- every rank times the
     # same number of whole groups, so rank 0's count x world is the job's)
     flops_slice = executed_flops(plan, timed_ids) / args.steps
@@ -1047,6 +1125,8 @@ def main():
             out["configs"] = other_configs(dev)
         if c3_amp is not None:
             out.setdefault("configs", {})["C3_amplitudes"] = c3_amp
+        if c3_strong is not None:
+            out.setdefault("configs", {})["C3_strong"] = c3_strong
         emit(out)
     else:
         fn.close()

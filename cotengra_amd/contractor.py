@@ -383,6 +383,34 @@ class HipContractor:
         finally:
             prog.close()
 
+    def run_share(self, ex, rank=0, world=1, progbar=False):
+        """``rank``'s share of the slices (``Plan.share_units``: whole slice groups ``rank, rank + world,
+        ...``; ``contract_mpi``'s round-robin, core.py:4070, for a plan without groups) through
+        ``ctg_exec_run_share`` -- in one call, or under ``progbar`` in chunks of whole units with a
+        synchronisation in between, so that the counter shows slices that are DONE."""
+        units, gs = ex.plan.share_units(rank, world)
+        prog = _Progress(progbar, units * gs) if progbar and units * gs > 1 else None
+        if prog is None or not prog.active:
+            ex.run_share(rank, world, 0, units)
+            return
+        import time
+
+        chunk = max(int(ex.batch) // gs, 1)
+        done = 0
+        try:
+            while done < units:
+                n = min(chunk, units - done)
+                t0 = time.perf_counter()
+                ex.run_share(rank, world, done, n)
+                ex.sync()
+                dt = time.perf_counter() - t0
+                done += n
+                prog.update(n * gs)
+                if dt < 0.1:   # tiny slices: fewer, larger chunks
+                    chunk *= 2
+        finally:
+            prog.close()
+
     def __call__(self, *arrays, **kwargs):
         backend = kwargs.pop("backend", None)  # noqa: F841  (inferred from arrays)
         progbar = kwargs.pop("progbar", self.progbar)
@@ -396,7 +424,7 @@ class HipContractor:
             ex = st["exec"]
             ex.set_strip_exponent(strip_exponent, check_zero)
             ex.zero_result()
-            self.run_slices(ex, 0, self.tree.multiplicity, 1, progbar)
+            self.run_share(ex, 0, 1, progbar)
             return self._finish(st, strip_exponent, check_zero)
 
     def contract_slice(self, arrays, i, strip_exponent=False, check_zero=False):
@@ -916,22 +944,18 @@ def _contract_resumable_locked(fn, tree, arrays, checkpoint, every, order, strip
     st = fn.setup(*arrays)
     ex = st["exec"]
     ex.set_strip_exponent(strip_exponent, check_zero)
-    total = len(range(rank, tree.multiplicity, world))
     plan = st["plan"]
-    # slice groups (plan.choose_slice_group): this rank's share is whole groups -- groups rank, rank + world, ...
-    # --, the count of the checkpoint runs along that order, chunks are whole groups
-    grouped = plan.group_size > 1 and not strip_exponent
-    if grouped:
-        gs = int(plan.group_size)
-        my_groups = range(rank, plan.nslices // gs, world)
-        total = len(my_groups) * gs
-        every = gs * max(1, -(-int(every) // gs))
+    # this rank's share is what the library deals it (Plan.share_units: whole slice groups rank, rank + world,
+    # ... -- single slices without group indices); the count of the checkpoint runs along that order and
+    # chunks are whole units
+    units, gs = plan.share_units(rank, world)
+    total = units * gs
+    grouped = gs > 1
+    every = gs * max(1, -(-int(every) // gs))
 
-        def ids_at(start, n):
-            out = []
-            for k in range(start // gs, -(-(start + n) // gs)):
-                out += plan.group_ids(my_groups[k])
-            return out[start % gs: start % gs + n]
+    def ids_at(start, n):
+        u0, u1 = start // gs, -(-(start + n) // gs)
+        return plan.rank_slice_ids(rank, world, u0, u1 - u0)[start - u0 * gs: start - u0 * gs + n]
     sig = tree_signature(tree, st["plan"].dtype, rank, world, strip_exponent, check_zero, order,
                          arrays=arrays, groups=plan.group_inds if grouped else None)
     saved = load_checkpoint(checkpoint, sig)
@@ -950,10 +974,10 @@ def _contract_resumable_locked(fn, tree, arrays, checkpoint, every, order, strip
     try:
         while budget > 0:
             n = min(int(every), budget)
-            if grouped:
+            if done % gs == 0 and n % gs == 0:
+                ex.run_share(rank, world, done // gs, n // gs)
+            else:   # (a run stopped inside a group by ``stop_after``)
                 ex.run_slice_list(ids_at(done, n))
-            else:
-                ex.run_slices(rank + done * world, n, world)
             done += n
             budget -= n
             result, exponent, zero = ex.get_state()

@@ -59,6 +59,9 @@ struct ctg_exec {
     // one), the ids of the slices of the launch at hand (device, `batch` entries)
     int group_d = 0;
     int64_t* d_batch_ids = nullptr;
+    int64_t* h_ids = nullptr;      // pinned staging of the ids of batched group launches (run_grouped)
+    size_t h_ids_cap = 0;
+    hipEvent_t ev_ids = nullptr;   // ... recorded after the last copy out of it
     int batch_nominal = 1;         // min(64, nslices, 8 GiB / arena): what the k-splits are chosen for
     int64_t scratch_total = 0;     // bytes of d_scratch (64 MiB x up to 8 for batching executors)
     // the launch list of one slice: steps that launch alone (cls < 0) and wave-front

@@ -446,8 +446,20 @@ void resolve_args(ctg_exec* e) {
                 a.zA *= d; a.zB *= d; a.zC *= d;
                 a.zsA *= d; a.zsB *= d; a.zsC *= d;
             } else if (r[W_KIND] == KIND_PAIR || r[W_KIND] == KIND_SINGLE) {
-                if (shared(r[W_A_PROD])) a.zqA = (int32_t)d;
-                if (r[W_KIND] == KIND_PAIR && shared(r[W_B_PROD])) a.zqB = (int32_t)d;
+                // Which step wrote an operand is read off the arena, not off W_A_PROD / W_B_PROD (those
+                // name PAIR / STEM2 producers only -- they drive the strip_exponent factors): the latest
+                // earlier step whose output starts where the operand starts.  A shared leaf-preprocessing
+                // step (KIND_SINGLE) feeding a per-slice step is found this way too.
+                auto writer = [&](int sw, int ow) -> int64_t {
+                    if (r[sw] != SPACE_ARENA) return -1;
+                    for (int64_t t = s - 1; t >= 0; --t) {
+                        const int64_t* w = &p->steps[t * STEP_WORDS];
+                        if (w[W_KIND] != KIND_ACCUM && w[W_C_SPACE] == SPACE_ARENA && w[W_C_OFF] == r[ow]) return t;
+                    }
+                    return -1;
+                };
+                if (shared(writer(W_A_SPACE, W_A_OFF))) a.zqA = (int32_t)d;
+                if (r[W_KIND] == KIND_PAIR && shared(writer(W_B_SPACE, W_B_OFF))) a.zqB = (int32_t)d;
             }
         }
         a.facA = a.facB = nullptr;
@@ -1138,14 +1150,68 @@ int64_t slice_group_key(const ctg_plan* p, int64_t sid) {
     return key;
 }
 
+// The digits of a slice id, least significant first (the last sliced index varies fastest), without
+// the projected ones: (stride in the slice id, extent, is a group index).
+struct SliceDigit { int64_t stride, size; bool group; };
+std::vector<SliceDigit> slice_digits(const ctg_plan* p) {
+    std::vector<SliceDigit> out;
+    int64_t stride = 1;
+    for (int64_t j = p->n_sliced - 1; j >= 0; --j) {
+        if (p->slice_fixed[j] >= 0) continue;
+        out.push_back({stride, p->slice_sizes[j], p->slice_group[j] == 1});
+        stride = (stride > INT64_MAX / p->slice_sizes[j]) ? INT64_MAX : stride * p->slice_sizes[j];
+    }
+    return out;
+}
+
+int64_t plan_group_size(const ctg_plan* p) {
+    int64_t d = 1;
+    for (int64_t j = 0; j < p->n_sliced; ++j)
+        if (p->slice_group[j] == 1 && p->slice_fixed[j] < 0) d *= p->slice_sizes[j];
+    return d;
+}
+
+// the slices of group g (g in [0, nslices / group size): its digits are the values of the sliced
+// indices that are not group indices), ascending, appended to `out`
+void group_members(const std::vector<SliceDigit>& digits, int64_t g, std::vector<int64_t>& out) {
+    int64_t base = 0, rem = g;
+    for (const SliceDigit& d : digits)
+        if (!d.group) {
+            base += (rem % d.size) * d.stride;
+            rem /= d.size;
+        }
+    const size_t at = out.size();
+    out.push_back(base);
+    for (const SliceDigit& d : digits)
+        if (d.group) {
+            const size_t n = out.size();
+            for (int64_t v = 1; v < d.size; ++v)
+                for (size_t i = at; i < n; ++i) out.push_back(out[i] + v * d.stride);
+        }
+    std::sort(out.begin() + at, out.end());
+}
+
+// A rank's share of the slices (ABI 6): the UNITS rank, rank + world, ... -- a unit is a whole slice
+// group (a single slice for a plan without group indices, which makes this core.py:4070's round-robin).
+struct Share { int64_t gsize, n_units_all, units; };
+int plan_share(const ctg_plan* p, int64_t rank, int64_t world, Share* out) {
+    if (world < 1 || rank < 0 || rank >= world) return fail(CTG_E_INVALID, "rank %lld of %lld", (long long)rank, (long long)world);
+    Share sh;
+    sh.gsize = plan_group_size(p);
+    sh.n_units_all = p->nslices / sh.gsize;
+    sh.units = rank < sh.n_units_all ? (sh.n_units_all - rank + world - 1) / world : 0;
+    *out = sh;
+    return CTG_OK;
+}
+
 // Slice groups: the given slices group by group -- same key (= all sliced indices but the group ones)
 // one after the other, in slice order within a group --, the steps the slices of a group share launched
 // when the key changes.  (Under strip_exponent every step keeps a scale per slice: the callers then take
 // the ordinary path, on which the shared steps are simply computed for every slice.)
-int run_grouped(ctg_exec* e, const std::vector<int64_t>& ids) {
+int run_grouped(ctg_exec* e, const int64_t* ids, size_t n_ids) {
     const ctg_plan* p = e->plan;
-    std::vector<std::pair<int64_t, int64_t>> order(ids.size());
-    for (size_t k = 0; k < ids.size(); ++k) order[k] = {slice_group_key(p, ids[k]), ids[k]};
+    std::vector<std::pair<int64_t, int64_t>> order(n_ids);
+    for (size_t k = 0; k < n_ids; ++k) order[k] = {slice_group_key(p, ids[k]), ids[k]};
     std::sort(order.begin(), order.end());
     if (e->group_d > 1) {
         // Batched launches of whole groups: slice-in-batch z = group * d + member.  A group that is not
@@ -1153,19 +1219,34 @@ int run_grouped(ctg_exec* e, const std::vector<int64_t>& ids) {
         // consistent as it is (z = 0: every quantum and multiplier drops out), its shared steps are
         // computed for it alone.
         const size_t d = (size_t)e->group_d;
-        std::vector<int64_t> full, rest;
+        std::vector<int64_t> rest;
+        // the ids of the batched launches are staged in pinned memory the executor keeps (the copies to
+        // the device are asynchronous; the event says when the previous call's have been consumed)
+        if (e->ev_ids) HIP_TRY(hipEventSynchronize(e->ev_ids));
+        if (e->h_ids_cap < n_ids) {
+            if (e->h_ids) (void)hipHostFree(e->h_ids);
+            e->h_ids = nullptr;
+            e->h_ids_cap = 0;
+            HIP_TRY(hipHostMalloc((void**)&e->h_ids, std::max<size_t>(n_ids, 4096) * sizeof(int64_t), hipHostMallocDefault));
+            e->h_ids_cap = std::max<size_t>(n_ids, 4096);
+        }
+        if (!e->ev_ids) HIP_TRY(hipEventCreateWithFlags(&e->ev_ids, hipEventDisableTiming));
+        size_t n_full = 0;
         for (size_t k = 0; k < order.size();) {
             size_t j = k;
             while (j < order.size() && order[j].first == order[k].first) ++j;
             bool whole = j - k == d;
             for (size_t i = k + 1; whole && i < j; ++i) whole = order[i].second != order[i - 1].second;
-            for (size_t i = k; i < j; ++i) (whole ? full : rest).push_back(order[i].second);
+            for (size_t i = k; i < j; ++i) {
+                if (whole) e->h_ids[n_full++] = order[i].second;
+                else rest.push_back(order[i].second);
+            }
             k = j;
         }
         e->group_key = -1;
-        for (size_t k = 0; k < full.size(); k += (size_t)e->batch) {
-            const int nb = (int)std::min<size_t>((size_t)e->batch, full.size() - k);
-            HIP_TRY(hipMemcpyAsync(e->d_batch_ids, full.data() + k, nb * sizeof(int64_t), hipMemcpyHostToDevice, e->stream));
+        for (size_t k = 0; k < n_full; k += (size_t)e->batch) {
+            const int nb = (int)std::min<size_t>((size_t)e->batch, n_full - k);
+            HIP_TRY(hipMemcpyAsync(e->d_batch_ids, e->h_ids + k, nb * sizeof(int64_t), hipMemcpyHostToDevice, e->stream));
             hipError_t err = launch_prologue(e->meta, e->d_state, e->d_soff, 0, e->stream, nb, 1, e->d_batch_ids);
             if (err != hipSuccess) return fail(CTG_E_HIP, "prologue launch failed: %s", hipGetErrorString(err));
             for (const ctg_exec::Issue& q : e->issue) {
@@ -1173,8 +1254,7 @@ int run_grouped(ctg_exec* e, const std::vector<int64_t>& ids) {
                 if (rc != CTG_OK) return rc;
             }
         }
-        // (the host buffer `full` must outlive the asynchronous copies)
-        if (!full.empty()) HIP_TRY(hipStreamSynchronize(e->stream));
+        if (n_full) HIP_TRY(hipEventRecord(e->ev_ids, e->stream));
         for (int64_t sid : rest) {
             hipError_t err = launch_prologue(e->meta, e->d_state, e->d_soff, sid, e->stream, 1, 1);
             if (err != hipSuccess) return fail(CTG_E_HIP, "prologue launch failed: %s", hipGetErrorString(err));
@@ -1200,6 +1280,7 @@ int run_grouped(ctg_exec* e, const std::vector<int64_t>& ids) {
     e->warm = true;
     return CTG_OK;
 }
+int run_grouped(ctg_exec* e, const std::vector<int64_t>& ids) { return run_grouped(e, ids.data(), ids.size()); }
 
 // Slice-invariant steps (no sliced input below them): once per upload.  Their
 // strip_exponent factors are computed here too and kept across slices.
@@ -1321,6 +1402,8 @@ int ctg_exec_destroy(ctg_exec* e) {
     if (e->d_lane_b) (void)hipFree(e->d_lane_b);
     if (e->d_group_items) (void)hipFree(e->d_group_items);
     if (e->d_fast_items) (void)hipFree(e->d_fast_items);
+    if (e->h_ids) (void)hipHostFree(e->h_ids);
+    if (e->ev_ids) (void)hipEventDestroy(e->ev_ids);
     if (e->d_fac) (void)hipFree(e->d_fac);
     if (e->d_counted) (void)hipFree(e->d_counted);
     if (e->d_fac_zero) (void)hipFree(e->d_fac_zero);
@@ -1640,9 +1723,19 @@ int ctg_exec_run_slices(ctg_exec* e, int64_t first, int64_t count, int64_t strid
         return CTG_OK;
     };
     if (p->has_groups && !e->strip) {
-        std::vector<int64_t> ids((size_t)count);
-        for (int64_t k = 0; k < count; ++k) ids[(size_t)k] = first + k * stride;
-        return run_grouped(e, ids);
+        // every slice of the tree: group by group (host memory bounded by the chunk, not by nslices)
+        if (first == 0 && stride == 1 && count == p->nslices) return ctg_exec_run_share(e, 0, 1, 0, -1);
+        // any other range: in chunks of ids (a group cut by a chunk boundary is computed slice by slice)
+        const int64_t chunk = (int64_t)1 << 20;
+        std::vector<int64_t> ids;
+        for (int64_t k0 = 0; k0 < count; k0 += chunk) {
+            const int64_t n = std::min(chunk, count - k0);
+            ids.resize((size_t)n);
+            for (int64_t k = 0; k < n; ++k) ids[(size_t)k] = first + (k0 + k) * stride;
+            const int rc = run_grouped(e, ids);
+            if (rc != CTG_OK) return rc;
+        }
+        return CTG_OK;
     }
     int64_t i = 0;
     // (strip_exponent keeps one scale per step and slice: no batching there)
@@ -1720,6 +1813,79 @@ int ctg_exec_run_slice_list(ctg_exec* e, const int64_t* ids, int64_t n) {
     for (int64_t k = 0; k < n; ++k) {
         const int rc = ctg_exec_run_slices(e, ids[k], 1, 1);
         if (rc != CTG_OK) return rc;
+    }
+    return CTG_OK;
+}
+
+int ctg_plan_share_units(const ctg_plan* p, int64_t rank, int64_t world, int64_t* units, int64_t* slices_per_unit) {
+    if (!p || !units) return fail(CTG_E_INVALID, "null argument");
+    Share sh;
+    const int rc = plan_share(p, rank, world, &sh);
+    if (rc != CTG_OK) return rc;
+    *units = sh.units;
+    if (slices_per_unit) *slices_per_unit = sh.gsize;
+    return CTG_OK;
+}
+
+int ctg_plan_share_slice_ids(const ctg_plan* p, int64_t rank, int64_t world, int64_t unit_first, int64_t unit_count,
+                             int64_t* ids) {
+    if (!p || (unit_count > 0 && !ids)) return fail(CTG_E_INVALID, "null argument");
+    Share sh;
+    const int rc = plan_share(p, rank, world, &sh);
+    if (rc != CTG_OK) return rc;
+    if (unit_count < 0) unit_count = sh.units - unit_first;
+    if (unit_first < 0 || unit_count < 0 || unit_first + unit_count > sh.units)
+        return fail(CTG_E_INVALID, "units [%lld, +%lld) outside the %lld of rank %lld", (long long)unit_first,
+                    (long long)unit_count, (long long)sh.units, (long long)rank);
+    const std::vector<SliceDigit> digits = slice_digits(p);
+    std::vector<int64_t> tmp;
+    for (int64_t u = 0; u < unit_count; ++u) {
+        tmp.clear();
+        group_members(digits, rank + (unit_first + u) * world, tmp);
+        for (size_t i = 0; i < tmp.size(); ++i) ids[u * sh.gsize + (int64_t)i] = tmp[i];
+    }
+    return CTG_OK;
+}
+
+int ctg_exec_run_share(ctg_exec* e, int64_t rank, int64_t world, int64_t unit_first, int64_t unit_count) {
+    if (!e) return fail(CTG_E_INVALID, "null argument");
+    const ctg_plan* p = e->plan;
+    Share sh;
+    {
+        const int rc = plan_share(p, rank, world, &sh);
+        if (rc != CTG_OK) return rc;
+    }
+    if (unit_count < 0) unit_count = sh.units - unit_first;
+    if (unit_first < 0 || unit_count < 0 || unit_first + unit_count > sh.units)
+        return fail(CTG_E_INVALID, "units [%lld, +%lld) outside the %lld of rank %lld", (long long)unit_first,
+                    (long long)unit_count, (long long)sh.units, (long long)rank);
+    if (unit_count == 0) return CTG_OK;
+    // no group indices: the round-robin of contract_mpi (core.py:4070) as one strided range
+    if (sh.gsize == 1) return ctg_exec_run_slices(e, rank + unit_first * world, unit_count, world);
+    HIP_TRY(hipSetDevice(e->device));
+    {
+        const int rc = run_invariants(e);
+        if (rc != CTG_OK) return rc;
+    }
+    // whole groups, a chunk of them at a time (a multiple of the launch batch when launches are batched)
+    const std::vector<SliceDigit> digits = slice_digits(p);
+    const int64_t want = std::max<int64_t>((int64_t)e->batch * 64, 8192);
+    const int64_t per_chunk = std::max<int64_t>(want / sh.gsize, 1);
+    std::vector<int64_t> ids;
+    for (int64_t u0 = 0; u0 < unit_count; u0 += per_chunk) {
+        const int64_t nu = std::min(per_chunk, unit_count - u0);
+        ids.clear();
+        for (int64_t u = 0; u < nu; ++u) group_members(digits, rank + (unit_first + u0 + u) * world, ids);
+        if (p->has_groups && !e->strip) {
+            const int rc = run_grouped(e, ids);
+            if (rc != CTG_OK) return rc;
+        } else {
+            // (strip_exponent keeps a scale per step and slice, or nothing is shared: slice by slice)
+            for (int64_t sid : ids) {
+                const int rc = ctg_exec_run_slices(e, sid, 1, 1);
+                if (rc != CTG_OK) return rc;
+            }
+        }
     }
     return CTG_OK;
 }

@@ -5,7 +5,7 @@ The reference's only distributed execution is ``ContractionTree.contract_mpi``
 (``range(rank, nslices, size)``, :4070), sum them locally, and meet in ONE
 ``Allreduce`` / ``Reduce`` of the output tensor (:4081, :4089).  Here the
 ranks are one process per MI355X, the local loop and sum run on the device
-inside ``ctg_exec_run_slices(first=rank, stride=world)``, and the single
+inside ``ctg_exec_run_share(rank, world)``, and the single
 collective is RCCL over xGMI on the executor's own stream
 (``ctg_exec_reduce``, ``include/ctg_hip.h``), reducing the resident result
 tensor in place.  There is no other inter-GPU traffic: inputs are tiny and
@@ -39,8 +39,13 @@ _COMMS = {}  # id(group) / id(mpi comm) -> runtime.Comm
 _COMMS_LOCK = threading.RLock()
 
 
-def slices_of_rank(nslices, rank, world):
-    """Round-robin partition of ``contract_mpi`` (core.py:4070)."""
+def slices_of_rank(nslices, rank, world, plan=None):
+    """This rank's slices.  Without a plan (or with one that has no slice groups): the round-robin
+    partition of ``contract_mpi`` (core.py:4070).  With slice groups: whole groups ``rank, rank +
+    world, ...`` (``Plan.rank_slice_ids``) -- what the HIP executor runs in ``ctg_exec_run_share``:
+    the steps a group shares are computed once per group and on one rank only."""
+    if plan is not None and plan.group_size > 1:
+        return [int(i) for i in plan.rank_slice_ids(rank, world)]
     return range(rank, nslices, world)
 
 
@@ -155,9 +160,13 @@ def contract_distributed(
             f"Need to have more slices than processes, but have "
             f"{tree.multiplicity} and {world} respectively."
         )
-    mine = slices_of_rank(tree.multiplicity, rank, world)
-
     if executor_factory is not None:
+        # (the injected executor is dealt the same share as the HIP executor: the plan -- host-side
+        # only -- says whether the tree has slice groups)
+        from .contractor import _result_dtype, _tree_contractor
+
+        plan = _tree_contractor(tree, order).get_plan(_result_dtype(arrays))[0]
+        mine = slices_of_rank(tree.multiplicity, rank, world, plan=plan)
         return _reduce_host(
             _injected_partial(tree, arrays, mine, executor_factory), None, tgroup, rank, root
         )
@@ -170,7 +179,8 @@ def contract_distributed(
         ex = st["exec"]
         ex.set_strip_exponent(strip_exponent, check_zero)
         ex.zero_result()
-        fn.run_slices(ex, rank, len(mine), world, progbar if rank == 0 else False)
+        # (whole slice groups rank, rank + world, ...: ctg_exec_run_share)
+        fn.run_share(ex, rank, world, progbar if rank == 0 else False)
         if ccomm is not None:
             # RCCL on the executor's stream, in place on the resident result
             ex.reduce(ccomm, root)

@@ -302,6 +302,42 @@ class Plan:
                 mult *= size
         return g
 
+    # ---- a rank's share of the slices (the library's rule: ctg_plan_share_units / ctg_exec_run_share) -----
+    def share_units(self, rank=0, world=1):
+        """``(units, slices per unit)`` of ``rank``'s share: the units ``rank, rank + world, ...`` where a
+        unit is a whole slice group -- what a group shares is then computed once per group, on one rank --
+        and a single slice for a plan without group indices, which is ``contract_mpi``'s round-robin
+        (core.py:4068-4076)."""
+        if world < 1 or not 0 <= rank < world:
+            raise ValueError(f"rank {rank} of {world}")
+        gs = int(self.group_size)
+        n_units = int(self.nslices) // gs
+        return (len(range(rank, n_units, world)), gs)
+
+    def rank_slice_ids(self, rank=0, world=1, unit_first=0, unit_count=None):
+        """Slice ids of (units ``[unit_first, unit_first + unit_count)`` of) ``rank``'s share, unit after
+        unit, ascending inside a unit: an int64 array.  The shares of the ranks are disjoint, cover
+        ``range(nslices)`` and differ by at most one unit."""
+        units, gs = self.share_units(rank, world)
+        if unit_count is None:
+            unit_count = units - unit_first
+        if unit_first < 0 or unit_count < 0 or unit_first + unit_count > units:
+            raise ValueError(f"units [{unit_first}, +{unit_count}) outside the {units} of rank {rank}")
+        g = rank + (unit_first + np.arange(unit_count, dtype=np.int64)) * world
+        if gs == 1 or len(g) == 0:
+            return g
+        digits = self._slice_digits()
+        base, rem = np.zeros_like(g), g.copy()
+        for stride, size, is_group in digits:
+            if not is_group:
+                base += (rem % size) * stride
+                rem //= size
+        ids = base[:, None]
+        for stride, size, is_group in digits:
+            if is_group:
+                ids = (ids[:, :, None] + (np.arange(size, dtype=np.int64) * stride)[None, None, :]).reshape(len(g), -1)
+        return np.sort(ids, axis=1).reshape(-1)
+
     @property
     def macs_shared_per_group(self):
         """Multiply-adds of the steps a group computes once."""

@@ -12,7 +12,7 @@ import os
 import numpy as np
 
 _LIB_PATH = os.environ.get("CTG_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libctg_hip.so")
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 # every symbol include/ctg_hip.h declares
 SYMBOLS = (
@@ -33,6 +33,9 @@ SYMBOLS = (
     "ctg_exec_get_exponent",
     "ctg_exec_run_slices",
     "ctg_exec_run_slice_list",
+    "ctg_plan_share_units",
+    "ctg_plan_share_slice_ids",
+    "ctg_exec_run_share",
     "ctg_exec_slice_batch",
     "ctg_exec_device_bytes",
     "ctg_stem_triple_instantiated",
@@ -135,6 +138,9 @@ def load():
         "ctg_exec_get_exponent": [vp, C.POINTER(C.c_double), C.POINTER(C.c_int)],
         "ctg_exec_run_slices": [vp, C.c_int64, C.c_int64, C.c_int64],
         "ctg_exec_run_slice_list": [vp, i64p, C.c_int64],
+        "ctg_plan_share_units": [vp, C.c_int64, C.c_int64, i64p, i64p],
+        "ctg_plan_share_slice_ids": [vp, C.c_int64, C.c_int64, C.c_int64, C.c_int64, i64p],
+        "ctg_exec_run_share": [vp, C.c_int64, C.c_int64, C.c_int64, C.c_int64],
         "ctg_exec_slice_batch": [vp, i64p],
         "ctg_exec_device_bytes": [vp, i64p],
         "ctg_stem_triple_instantiated": [C.c_int] * 9,
@@ -226,6 +232,21 @@ class DevicePlan:
         _check(load().ctg_plan_nslices(self.handle, C.byref(n)))
         return n.value
 
+    def share_units(self, rank=0, world=1):
+        """``(units, slices per unit)`` of ``rank``'s share (``ctg_plan_share_units``): whole slice
+        groups ``rank, rank + world, ...``; single slices for a plan without group indices."""
+        u, g = C.c_int64(), C.c_int64()
+        _check(load().ctg_plan_share_units(self.handle, int(rank), int(world), C.byref(u), C.byref(g)))
+        return u.value, g.value
+
+    def share_slice_ids(self, rank=0, world=1, unit_first=0, unit_count=-1):
+        """Slice ids of the units ``[unit_first, unit_first + unit_count)`` of ``rank``'s share."""
+        units, gsize = self.share_units(rank, world)
+        n = units - unit_first if unit_count < 0 else unit_count
+        out = np.empty(max(n, 0) * gsize, dtype=np.int64)
+        _check(load().ctg_plan_share_slice_ids(self.handle, int(rank), int(world), int(unit_first), int(n), _i64p(out)))
+        return out
+
     def workspace_bytes(self):
         out = (C.c_int64 * 4)()
         _check(load().ctg_plan_workspace_bytes(self.handle, out))
@@ -313,6 +334,12 @@ class Executor:
         groups in the plan, group by group (``ctg_exec_run_slice_list``)."""
         arr = np.ascontiguousarray(ids, dtype=np.int64)
         _check(load().ctg_exec_run_slice_list(self.handle, arr.ctypes.data_as(C.POINTER(C.c_int64)), arr.size))
+
+    def run_share(self, rank=0, world=1, unit_first=0, unit_count=-1):
+        """Contract units ``[unit_first, unit_first + unit_count)`` of ``rank``'s share of the slices
+        (``ctg_exec_run_share``: whole slice groups ``rank, rank + world, ...``; the round-robin of
+        ``contract_mpi``, core.py:4070, for a plan without groups) and add them to the result."""
+        _check(load().ctg_exec_run_share(self.handle, int(rank), int(world), int(unit_first), int(unit_count)))
 
     def run_slices(self, first=0, count=None, stride=1):
         if count is None:

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define CTG_ABI_VERSION 5
+#define CTG_ABI_VERSION 6
 
 /* element types of the tensors (reference tests cover all four:
  * tests/test_compute.py:102-115) */
@@ -185,6 +185,22 @@ int ctg_exec_slice_batch(ctg_exec* exec, int64_t* batch);
  * pass whole groups to get the saving; the sum does not depend on the grouping beyond the order of
  * its floating-point additions. */
 int ctg_exec_run_slice_list(ctg_exec* exec, const int64_t* ids, int64_t n);
+/* ABI 6.  A rank's SHARE of the slices, as the library deals them: the units rank, rank + world, ... where a
+ * unit is a whole slice group (ctg_plan_desc.slice_group; what a group shares is then computed once per
+ * group on exactly one rank) and, for a plan without group indices, a single slice -- which is the
+ * round-robin `range(rank, nslices, size)` of contract_mpi (core.py:4068-4076).  The shares of the ranks
+ * are disjoint, cover every slice and differ by at most one unit.
+ *   ctg_plan_share_units      -> how many units rank holds and the slices in a unit (host only);
+ *   ctg_plan_share_slice_ids  -> the slice ids of units [unit_first, unit_first + unit_count) of the
+ *                                share, unit after unit, ascending inside a unit (unit_count < 0: to the
+ *                                end; `ids` holds unit_count * slices_per_unit words) (host only);
+ *   ctg_exec_run_share        -> contract those units and accumulate them like ctg_exec_run_slices; host
+ *                                memory stays bounded by a chunk of groups whatever nslices is.
+ * A checkpointing caller counts finished UNITS of its share and resumes with unit_first = that count. */
+int ctg_plan_share_units(const ctg_plan* plan, int64_t rank, int64_t world, int64_t* units, int64_t* slices_per_unit);
+int ctg_plan_share_slice_ids(const ctg_plan* plan, int64_t rank, int64_t world, int64_t unit_first,
+                             int64_t unit_count, int64_t* ids);
+int ctg_exec_run_share(ctg_exec* exec, int64_t rank, int64_t world, int64_t unit_first, int64_t unit_count);
 /* ABI 4.  Device memory this executor holds right now: inputs space, arena x slice batch,
  * tables, the result if it owns it, the scratch buffer if the plan has a step that needs one
  * (allocated by ctg_exec_create).  What a cache of contractors -- the reference keeps them

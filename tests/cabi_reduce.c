@@ -121,10 +121,14 @@ int main(int argc, char** argv) {
     }
     CHECK(ctg_comm_init(id, rank, world, device, &comm));
 
-    /* my share of the slices, accumulated on the device; then ONE collective */
-    const int64_t mine = (nslices - rank + world - 1) / world;
+    /* my share of the slices as the library deals them -- whole slice groups rank, rank + world, ...; single
+     * slices round-robin (core.py:4070) for a plan without group indices --, accumulated on the device; then
+     * ONE collective */
+    int64_t units = 0, per_unit = 1;
+    CHECK(ctg_plan_share_units(plan, rank, world, &units, &per_unit));
+    const int64_t mine = units * per_unit;
     CHECK(ctg_exec_zero_result(ex));
-    CHECK(ctg_exec_run_slices(ex, rank, mine, world));
+    CHECK(ctg_exec_run_share(ex, rank, world, 0, units));
     CHECK(ctg_exec_reduce(ex, comm, -1));
     double* out = (double*)malloc((size_t)d.result_elems * 2 * sizeof(double));
     CHECK(ctg_exec_download_result(ex, out));

@@ -47,7 +47,15 @@ def _worker(rank, world, port, root, q):
         arrays = ca.make_arrays_from_inputs(tree.inputs, tree.size_dict, seed=5, dtype="complex128")
 
         def executor(tree_, arrays_, mine):
-            assert list(mine) == list(slices_of_rank(tree_.nslices, rank, world))
+            # (whole slice groups rank, rank + world, ... when the plan has groups; core.py:4070's
+            # round-robin otherwise)
+            from cotengra_amd import plan as P
+
+            plan_ = P.compile_tree(tree_, "complex128")
+            want = list(slices_of_rank(tree_.nslices, rank, world, plan=plan_))
+            assert list(mine) == want
+            if plan_.group_size == 1:
+                assert want == list(range(rank, tree_.nslices, world))
             return sum(orc.contract_slice(tree_, arrays_, i) for i in mine)
 
         out = contract_distributed(tree, arrays, root=root, executor_factory=executor)

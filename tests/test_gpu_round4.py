@@ -366,7 +366,7 @@ def _n_gpus():
 
 def test_two_ranks_plain_c_driver_and_bench_line(tmp_path):
     """``tests/cabi_reduce`` with world = 2 (no Python in the ranks: plan file -> executors ->
-    RCCL unique id through a file -> ``ctg_exec_run_slices(first = rank, stride = 2)`` ->
+    RCCL unique id through a file -> ``ctg_exec_run_share(rank, 2)`` ->
     ``ctg_exec_reduce``) and ``bench.py --gpus 2 --headline-only``: two distinct devices, the
     reduce behind the C ABI, the 2-rank amplitude equal to the 1-rank one within the
     single-precision gate, and the per-rank slice times (load balance) printed."""
@@ -388,7 +388,9 @@ def test_two_ranks_plain_c_driver_and_bench_line(tmp_path):
                "--headline-only", "--no-cpu-baseline"]
         r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
         assert r.returncode == 0, r.stderr[-2000:]
-        return json.loads(r.stdout.strip().splitlines()[-1])
+        line = r.stdout.strip().splitlines()[-1]
+        assert len(line) < 4096                       # (the compact record; the full one is a file)
+        return json.load(open(os.path.join(ROOT, json.loads(line)["full_record"])))
 
     two, one = bench(2), bench(1)
     assert two["n_gpus"] == 2 and two["distinct_gpus"] == 2
@@ -404,7 +406,8 @@ def test_two_ranks_plain_c_driver_and_bench_line(tmp_path):
             "--headline-only", "--no-cpu-baseline"]
     r1 = subprocess.run(cmd1, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
     assert r1.returncode == 0, r1.stderr[-2000:]
-    a1 = complex(*json.loads(r1.stdout.strip().splitlines()[-1])["config"]["partial_amplitude"])
+    full1 = json.load(open(os.path.join(ROOT, json.loads(r1.stdout.strip().splitlines()[-1])["full_record"])))
+    a1 = complex(*full1["config"]["partial_amplitude"])
     a2 = complex(*two["config"]["partial_amplitude"])
     assert abs(a2 - a1) <= 1e-4 * abs(a1), (a1, a2)
 
