@@ -39,7 +39,9 @@ def test_shared_single_step_feeds_a_per_slice_step(dtype, extra, monkeypatch):
     tol = 1e-10 if dtype == "complex128" else G.single_gate(ref, orc.contract(tree, arrays))
     fn = HipContractor(tree)
     plan = fn.get_plan(dtype)[0]
-    assert plan.group_size >= 2 and plan.steps[0].kind == 0 and plan.steps[0].group
+    assert plan.group_size >= 2 and plan.steps[0].kind == 0
+    if not extra:     # (the advisor's tree itself: the preprocessing step is shared, its consumer is not)
+        assert plan.steps[0].group and plan.group_inds == ("g",)
     ex = fn.setup(*arrays)["exec"]
     assert ex.batch >= plan.group_size          # batched launches of whole groups
     got = complex(np.asarray(fn(*arrays)))
