@@ -980,7 +980,8 @@ def _contract_resumable_locked(fn, tree, arrays, checkpoint, every, order, strip
                 ex.run_slice_list(ids_at(done, n))
             done += n
             budget -= n
-            result, exponent, zero = ex.get_state()
+            # (the running sum in the precision the executor carries it in: double for single-precision trees)
+            result, exponent, zero = ex.get_state_wide()
             save_checkpoint(checkpoint, sig, done, result, exponent, zero)
             if prog.active:
                 prog.update(n)

@@ -202,15 +202,20 @@ int ctg_exec_reduce(ctg_exec* e, ctg_comm* c, int root) {
         hipLaunchKernelGGL(merge_prepare_kernel, dim3(1), dim3(1), 0, e->stream, e->d_strip, c->d_emax);
         HIP_TRY_C(hipGetLastError());
         HIP_TRY_C(launch_rescale(p->dtype, e->d_result, p->result_elems, e->d_strip, e->stream));
+        if (e->d_wide) HIP_TRY_C(launch_rescale(p->dtype + 1, e->d_wide, p->result_elems, e->d_strip, e->stream));
     }
-    // complex tensors travel as pairs of reals
-    const bool dbl = p->dtype == CTG_F64 || p->dtype == CTG_C128;
+    // complex tensors travel as pairs of reals; single-precision results of a sliced tree travel as their
+    // double-precision running sums (16 bytes per complex element) and are rounded once, after the sum
+    const bool dbl = p->dtype == CTG_F64 || p->dtype == CTG_C128 || e->d_wide != nullptr;
     const size_t count = (size_t)p->result_elems * ((p->dtype == CTG_C64 || p->dtype == CTG_C128) ? 2 : 1);
     const ncclDataType_t dt = dbl ? ncclDouble : ncclFloat;
+    void* buf = e->d_wide ? (void*)e->d_wide : (void*)e->d_result;
     if (root < 0)
-        RCCL_TRY(api, api->AllReduce(e->d_result, e->d_result, count, dt, ncclSum, c->comm, e->stream));
+        RCCL_TRY(api, api->AllReduce(buf, buf, count, dt, ncclSum, c->comm, e->stream));
     else
-        RCCL_TRY(api, api->Reduce(e->d_result, e->d_result, count, dt, ncclSum, root, c->comm, e->stream));
+        RCCL_TRY(api, api->Reduce(buf, buf, count, dt, ncclSum, root, c->comm, e->stream));
+    if (e->d_wide && (root < 0 || root == c->rank))
+        HIP_TRY_C(launch_narrow(p->dtype, e->d_result, e->d_wide, p->result_elems, e->stream));
     return CTG_OK;
 }
 
@@ -229,12 +234,52 @@ int ctg_exec_get_state(ctg_exec* e, void* host_result, double* exponent, int* ze
     return CTG_OK;
 }
 
+static int set_strip_state(ctg_exec* e, double exponent, int zero);
+
+int ctg_exec_state_dtype(ctg_exec* e, int* dtype) {
+    if (!e || !dtype) return cfail(CTG_E_INVALID, "null argument");
+    *dtype = e->d_wide ? e->plan->dtype + 1 : e->plan->dtype;   // (CTG_F32 -> CTG_F64, CTG_C64 -> CTG_C128)
+    return CTG_OK;
+}
+
+int ctg_exec_get_state_wide(ctg_exec* e, void* host_sum, double* exponent, int* zero) {
+    if (!e || !host_sum) return cfail(CTG_E_INVALID, "null argument");
+    if (!e->d_wide) return ctg_exec_get_state(e, host_sum, exponent, zero);
+    HIP_TRY_C(hipSetDevice(e->device));
+    HIP_TRY_C(hipStreamSynchronize(e->stream));
+    HIP_TRY_C(hipMemcpy(host_sum, e->d_wide, e->plan->result_elems * 2 * ctg_item_size(e->plan->dtype), hipMemcpyDeviceToHost));
+    StripState st{};
+    HIP_TRY_C(hipMemcpy(&st, e->d_strip, sizeof(st), hipMemcpyDeviceToHost));
+    if (exponent) *exponent = e->strip ? st.E : 0.0;
+    if (zero) *zero = e->strip ? st.zero : 0;
+    return CTG_OK;
+}
+
+int ctg_exec_set_state_wide(ctg_exec* e, const void* host_sum, double exponent, int zero) {
+    if (!e || !host_sum) return cfail(CTG_E_INVALID, "null argument");
+    if (!e->d_wide) return ctg_exec_set_state(e, host_sum, exponent, zero);
+    HIP_TRY_C(hipSetDevice(e->device));
+    HIP_TRY_C(hipStreamSynchronize(e->stream));
+    HIP_TRY_C(hipMemcpy(e->d_wide, host_sum, e->plan->result_elems * 2 * ctg_item_size(e->plan->dtype), hipMemcpyHostToDevice));
+    HIP_TRY_C(launch_narrow(e->plan->dtype, e->d_result, e->d_wide, e->plan->result_elems, e->stream));
+    HIP_TRY_C(hipStreamSynchronize(e->stream));
+    return set_strip_state(e, exponent, zero);
+}
+
 int ctg_exec_set_state(ctg_exec* e, const void* host_result, double exponent, int zero) {
     if (!e || !host_result) return cfail(CTG_E_INVALID, "null argument");
     HIP_TRY_C(hipSetDevice(e->device));
     HIP_TRY_C(hipStreamSynchronize(e->stream));
     HIP_TRY_C(hipMemcpy(e->d_result, host_result, e->plan->result_elems * ctg_item_size(e->plan->dtype),
                         hipMemcpyHostToDevice));
+    if (e->d_wide) {   // (a state in the result's own precision: the running sum starts from it, exactly)
+        HIP_TRY_C(launch_widen(e->plan->dtype, e->d_wide, e->d_result, e->plan->result_elems, e->stream));
+        HIP_TRY_C(hipStreamSynchronize(e->stream));
+    }
+    return set_strip_state(e, exponent, zero);
+}
+
+static int set_strip_state(ctg_exec* e, double exponent, int zero) {
     StripState st{};
     st.E = e->strip ? exponent : -HUGE_VAL;
     st.e_slice = -HUGE_VAL;

@@ -513,12 +513,19 @@ size_t stem2_lds_bytes(const StemArgs& p);
 hipError_t launch_stem2(const StemArgs& p, hipStream_t stream);
 void stem2_kernel_name(const StemArgs& p, char* buf, size_t n);
 hipError_t launch_single(int dtype, const StepArgs& p, hipStream_t stream);
-hipError_t launch_accum(int dtype, const StepArgs& p, const StripState* st, hipStream_t stream);
+hipError_t launch_accum(int dtype, const StepArgs& p, const StripState* st, void* wide, const double* inscale, hipStream_t stream);
+// (single-precision trees) inputs far from 1 are brought to [1, 2) by an exact power of two at upload; inscale[0] =
+// the product of the powers taken out, inscale[1] = its log10
+hipError_t launch_prescale_inputs(int dtype, void* inputs, const int64_t* offs, const int64_t* sizes, int64_t n_inputs,
+                                  int* shift_total, double* inscale, hipStream_t stream);
+// (float / complex64 results: the double-precision running sum next to the result -- ctg_kernels_valu.hip)
+hipError_t launch_narrow(int dtype, void* result, const void* wide, int64_t n, hipStream_t stream);
+hipError_t launch_widen(int dtype, void* wide, const void* result, int64_t n, hipStream_t stream);
 
 hipError_t launch_maxabs(int dtype, const void* x, int64_t n, double* fac, hipStream_t stream);
 // e_slice = sum_s log10(fac[s]) over the listed steps; coefficients for the accumulate
 hipError_t launch_strip_prepare(const double* fac, const int32_t* counted, int64_t n_steps,
-                                int64_t root_step, int check_zero, StripState* st, hipStream_t stream);
+                                int64_t root_step, int check_zero, StripState* st, const double* inscale, hipStream_t stream);
 hipError_t launch_rescale(int dtype, void* result, int64_t n, const StripState* st, hipStream_t stream);
 
 struct SliceMeta {

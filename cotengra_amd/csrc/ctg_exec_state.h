@@ -34,6 +34,13 @@ struct ctg_exec {
     char* d_arena = nullptr;
     char* d_result = nullptr;
     bool owns_result = false;
+    // float / complex64 results of a sliced tree: the running sum of the slices in double precision (same
+    // element offsets as the result, which always holds this sum rounded once); null otherwise
+    char* d_wide = nullptr;
+    // single-precision trees: [n_inputs offsets | n_inputs sizes] of the inputs space, and {2^S, S log10(2), (int) S}
+    // -- the power of two taken out of the inputs at upload (prescale_inputs_kernel); null otherwise
+    int64_t* d_in_tab = nullptr;
+    double* d_inscale = nullptr;
     int64_t* d_tables = nullptr;
     int64_t* d_misc = nullptr;  // [state(2) | zero(1) | soff(n_leaves) | sizes | fixed | strides]
     int64_t* d_state = nullptr;

@@ -417,9 +417,32 @@ hipError_t launch_single(int dtype, const StepArgs& p, hipStream_t stream) {
 // The slices of a batch are added one after another by the same thread, in slice
 // order: the sum is formed exactly as by one launch per slice (the left fold of
 // gather_slices, core.py:3842-3844), whichever way the slices were batched.
+//
+// W (round 5): single-precision results are summed in DOUBLE precision.  The running sum lives in a
+// double-precision copy of the result tensor (``wide``, same element offsets) and the result itself
+// is that sum rounded once: a left fold of 2^20 slice amplitudes in fp32 loses ~N eps / sqrt(2) of one
+// term -- 4e-5 of the m20 amplitude, more than the whole 1e-5 budget -- where the reference has the
+// same flaw (core.py:3842-3844 adds in the arrays' dtype).  Double-precision trees: W = T, no copy.
+template <typename T> struct wide_of { typedef T type; };
+template <> struct wide_of<float> { typedef double type; };
+template <> struct wide_of<c64> { typedef c128 type; };
+__device__ __forceinline__ double widen(float a) { return (double)a; }
+__device__ __forceinline__ double widen(double a) { return a; }
+__device__ __forceinline__ c128 widen(c64 a) { return c128{(double)a.re, (double)a.im}; }
+__device__ __forceinline__ c128 widen(c128 a) { return a; }
+__device__ __forceinline__ void narrow_to(float& d, double a) { d = (float)a; }
+__device__ __forceinline__ void narrow_to(double& d, double a) { d = a; }
+__device__ __forceinline__ void narrow_to(c64& d, c128 a) { d = c64{(float)a.re, (float)a.im}; }
+__device__ __forceinline__ void narrow_to(c128& d, c128 a) { d = a; }
+
 template <typename T>
-__global__ __launch_bounds__(256) void accum_kernel(StepArgs p, const StripState* st) {
-    const double coef = st ? st->coefm : 1.0;
+__global__ __launch_bounds__(256) void accum_kernel(StepArgs p, const StripState* st, void* wide_, const double* inscale) {
+    typedef typename wide_of<T>::type W;
+    W* const wide = (W*)wide_;   // null: the result itself is the running sum
+    // (inscale: the power of two taken out of the input tensors at upload, prescale_inputs_kernel; a
+    // strip_exponent run carries it in the exponent instead: strip_prepare_kernel)
+    const double coef = st ? st->coefm : (inscale ? inscale[0] : 1.0);
+    const bool scaled = st != nullptr || coef != 1.0;
     for (int64_t row = (int64_t)blockIdx.x * 256 + threadIdx.x; row < p.R;
          row += (int64_t)gridDim.x * 256) {
         int64_t hi, lo;
@@ -429,44 +452,140 @@ __global__ __launch_bounds__(256) void accum_kernel(StepArgs p, const StripState
         // their values are fetched eight at a time (independent loads) and a result
         // element that consecutive slices share (inner-sliced indices: all of them) stays
         // in a register between them instead of going through memory 64 times.
-        T* cur = nullptr;
-        T sum = zero_of(T{});
+        int64_t cur = -1;
+        W sum = zero_of(W{});
+        auto flush = [&]() {
+            if (cur < 0) return;
+            if (wide) wide[cur] = sum;
+            narrow_to(((T*)p.C)[cur], sum);
+        };
         const int64_t z_end = (int64_t)p.z0 + p.nz;
         for (int64_t z0 = p.z0; z0 < z_end; z0 += 8) {
             T av[8];
-            T* cp[8];
+            int64_t cp[8];
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
                 const int64_t z = z0 + i < z_end ? z0 + i : z_end - 1;
                 av[i] = ((const T*)p.A + p.soffA[z * p.zsA] + z * p.zA)[ra];
-                cp[i] = (T*)p.C + p.soffC[z * p.zsC] + z * p.zC + rc;
+                cp[i] = p.soffC[z * p.zsC] + z * p.zC + rc;
             }
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
                 if (z0 + i >= z_end) break;
                 if (cp[i] != cur) {
-                    if (cur) *cur = sum;
+                    flush();
                     cur = cp[i];
-                    sum = *cur;
+                    sum = wide ? wide[cur] : widen(((const T*)p.C)[cur]);
                 }
-                sum = add_of(sum, st ? scale_of(av[i], coef) : av[i]);
+                sum = add_of(sum, scaled ? scale_of(widen(av[i]), coef) : widen(av[i]));
             }
         }
-        if (cur) *cur = sum;
+        flush();
     }
 }
 
-hipError_t launch_accum(int dtype, const StepArgs& p, const StripState* st, hipStream_t stream) {
+hipError_t launch_accum(int dtype, const StepArgs& p, const StripState* st, void* wide, const double* inscale, hipStream_t stream) {
     int64_t blocks = (p.R + 255) / 256;
     if (blocks > (1 << 20)) blocks = 1 << 20;
     if (blocks < 1) blocks = 1;
     switch (dtype) {
-        case 0: hipLaunchKernelGGL(accum_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, stream, p, st); break;
-        case 1: hipLaunchKernelGGL(accum_kernel<double>, dim3((unsigned)blocks), dim3(256), 0, stream, p, st); break;
-        case 2: hipLaunchKernelGGL(accum_kernel<c64>, dim3((unsigned)blocks), dim3(256), 0, stream, p, st); break;
-        case 3: hipLaunchKernelGGL(accum_kernel<c128>, dim3((unsigned)blocks), dim3(256), 0, stream, p, st); break;
+        case 0: hipLaunchKernelGGL(accum_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, stream, p, st, wide, inscale); break;
+        case 1: hipLaunchKernelGGL(accum_kernel<double>, dim3((unsigned)blocks), dim3(256), 0, stream, p, st, nullptr, inscale); break;
+        case 2: hipLaunchKernelGGL(accum_kernel<c64>, dim3((unsigned)blocks), dim3(256), 0, stream, p, st, wide, inscale); break;
+        case 3: hipLaunchKernelGGL(accum_kernel<c128>, dim3((unsigned)blocks), dim3(256), 0, stream, p, st, nullptr, inscale); break;
         default: return hipErrorInvalidValue;
     }
+    return hipGetLastError();
+}
+
+// result <- the double-precision running sum, rounded (after the sum was changed from outside the accumulate
+// kernel: the collective, set_state); wide <- result widened (a state given in the result's own precision)
+template <typename T>
+__global__ __launch_bounds__(256) void narrow_kernel(T* __restrict__ x, const typename wide_of<T>::type* __restrict__ w, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) narrow_to(x[i], w[i]);
+}
+template <typename T>
+__global__ __launch_bounds__(256) void widen_kernel(typename wide_of<T>::type* __restrict__ w, const T* __restrict__ x, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) w[i] = widen(x[i]);
+}
+hipError_t launch_narrow(int dtype, void* result, const void* wide, int64_t n, hipStream_t stream) {
+    int64_t blocks = (n + 255) / 256;
+    if (blocks > 65536) blocks = 65536;
+    if (blocks < 1) blocks = 1;
+    if (dtype == 0) hipLaunchKernelGGL(narrow_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, stream, (float*)result, (const double*)wide, n);
+    else if (dtype == 2) hipLaunchKernelGGL(narrow_kernel<c64>, dim3((unsigned)blocks), dim3(256), 0, stream, (c64*)result, (const c128*)wide, n);
+    else return hipErrorInvalidValue;
+    return hipGetLastError();
+}
+hipError_t launch_widen(int dtype, void* wide, const void* result, int64_t n, hipStream_t stream) {
+    int64_t blocks = (n + 255) / 256;
+    if (blocks > 65536) blocks = 65536;
+    if (blocks < 1) blocks = 1;
+    if (dtype == 0) hipLaunchKernelGGL(widen_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, stream, (double*)wide, (const float*)result, n);
+    else if (dtype == 2) hipLaunchKernelGGL(widen_kernel<c64>, dim3((unsigned)blocks), dim3(256), 0, stream, (c128*)wide, (const c64*)result, n);
+    else return hipErrorInvalidValue;
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------- //
+// input tensors far from 1: an exact power of two comes out at upload
+// ------------------------------------------------------------------------- //
+
+// Single-precision trees.  An input whose largest |element| lies outside [2^-32, 2^32) is multiplied by the
+// power of two that brings it to [1, 2) -- exact -- and the powers taken out are summed; the accumulate step
+// multiplies them back in (double precision), a strip_exponent run adds them to its exponent.  Inputs in the
+// range are not touched (bit-identical results).  What this buys: the reference normalises after EVERY step
+// under strip_exponent (contract.py:816-829); here normalisation is lazy -- the consumer's epilogue scales --
+// so two raw inputs below 2^-40 meeting in one fused pair would underflow the fp32 intermediate before any
+// scale is applied, and the bf16 x 3 split loses its third limb on an operand below 2^-110.  After this pass
+// every input is O(1) or within 2^+-32 of it.  One workgroup per input (they are KBs).
+__device__ __forceinline__ double abs_max_part(float a) { return fabs((double)a); }
+__device__ __forceinline__ double abs_max_part(c64 a) { return fmax(fabs((double)a.re), fabs((double)a.im)); }
+
+template <typename T>
+__global__ __launch_bounds__(256) void prescale_inputs_kernel(T* inputs, const int64_t* offs, const int64_t* sizes,
+                                                              int* shift_total) {
+    __shared__ double red[256];
+    T* x = inputs + offs[blockIdx.x];
+    const int64_t n = sizes[blockIdx.x];
+    double mx = 0.0;
+    for (int64_t i = threadIdx.x; i < n; i += 256) {
+        const double a = abs_max_part(x[i]);
+        if (a > mx && a < __longlong_as_double(0x7ff0000000000000ll)) mx = a;   // (inf / nan: left alone)
+    }
+    red[threadIdx.x] = mx;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o && red[threadIdx.x + o] > red[threadIdx.x]) red[threadIdx.x] = red[threadIdx.x + o];
+        __syncthreads();
+    }
+    mx = red[0];
+    if (mx == 0.0) return;
+    int ex;
+    (void)frexp(mx, &ex);
+    ex -= 1;   // mx = m 2^ex with m in [1, 2)
+    if (ex >= -32 && ex < 32) return;
+    const double f = ldexp(1.0, -ex);
+    for (int64_t i = threadIdx.x; i < n; i += 256) x[i] = scale_of(x[i], f);
+    if (threadIdx.x == 0) atomicAdd(shift_total, ex);
+}
+
+__global__ void prescale_finish_kernel(const int* shift_total, double* inscale) {
+    inscale[0] = ldexp(1.0, *shift_total);                 // 2^S (inf / 0 beyond the double range, as the product would be)
+    inscale[1] = (double)*shift_total * 0.30102999566398120;   // S log10(2)
+}
+
+hipError_t launch_prescale_inputs(int dtype, void* inputs, const int64_t* offs, const int64_t* sizes, int64_t n_inputs,
+                                  int* shift_total, double* inscale, hipStream_t stream) {
+    hipError_t err = hipMemsetAsync(shift_total, 0, sizeof(int), stream);
+    if (err != hipSuccess) return err;
+    if (dtype == 0)
+        hipLaunchKernelGGL(prescale_inputs_kernel<float>, dim3((unsigned)n_inputs), dim3(256), 0, stream, (float*)inputs, offs, sizes, shift_total);
+    else if (dtype == 2)
+        hipLaunchKernelGGL(prescale_inputs_kernel<c64>, dim3((unsigned)n_inputs), dim3(256), 0, stream, (c64*)inputs, offs, sizes, shift_total);
+    else
+        return hipErrorInvalidValue;
+    hipLaunchKernelGGL(prescale_finish_kernel, dim3(1), dim3(1), 0, stream, shift_total, inscale);
     return hipGetLastError();
 }
 
@@ -510,8 +629,8 @@ hipError_t launch_maxabs(int dtype, const void* x, int64_t n, double* fac, hipSt
 // (AdderWithMaybeExponentStripped, core.py:125-172): E' = max(E, e),
 // result = result * 10^(E-E') + slice * 10^(e-E') / fac_root
 __global__ void strip_prepare_kernel(const double* fac, const int32_t* counted, int64_t n_steps,
-                                     int64_t root_step, int check_zero, StripState* st) {
-    double e = 0.0;
+                                     int64_t root_step, int check_zero, StripState* st, const double* inscale) {
+    double e = inscale ? inscale[1] : 0.0;   // log10 of the power of two taken out of the inputs at upload
     bool zero = false;
     for (int64_t s = 0; s < n_steps; ++s) {
         if (!counted[s]) continue;
@@ -537,9 +656,9 @@ __global__ void strip_prepare_kernel(const double* fac, const int32_t* counted, 
 }
 
 hipError_t launch_strip_prepare(const double* fac, const int32_t* counted, int64_t n_steps,
-                                int64_t root_step, int check_zero, StripState* st, hipStream_t stream) {
+                                int64_t root_step, int check_zero, StripState* st, const double* inscale, hipStream_t stream) {
     hipLaunchKernelGGL(strip_prepare_kernel, dim3(1), dim3(1), 0, stream, fac, counted, n_steps,
-                       root_step, check_zero, st);
+                       root_step, check_zero, st, inscale);
     return hipGetLastError();
 }
 

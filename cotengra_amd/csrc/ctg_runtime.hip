@@ -948,6 +948,15 @@ int ensure_scratch(ctg_exec* e) {
     return CTG_OK;
 }
 
+// the double-precision running sum an accumulate step adds into (float / complex64 results; null: none):
+// the same element offset as the step's result operand
+void* wide_of_step(const ctg_exec* e, int64_t s) {
+    if (!e->d_wide) return nullptr;
+    const int64_t* r = &e->plan->steps[s * STEP_WORDS];
+    if (r[W_C_SPACE] != SPACE_RESULT) return nullptr;
+    return e->d_wide + r[W_C_OFF] * 2 * kItemSize[e->plan->dtype];
+}
+
 int launch_step(ctg_exec* e, int64_t s, hipStream_t stream) {
     const ctg_plan* p = e->plan;
     const int64_t* r = &p->steps[s * STEP_WORDS];
@@ -963,12 +972,14 @@ int launch_step(ctg_exec* e, int64_t s, hipStream_t stream) {
         case KIND_ACCUM:
             if (e->strip) {
                 err = launch_strip_prepare(e->d_fac, e->d_counted, p->n_steps, e->root_step,
-                                           e->check_zero, e->d_strip, stream);
+                                           e->check_zero, e->d_strip, e->d_inscale, stream);
                 if (err == hipSuccess)
                     err = launch_rescale(p->dtype, e->d_result, p->result_elems, e->d_strip, stream);
-                if (err == hipSuccess) err = launch_accum(p->dtype, e->args[s], e->d_strip, stream);
+                if (err == hipSuccess && e->d_wide)
+                    err = launch_rescale(p->dtype + 1, e->d_wide, p->result_elems, e->d_strip, stream);
+                if (err == hipSuccess) err = launch_accum(p->dtype, e->args[s], e->d_strip, wide_of_step(e, s), nullptr, stream);
             } else {
-                err = launch_accum(p->dtype, e->args[s], nullptr, stream);
+                err = launch_accum(p->dtype, e->args[s], nullptr, wide_of_step(e, s), e->d_inscale, stream);
             }
             break;
         case KIND_STEM2: {
@@ -1393,6 +1404,9 @@ int ctg_exec_destroy(ctg_exec* e) {
     if (e->d_inputs) (void)hipFree(e->d_inputs);
     if (e->d_arena) (void)hipFree(e->d_arena);
     if (e->d_result && e->owns_result) (void)hipFree(e->d_result);
+    if (e->d_wide) (void)hipFree(e->d_wide);
+    if (e->d_in_tab) (void)hipFree(e->d_in_tab);
+    if (e->d_inscale) (void)hipFree(e->d_inscale);
     if (e->d_tables) (void)hipFree(e->d_tables);
     if (e->d_misc) (void)hipFree(e->d_misc);
     if (e->d_scratch) (void)hipFree(e->d_scratch);
@@ -1492,6 +1506,30 @@ int ctg_exec_create(const ctg_plan* p, int device, void* stream, void* ext_resul
     } else {
         HIP_TRY_E(hipMalloc((void**)&e->d_result, p->result_elems * isz));
         e->owns_result = true;
+    }
+    if ((p->dtype == CTG_F32 || p->dtype == CTG_C64) && !env_on("CTG_NO_PRESCALE")) {
+        // single-precision trees: inputs far from 1 lose an exact power of two at upload (prescale_inputs_kernel)
+        std::vector<int64_t> tab(2 * p->n_inputs);
+        for (int64_t i = 0; i < p->n_inputs; ++i) {
+            tab[i] = p->input_offsets[i];
+            tab[p->n_inputs + i] = p->input_sizes[i];
+        }
+        HIP_TRY_E(hipMalloc((void**)&e->d_in_tab, tab.size() * 8));
+        HIP_TRY_E(hipMemcpy(e->d_in_tab, tab.data(), tab.size() * 8, hipMemcpyHostToDevice));
+        HIP_TRY_E(hipMalloc((void**)&e->d_inscale, 2 * sizeof(double) + sizeof(int64_t)));
+        const double init[3] = {1.0, 0.0, 0.0};
+        HIP_TRY_E(hipMemcpy(e->d_inscale, init, sizeof(init), hipMemcpyHostToDevice));
+    }
+    {
+        // float / complex64 results of a tree with more than one slice: the slices are summed in double
+        // precision (accum_kernel)
+        bool sums = false;
+        for (int64_t s = 0; s < p->n_steps; ++s) sums = sums || p->steps[s * STEP_WORDS + W_KIND] == KIND_ACCUM;
+        sums = sums && p->nslices > 1;
+        if (sums && (p->dtype == CTG_F32 || p->dtype == CTG_C64) && !env_on("CTG_NO_WIDE_SUM")) {
+            HIP_TRY_E(hipMalloc((void**)&e->d_wide, p->result_elems * 2 * isz));
+            HIP_TRY_E(hipMemsetAsync(e->d_wide, 0, p->result_elems * 2 * isz, e->stream));
+        }
     }
     HIP_TRY_E(hipMalloc((void**)&e->d_tables, p->tables.size() * 8));
     // (split heuristics are always computed with kScratchBytes; a batching executor gets
@@ -1610,6 +1648,9 @@ int ctg_exec_upload_inputs_host(ctg_exec* e, const void* const* ptrs) {
     }
     HIP_TRY(hipStreamSynchronize(e->stream));
     HIP_TRY(hipMemcpy(e->d_inputs, staging.data(), staging.size(), hipMemcpyHostToDevice));
+    if (e->d_inscale)
+        HIP_TRY(launch_prescale_inputs(p->dtype, e->d_inputs, e->d_in_tab, e->d_in_tab + p->n_inputs, p->n_inputs,
+                                       (int*)(e->d_inscale + 2), e->d_inscale, e->stream));
     e->invariants_ready = false;
     e->group_key = -1;
     return CTG_OK;
@@ -1625,6 +1666,9 @@ int ctg_exec_upload_inputs_device(ctg_exec* e, const void* const* ptrs) {
         HIP_TRY(hipMemcpyAsync(e->d_inputs + p->input_offsets[i] * isz, ptrs[i],
                                p->input_sizes[i] * isz, hipMemcpyDeviceToDevice, e->stream));
     }
+    if (e->d_inscale)
+        HIP_TRY(launch_prescale_inputs(p->dtype, e->d_inputs, e->d_in_tab, e->d_in_tab + p->n_inputs, p->n_inputs,
+                                       (int*)(e->d_inscale + 2), e->d_inscale, e->stream));
     e->invariants_ready = false;
     e->group_key = -1;
     return CTG_OK;
@@ -1635,6 +1679,8 @@ int ctg_exec_zero_result(ctg_exec* e) {
     HIP_TRY(hipSetDevice(e->device));
     HIP_TRY(hipMemsetAsync(e->d_result, 0, e->plan->result_elems * kItemSize[e->plan->dtype],
                            e->stream));
+    if (e->d_wide)
+        HIP_TRY(hipMemsetAsync(e->d_wide, 0, e->plan->result_elems * 2 * kItemSize[e->plan->dtype], e->stream));
     StripState init{};
     init.E = -HUGE_VAL;
     init.e_slice = -HUGE_VAL;
@@ -1908,6 +1954,7 @@ int ctg_exec_device_bytes(ctg_exec* e, int64_t* bytes) {
     const int64_t isz = kItemSize[p->dtype];
     int64_t n = p->inputs_elems * isz + p->arena_elems * isz * std::max(e->batch, 1) + (int64_t)p->tables.size() * 8;
     if (e->owns_result) n += p->result_elems * isz;
+    if (e->d_wide) n += p->result_elems * 2 * isz;
     if (e->d_scratch) n += e->scratch_total;
     *bytes = n;
     return CTG_OK;

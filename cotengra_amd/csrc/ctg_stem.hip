@@ -296,10 +296,25 @@ __device__ __forceinline__ void settle(T& v) {
 // kept in registers), and after a barrier scatters its result over it as the second intermediate
 // ([rows2][ld2], mid2_row[rowM] + mid2_col[nM]) which the last step reads.  PACKM: its 16 columns.  Static
 // shapes, X / Y form; four barriers per tile instead of two.
+// XM (round 5; bf16 x 3): no sign flips of limbs.  The real part of a product is kept as TWO accumulators --
+// Xp += Re a Re b, Xm += Im a Im b, X = Xp - Xm where the tile is handed on (16 subtractions per 32 x 32
+// tile instead of 12 XORs per 16 k of either step) -- and step 2 multiplies 16 k of ONE component per
+// instruction (the lane halves take k-blocks 2 c and 2 c + 1 of the same plane) instead of pairing Re | Im.
+// LM (round 5; needs XM): the intermediate lives in LDS as bf16 LIMBS, fragment-ready for step 2 --
+// [plane][row2][block of 8 k][limb][k & 7], a lane's 8 values of one limb are 16 contiguous bytes -- split
+// ONCE by the scatter (two ANDs, two subtractions per value, three 2-byte writes that take the high halves
+// where they are) instead of once per work item of step 2 (5.5 instructions per value and per column group:
+// profiles/r4_stem_sq_counters.txt counted 5.6 vector instructions per MFMA, most of them this).  Half again
+// as much LDS as the fp32 intermediate: B1's planes share its memory when the fragments live in registers.
 template <bool PACK1, bool PACK2, int RT1, int CS1, int NCH, int IT2, bool BR1 = false, int K2Q = 0, bool VEC = false,
-          bool BF3 = false, bool RI2 = false, bool ONE = false, int ITM = 0, bool PACKM = false>
+          bool BF3 = false, bool RI2 = false, bool ONE = false, int ITM = 0, bool PACKM = false, bool XM = false,
+          bool LM = false>
 __global__ __launch_bounds__(SW * 64, 1) void stem2_kernel(StemArgs p) {
     constexpr bool TRI = ITM > 0;
+    static_assert(!XM || (BF3 && !TRI && NCH > 0), "two-accumulator real part: bf16 x 3, static, no three-step tile");
+    static_assert(!LM || (XM && !ONE), "limb intermediate: the round-5 form of a pair");
+    constexpr bool XM1 = XM && !PACK1;   // step 1 keeps Xm (16 columns: the sign lives in B1's third plane)
+    constexpr bool XM2 = XM && !PACK2;   // step 2 likewise
     static_assert(!TRI || (NCH > 0 && IT2 > 0 && !RI2 && !ONE && K2Q == 0), "three-step tile: static, X / Y form");
     static_assert(!ONE || (!PACK1 && !PACK2 && !RI2 && IT2 == 0 && K2Q == 0), "one step: >= 32 columns, nothing of step 2");
     static_assert(!PACK1 || CS1 == 1, "16 columns are one group");
@@ -344,9 +359,29 @@ __global__ __launch_bounds__(SW * 64, 1) void stem2_kernel(StemArgs p) {
     const int ROW1 = bf3_row(K1, true), ROW2 = bf3_row(K2, false), ROWM = TRI ? bf3_row(KM, false) : 0;
     unsigned short* Q1 = (unsigned short*)smem;            // [2|3][N1][ROW1]
     unsigned short* QM = Q1 + (PACK1 ? 3 : 2) * N1 * ROW1; // [2|3][NM][ROWM] (three-step tile)
-    unsigned short* Q2 = QM + (TRI ? (PACKM ? 3 : 2) * NM * ROWM : 0);   // [2|3][N2][ROW2]
+    unsigned short* Q2 = QM + (TRI ? (PACKM ? 3 : 2) * NM * ROWM : 0);   // [2|3][N2][ROW2]   (LM + BR1: see below)
     if constexpr (BF3) mid = (float*)(Q2 + (PACK2 ? 3 : 2) * N2 * ROW2);
-    int64_t* oc_s = (int64_t*)(mid + mid_floats);          // [N2] column offsets of the result
+    // LM: the intermediate as limbs -- [row2][block of 8 k][Re | Im][limb][k & 7]: a value's Im part sits 48
+    // bytes behind its Re part, its limbs 16 and 32 bytes behind the first (immediate offsets of the scatter's
+    // writes, whatever K2 is: 16 address registers in all); row pitch RPS shorts (K2 / 8 blocks of 48 + 8 of
+    // padding: 16-byte reads of 32 consecutive rows hit every bank once).  B1's planes, dead once its
+    // fragments are in registers (before the first scatter's barrier), lie over it
+    const int RPS = LM ? (K2 >> 3) * 48 + 8 : 0;
+    constexpr int PLS = 24;   // Re -> Im, in shorts
+    if constexpr (LM) {
+        if constexpr (BR1) {
+            Q2 = (unsigned short*)smem;
+            mid = (float*)(Q2 + (PACK2 ? 3 : 2) * N2 * ROW2);
+            Q1 = (unsigned short*)mid;
+        }
+        mid_floats = (p.rows2 * RPS) >> 1;   // (rows2 x RPS shorts)
+        if constexpr (BR1) {
+            const int q1f = ((PACK1 ? 3 : 2) * N1 * ROW1 + 1) >> 1;
+            mid_floats = mid_floats > q1f ? mid_floats : q1f;
+        }
+    }
+    unsigned short* const midq = (unsigned short*)mid;
+    int64_t* oc_s = (int64_t*)(mid + ((mid_floats + 1) & ~1));   // [N2] column offsets of the result
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -441,13 +476,19 @@ __global__ __launch_bounds__(SW * 64, 1) void stem2_kernel(StemArgs p) {
         b2x = P2 + ((kk ? 1 : 0) * N2 + l31) * LDB2;
         b2y = P2 + ((kk ? 0 : 1) * N2 + l31) * LDB2;
     }
+    // LM: an offset row2 * LD2 + k2 of the planner's tables in the limb layout (shorts): row2 * RPS + block * 48 + k2 % 8
+    auto lm_off = [&](int e) __attribute__((always_inline)) {
+        const int r2 = e / p.ld2, k2 = e - r2 * p.ld2;
+        return r2 * RPS + (k2 >> 3) * 48 + (k2 & 7);
+    };
+    auto mid_off = [&](int e) __attribute__((always_inline)) { return LM ? lm_off(e) : ri_off(e); };
     // scatter of the step-1 accumulators: lane part of mid_row[row] + mid_col[n]
     // (RI2 with 16 columns: the lanes of columns 16-31 hold imaginary parts -> plane Im, and
     // once more negated -> plane -Im)
     int mid_lane = 0;
     if constexpr (!ONE) {
-        if (PACK1) mid_lane = ri_off((int)p.mid_col[l31 & 15]) + (l31 >> 4) * (RI2 ? LD2 : PLANE1) + ri_off((int)p.mid_row[4 * kk]);
-        else mid_lane = ri_off((int)p.mid_col[wcol + l31]) + ri_off((int)p.mid_row[4 * kk]);
+        if (PACK1) mid_lane = mid_off((int)p.mid_col[l31 & 15]) + (l31 >> 4) * (LM ? PLS : RI2 ? LD2 : PLANE1) + mid_off((int)p.mid_row[4 * kk]);
+        else mid_lane = mid_off((int)p.mid_col[wcol + l31]) + mid_off((int)p.mid_row[4 * kk]);
     }
     settle(mid_lane);
     // (accumulator register t is row rowmap(t) = bits 0, 1, 3, 4 of t's four bits: the tables are
@@ -455,13 +496,13 @@ __global__ __launch_bounds__(SW * 64, 1) void stem2_kernel(StemArgs p) {
     // used replace 16-entry arrays that did not fit the scalar registers)
     int mid_o[4];
 #pragma unroll
-    for (int b = 0; b < 4; ++b) mid_o[b] = ONE ? 0 : ri_off((int)sload64(p.mid_row + (b < 2 ? 1 << b : 2 << b)));
+    for (int b = 0; b < 4; ++b) mid_o[b] = ONE ? 0 : mid_off((int)sload64(p.mid_row + (b < 2 ? 1 << b : 2 << b)));
     // (the row tiles' parts, per unit of this wave: scalar, fixed for the whole kernel)
     int mid_rt[RT1];
     int64_t one_rt[RT1];   // ONE: the result's offset of this wave's row tile, per unit
 #pragma unroll
     for (int m = 0; m < RT1; ++m) {
-        mid_rt[m] = ONE ? 0 : __builtin_amdgcn_readfirstlane(ri_off((int)sload64(p.mid_row + 32 * (wrt + RTW * m))));
+        mid_rt[m] = ONE ? 0 : __builtin_amdgcn_readfirstlane(mid_off((int)sload64(p.mid_row + 32 * (wrt + RTW * m))));
         one_rt[m] = ONE ? sload64(p.out_row + 32 * (wrt + RTW * m)) : 0;
     }
     // ONE: this lane's column of the result (its column of step 1)
@@ -631,6 +672,28 @@ __global__ __launch_bounds__(SW * 64, 1) void stem2_kernel(StemArgs p) {
             r[2 * q] = c64{(float)(base + kj[2 * q]), (float)a_lane};
             r[2 * q + 1] = c64{(float)(base + kj[2 * q + 1]), (float)a_lane};
 #else
+            if constexpr (XM) {
+                // the task's base as a SCALAR byte address (kept from being folded into a per-lane 64-bit address
+                // that costs a vector add per load): scalar base + 32-bit lane offset is the load's addressing mode
+                typedef const __attribute__((address_space(1))) char* gptr;
+                uint64_t u0 = (uint64_t)A + ((uint64_t)(base + kj[2 * q]) << 3);
+                uint64_t u1 = (uint64_t)A + ((uint64_t)(base + kj[2 * q + 1]) << 3);
+                asm volatile("" : "+s"(u0), "+s"(u1));
+                settle(a_lane);   // (the zero-extension stays in this block: instruction selection is per block)
+                const unsigned al = a_lane;
+                if (VEC) {
+                    const f32x4 v = *(const __attribute__((address_space(1))) f32x4*)((gptr)u0 + al);
+                    r[2 * q] = c64{v[0], v[1]};
+                    r[2 * q + 1] = c64{v[2], v[3]};
+                } else {
+                    typedef float f32x2 __attribute__((ext_vector_type(2)));
+                    const f32x2 v0 = *(const __attribute__((address_space(1))) f32x2*)((gptr)u0 + al);
+                    const f32x2 v1 = *(const __attribute__((address_space(1))) f32x2*)((gptr)u1 + al);
+                    r[2 * q] = c64{v0[0], v0[1]};
+                    r[2 * q + 1] = c64{v1[0], v1[1]};
+                }
+                return;
+            }
             const char* sb = (const char*)(A + (base + kj[2 * q]));   // uniform: the load's scalar base
 #ifdef CTG_STEM_BOUNDS
             {
@@ -666,6 +729,7 @@ __global__ __launch_bounds__(SW * 64, 1) void stem2_kernel(StemArgs p) {
     };
 
     f32x16 ax[RT1], ay[RT1];
+    f32x16 axm[XM1 ? RT1 : 1];   // XM: the Im a Im b half of the real parts (X = ax - axm)
     // one task: 16 k of MFMAs on the gathered registers, each register refilled (two tasks
     // ahead) as soon as the MFMAs reading it have been issued
     // Deferred stores: the 16 (8) stores of a work item of step 2 are not issued behind its last
@@ -735,7 +799,7 @@ __global__ __launch_bounds__(SW * 64, 1) void stem2_kernel(StemArgs p) {
             for (int q = 0; q < 4; ++q) fire2(r, q, base, always_tag);
 #pragma unroll
             for (int q = 0; q < 3; ++q) {
-                if (!PACK1) n3[q] = __builtin_bit_cast(bf16x8, __builtin_bit_cast(u32x4, i3[q]) ^ 0x80008000u);
+                if (!PACK1 && !XM1) n3[q] = __builtin_bit_cast(bf16x8, __builtin_bit_cast(u32x4, i3[q]) ^ 0x80008000u);
                 if constexpr (BR1) {
                     bp3[q] = b1r3[ch][q][0];
                     bq3[q] = b1r3[ch][q][1];
@@ -745,15 +809,26 @@ __global__ __launch_bounds__(SW * 64, 1) void stem2_kernel(StemArgs p) {
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
+            // (XM: a unit's first task starts its accumulators from a zero C operand -- an inline constant of the
+            // instruction -- instead of 48 register clears per tile; ch is a constant of the unrolled tile)
+            const bool fresh = XM && STATIC && ch == 0;
+            f32x16 zero16;
+#pragma unroll
+            for (int u = 0; u < 16; ++u) zero16[u] = 0.f;
 #pragma unroll
             for (int t = 0; t < 6; ++t) {
                 const int ta = bf3_ta(t), tb = bf3_tb(t);
                 if (PACK1) {
-                    ax[m] = mfma_bf(r3[ta], bp3[tb], ax[m]);
+                    ax[m] = mfma_bf(r3[ta], bp3[tb], (fresh && t == 0) ? zero16 : ax[m]);
                     ax[m] = mfma_bf(i3[ta], bq3[tb], ax[m]);
+                } else if constexpr (XM1) {
+                    ax[m] = mfma_bf(r3[ta], bp3[tb], (fresh && t == 0) ? zero16 : ax[m]);
+                    ay[m] = mfma_bf(r3[ta], bq3[tb], (fresh && t == 0) ? zero16 : ay[m]);
+                    axm[m] = mfma_bf(i3[ta], bq3[tb], (fresh && t == 0) ? zero16 : axm[m]);
+                    ay[m] = mfma_bf(i3[ta], bp3[tb], ay[m]);
                 } else {
-                    ax[m] = mfma_bf(r3[ta], bp3[tb], ax[m]);
-                    ay[m] = mfma_bf(r3[ta], bq3[tb], ay[m]);
+                    ax[m] = mfma_bf(r3[ta], bp3[tb], (fresh && t == 0) ? zero16 : ax[m]);
+                    ay[m] = mfma_bf(r3[ta], bq3[tb], (fresh && t == 0) ? zero16 : ay[m]);
                     ax[m] = mfma_bf(n3[ta], bq3[tb], ax[m]);
                     ay[m] = mfma_bf(i3[ta], bp3[tb], ay[m]);
                 }
@@ -804,14 +879,39 @@ __global__ __launch_bounds__(SW * 64, 1) void stem2_kernel(StemArgs p) {
         __builtin_amdgcn_sched_barrier(0);
     };
     auto zero_acc = [&](int m) __attribute__((always_inline)) {
+        if constexpr (XM && STATIC) return;   // (the first task of a unit takes a zero C operand)
 #pragma unroll
         for (int t = 0; t < 16; ++t) {
             ax[m][t] = 0.f;
             if (!PACK1) ay[m][t] = 0.f;
+            if constexpr (XM1) axm[m][t] = 0.f;
         }
     };
     // the 32 x (32 | 16) accumulators of every unit -> the shared intermediate tile
+    // LM: one value -> its three limbs at dst[0], dst[8], dst[16] (the high halves of x, x - limb 1, and of
+    // what is left of that)
+    auto put3 = [&](unsigned short* dst, float x) __attribute__((always_inline)) {
+        const unsigned u = __builtin_bit_cast(unsigned, x);
+        const float r1 = x - __builtin_bit_cast(float, u & 0xffff0000u);
+        const unsigned u1 = __builtin_bit_cast(unsigned, r1);
+        const float r2 = r1 - __builtin_bit_cast(float, u1 & 0xffff0000u);
+        dst[0] = (unsigned short)(u >> 16);
+        dst[8] = (unsigned short)(u1 >> 16);
+        dst[16] = (unsigned short)(__builtin_bit_cast(unsigned, r2) >> 16);
+    };
     auto scatter = [&]() __attribute__((always_inline)) {
+        if constexpr (LM) {
+#pragma unroll
+            for (int m = 0; m < RT1; ++m) {
+                unsigned short* dst = midq + (mid_lane + mid_rt[m]);
+#pragma unroll
+                for (int t = 0; t < 16; ++t) {
+                    put3(dst + mid_t(t), XM1 ? ax[m][t] - axm[m][t] : ax[m][t]);
+                    if (!PACK1) put3(dst + PLS + mid_t(t), ay[m][t]);
+                }
+            }
+            return;
+        }
 #pragma unroll
         for (int m = 0; m < RT1; ++m) {
             float* dst = mid + (mid_lane + mid_rt[m]);
@@ -820,7 +920,7 @@ __global__ __launch_bounds__(SW * 64, 1) void stem2_kernel(StemArgs p) {
 #ifdef CTG_STEM_KO_SCATTER
                 if (ax[m][t] != 12345.678f) continue;
 #endif
-                dst[mid_t(t)] = ax[m][t];
+                dst[mid_t(t)] = XM1 ? ax[m][t] - axm[m][t] : ax[m][t];
                 if constexpr (RI2) {
                     // third plane: -Im (16 columns: the lanes of columns 16-31 hold the imaginary parts)
                     if constexpr (PACK1) {
@@ -912,10 +1012,12 @@ __global__ __launch_bounds__(SW * 64, 1) void stem2_kernel(StemArgs p) {
         if constexpr (DRAIN && (K2Q == 0 || BF3)) drain(0, NST, std::integral_constant<int, 0>{}, scaled_tag);   // (run-time trip count below: no slots to put them in)
         const int cg = item / n_rt2, rt2 = item - cg * n_rt2;
         f32x16 cx, cy;
+        if constexpr (!XM2) {
 #pragma unroll
-        for (int t = 0; t < 16; ++t) {
-            cx[t] = 0.f;
-            if (!PACK2) cy[t] = 0.f;
+            for (int t = 0; t < 16; ++t) {
+                cx[t] = 0.f;
+                if (!PACK2) cy[t] = 0.f;
+            }
         }
         const float* a_base = mid + kk * PLANE + (rt2 * 32 + l31) * LD2;
         const float* bxp = b2x + cg * 32 * LDB2;
@@ -924,7 +1026,76 @@ __global__ __launch_bounds__(SW * 64, 1) void stem2_kernel(StemArgs p) {
         const int64_t c_col = oc_s[PACK2 ? (l31 & 15) : cg * 32 + l31];
         const int nq = K2 >> 2;   // >= 4, even
         f32x4 af[2], bx[2], by[2];
-        if constexpr (BF3) {
+        f32x16 cxm;   // XM2: the Im a Im b half of the real parts
+        if constexpr (XM2) {
+            // 16 k of one component per instruction: the lane halves take the blocks 2 c, 2 c + 1 of the Re
+            // and of the Im plane; Xp += Re Re, Y += Re Im, Xm += Im Im, Y += Im Re -- no sign anywhere
+            const unsigned short* bR = Q2 + (cg * 32 + l31) * ROW2 + kk * 24;
+            const unsigned short* bI = bR + N2 * ROW2;
+            const unsigned short* aRq = midq + (rt2 * 32 + l31) * RPS + kk * 48;   // LM: block 2 c + kk
+            const float* aRf = mid + (rt2 * 32 + l31) * LD2 + kk * 8;              // fp32 intermediate
+            // fragments of chunk c into set F: A' from the limb planes (LM) or split here, B' from its planes
+            struct Frag { bf16x8 ar[3], ai[3], br[3], bi[3]; };
+            auto load_frag = [&](Frag& F, int c) __attribute__((always_inline)) {
+                if constexpr (LM) {
+#pragma unroll
+                    for (int q = 0; q < 3; ++q) {
+                        F.ar[q] = *(const bf16x8*)(aRq + c * 96 + q * 8);
+                        F.ai[q] = *(const bf16x8*)(aRq + PLS + c * 96 + q * 8);
+                    }
+                } else {
+                    const f32x4 r0 = *(const f32x4*)(aRf + 16 * c), r1 = *(const f32x4*)(aRf + 16 * c + 4);
+                    const f32x4 i0 = *(const f32x4*)(aRf + PLANE + 16 * c), i1 = *(const f32x4*)(aRf + PLANE + 16 * c + 4);
+                    const float re8[8] = {r0[0], r0[1], r0[2], r0[3], r1[0], r1[1], r1[2], r1[3]};
+                    const float im8[8] = {i0[0], i0[1], i0[2], i0[3], i1[0], i1[1], i1[2], i1[3]};
+                    split3(re8, F.ar);
+                    split3(im8, F.ai);
+                }
+#pragma unroll
+                for (int q = 0; q < 3; ++q) {
+                    F.br[q] = *(const bf16x8*)(bR + c * 48 + q * 8);
+                    F.bi[q] = *(const bf16x8*)(bI + c * 48 + q * 8);
+                }
+            };
+            // 24 MFMAs of one chunk; first_tag: the item's first chunk starts from a zero C operand
+            auto mul_frag = [&](const Frag& F, auto first_tag) __attribute__((always_inline)) {
+                constexpr bool FIRST = decltype(first_tag)::value;
+                f32x16 zero16;
+#pragma unroll
+                for (int u = 0; u < 16; ++u) zero16[u] = 0.f;
+#pragma unroll
+                for (int t = 0; t < 6; ++t) {
+                    const int ta = bf3_ta(t), tb = bf3_tb(t);
+                    cx = mfma_bf(F.ar[ta], F.br[tb], (FIRST && t == 0) ? zero16 : cx);
+                    cy = mfma_bf(F.ar[ta], F.bi[tb], (FIRST && t == 0) ? zero16 : cy);
+                    cxm = mfma_bf(F.ai[ta], F.bi[tb], (FIRST && t == 0) ? zero16 : cxm);
+                    cy = mfma_bf(F.ai[ta], F.br[tb], cy);
+                }
+            };
+            // (one fragment set: B1's fragments, the gathers in flight and three accumulators leave no room for a
+            // second one -- the other wave of the SIMD covers the LDS latency)
+            const int nc = K2 >> 4;   // 1, 2, 4 or 8
+            Frag F0;
+            load_frag(F0, 0);
+            mul_frag(F0, std::true_type{});
+            for (int c = 1; c < nc; ++c) {
+                load_frag(F0, c);
+                mul_frag(F0, std::false_type{});
+            }
+        } else if constexpr (BF3 && LM) {
+            // 16 columns, limb intermediate: the lane's plane (Re | Im by k-row) of its row, 8 k per instruction
+            const unsigned short* aq = midq + kk * PLS + (rt2 * 32 + l31) * RPS;
+            for (int kb = 0; kb < (K2 >> 3); ++kb) {
+                bf16x8 a3[3], bx3[3];
+#pragma unroll
+                for (int q = 0; q < 3; ++q) {
+                    a3[q] = *(const bf16x8*)(aq + kb * 48 + q * 8);
+                    bx3[q] = *(const bf16x8*)(q2x + kb * 24 + q * 8);
+                }
+#pragma unroll
+                for (int t = 0; t < 6; ++t) cx = mfma_bf(a3[bf3_ta(t)], bx3[bf3_tb(t)], cx);
+            }
+        } else if constexpr (BF3) {
             // 8 k per instruction: the row's 8 values of this lane's plane, split; B2 from its planes
             const unsigned short* bxq = q2x + (PACK2 ? 0 : cg * 32 * ROW2);
             const unsigned short* byq = PACK2 ? nullptr : q2y + cg * 32 * ROW2;
@@ -1025,7 +1196,8 @@ __global__ __launch_bounds__(SW * 64, 1) void stem2_kernel(StemArgs p) {
 #pragma unroll
                 for (int t = 0; t < 16; ++t) {
                     float2 v;
-                    v.x = SC ? cx[t] * alpha : cx[t];
+                    const float xr = XM2 ? cx[t] - cxm[t] : cx[t];
+                    v.x = SC ? xr * alpha : xr;
                     v.y = SC ? cy[t] * alpha : cy[t];
                     pv[t] = v;
                 }
@@ -1111,7 +1283,8 @@ __global__ __launch_bounds__(SW * 64, 1) void stem2_kernel(StemArgs p) {
 #pragma unroll
         for (int t = 0; t < 16; ++t) {
             float2 v;
-            v.x = SC ? ax[m][t] * alpha : ax[m][t];
+            const float xr = XM1 ? ax[m][t] - axm[m][t] : ax[m][t];
+            v.x = SC ? xr * alpha : xr;
             v.y = SC ? ay[m][t] * alpha : ay[m][t];
             pv[RI2 ? 0 : t] = v;
         }
@@ -1261,6 +1434,11 @@ extern "C" int ctg_debug_stem_oob(unsigned long long out[2], int reset) {
 namespace ctg {
 #endif
 
+#ifdef CTG_STEM_DEV_ONE
+// (kernel development: ONE instantiation, compiled in half a minute -- hipcc -DCTG_STEM_DEV_ONE="<template arguments>" -c
+// ctg_stem.hip -save-temps; the object is not linkable into the library)
+template __global__ void stem2_kernel<CTG_STEM_DEV_ONE>(StemArgs);
+#else
 size_t stem2_lds_bytes(const StemArgs& p) {
     const size_t b1 = (size_t)(p.N1 == 16 ? 3 : 2) * p.N1 * (p.K1 + 4);
     const size_t b2 = (size_t)(p.N2 == 16 ? 3 : 2) * p.N2 * (p.K2 + 4);
@@ -1275,6 +1453,16 @@ static size_t stem2_lds_bytes_bf3(const StemArgs& p) {
     return 2 * (q1 + q2) + 4 * (size_t)2 * p.rows2 * p.ld2 + 8 * (size_t)p.N2 + 64;   // (+ the reduction scratch)
 }
 
+// ... and with the intermediate as bf16 limbs (LM): 6 bytes per value and plane + 16 of padding per row; B1's planes
+// lie over it when its fragments live in registers (up to two chunks of K1)
+static size_t stem2_lds_bytes_lm(const StemArgs& p) {
+    const size_t q1 = 2 * (size_t)(p.N1 == 16 ? 3 : 2) * p.N1 * ((p.K1 >> 4) * 48 + 8);
+    const size_t q2 = 2 * (size_t)(p.N2 == 16 ? 3 : 2) * p.N2 * ((p.K2 >> 3) * 24 + 8);
+    const size_t mid = (size_t)p.rows2 * ((p.K2 >> 3) * 96 + 16);
+    const bool br1 = p.K1 <= 32;
+    return q2 + (br1 ? (mid > q1 ? mid : q1) : q1 + mid) + 8 * (size_t)p.N2 + 64 + 8;
+}
+
 // ... and of the row-interleaved step 2 (RI2): three planes of the intermediate; B2's staging
 // planes share them when its fragments go to registers
 static size_t stem2_lds_bytes_ri2(const StemArgs& p, bool b2_in_regs) {
@@ -1285,21 +1473,26 @@ static size_t stem2_lds_bytes_ri2(const StemArgs& p, bool b2_in_regs) {
 }
 
 template <bool PACK1, bool PACK2, int RT1, int CS1, int NCH, int IT2, bool BR1 = false, int K2Q = 0, bool VEC = false,
-          bool BF3 = false, bool RI2 = false>
-static hipError_t launch_stem2_t(const StemArgs& p, hipStream_t stream) {
-    auto kern = stem2_kernel<PACK1, PACK2, RT1, CS1, NCH, IT2, BR1, K2Q, VEC, BF3, RI2>;
+          bool BF3 = false, bool RI2 = false, bool XM = false, bool LM = false>
+static hipError_t launch_stem2_t(const StemArgs& p_, hipStream_t stream) {
+    const StemArgs& p = p_;
+    auto kern = stem2_kernel<PACK1, PACK2, RT1, CS1, NCH, IT2, BR1, K2Q, VEC, BF3, RI2, false, 0, false, XM, LM>;
     static unsigned long long ready = 0;   // (bit per device)
     {
         const hipError_t e = lds_opt_in((const void*)kern, 160 * 1024, &ready);
         if (e != hipSuccess) return e;
     }
-    const size_t smem = BF3 ? stem2_lds_bytes_bf3(p) : (RI2 ? stem2_lds_bytes_ri2(p, K2Q > 0) : stem2_lds_bytes(p));
+    const size_t smem = LM ? stem2_lds_bytes_lm(p)
+                           : BF3 ? stem2_lds_bytes_bf3(p) : (RI2 ? stem2_lds_bytes_ri2(p, K2Q > 0) : stem2_lds_bytes(p));
     // persistent: one workgroup per CU (the tile owns most of the CU's LDS)
     int64_t blocks = p.n_tiles < 256 ? p.n_tiles : 256;
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks, 1), dim3(SW * 64), smem, stream, p);
     return hipGetLastError();
 }
 
+#ifndef CTG_STEM_FORM
+#define CTG_STEM_FORM 2
+#endif
 // the first half alone (ONE): B1's planes and the column table
 static size_t stem2_lds_bytes_one(const StemArgs& p, bool bf3) {
     if (bf3) return 2 * (size_t)2 * p.N1 * ((p.K1 >> 4) * 48 + 8) + 8 * (size_t)p.N1 + 64;
@@ -1308,7 +1501,9 @@ static size_t stem2_lds_bytes_one(const StemArgs& p, bool bf3) {
 
 template <int RT1, int CS1, int NCH, bool BR1, bool VEC, bool BF3>
 static hipError_t launch_stem1_t(const StemArgs& p, hipStream_t stream) {
-    auto kern = stem2_kernel<false, false, RT1, CS1, NCH, 0, BR1, 0, VEC, BF3, false, true>;
+    // (bf16 x 3, static: the two-accumulator form of the real parts, round 5 -- XM; CTG_STEM_FORM=0 builds keep round 4's)
+    constexpr bool XM = BF3 && NCH > 0 && CTG_STEM_FORM >= 1;
+    auto kern = stem2_kernel<false, false, RT1, CS1, NCH, 0, BR1, 0, VEC, BF3, false, true, 0, false, XM, false>;
     static unsigned long long ready = 0;   // (bit per device)
     {
         const hipError_t e = lds_opt_in((const void*)kern, 160 * 1024, &ready);
@@ -1600,6 +1795,22 @@ static bool stem2_bf3(const StemArgs& p) {
     return want && stem2_has_geo(stem2_shape(p, true)) && (p.K2 & 7) == 0 && stem2_lds_bytes_bf3(p) <= 160 * 1024;
 }
 
+// Form of a bf16 x 3 pair (round 5).  2: two-accumulator real parts and the intermediate as bf16 limbs (XM + LM)
+// where that fits the LDS; 1: two-accumulator real parts, fp32 intermediate split by step 2 (XM); 0: the round-4
+// form (sign flips on limbs) -- experiment builds only (-DCTG_STEM_FORM=0 / 1 cap the form; tools/build_variants.py)
+static int stem2_bf3_form(const StemArgs& p) {
+    int form = CTG_STEM_FORM;
+    if (const char* v = getenv("CTG_STEM_FORM")) form = atoi(v) < form ? atoi(v) : form;
+#if !(CTG_STEM_FORM == 0 || defined(CTG_STEM_FORM_ALL))
+    if (form < 1) form = 1;   // (the round-4 form of these shapes exists in experiment builds only)
+#endif
+    if (form >= 2 && stem2_lds_bytes_lm(p) > 160 * 1024) form = 1;
+    // four items of step 2 per wave and tile: the pending stores of one item, three accumulators and the fragments
+    // of the next do not fit the registers next to B1's fragments (the compiler spills 12-46 of them): round-4 form
+    if ((p.rows2 / 32) * p.ng2 >= 4 * SW) form = 0;
+    return form < 0 ? 0 : form;
+}
+
 // the instantiation a step runs on, spelled like its symbol in a kernel trace
 void stem2_kernel_name(const StemArgs& p, char* buf, size_t n) {
     const StemShape s = stem2_shape(p);
@@ -1612,13 +1823,23 @@ void stem2_kernel_name(const StemArgs& p, char* buf, size_t n) {
     }
     if (p.one) {
         const bool st = stem1_static(s), b3 = stem2_bf3(p);
-        snprintf(buf, n, "stem2_kernel<false,false,%d,%d,%d,0,%s,0,%s,%s,false,true>", s.rt1, s.cs1, st ? s.nch : 0,
-                 tf(st && (b3 ? s.nch <= 2 : p.K1 <= 64)), tf(s.vec), tf(b3));
+        if (st && b3 && CTG_STEM_FORM >= 1)
+            snprintf(buf, n, "stem2_kernel<false,false,%d,%d,%d,0,%s,0,%s,true,false,true,0,false,true,false>", s.rt1, s.cs1,
+                     s.nch, tf(s.nch <= 2), tf(s.vec));
+        else
+            snprintf(buf, n, "stem2_kernel<false,false,%d,%d,%d,0,%s,0,%s,%s,false,true>", s.rt1, s.cs1, st ? s.nch : 0,
+                     tf(st && (b3 ? s.nch <= 2 : p.K1 <= 64)), tf(s.vec), tf(b3));
         return;
     }
-    if (stem2_bf3(p))
-        snprintf(buf, n, "stem2_kernel<%s,%s,%d,%d,%d,%d,%s,0,%s,true,false,false>", tf(s.p1), tf(s.p2), s.rt1, s.cs1, s.nch,
-                 s.it2, tf(s.nch <= 2), tf(s.vec));
+    if (stem2_bf3(p)) {
+        const int form = stem2_bf3_form(p);
+        if (form == 0)
+            snprintf(buf, n, "stem2_kernel<%s,%s,%d,%d,%d,%d,%s,0,%s,true,false,false>", tf(s.p1), tf(s.p2), s.rt1, s.cs1,
+                     s.nch, s.it2, tf(s.nch <= 2), tf(s.vec));
+        else
+            snprintf(buf, n, "stem2_kernel<%s,%s,%d,%d,%d,%d,%s,0,%s,true,false,false,0,false,true,%s>", tf(s.p1), tf(s.p2),
+                     s.rt1, s.cs1, s.nch, s.it2, tf(s.nch <= 2), tf(s.vec), tf(form == 2));
+    }
     else if (stem2_variant(p))
         snprintf(buf, n, "stem2_kernel<%s,%s,%d,%d,%d,%d,%s,%d,%s,false,%s,false>", tf(s.p1), tf(s.p2), s.rt1, s.cs1, s.nch,
                  s.it2, tf(s.br1), s.k2q, tf(s.vec), tf(s.ri2));
@@ -1663,9 +1884,33 @@ hipError_t launch_stem2(const StemArgs& p, hipStream_t stream) {
     }
     if (stem2_bf3(p)) {
         const StemShape s = stem2_shape(p, true);
+        const int form = stem2_bf3_form(p);
+#if CTG_STEM_FORM >= 2
+#define CTG_STEM_GO3_LM(P1, P2, R, CS, NC, IT, V) \
+        if constexpr (IT < 4) { if (form == 2) return launch_stem2_t<P1, P2, R, CS, NC, IT, (NC <= 2), 0, V, true, false, true, true>(p, stream); }
+#else
+#define CTG_STEM_GO3_LM(P1, P2, R, CS, NC, IT, V)
+#endif
+#if CTG_STEM_FORM >= 1
+#define CTG_STEM_GO3_XM(P1, P2, R, CS, NC, IT, V) \
+        if constexpr (IT < 4) { if (form == 1) return launch_stem2_t<P1, P2, R, CS, NC, IT, (NC <= 2), 0, V, true, false, true, false>(p, stream); }
+#else
+#define CTG_STEM_GO3_XM(P1, P2, R, CS, NC, IT, V)
+#endif
+#if CTG_STEM_FORM == 0 || defined(CTG_STEM_FORM_ALL)
+#define CTG_STEM_GO3_R4(P1, P2, R, CS, NC, IT, V) \
+        if (form == 0) return launch_stem2_t<P1, P2, R, CS, NC, IT, (NC <= 2), 0, V, true>(p, stream);
+#else
+#define CTG_STEM_GO3_R4(P1, P2, R, CS, NC, IT, V) \
+        if constexpr (IT >= 4) { if (form == 0) return launch_stem2_t<P1, P2, R, CS, NC, IT, (NC <= 2), 0, V, true>(p, stream); }
+#endif
 #define CTG_STEM_GO3(P1, P2, R, CS, NC, IT, V)                                                          \
-    if (s.p1 == P1 && s.p2 == P2 && s.rt1 == R && s.cs1 == CS && s.nch == NC && s.it2 == IT && s.vec == V) \
-        return launch_stem2_t<P1, P2, R, CS, NC, IT, (NC <= 2), 0, V, true>(p, stream);
+    if (s.p1 == P1 && s.p2 == P2 && s.rt1 == R && s.cs1 == CS && s.nch == NC && s.it2 == IT && s.vec == V) { \
+        CTG_STEM_GO3_LM(P1, P2, R, CS, NC, IT, V)                                                       \
+        CTG_STEM_GO3_XM(P1, P2, R, CS, NC, IT, V)                                                       \
+        CTG_STEM_GO3_R4(P1, P2, R, CS, NC, IT, V)                                                       \
+        return hipErrorInvalidValue;                                                                    \
+    }
         CTG_STEM_GEO(CTG_STEM_GO3)
 #undef CTG_STEM_GO3
     }
@@ -1698,9 +1943,12 @@ hipError_t launch_stem2(const StemArgs& p, hipStream_t stream) {
     return hipErrorInvalidValue;
 }
 
+#endif   // CTG_STEM_DEV_ONE
 }  // namespace ctg
 
+#ifndef CTG_STEM_DEV_ONE
 // (include/ctg_hip.h) is there a three-step tile kernel for this shape?  A pure function of the shape.
 extern "C" int ctg_stem_triple_instantiated(int p1, int pm, int p2, int rt1, int cs1, int nch, int itm, int it2, int vec) {
     return ctg::stem3_instantiated_c(p1 != 0, pm != 0, p2 != 0, rt1, cs1, nch, itm, it2, vec != 0) ? 1 : 0;
 }
+#endif   // CTG_STEM_DEV_ONE

@@ -48,6 +48,9 @@ SYMBOLS = (
     "ctg_exec_download_arena",
     "ctg_exec_get_state",
     "ctg_exec_set_state",
+    "ctg_exec_state_dtype",
+    "ctg_exec_get_state_wide",
+    "ctg_exec_set_state_wide",
     "ctg_comm_get_unique_id",
     "ctg_comm_init",
     "ctg_comm_info",
@@ -153,6 +156,9 @@ def load():
         "ctg_exec_download_arena": [vp, C.c_int64, C.c_int64, vp],
         "ctg_exec_get_state": [vp, vp, C.POINTER(C.c_double), C.POINTER(C.c_int)],
         "ctg_exec_set_state": [vp, vp, C.c_double, C.c_int],
+        "ctg_exec_state_dtype": [vp, C.POINTER(C.c_int)],
+        "ctg_exec_get_state_wide": [vp, vp, C.POINTER(C.c_double), C.POINTER(C.c_int)],
+        "ctg_exec_set_state_wide": [vp, vp, C.c_double, C.c_int],
         "ctg_comm_get_unique_id": [vp],
         "ctg_comm_init": [vp, C.c_int, C.c_int, C.c_int, C.POINTER(vp)],
         "ctg_comm_info": [vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)],
@@ -404,11 +410,35 @@ class Executor:
         return out, e.value, bool(z.value)
 
     def set_state(self, result, exponent=0.0, zero=False):
-        """Restore what ``get_state`` returned (instead of ``zero_result``)."""
-        arr = np.ascontiguousarray(result, dtype=np.dtype(self.plan.dtype))
+        """Restore what ``get_state`` / ``get_state_wide`` returned (instead of ``zero_result``): an array in
+        the executor's state dtype -- the double-precision running sum of a single-precision sliced tree --
+        continues the sum with the bits an uninterrupted run would carry; one in the plan's own dtype restarts
+        it from the rounded values."""
+        arr = np.asarray(result)
+        wide = self.state_dtype()
+        if arr.dtype == wide and wide != np.dtype(self.plan.dtype):
+            arr = np.ascontiguousarray(arr)
+            fn = load().ctg_exec_set_state_wide
+        else:
+            arr = np.ascontiguousarray(arr, dtype=np.dtype(self.plan.dtype))
+            fn = load().ctg_exec_set_state
         if arr.size != int(np.prod(self.plan.result_shape, dtype=np.int64)):
             raise ValueError(f"state has {arr.size} elements, the plan's result {self.plan.result_shape}")
-        _check(load().ctg_exec_set_state(self.handle, C.c_void_p(arr.ctypes.data), float(exponent), int(bool(zero))))
+        _check(fn(self.handle, C.c_void_p(arr.ctypes.data), float(exponent), int(bool(zero))))
+
+    def state_dtype(self):
+        """Element type of the running sum (``ctg_exec_state_dtype``): float64 / complex128 for a
+        float32 / complex64 sliced tree, else the plan's dtype."""
+        d = C.c_int()
+        _check(load().ctg_exec_state_dtype(self.handle, C.byref(d)))
+        return np.dtype(("float32", "float64", "complex64", "complex128")[d.value])
+
+    def get_state_wide(self):
+        """``(running sum in state_dtype, exponent, zero)``: what a checkpoint stores."""
+        out = np.empty(self.plan.result_shape, dtype=self.state_dtype())
+        e, z = C.c_double(), C.c_int()
+        _check(load().ctg_exec_get_state_wide(self.handle, C.c_void_p(out.ctypes.data), C.byref(e), C.byref(z)))
+        return out, e.value, bool(z.value)
 
     # -- multi-GPU ---------------------------------------------------------- #
 

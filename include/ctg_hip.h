@@ -258,6 +258,17 @@ int ctg_exec_download_arena(ctg_exec* exec, int64_t offset, int64_t n, void* hos
  * it stopped: resuming is bit-identical to an uninterrupted run. */
 int ctg_exec_get_state(ctg_exec* exec, void* host_result, double* exponent, int* zero);
 int ctg_exec_set_state(ctg_exec* exec, const void* host_result, double exponent, int zero);
+/* ABI 6.  Single-precision results (CTG_F32 / CTG_C64) of a sliced tree are summed in DOUBLE precision: the
+ * executor keeps the running sum of the slices as CTG_F64 / CTG_C128 next to the result tensor, which always
+ * holds that sum rounded once (a left fold of 2^20 slices in fp32 -- what the reference does, core.py:3842-3844
+ * -- loses more than the 1e-5 this library promises); ctg_exec_reduce sums the ranks' double-precision sums.
+ * The state of an interrupted run therefore is that sum: `ctg_exec_state_dtype` says in which element type
+ * (the plan's own when there is no wider sum), `_wide` get / set move it (result_elems elements of that type);
+ * the narrow pair above still works -- `ctg_exec_set_state` restarts the sum from the rounded values, which
+ * is exact but not the bits an uninterrupted run would have carried. */
+int ctg_exec_state_dtype(ctg_exec* exec, int* dtype);
+int ctg_exec_get_state_wide(ctg_exec* exec, void* host_sum, double* exponent, int* zero);
+int ctg_exec_set_state_wide(ctg_exec* exec, const void* host_sum, double exponent, int zero);
 
 /* Multi-GPU: one process (or thread) per GPU, each with its own exec running
  * ctg_exec_run_slices(first = rank, stride = world) -- the round-robin of

@@ -102,7 +102,9 @@ def stem_flags(name):
     t = [x == "true" for x in a]
     return {"pack1": t[0], "pack2": t[1], "rt1": int(a[2]), "cs1": int(a[3]), "nch": int(a[4]), "it2": int(a[5]),
             "br1": t[6], "k2q": int(a[7]), "vec": t[8], "bf3": t[9], "ri2": t[10], "one": t[11],
-            "itm": int(a[12]) if len(a) > 12 else 0, "packm": t[13] if len(t) > 13 else False}
+            "itm": int(a[12]) if len(a) > 12 else 0, "packm": t[13] if len(t) > 13 else False,
+            # round 5: two-accumulator real parts / the intermediate as bf16 limbs
+            "xm": t[14] if len(t) > 14 else False, "lm": t[15] if len(t) > 15 else False}
 
 
 def stem_network(nq, gates, seed, sliced=0):

@@ -256,7 +256,9 @@ def test_bf16x3_operands_at_the_bottom_of_the_fp32_range(fuse_whatever_fits, mon
     print({m: f"{v:.2e}" for m, v in e.items()})
     assert e["fp32, tiny small operand"] <= 1e-5 and e["bf16x3"] <= 1e-5
     assert e["bf16x3, tiny small operand"] <= max(2.0 * e["fp32, tiny small operand"], 1e-6)
-    assert e["bf16x3, tiny big operand"] <= 2.0**-14          # the documented loss, bounded
+    # (round 5: an input that small loses its power of two at upload -- prescale_inputs_kernel -- and the split
+    # sees an O(1) operand: the fp32 kernel's own error, no longer the 2^-14 that round 4 documented)
+    assert e["bf16x3, tiny big operand"] <= max(2.0 * e["fp32, tiny big operand"], 1e-6)
 
 
 @pytest.mark.parametrize("case,log2_scale,underflows", [(10, -16, True), (0, -12, False), (4, -12, False)])

@@ -192,3 +192,169 @@ def test_contract_mpi_over_rccl_two_gpus():
         p.join(timeout=600)
     results = sorted(q.get(timeout=10) for _ in procs)
     assert results == [(0, True), (1, True)]
+
+
+# ---------------------------------------------------------------------- #
+# the slices are summed in double precision (accum_kernel's wide running sum)
+# ---------------------------------------------------------------------- #
+
+
+def test_slices_are_summed_in_double_precision(monkeypatch):
+    """4096 slices of an m20 tree narrowed to CPU size.  The per-slice values the device adds are fetched
+    one by one (``contract_slice``: the same kernels, bit for bit); their exact sum in float64 is what the
+    device's total must be after ONE rounding -- the complex64 left fold of the same values (what
+    ``gather_slices``, core.py:3842-3844, and this executor until round 4 did) is measurably further off.
+    The state of an interrupted run is the double-precision sum: get / set round-trip to the same bits."""
+    from test_tree_fixtures import narrowed
+
+    monkeypatch.setenv("CTG_SLICE_GROUPS", "0")     # (one slice at a time must be the same arithmetic as all at once)
+    tree = ca.tree_from_record(ca.load_network(os.path.join(ROOT, "tests", "golden", "trees", "sycamore_m20_w32_r4.json")))
+    small = narrowed(tree, 10)
+    arrays = ca.make_arrays_from_inputs(small.inputs, small.size_dict, seed=42, dtype="complex64", rescale=True)
+    n = 4096
+    fn = HipContractor(small, handle_slicing=True)
+    st = fn.setup(*arrays)
+    ex = st["exec"]
+    assert ex.state_dtype() == np.dtype("complex128")
+    vals = np.empty(n, dtype=np.complex64)
+    for i in range(n):
+        ex.zero_result()
+        ex.run_slices(i, 1, 1)
+        vals[i] = ex.download_result()
+    exact = vals.astype(np.complex128).sum()
+    fold32 = np.complex64(0)
+    for v in vals:
+        fold32 = np.complex64(fold32 + v)
+    ex.zero_result()
+    ex.run_slices(0, n, 1)
+    dev = complex(ex.download_result())
+    wide, _, _ = ex.get_state_wide()
+    err_dev, err_fold = abs(dev - exact) / abs(exact), abs(complex(fold32) - exact) / abs(exact)
+    print(f"sum of {n} slices: device {err_dev:.2e}, complex64 left fold {err_fold:.2e} (relative to the exact sum)")
+    assert abs(complex(wide) - exact) <= 1e-12 * abs(exact)
+    assert err_dev <= 1.2e-7                       # one rounding to single precision
+    assert err_fold >= 4.0 * err_dev               # the fp32 running sum is measurably worse
+    # resume: half, state out, state in (a fresh sum), other half -> the same bits as in one go
+    ex.zero_result()
+    ex.run_slices(0, n // 2, 1)
+    mid, e_, z_ = ex.get_state_wide()
+    assert mid.dtype == np.complex128
+    ex.zero_result()
+    ex.set_state(mid, e_, z_)
+    ex.run_slices(n // 2, n // 2, 1)
+    again, _, _ = ex.get_state_wide()
+    assert complex(again) == complex(wide) and complex(ex.download_result()) == dev
+    # against the oracle: a 256-slice prefix in complex128
+    ex.zero_result()
+    ex.run_slices(0, 256, 1)
+    got = complex(ex.download_result())
+    a128 = [a.astype("complex128") for a in arrays]
+    ref = sum(complex(orc.contract_slice(small, a128, i)) for i in range(256))
+    assert abs(got - ref) <= 1e-5 * abs(ref)
+    fn.close()
+    # the switch: CTG_NO_WIDE_SUM=1 is the round-4 arithmetic
+    monkeypatch.setenv("CTG_NO_WIDE_SUM", "1")
+    fn2 = HipContractor(small, handle_slicing=True)
+    ex2 = fn2.setup(*arrays)["exec"]
+    assert ex2.state_dtype() == np.dtype("complex64")
+    ex2.zero_result()
+    ex2.run_slices(0, n, 1)
+    old = complex(ex2.download_result())
+    fn2.close()
+    assert abs(old - exact) / abs(exact) >= err_dev
+
+
+def test_outer_sliced_and_real_trees_keep_their_results_with_the_wide_sum():
+    """float32 and complex64 golden trees whose sliced indices are output indices (every slice lands in its own
+    chunk of the result) and inner-sliced ones: against the oracle, and the wide state has the result's shape."""
+    for name in ("rand_s42_r3_o1_hi0_ho0_outsliced", "lattice8x8_sliced", "C5_hyper200"):
+        case = next(c for c in G.cases("tree") if c["name"] == name)
+        tree = G.tree_of(case)
+        for dtype in ("complex64", "float32"):
+            arrays = G.arrays_of(case, "complex128", tree)
+            if dtype == "float32":
+                arrays = [np.ascontiguousarray(a.real) for a in arrays]
+            ref = np.asarray(orc.contract(tree, [a.astype("float64" if dtype == "float32" else "complex128") for a in arrays]))
+            arrays = [a.astype(dtype) for a in arrays]
+            fn = HipContractor(tree)
+            got = np.asarray(fn(*arrays))
+            st = fn.setup(*arrays)
+            wide = st["exec"].state_dtype()
+            fn.close()
+            assert wide == np.dtype("float64" if dtype == "float32" else "complex128")
+            tol = G.single_gate(ref, orc.contract(tree, arrays)) * np.abs(ref).max()
+            assert got.shape == ref.shape and np.abs(got - ref).max() <= tol, (name, dtype)
+
+
+# ---------------------------------------------------------------------- #
+# input tensors far from 1: an exact power of two comes out at upload (prescale_inputs_kernel)
+# ---------------------------------------------------------------------- #
+
+
+@pytest.fixture
+def fuse_whatever_fits(monkeypatch):
+    from cotengra_amd import stem
+    monkeypatch.setattr(stem, "gather_rate", lambda run_bytes: 5.4e12)
+
+
+@pytest.mark.parametrize("bf16x3", ["1", "0"])
+def test_inputs_at_2_to_the_minus_45_under_strip_exponent(bf16x3, fuse_whatever_fits, monkeypatch):
+    """The 7-gate stem with every raw (Frobenius-normalised) input scaled by 2^-45: the value, ~2^-400, exists
+    only as mantissa x 10^exponent.  The reference normalises after every step (contract.py:816-829); this
+    executor normalises lazily, and two such inputs meeting in one fused pair used to underflow the fp32
+    intermediate before any scale was applied (round 4: DOCUMENTED; the test then stopped at 2^-16).  The
+    inputs now lose their power of two at upload (exact) and the exponent gets it back."""
+    monkeypatch.setenv("CTG_STEM_BF16X3", bf16x3)
+    nq, gates = G.STEM_CASES[10]
+    tree = G.stem_network(nq, gates, 1000)
+    arrays = ca.make_arrays_from_inputs(tree.inputs, tree.size_dict, seed=10, dtype="complex64")
+    ref = np.asarray(orc.contract(tree, [a.astype("complex128") for a in arrays]))
+    shift = -45 * len(arrays)
+    scaled = [(a * np.float32(2.0**-45)).astype("complex64") for a in arrays]
+    fn = HipContractor(tree, fuse=True, fuse_min_elems=1 << 10)
+    m, e = fn(*scaled, strip_exponent=True)
+    names = [n for n in fn.setup(*scaled)["exec"].step_kernels() if n.startswith("stem2_kernel")]
+    fn.close()
+    assert names
+    # mantissa x 10^e = ref x 2^shift: compare in logarithms (the value is far below every float range)
+    got_log10 = np.log10(np.abs(np.asarray(m).astype("complex128")).max()) + e
+    want_log10 = np.log10(np.abs(ref).max()) + shift * np.log10(2.0)
+    assert abs(got_log10 - want_log10) <= 1e-5
+    mant = np.asarray(m).astype("complex128") / np.abs(np.asarray(m)).max()
+    assert np.abs(mant - ref / np.abs(ref).max()).max() <= 1e-5
+
+
+@pytest.mark.parametrize("bf16x3", ["1", "0"])
+def test_inputs_at_both_ends_of_the_fp32_range(bf16x3, fuse_whatever_fits, monkeypatch):
+    """Inputs alternately scaled by 2^+50 and 2^-50 (and the big state by 2^-104: the round-4 'tiny big
+    operand', which cost the bf16 x 3 split its third limb -- accepted then up to 2^-14): the value is an
+    ordinary number, every un-prescaled fp32 intermediate would overflow or underflow on the way.  Both
+    arithmetics at the fp32 kernel's own accuracy; inputs inside [2^-32, 2^32) are not touched (same bits
+    as with the pass switched off)."""
+    monkeypatch.setenv("CTG_STEM_BF16X3", bf16x3)
+    nq, gates = G.STEM_CASES[10]
+    tree = G.stem_network(nq, gates, 1000)
+    arrays = ca.make_arrays_from_inputs(tree.inputs, tree.size_dict, seed=10, dtype="complex64", rescale=True)
+    ref = np.asarray(orc.contract(tree, [a.astype("complex128") for a in arrays]))
+    scale = np.abs(ref).max()
+    fn = HipContractor(tree, fuse=True, fuse_min_elems=1 << 10)
+    plain = np.asarray(fn(*arrays))
+    e_plain = np.abs(plain - ref).max() / scale
+    # (an even number of small inputs: the powers cancel)
+    n_small = (len(arrays) - 1) // 2 * 2
+    powers = [0] + [50 if i % 2 else -50 for i in range(n_small)] + [0] * (len(arrays) - 1 - n_small)
+    ends = [(a * np.float32(2.0**p)).astype("complex64") for a, p in zip(arrays, powers)]
+    got = np.asarray(fn(*ends))
+    assert np.array_equal(got, plain)               # exact powers of two out and back in: the same bits
+    tiny = list(arrays)
+    tiny[0] = (arrays[0] * np.float32(2.0**-104)).astype("complex64")
+    got_t = np.asarray(fn(*tiny)).astype("complex128") * 2.0**104
+    e_tiny = np.abs(got_t - ref).max() / scale
+    fn.close()
+    print(f"plain {e_plain:.2e}, big operand at 2^-104: {e_tiny:.2e}")
+    assert e_plain <= 1e-5 and e_tiny <= max(2.0 * e_plain, 1e-6)
+    monkeypatch.setenv("CTG_NO_PRESCALE", "1")
+    fn0 = HipContractor(tree, fuse=True, fuse_min_elems=1 << 10)
+    off = np.asarray(fn0(*arrays))
+    fn0.close()
+    assert np.array_equal(off, plain)

@@ -15,7 +15,7 @@ for spec in sys.argv[1:]:
     name, _, flags = spec.partition("=")
     jobs.append((name, [f for f in flags.split(",") if f]))
 g.build()  # the default objects first: variants share every source the flags do not touch
-KERNEL_SOURCES = ["ctg_pair_mfma.hip", "ctg_pair_mfma_f64.hip", "ctg_stem.hip", "ctg_runtime.hip"]
+KERNEL_SOURCES = os.environ.get("CTG_VARIANT_SOURCES", "ctg_pair_mfma.hip,ctg_pair_mfma_f64.hip,ctg_stem.hip,ctg_runtime.hip").split(",")
 with ThreadPoolExecutor(8) as pool:
     list(pool.map(lambda j: g.build(extra_flags=j[1], lib=os.path.join(out, f"libctg_{j[0]}.so"),
                                     flag_sources=KERNEL_SOURCES), jobs))
