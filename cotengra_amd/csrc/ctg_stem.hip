@@ -58,6 +58,15 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 __device__ unsigned long long ctg_stem_oob[2];
 #endif
 
+#ifdef CTG_STEM_TIMELINE
+// Timeline experiment build (tools/build_variants.py tl=-DCTG_STEM_TIMELINE, tools/exp_stem_timeline.py): the 8 waves
+// of workgroup 0 stamp the shader clock at the phase boundaries of their first CTG_TL_TILES tiles -- [wave][tile][0..5]
+// = tile start, step 1 issued, past barrier 1, scatter done, past barrier 2, step 2 issued.
+#define CTG_TL_TILES 256
+__device__ unsigned long long ctg_stem_tl[8][CTG_TL_TILES][6];
+__device__ int ctg_stem_tl_on;   // set per launch by the host: CTG_TL_SHAPE="K1,N1,K2,N2" (and the first match only)
+#endif
+
 namespace {
 
 constexpr int SW = 8;            // waves per workgroup
@@ -239,6 +248,17 @@ __device__ __forceinline__ float pow2f(int ex) {   // 2^ex, -126 <= ex <= 127
 #define CTG_STEM_SYNC() __builtin_amdgcn_wave_barrier()
 #else
 #define CTG_STEM_SYNC() __syncthreads()
+#endif
+
+#ifdef CTG_STEM_TIMELINE
+#define CTG_TL_STAMP(k)                                                                                   \
+    do {                                                                                                  \
+        if (blockIdx.x == 0 && lane == 0 && tl_n < CTG_TL_TILES && ctg_stem_tl_on)                        \
+            ctg_stem_tl[wave][tl_n][k] = __builtin_readcyclecounter();                                    \
+        if ((k) == 5) ++tl_n;                                                                             \
+    } while (0)
+#else
+#define CTG_TL_STAMP(k) do {} while (0)
 #endif
 
 template <typename T>
@@ -572,14 +592,24 @@ __global__ __launch_bounds__(SW * 64, 1) void stem2_kernel(StemArgs p) {
     const int ri_rts = RI2 ? SW / p.ng2 : 0;
     const float* ri_b = P2 + (kk * N2 + ri_cg * 32 + l31) * LDB2;
 
-    float alpha = 1.f;
-    if (p.facA != nullptr) {
-        const double f = (*p.facA) * (*p.facB1) * (*p.facB2) * (TRI ? *p.facBM : 1.0);
-        alpha = (f == 0.0 && p.check_zero) ? 0.f : (float)(1.0 / f * (BF3 ? exp2((double)bf3_ex) : 1.0));
-    } else if (BF3 && bf3_ex != 0) {
-        alpha = (float)exp2((double)bf3_ex);
+    // The factor the stores apply, as TWO floats (alpha x alpha2): the powers of two taken out of the small operands
+    // add up -- two operands near 2^-70 give 2^-140, not a float -- while the result itself may well be one
+    // (the big operand compensates): applied one after the other, each inside the float range, the product of an
+    // fp32 value with 2^bf3_ex is exact wherever the fp32 kernel's step-by-step product is (advisor, round 4).
+    float alpha = 1.f, alpha2 = 1.f;
+    {
+        int e1 = bf3_ex < -126 ? -126 : (bf3_ex > 126 ? 126 : bf3_ex);
+        int e2 = bf3_ex - e1;
+        e2 = e2 < -126 ? -126 : (e2 > 126 ? 126 : e2);   // (beyond 2^+-252: the result is out of range anyway)
+        if (p.facA != nullptr) {
+            const double f = (*p.facA) * (*p.facB1) * (*p.facB2) * (TRI ? *p.facBM : 1.0);
+            alpha = (f == 0.0 && p.check_zero) ? 0.f : (float)(1.0 / f * (BF3 ? exp2((double)e1) : 1.0));
+        } else if (BF3 && bf3_ex != 0) {
+            alpha = pow2f(e1);
+        }
+        if (BF3 && e2 != 0) alpha2 = pow2f(e2);
     }
-    const bool scaled = __builtin_amdgcn_readfirstlane(alpha != 1.f);   // (strip_exponent runs only)
+    const bool scaled = __builtin_amdgcn_readfirstlane(alpha != 1.f || alpha2 != 1.f);   // (strip_exponent runs, rescaled operands)
     __syncthreads();
 
 #ifdef CTG_STEM_KO_BFRAG
@@ -728,6 +758,9 @@ __global__ __launch_bounds__(SW * 64, 1) void stem2_kernel(StemArgs p) {
         for (int q = 0; q < 4; ++q) fire2(r, q, base, always_tag);
     };
 
+#ifdef CTG_STEM_TIMELINE
+    int tl_n = 0;
+#endif
     f32x16 ax[RT1], ay[RT1];
     f32x16 axm[XM1 ? RT1 : 1];   // XM: the Im a Im b half of the real parts (X = ax - axm)
     // one task: 16 k of MFMAs on the gathered registers, each register refilled (two tasks
@@ -770,8 +803,8 @@ __global__ __launch_bounds__(SW * 64, 1) void stem2_kernel(StemArgs p) {
                 v.x = cr[SET][i >> 3][2 * (i & 7)];
                 v.y = cr[SET][i >> 3][2 * (i & 7) + 1];
                 if constexpr (decltype(scaled_tag)::value) {
-                    v.x *= alpha;
-                    v.y *= alpha;
+                    v.x = v.x * alpha * alpha2;
+                    v.y = v.y * alpha * alpha2;
                 }
                 store2(pdst + 2 * out_t(i), v);
             } else {
@@ -1187,8 +1220,8 @@ __global__ __launch_bounds__(SW * 64, 1) void stem2_kernel(StemArgs p) {
                     v.x = hi ? got : cx[t];
                     v.y = hi ? cx[t + 1] : got;
                     if (SC) {
-                        v.x *= alpha;
-                        v.y *= alpha;
+                        v.x = v.x * alpha * alpha2;
+                        v.y = v.y * alpha * alpha2;
                     }
                     pv[t >> 1] = v;
                 }
@@ -1197,8 +1230,8 @@ __global__ __launch_bounds__(SW * 64, 1) void stem2_kernel(StemArgs p) {
                 for (int t = 0; t < 16; ++t) {
                     float2 v;
                     const float xr = XM2 ? cx[t] - cxm[t] : cx[t];
-                    v.x = SC ? xr * alpha : xr;
-                    v.y = SC ? cy[t] * alpha : cy[t];
+                    v.x = SC ? xr * alpha * alpha2 : xr;
+                    v.y = SC ? cy[t] * alpha * alpha2 : cy[t];
                     pv[t] = v;
                 }
             }
@@ -1284,8 +1317,8 @@ __global__ __launch_bounds__(SW * 64, 1) void stem2_kernel(StemArgs p) {
         for (int t = 0; t < 16; ++t) {
             float2 v;
             const float xr = XM1 ? ax[m][t] - axm[m][t] : ax[m][t];
-            v.x = SC ? xr * alpha : xr;
-            v.y = SC ? ay[m][t] * alpha : ay[m][t];
+            v.x = SC ? xr * alpha * alpha2 : xr;
+            v.y = SC ? ay[m][t] * alpha * alpha2 : ay[m][t];
             pv[RI2 ? 0 : t] = v;
         }
         pdst = C + 2 * (c_tile + one_rt[m] + out_lane + one_col);
@@ -1326,6 +1359,7 @@ __global__ __launch_bounds__(SW * 64, 1) void stem2_kernel(StemArgs p) {
                 g += tile_step;
                 return;
             }
+            CTG_TL_STAMP(0);
             static_for<0, RT1>([&](auto mi) __attribute__((always_inline)) {
                 constexpr int M = decltype(mi)::value;
                 zero_acc(M);
@@ -1337,8 +1371,11 @@ __global__ __launch_bounds__(SW * 64, 1) void stem2_kernel(StemArgs p) {
                             std::integral_constant<int, (!FIRST && M == 0 && CH == 0) ? LASTSET : -1>{}, scaled_tag);
                 });
             });
+            CTG_TL_STAMP(1);
             CTG_STEM_SYNC();   // all waves have finished step 2 of the previous tile
+            CTG_TL_STAMP(2);
             scatter();
+            CTG_TL_STAMP(3);
             const int64_t c_tile = tile_c(g);
             int64_t c_rows[IT2 > 0 ? IT2 : 1];
             static_for<0, IT2>([&](auto ii) __attribute__((always_inline)) {
@@ -1352,6 +1389,7 @@ __global__ __launch_bounds__(SW * 64, 1) void stem2_kernel(StemArgs p) {
                 }
             });
             CTG_STEM_SYNC();
+            CTG_TL_STAMP(4);
             if constexpr (TRI) {
                 static_for<0, ITM>([&](auto ii) __attribute__((always_inline)) { item_mid(ii); });
                 CTG_STEM_SYNC();   // every wave has read the first intermediate: the second goes over it
@@ -1366,6 +1404,7 @@ __global__ __launch_bounds__(SW * 64, 1) void stem2_kernel(StemArgs p) {
                 else
                     item2(wave + SW * I, c_rows[I], scaled_tag, std::integral_constant<bool, (I > 0)>{}, std::true_type{});
             });
+            CTG_TL_STAMP(5);
             g += tile_step;
         };
         auto pass = [&](auto peel_tag) __attribute__((always_inline)) {
@@ -1419,6 +1458,21 @@ __global__ __launch_bounds__(SW * 64, 1) void stem2_kernel(StemArgs p) {
     if (scaled) run(std::true_type{});
     else run(std::false_type{});
 }
+
+#ifdef CTG_STEM_TIMELINE
+}  // namespace ctg
+// (experiment build only; not in include/ctg_hip.h) the stamps of the last launch: 8 x CTG_TL_TILES x 6 words
+extern "C" int ctg_debug_stem_timeline(unsigned long long* out, int reset) {
+    if (hipDeviceSynchronize() != hipSuccess) return -1;
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(ctg::ctg_stem_tl), sizeof(unsigned long long) * 8 * CTG_TL_TILES * 6) != hipSuccess) return -1;
+    if (reset) {
+        static unsigned long long z[8 * CTG_TL_TILES * 6];
+        if (hipMemcpyToSymbol(HIP_SYMBOL(ctg::ctg_stem_tl), z, sizeof(z)) != hipSuccess) return -1;
+    }
+    return 0;
+}
+namespace ctg {
+#endif
 
 #ifdef CTG_STEM_BOUNDS
 }  // namespace ctg
@@ -1482,6 +1536,16 @@ static hipError_t launch_stem2_t(const StemArgs& p_, hipStream_t stream) {
         const hipError_t e = lds_opt_in((const void*)kern, 160 * 1024, &ready);
         if (e != hipSuccess) return e;
     }
+#ifdef CTG_STEM_TIMELINE
+    {
+        static int taken = 0;
+        int on = 0, k1 = 0, n1 = 0, k2 = 0, n2 = 0;
+        if (const char* v = getenv("CTG_TL_SHAPE"))
+            if (sscanf(v, "%d,%d,%d,%d", &k1, &n1, &k2, &n2) == 4 && k1 == p.K1 && n1 == p.N1 && k2 == p.K2 && n2 == p.N2 && !taken)
+                on = taken = 1;
+        (void)hipMemcpyToSymbolAsync(HIP_SYMBOL(ctg::ctg_stem_tl_on), &on, sizeof(int), 0, hipMemcpyHostToDevice, stream);
+    }
+#endif
     const size_t smem = LM ? stem2_lds_bytes_lm(p)
                            : BF3 ? stem2_lds_bytes_bf3(p) : (RI2 ? stem2_lds_bytes_ri2(p, K2Q > 0) : stem2_lds_bytes(p));
     // persistent: one workgroup per CU (the tile owns most of the CU's LDS)

@@ -265,7 +265,7 @@ def modelled_seconds(tree, model=None, dtype="complex64"):
     plan = compile_tree(tree, dtype)
     itemsize = plan.itemsize
     t = 0.0
-    share = 0.5 ** len(plan.group_inds)   # (a step shared by a group of slices costs a slice its share)
+    share = 1.0 / plan.group_size   # (a step shared by a group of slices costs a slice its share)
     for s in plan.steps:
         if not s.macs:
             continue

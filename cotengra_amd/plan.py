@@ -787,7 +787,8 @@ def choose_slice_group(tree, plan):
                 continue
             g = set(chosen) | {ix}
             shared = [s for s, _, d in rows if d and not (g & d)]
-            saving = sum(t for _, t, d in rows if d and not (g & d)) * (1.0 - 0.5 ** len(g))
+            # (a shared step costs a slice 1 / group size of itself: the extents of the group indices, not 2 each)
+            saving = sum(t for _, t, d in rows if d and not (g & d)) * (1.0 - 1.0 / prod(tree.size_dict[i_] for i_ in g))
             ids = {id(s.c) for s in shared}
             kept = sum(op.size for s, _, d in rows if (g & d)
                        for op in (s.a, s.b, getattr(s, "b2", None), getattr(s, "bm", None))
