@@ -274,8 +274,8 @@ def dominant_kernel(rows, flops_per_mac):
     return name, dom, by_name
 
 
-# RI2, ONE, ITM, PACKM, XM, LM of stem2_kernel (template arguments 11-16)
-STEM2_TEMPLATE_DEFAULTS = ("false", "false", "0", "false", "false", "false")
+# RI2, ONE, ITM, PACKM, XM, LM, WS of stem2_kernel (template arguments 11-17)
+STEM2_TEMPLATE_DEFAULTS = ("false", "false", "0", "false", "false", "false", "false")
 
 
 def norm_kernel_name(name):

@@ -326,14 +326,31 @@ __device__ __forceinline__ void settle(T& v) {
 // where they are) instead of once per work item of step 2 (5.5 instructions per value and per column group:
 // profiles/r4_stem_sq_counters.txt counted 5.6 vector instructions per MFMA, most of them this).  Half again
 // as much LDS as the fp32 intermediate: B1's planes share its memory when the fragments live in registers.
-template <bool PACK1, bool PACK2, int RT1, int CS1, int NCH, int IT2, bool BR1 = false, int K2Q = 0, bool VEC = false,
+// WS (round 5; needs XM, a pair, static): the waves SPECIALISE.  Waves 0-3 (one per SIMD) are producers: they
+// gather, run step 1 for ALL units of the tile (twice RT1_ each) and scatter; waves 4-7 are consumers: they run
+// step 2 for all its work items (twice IT2_ each) and store.  The producers work one tile ahead -- step 1 of tile
+// t + 1 (registers only: B1's fragments live there) overlaps step 2 of tile t -- so that the two waves of a SIMD
+// are never in the same phase: the phase timeline of the symmetric kernel (profiles/r5_stem_timeline_knockout.txt)
+// shows its matrix phases at 55-64 % of the issue rate -- both waves of a SIMD wait for the LDS or split operands
+// at the same moments -- and 24 % of a tile outside them (barrier waits, scatter).  Same tile, same tables, same
+// LDS; the only serial part left is the producers' scatter between the two barriers (the consumers drain
+// their pending stores there).  A consumer has the registers for two fragment sets: the loads and splits of
+// chunk c + 1 go out before the MFMAs of chunk c.
+template <bool PACK1, bool PACK2, int RT1_, int CS1, int NCH, int IT2_, bool BR1 = false, int K2Q = 0, bool VEC = false,
           bool BF3 = false, bool RI2 = false, bool ONE = false, int ITM = 0, bool PACKM = false, bool XM = false,
-          bool LM = false>
+          bool LM = false, bool WS = false>
 __global__ __launch_bounds__(SW * 64, 1) void stem2_kernel(StemArgs p) {
     constexpr bool TRI = ITM > 0;
+    static_assert(!WS || (XM && !LM && !ONE && IT2_ > 0 && IT2_ <= 2 && (PACK1 || RT1_ == 1)), "specialised waves: a static bf16 x 3 pair, fp32 intermediate");
+    constexpr int PW = WS ? 4 : SW;               // waves that run step 1 (and, symmetric kernel, step 2)
+    constexpr int RT1 = WS ? 2 * RT1_ : RT1_;     // units of step 1 per such wave
+    constexpr int IT2 = WS ? 2 * IT2_ : IT2_;     // work items of step 2 per consumer (symmetric: per wave)
     static_assert(!XM || (BF3 && !TRI && NCH > 0), "two-accumulator real part: bf16 x 3, static, no three-step tile");
     static_assert(!LM || (XM && !ONE), "limb intermediate: the round-5 form of a pair");
-    constexpr bool XM1 = XM && !PACK1;   // step 1 keeps Xm (16 columns: the sign lives in B1's third plane)
+    // step 1 keeps Xm (16 columns: the sign lives in B1's third plane; specialised waves: a producer holds the
+    // accumulators of TWO units until the barrier -- a third one per unit does not fit next to B1's fragments, and the
+    // 12 sign flips per task cost a producer nothing: it has half a tile of slack)
+    constexpr bool XM1 = XM && !PACK1 && !WS;
     constexpr bool XM2 = XM && !PACK2;   // step 2 likewise
     static_assert(!TRI || (NCH > 0 && IT2 > 0 && !RI2 && !ONE && K2Q == 0), "three-step tile: static, X / Y form");
     static_assert(!ONE || (!PACK1 && !PACK2 && !RI2 && IT2 == 0 && K2Q == 0), "one step: >= 32 columns, nothing of step 2");
@@ -341,7 +358,7 @@ __global__ __launch_bounds__(SW * 64, 1) void stem2_kernel(StemArgs p) {
     static_assert(!BR1 || NCH > 0, "B1 in registers needs the chunk count at compile time");
     static_assert(K2Q == 0 || PACK2 || IT2 == 1 || RI2, "B2 in registers: one column group per wave");
     static_assert(!RI2 || (!PACK2 && !BF3 && NCH > 0 && IT2 > 0), "row-interleaved step 2: fp32, >= 32 columns, static");
-    constexpr int RTW = SW / CS1;   // row tiles the 8 waves cover at once
+    constexpr int RTW = PW / CS1;   // row tiles the waves of step 1 cover at once
     constexpr bool STATIC = NCH > 0;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     // (K2 is a compile-time constant where B2's fragments live in registers: LDS offsets that are
@@ -408,8 +425,10 @@ __global__ __launch_bounds__(SW * 64, 1) void stem2_kernel(StemArgs p) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int kk = lane >> 5;
     const int l31 = lane & 31;
-    const int wrt = wave / CS1;            // this wave's row tile (within a round of RTW)
-    const int wcol = (wave % CS1) * 32;    // ... and first column of step 1
+    const bool producer = !WS || wave < PW;
+    const int wave1 = WS ? (wave & (PW - 1)) : wave;   // index among the waves of its role
+    const int wrt = wave1 / CS1;           // this wave's row tile (within a round of RTW)
+    const int wcol = (wave1 % CS1) * 32;   // ... and first column of step 1
 
     const int64_t z = (int64_t)p.z0 + blockIdx.y;
     const c64* __restrict__ A = (const c64*)p.A + (sload64(p.soffA + z * p.zsA) + z * p.zA);
@@ -1105,15 +1124,35 @@ __global__ __launch_bounds__(SW * 64, 1) void stem2_kernel(StemArgs p) {
                     cy = mfma_bf(F.ai[ta], F.br[tb], cy);
                 }
             };
-            // (one fragment set: B1's fragments, the gathers in flight and three accumulators leave no room for a
-            // second one -- the other wave of the SIMD covers the LDS latency)
             const int nc = K2 >> 4;   // 1, 2, 4 or 8
-            Frag F0;
-            load_frag(F0, 0);
-            mul_frag(F0, std::true_type{});
-            for (int c = 1; c < nc; ++c) {
-                load_frag(F0, c);
-                mul_frag(F0, std::false_type{});
+            if constexpr (WS) {
+                // a consumer has room for two fragment sets: the loads (and splits) of chunk c + 1 are issued
+                // before the MFMAs of chunk c
+                Frag F0, F1;
+                load_frag(F0, 0);
+                if (nc == 1) {
+                    mul_frag(F0, std::true_type{});
+                } else {
+                    load_frag(F1, 1);
+                    mul_frag(F0, std::true_type{});
+                    for (int c = 2; c < nc; c += 2) {
+                        load_frag(F0, c);
+                        mul_frag(F1, std::false_type{});
+                        load_frag(F1, c + 1);
+                        mul_frag(F0, std::false_type{});
+                    }
+                    mul_frag(F1, std::false_type{});
+                }
+            } else {
+                // (one fragment set: B1's fragments, the gathers in flight and three accumulators leave no room for a
+                // second one -- the other wave of the SIMD covers the LDS latency)
+                Frag F0;
+                load_frag(F0, 0);
+                mul_frag(F0, std::true_type{});
+                for (int c = 1; c < nc; ++c) {
+                    load_frag(F0, c);
+                    mul_frag(F0, std::false_type{});
+                }
             }
         } else if constexpr (BF3 && LM) {
             // 16 columns, limb intermediate: the lane's plane (Re | Im by k-row) of its row, 8 k per instruction
@@ -1332,7 +1371,65 @@ __global__ __launch_bounds__(SW * 64, 1) void stem2_kernel(StemArgs p) {
     // strip_exponent run: a branch around the stores inside the steady state gives the
     // compiler paths with fewer stores than there are, and it waits accordingly)
     auto run = [&](auto scaled_tag) __attribute__((always_inline)) {
-    if constexpr (STATIC) {
+    if constexpr (WS) {
+        // ---- specialised waves: producers one tile ahead of the consumers ---------------------------------
+        constexpr int NT = RT1 * NCH;            // tasks per tile and producer
+        constexpr int U = (NT & 1) ? 2 : 1;      // tiles per pass: the gather register sets alternate
+        // step 1 of the producer's next tile: every unit, every chunk (no stores on this side: a wait for a
+        // gather counts gathers only)
+        auto step1 = [&](auto slot0_tag) __attribute__((always_inline)) {
+            constexpr int SLOT0 = decltype(slot0_tag)::value;
+            static_for<0, RT1>([&](auto mi) __attribute__((always_inline)) {
+                constexpr int M = decltype(mi)::value;
+                static_for<0, NCH>([&](auto ci) __attribute__((always_inline)) {
+                    constexpr int CH = decltype(ci)::value;
+                    consume(regs[(SLOT0 + M * NCH + CH) & 1], M, CH, std::true_type{}, std::integral_constant<int, -1>{}, scaled_tag);
+                });
+            });
+        };
+        // step 2 of the consumer's tile: its items one after the other; the stores of an item go out at the head
+        // of the next one, those of the last item after the next barrier (while the producers scatter)
+        auto step2 = [&](int64_t gc) __attribute__((always_inline)) {
+            const int64_t c_tile = tile_c(gc);
+            int64_t c_rows[IT2];
+            static_for<0, IT2>([&](auto ii) __attribute__((always_inline)) {
+                c_rows[decltype(ii)::value] = item_row(wave1 + PW * decltype(ii)::value, c_tile);
+            });
+            static_for<0, IT2>([&](auto ii) __attribute__((always_inline)) {
+                constexpr int I = decltype(ii)::value;
+                item2(wave1 + PW * I, c_rows[I], scaled_tag, std::integral_constant<bool, (I > 0)>{}, std::true_type{});
+            });
+        };
+        // (one loop per role: what a role keeps in registers across tiles -- the producers' accumulators, gather
+        // registers and B1 fragments; the consumers' pending stores -- must not be live in the other's loop.  Both
+        // loops pass the same two barriers per tile.)
+        if (producer) {
+            issue(regs[0], std::true_type{});
+            issue(regs[1], std::true_type{});
+            prep(std::true_type{});
+            step1(std::integral_constant<int, 0>{});
+            // tiles t, t + 1 (U = 2: the gather register sets swap roles from one tile to the next)
+            for (int64_t t = 0; t < my_tiles; t += U) {
+                static_for<0, U>([&](auto ui) __attribute__((always_inline)) {
+                    constexpr int UI = decltype(ui)::value;
+                    if (t + UI < my_tiles) {
+                        CTG_STEM_SYNC();   // the consumers have read tile t - 1's intermediate; tile t's accumulators are complete
+                        scatter();
+                        CTG_STEM_SYNC();
+                        if (t + UI + 1 < my_tiles) step1(std::integral_constant<int, ((UI + 1) * NT) & 1>{});
+                    }
+                });
+            }
+        } else {
+            for (int64_t t = 0; t < my_tiles; ++t) {
+                CTG_STEM_SYNC();
+                if (t > 0) drain(0, NST, std::integral_constant<int, 0>{}, scaled_tag);   // the last item's stores: while the producers scatter
+                CTG_STEM_SYNC();
+                step2(tile0 + t * tile_step);
+            }
+            drain(0, NST, std::integral_constant<int, 0>{}, scaled_tag);
+        }
+    } else if constexpr (STATIC) {
         constexpr int NT = RT1 * NCH;            // tasks per tile and wave
         constexpr int U = (NT & 1) ? 2 : 1;      // tiles per pass: the register sets alternate
         constexpr int LASTSET = RI2 ? ((IT2 > 0 ? IT2 - 1 : 0) & (NSET - 1)) : 0;
@@ -1527,10 +1624,10 @@ static size_t stem2_lds_bytes_ri2(const StemArgs& p, bool b2_in_regs) {
 }
 
 template <bool PACK1, bool PACK2, int RT1, int CS1, int NCH, int IT2, bool BR1 = false, int K2Q = 0, bool VEC = false,
-          bool BF3 = false, bool RI2 = false, bool XM = false, bool LM = false>
+          bool BF3 = false, bool RI2 = false, bool XM = false, bool LM = false, bool WS = false>
 static hipError_t launch_stem2_t(const StemArgs& p_, hipStream_t stream) {
     const StemArgs& p = p_;
-    auto kern = stem2_kernel<PACK1, PACK2, RT1, CS1, NCH, IT2, BR1, K2Q, VEC, BF3, RI2, false, 0, false, XM, LM>;
+    auto kern = stem2_kernel<PACK1, PACK2, RT1, CS1, NCH, IT2, BR1, K2Q, VEC, BF3, RI2, false, 0, false, XM, LM, WS>;
     static unsigned long long ready = 0;   // (bit per device)
     {
         const hipError_t e = lds_opt_in((const void*)kern, 160 * 1024, &ready);
@@ -1554,8 +1651,13 @@ static hipError_t launch_stem2_t(const StemArgs& p_, hipStream_t stream) {
     return hipGetLastError();
 }
 
+// Form of the bf16 x 3 kernels the library is built with.  1 (the product): two-accumulator real parts, fp32 intermediate.
+// The two other round-5 forms were measured next to it on the headline tree and are experiment builds
+// (tools/build_variants.py lm=-DCTG_STEM_FORM=2,-DCTG_STEM_LM  ws=-DCTG_STEM_FORM=3,-DCTG_STEM_WS; profiles/r5_forms_*.txt):
+// 2 the intermediate as bf16 limbs (40 % fewer vector instructions, 3-4 % SLOWER: the split moves into the scatter
+// between the two barriers, where no wave has MFMAs to hide it), 3 specialised waves (same time as form 1 to 1 %).
 #ifndef CTG_STEM_FORM
-#define CTG_STEM_FORM 2
+#define CTG_STEM_FORM 1
 #endif
 // the first half alone (ONE): B1's planes and the column table
 static size_t stem2_lds_bytes_one(const StemArgs& p, bool bf3) {
@@ -1611,7 +1713,12 @@ static hipError_t launch_stem3_t(const StemArgs& p, hipStream_t stream) {
 // gathers): the shapes the time-to-solution trees (sycamore_m20_w32_r4 / w33_bf3, first seven) and the
 // test stems (last five) take when every tile that fits is chosen; there is no run-time-count variant --
 // the planner asks ctg_stem_triple_instantiated before it emits one
-#ifdef CTG_STEM_TRI_DEV
+// ROUND 5: measured slower than pairs on every tree (DESIGN / HISTORY section 8), so the product library is built
+// WITHOUT these kernels -- ctg_stem_triple_instantiated answers 0 for every shape and the planner never emits a
+// middle stage; an experiment build has them (tools/build_variants.py triples=-DCTG_STEM_TRIPLES_BUILD).
+#if !defined(CTG_STEM_TRIPLES_BUILD)
+#define CTG_STEM_TRI(X)
+#elif defined(CTG_STEM_TRI_DEV)
 #define CTG_STEM_TRI(X) \
     X(true, true, true, 2, 1, 1, 2, 2, false) X(false, false, false, 1, 1, 2, 1, 1, false) \
     X(true, false, true, 2, 1, 1, 1, 1, false) X(true, false, false, 1, 1, 1, 1, 1, true)
@@ -1859,19 +1966,30 @@ static bool stem2_bf3(const StemArgs& p) {
     return want && stem2_has_geo(stem2_shape(p, true)) && (p.K2 & 7) == 0 && stem2_lds_bytes_bf3(p) <= 160 * 1024;
 }
 
-// Form of a bf16 x 3 pair (round 5).  2: two-accumulator real parts and the intermediate as bf16 limbs (XM + LM)
-// where that fits the LDS; 1: two-accumulator real parts, fp32 intermediate split by step 2 (XM); 0: the round-4
-// form (sign flips on limbs) -- experiment builds only (-DCTG_STEM_FORM=0 / 1 cap the form; tools/build_variants.py)
+// Form of a bf16 x 3 pair (round 5): 1 = two-accumulator real parts, fp32 intermediate split by step 2 (XM: the
+// product); 0 = the round-4 form (sign flips on limbs: pairs with four items per wave keep it, all others only in
+// experiment builds); 2 / 3 = limb intermediate / specialised waves (experiment builds).  CTG_STEM_FORM in the
+// environment lowers the form a build offers.
 static int stem2_bf3_form(const StemArgs& p) {
     int form = CTG_STEM_FORM;
     if (const char* v = getenv("CTG_STEM_FORM")) form = atoi(v) < form ? atoi(v) : form;
 #if !(CTG_STEM_FORM == 0 || defined(CTG_STEM_FORM_ALL))
     if (form < 1) form = 1;   // (the round-4 form of these shapes exists in experiment builds only)
 #endif
-    if (form >= 2 && stem2_lds_bytes_lm(p) > 160 * 1024) form = 1;
+#ifndef CTG_STEM_LM
+    if (form == 2) form = 1;  // (the limb intermediate: experiment builds, -DCTG_STEM_LM)
+#endif
+#ifndef CTG_STEM_WS
+    if (form == 3) form = 1;  // (specialised waves: experiment builds, -DCTG_STEM_WS)
+#endif
+    if (form == 2 && stem2_lds_bytes_lm(p) > 160 * 1024) form = 1;
+    const int items = (p.rows2 / 32) * p.ng2, units = (1 << (p.nr1 - 5)) * (p.N1 >= 32 ? p.N1 / 32 : 1);
+    // specialised waves: a producer takes two of the symmetric kernel's shares of step 1, a consumer two of step 2 --
+    // at most two items per wave there, and one unit per wave unless step 1 has 16 columns (one accumulator per unit)
+    if (form == 3 && !(items <= 2 * SW && (p.N1 == 16 || units == SW))) form = 1;
     // four items of step 2 per wave and tile: the pending stores of one item, three accumulators and the fragments
     // of the next do not fit the registers next to B1's fragments (the compiler spills 12-46 of them): round-4 form
-    if ((p.rows2 / 32) * p.ng2 >= 4 * SW) form = 0;
+    if (items >= 4 * SW) form = 0;
     return form < 0 ? 0 : form;
 }
 
@@ -1901,8 +2019,8 @@ void stem2_kernel_name(const StemArgs& p, char* buf, size_t n) {
             snprintf(buf, n, "stem2_kernel<%s,%s,%d,%d,%d,%d,%s,0,%s,true,false,false>", tf(s.p1), tf(s.p2), s.rt1, s.cs1,
                      s.nch, s.it2, tf(s.nch <= 2), tf(s.vec));
         else
-            snprintf(buf, n, "stem2_kernel<%s,%s,%d,%d,%d,%d,%s,0,%s,true,false,false,0,false,true,%s>", tf(s.p1), tf(s.p2),
-                     s.rt1, s.cs1, s.nch, s.it2, tf(s.nch <= 2), tf(s.vec), tf(form == 2));
+            snprintf(buf, n, "stem2_kernel<%s,%s,%d,%d,%d,%d,%s,0,%s,true,false,false,0,false,true,%s,%s>", tf(s.p1), tf(s.p2),
+                     s.rt1, s.cs1, s.nch, s.it2, tf(s.nch <= 2), tf(s.vec), tf(form == 2), tf(form == 3));
     }
     else if (stem2_variant(p))
         snprintf(buf, n, "stem2_kernel<%s,%s,%d,%d,%d,%d,%s,%d,%s,false,%s,false>", tf(s.p1), tf(s.p2), s.rt1, s.cs1, s.nch,
@@ -1949,7 +2067,13 @@ hipError_t launch_stem2(const StemArgs& p, hipStream_t stream) {
     if (stem2_bf3(p)) {
         const StemShape s = stem2_shape(p, true);
         const int form = stem2_bf3_form(p);
-#if CTG_STEM_FORM >= 2
+#if CTG_STEM_FORM >= 3 && defined(CTG_STEM_WS)
+#define CTG_STEM_GO3_WS(P1, P2, R, CS, NC, IT, V) \
+        if constexpr (IT <= 2 && (P1 || R == 1)) { if (form == 3) return launch_stem2_t<P1, P2, R, CS, NC, IT, (NC <= 2), 0, V, true, false, true, false, true>(p, stream); }
+#else
+#define CTG_STEM_GO3_WS(P1, P2, R, CS, NC, IT, V)
+#endif
+#if CTG_STEM_FORM >= 2 && defined(CTG_STEM_LM)
 #define CTG_STEM_GO3_LM(P1, P2, R, CS, NC, IT, V) \
         if constexpr (IT < 4) { if (form == 2) return launch_stem2_t<P1, P2, R, CS, NC, IT, (NC <= 2), 0, V, true, false, true, true>(p, stream); }
 #else
@@ -1970,6 +2094,7 @@ hipError_t launch_stem2(const StemArgs& p, hipStream_t stream) {
 #endif
 #define CTG_STEM_GO3(P1, P2, R, CS, NC, IT, V)                                                          \
     if (s.p1 == P1 && s.p2 == P2 && s.rt1 == R && s.cs1 == CS && s.nch == NC && s.it2 == IT && s.vec == V) { \
+        CTG_STEM_GO3_WS(P1, P2, R, CS, NC, IT, V)                                                       \
         CTG_STEM_GO3_LM(P1, P2, R, CS, NC, IT, V)                                                       \
         CTG_STEM_GO3_XM(P1, P2, R, CS, NC, IT, V)                                                       \
         CTG_STEM_GO3_R4(P1, P2, R, CS, NC, IT, V)                                                       \

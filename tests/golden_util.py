@@ -104,7 +104,8 @@ def stem_flags(name):
             "br1": t[6], "k2q": int(a[7]), "vec": t[8], "bf3": t[9], "ri2": t[10], "one": t[11],
             "itm": int(a[12]) if len(a) > 12 else 0, "packm": t[13] if len(t) > 13 else False,
             # round 5: two-accumulator real parts / the intermediate as bf16 limbs
-            "xm": t[14] if len(t) > 14 else False, "lm": t[15] if len(t) > 15 else False}
+            "xm": t[14] if len(t) > 14 else False, "lm": t[15] if len(t) > 15 else False,
+            "ws": t[16] if len(t) > 16 else False}   # (specialised waves)
 
 
 def stem_network(nq, gates, seed, sliced=0):

@@ -424,8 +424,11 @@ def test_three_step_tiles_on_device(seed, bf16x3, monkeypatch):
     serve an executor whose arithmetic is switched afterwards -- against the complex128 oracle within the
     gate of the unfused HIP path; the kernel that ran carries a middle stage (its last two template
     arguments)."""
-    from cotengra_amd import stem
+    from cotengra_amd import runtime, stem
 
+    if runtime.load().ctg_stem_triple_instantiated(1, 0, 1, 2, 1, 1, 1, 1, 0) != 1:
+        pytest.skip("library built without three-step tiles (round 5: slower than pairs on every tree; "
+                    "tools/build_variants.py triples=-DCTG_STEM_TRIPLES_BUILD)")
     monkeypatch.setenv("CTG_STEM_TRIPLES", "1")
     monkeypatch.delenv("CTG_STEM_BF16X3", raising=False)
     monkeypatch.setattr(stem, "gather_rate", lambda run_bytes: 5.4e12)

@@ -94,6 +94,8 @@ def test_shares_of_all_ranks_add_up(name, groups, monkeypatch):
     scale = np.abs(ref).max()
     if tree.nslices > 4096:
         # (C5: 3.9e9 slices -- windows of a few units of every rank's share against the oracle's slices)
+        from cotengra_amd.distributed import scatter_slices
+
         a128 = [np.asarray(a).astype("complex128") for a in arrays]
         for world in (3, 8):
             ex.zero_result()
@@ -104,9 +106,11 @@ def test_shares_of_all_ranks_add_up(name, groups, monkeypatch):
                 ex.run_share(rank, world, u0, 2)
                 ids = plan.rank_slice_ids(rank, world, u0, 2)
                 assert len(ids) == 2 * gs and len({int(plan.group_of(int(i))) for i in ids}) == 2
-                want = want + sum(np.asarray(orc.contract_slice(tree, a128, int(i))) for i in ids)
+                # (sliced OUTPUT indices: every slice lands in its own chunk of the result)
+                want = want + scatter_slices(tree, [int(i) for i in ids],
+                                             [np.asarray(orc.contract_slice(tree, a128, int(i))) for i in ids])
             got = np.asarray(ex.download_result())
-            assert np.abs(got - want).max() <= 1e-10 * np.abs(want).max()
+            assert got.shape == want.shape and np.abs(got - want).max() <= 1e-10 * np.abs(want).max()
         fn.close()
         return
     for world in (1, 2, 3, 5):
@@ -287,7 +291,7 @@ def test_outer_sliced_and_real_trees_keep_their_results_with_the_wide_sum():
     for name in ("rand_s42_r3_o1_hi0_ho0_outsliced", "lattice8x8_sliced", "rand_s42_r2_o2_hi0_ho2_outsliced"):
         case = next(c for c in G.cases("tree") if c["name"] == name)
         tree = G.tree_of(case)
-        for dtype in ("complex64", "float32"):
+        for dtype in (("complex64", "float32") if "ho2" not in name else ("complex64",)):   # (the oracle itself refuses the real parts of the hyper-output tree)
             arrays = G.arrays_of(case, "complex128", tree)
             if dtype == "float32":
                 arrays = [np.ascontiguousarray(a.real) for a in arrays]
