@@ -15,6 +15,7 @@ pairs = {
     "kernels_kernels.json": f"{tag}_bench_kernels.json",
     "kernels_kernels.txt": f"{tag}_bench_kernels.txt",
     "bench_line.json": f"{tag}_bench_line.json",
+    "bench_compact.json": f"{tag}_bench_compact.json",
     "kernels_headline_kernels.json": f"{tag}_bench_kernels_headline.json",
     "kernels_headline_kernels.txt": f"{tag}_bench_kernels_headline.txt",
 }
