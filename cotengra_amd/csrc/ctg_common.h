@@ -148,6 +148,9 @@ struct StepArgs {
     // slice groups in a batched launch (round 4): operand A / B was written by a step the zq slices of a
     // group share -- it lives with the group's first slice: slice-in-batch z reads it at z / zq * zq (0, 1: off)
     int32_t zqA, zqB;
+    // this executor multiplies its long tiled steps (and its stem pairs) with bf16 x 3 products
+    // (ctg_exec_set_stem_arithmetic; csrc/ctg_pair_mfma.hip: pair_mfma_bf3_kernel)
+    int32_t bf3;
 };
 
 // Kernel arguments of a STEM2 step.

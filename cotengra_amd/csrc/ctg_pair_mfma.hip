@@ -858,6 +858,256 @@ __global__ __launch_bounds__(256, Cfg::FAST_BLOCKS) void pair_mfma_fast_kernel(S
 #endif
 }
 
+// ------------------------------------------------------------------------- //
+// The tiled fast path with fp32 products as SIX bf16 products (round 5).
+//
+// Same tiles, same gather order, same tile map, same split-K slabs and the same per-thread constants
+// (FastLane / MfmaHints::lane) as pair_mfma_fast_kernel -- what changes is the arithmetic, as in the
+// fused stem kernel (ctg_stem.hip, DESIGN 4.2 / HISTORY 4b): every fp32 operand is split EXACTLY
+// into three bfloat16 limbs, the six cross terms above 2^-24 are accumulated in fp32 by
+// v_mfma_f32_32x32x16_bf16 (16x the fp32 MFMA rate for 6x the products).  The split happens ONCE per
+// element, where a thread stages what it gathered into LDS (two ANDs and two subtractions per value, three
+// 2-byte writes that take the high halves where they are); the LDS tile holds limb planes
+//     [Re | Im][limb][k-block of 8][row][8 k]        (a lane's 8 values of one limb: 16 contiguous bytes)
+// so a fragment is one ds_read_b128 and the k-step's 16 k are ONE instruction per (component pair, limb pair).
+// Complex on real matrix cores: 32 complex columns per tile, X += Re a Re b + Im a (-Im b), Y += Re a Im b +
+// Im a Re b -- the sign lives in a negated copy of Im b's limbs (12 XORs per k-step and column tile), a lane
+// ends up with Re and Im of the same element: 8-byte stores, no lane exchange.  Steps with K >= 64 take it
+// when the executor multiplies its stem pairs this way (ctg_exec_set_stem_arithmetic; CTG_PAIR_BF16X3=0
+// keeps fp32 products here); the wave-front GROUPED launches of small steps stay on fp32 products.
+typedef __bf16 pbf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned pu32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ constexpr int pbf3_ta(int t) { return t < 3 ? 0 : (t == 5 ? 2 : 1); }
+__device__ __forceinline__ constexpr int pbf3_tb(int t) { return t == 1 || t == 4 ? 1 : (t == 2 ? 2 : 0); }
+
+template <typename Cfg, bool VEC_A>
+__global__ __launch_bounds__(256, 1) void pair_mfma_bf3_kernel(StepArgs p, MfmaHints h, int64_t tiles_m, int64_t tiles_n,
+                                                              int64_t k_chunk, float* __restrict__ partial) {
+    constexpr int BM = Cfg::BM, BN = Cfg::BN, BK = Cfg::BK;
+    static_assert(BK == 16 && BM == 128 && (BN == 64 || BN == 128), "one bf16 MFMA k-step per tile step");
+    constexpr int WTM = 64, WTN = BN / 2;        // 2 x 2 waves: 64 rows x (32 | 64) complex columns each
+    constexpr int FM = 2, FN = WTN / 32;
+    constexpr int NA = VEC_A ? Cfg::A_PER_T / 2 : Cfg::A_PER_T;
+    // limb planes, in shorts: [buf][comp 2][limb 3][kb 2][rows][8]
+    constexpr int APL = 2 * BM * 8, BPL = 2 * BN * 8;          // one (comp, limb) plane of A / B
+    constexpr int ASZ = 6 * APL, BSZ = 6 * BPL;
+    extern __shared__ __attribute__((aligned(16))) unsigned short lds_q[];
+    typedef FastLane<Cfg, VEC_A> Lane;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int kk = lane >> 5, l31 = lane & 31;
+    const int64_t S_split = k_chunk;
+    const TileMap tmap = map_tile((blockIdx.x & ~7u) | ((blockIdx.x + blockIdx.y) & 7u), tiles_m * S_split, tiles_n);
+    if (!tmap.valid) return;
+    const int64_t bz = blockIdx.z;
+    const int64_t unit = uniform64(tmap.unit), tn = uniform64(tmap.tn);
+    const int64_t ksplit = uniform64(unit / tiles_m);
+    const int64_t tm = unit - ksplit * tiles_m;
+    const int64_t m0 = tm * BM, n0 = tn * BN;
+    int64_t rhi, rlo;
+    split_row(p, m0, rhi, rlo);
+    rhi = uniform64(rhi);
+    rlo = uniform64(rlo);
+    const c64* __restrict__ A = (const c64*)p.A + zoffA_s(p) + sload64(p.bA + bz) + sload64(p.rowA.hi + rhi) + sload64(p.rowA.lo + rlo);
+    const c64* __restrict__ B = (const c64*)p.B + zoffB_s(p) + sload64(p.bB + bz) + sload64(p.nB + n0);
+    float* __restrict__ C = (float*)((c64*)p.C + zoffC_s(p) + sload64(p.bC + bz) + sload64(p.rowC.hi + rhi) +
+                                     sload64(p.rowC.lo + rlo) + sload64(p.nC + n0));
+    const int64_t nk_total = p.K / BK;
+    const int64_t nk = uniform64((nk_total - ksplit + S_split - 1) / S_split);
+
+    // per-thread constants of the gather (shared with the fp32 fast kernel); the LDS slots are decoded from
+    // its swizzled float offsets: element (row, k) of the tile
+    unsigned a_off[NA], a_ldsf[Lane::NAL], b_ldsf[Lane::NBL], b_off[Cfg::B_PER_T];
+    if (h.lane != nullptr) {
+        unsigned w[Lane::NQ * 4];
+        const uint4* L = (const uint4*)h.lane;
+#pragma unroll
+        for (int q = 0; q < Lane::NQ; ++q) {
+            const uint4 v = L[q * 256 + tid];
+            w[4 * q] = v.x;
+            w[4 * q + 1] = v.y;
+            w[4 * q + 2] = v.z;
+            w[4 * q + 3] = v.w;
+        }
+        Lane::unpack_words(w, a_off, a_ldsf, b_off, b_ldsf);
+    } else {
+        Lane::compute(p, h, tid, a_off, a_ldsf, b_off, b_ldsf);
+    }
+    // short index of element (r, c) inside a (comp, limb) plane: [kb][row][8]
+    auto slot_of = [](unsigned o, int rows, int rowscale) {
+        const int r = (int)(o / Lane::LD), sl = (int)(o % Lane::LD);
+        const int c = (((sl >> 1) ^ Lane::fsw(r)) << 1) | (sl & 1);
+        return (unsigned)((c >> 3) * rows * 8 + (r / rowscale) * 8 + (c & 7));
+    };
+    unsigned short a_q[Cfg::A_PER_T], b_q[Cfg::B_PER_T];
+#pragma unroll
+    for (int j = 0; j < Cfg::A_PER_T; ++j)
+        a_q[j] = (unsigned short)slot_of((j & 1) ? a_ldsf[j / 2] >> 16 : a_ldsf[j / 2] & 0xffffu, BM, 1);
+#pragma unroll
+    for (int j = 0; j < Cfg::B_PER_T; ++j)   // (the fp32 kernel stages column n at row 2 n of its B' tile)
+        b_q[j] = (unsigned short)slot_of((j & 1) ? b_ldsf[j / 2] >> 16 : b_ldsf[j / 2] & 0xffffu, BN, 2);
+
+    c64 a_reg[Cfg::A_PER_T], b_reg[Cfg::B_PER_T];
+    int64_t kAh = 0, kAl = 0, kBh = 0, kBl = 0;
+    auto k_bases = [&](int64_t step) {
+        const int64_t k = uniform64((step * S_split + ksplit) * BK);
+        const int64_t kh = k >> p.k_lo_shift, kl = k & (p.k_lo - 1);
+        kAh = sload64(p.kA.hi + kh);
+        kAl = sload64(p.kA.lo + kl);
+        kBh = sload64(p.kB.hi + kh);
+        kBl = sload64(p.kB.lo + kl);
+    };
+    auto gather = [&]() {
+        const c64* Ak = A + kAh + kAl;
+        if (VEC_A) {
+#pragma unroll
+            for (int j = 0; j < NA; ++j) {
+                const f32x4 v = *(const f32x4*)(Ak + a_off[j]);
+                a_reg[2 * j] = c64{v[0], v[1]};
+                a_reg[2 * j + 1] = c64{v[2], v[3]};
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < NA; ++j) a_reg[j] = Ak[a_off[j]];
+        }
+        const c64* Bk = B + kBh + kBl;
+#pragma unroll
+        for (int j = 0; j < Cfg::B_PER_T; ++j) b_reg[j] = Bk[b_off[j]];
+    };
+    // one value -> its three limbs, planes PL shorts apart
+    auto put3 = [&](unsigned short* d, int PL, float x) __attribute__((always_inline)) {
+        const unsigned u = __builtin_bit_cast(unsigned, x);
+        const float r1 = x - __builtin_bit_cast(float, u & 0xffff0000u);
+        const unsigned u1 = __builtin_bit_cast(unsigned, r1);
+        const float r2 = r1 - __builtin_bit_cast(float, u1 & 0xffff0000u);
+        d[0] = (unsigned short)(u >> 16);
+        d[PL] = (unsigned short)(u1 >> 16);
+        d[2 * PL] = (unsigned short)(__builtin_bit_cast(unsigned, r2) >> 16);
+    };
+    auto stage = [&](int buf) {
+        unsigned short* As = lds_q + buf * (ASZ + BSZ);
+        unsigned short* Bs = As + ASZ;
+#pragma unroll
+        for (int j = 0; j < Cfg::A_PER_T; ++j) {
+            put3(As + a_q[j], APL, a_reg[j].re);
+            put3(As + 3 * APL + a_q[j], APL, a_reg[j].im);
+        }
+#pragma unroll
+        for (int j = 0; j < Cfg::B_PER_T; ++j) {
+            put3(Bs + b_q[j], BPL, b_reg[j].re);
+            put3(Bs + 3 * BPL + b_q[j], BPL, b_reg[j].im);
+        }
+    };
+
+    f32x16 ax[FM][FN], ay[FM][FN];
+    const float alpha = (float)step_alpha(p);
+    // fragment bases: lane = (row | column l31, k-block kk)
+    const int a_frag = kk * BM * 8 + (wm * WTM + l31) * 8;
+    const int b_frag = kk * BN * 8 + (wn * WTN + l31) * 8;
+    auto k_step = [&](int buf, auto first_tag) {
+        constexpr bool FIRST = decltype(first_tag)::value;
+        const unsigned short* As = lds_q + buf * (ASZ + BSZ);
+        const unsigned short* Bs = As + ASZ;
+        f32x16 zero16;
+#pragma unroll
+        for (int u = 0; u < 16; ++u) zero16[u] = 0.f;
+        pbf16x8 aR[FM][3], aI[FM][3];
+#pragma unroll
+        for (int i = 0; i < FM; ++i)
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                aR[i][q] = *(const pbf16x8*)(As + q * APL + a_frag + i * 32 * 8);
+                aI[i][q] = *(const pbf16x8*)(As + (3 + q) * APL + a_frag + i * 32 * 8);
+            }
+#pragma unroll
+        for (int j = 0; j < FN; ++j) {
+            pbf16x8 bR[3], bI[3], nI[3];
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                bR[q] = *(const pbf16x8*)(Bs + q * BPL + b_frag + j * 32 * 8);
+                bI[q] = *(const pbf16x8*)(Bs + (3 + q) * BPL + b_frag + j * 32 * 8);
+                nI[q] = __builtin_bit_cast(pbf16x8, __builtin_bit_cast(pu32x4, bI[q]) ^ 0x80008000u);
+            }
+#pragma unroll
+            for (int t = 0; t < 6; ++t) {
+                const int ta = pbf3_ta(t), tb = pbf3_tb(t);
+#pragma unroll
+                for (int i = 0; i < FM; ++i) {
+                    ax[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aR[i][ta], bR[tb], (FIRST && t == 0) ? zero16 : ax[i][j], 0, 0, 0);
+                    ay[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aR[i][ta], bI[tb], (FIRST && t == 0) ? zero16 : ay[i][j], 0, 0, 0);
+                }
+#pragma unroll
+                for (int i = 0; i < FM; ++i) {
+                    ax[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aI[i][ta], nI[tb], ax[i][j], 0, 0, 0);
+                    ay[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aI[i][ta], bR[tb], ay[i][j], 0, 0, 0);
+                }
+            }
+        }
+    };
+
+    // pipeline: gather k-step t + 1 into registers while the MFMAs of k-step t run; split and stage it into the
+    // other LDS buffer; one barrier per k-step
+    k_bases(0);
+    gather();
+    stage(0);
+    if (nk > 1) {
+        k_bases(1);
+        gather();
+    }
+    __syncthreads();
+    k_step(0, std::true_type{});
+    for (int64_t kt = 1; kt < nk; ++kt) {
+        const int buf = (int)(kt & 1);
+        stage(buf);                      // (k-step kt: gathered during k-step kt - 1)
+        if (kt + 1 < nk) {
+            k_bases(kt + 1);
+            gather();
+        }
+        __syncthreads();
+        k_step(buf, std::false_type{});
+    }
+
+    // epilogue: accumulator register t of a tile is row rowmap(t) + 4 kk, the lane's column is l31
+    if (partial != nullptr) {
+        const int64_t ldp = 2 * tiles_n * BN;
+        float* slab = partial + ((((int64_t)blockIdx.y * gridDim.z + bz) * S_split + ksplit) * (tiles_m * BM)) * ldp;
+#pragma unroll
+        for (int j = 0; j < FN; ++j) {
+            const int64_t col = 2 * (n0 + wn * WTN + j * 32 + l31);
+#pragma unroll
+            for (int i = 0; i < FM; ++i)
+#pragma unroll
+                for (int t = 0; t < 16; ++t) {
+                    const int64_t row = m0 + wm * WTM + i * 32 + (t & 3) + 8 * (t >> 2) + 4 * kk;
+                    float2 v;
+                    v.x = ax[i][j][t];
+                    v.y = ay[i][j][t];
+                    *(float2*)(slab + row * ldp + col) = v;
+                }
+        }
+        return;
+    }
+    unsigned co[FN];
+#pragma unroll
+    for (int j = 0; j < FN; ++j) co[j] = (unsigned)p.nC[wn * WTN + j * 32 + l31];
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+            const unsigned ro = (unsigned)p.rowC.lo[wm * WTM + i * 32 + (t & 3) + 8 * (t >> 2) + 4 * kk];
+#pragma unroll
+            for (int j = 0; j < FN; ++j) {
+                float2 v;
+                v.x = ax[i][j][t] * alpha;
+                v.y = ay[i][j][t] * alpha;
+                *(float2*)(C + 2 * (size_t)(ro + co[j])) = v;
+            }
+        }
+}
+
 // sum the split-K slabs in a fixed order and scatter into C.  A block reduces
 // 32 outputs: 8 thread groups each add every 8th slab (loads unrolled so many
 // are in flight), then the 8 partial sums are combined in a fixed order.
@@ -906,6 +1156,18 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(StepArgs p, int64_t 
     }
 }
 
+// Arithmetic of the long tiled steps: bf16 x 3 products when the executor multiplies its stem pairs that way
+// (StepArgs::bf3: ctg_exec_set_stem_arithmetic, default on) unless CTG_PAIR_BF16X3 / CTG_STEM_BF16X3 in the
+// environment say otherwise ("0" / "" = fp32 products; read at every launch, tests switch within a process).
+static bool pair_bf16x3_on(const StepArgs& p) {
+    auto off = [](const char* v) { return v != nullptr && (v[0] == '\0' || (v[0] == '0' && v[1] == '\0')); };
+    const char* v = getenv("CTG_PAIR_BF16X3");
+    if (v != nullptr) return !off(v);
+    v = getenv("CTG_STEM_BF16X3");
+    if (v != nullptr) return !off(v);
+    return p.bf3 != 0;
+}
+
 template <typename Cfg>
 static hipError_t launch_cfg(const StepArgs& p, const MfmaHints& h, void* scratch,
                              int64_t scratch_bytes, hipStream_t stream) {
@@ -933,6 +1195,32 @@ static hipError_t launch_cfg(const StepArgs& p, const MfmaHints& h, void* scratc
     if (gx > 0x7fffffffll || p.nz > 65535) return hipErrorInvalidValue;
     const dim3 grid((unsigned)gx, (unsigned)p.nz, (unsigned)p.Bt);
     float* part = S > 1 ? (float*)scratch : (float*)nullptr;
+    if constexpr (Cfg::BN >= 64) {
+        // fp32 products as six bf16 products (pair_mfma_bf3_kernel): long contractions on full tiles
+        if (h.fast && p.K >= 64 && pair_bf16x3_on(p)) {
+            constexpr size_t smem = 2 * 2 * 6 * (size_t)(2 * Cfg::BM * 8 + 2 * Cfg::BN * 8);
+            static unsigned long long ready[2] = {0, 0};
+            const void* fn = h.vecA ? (const void*)pair_mfma_bf3_kernel<Cfg, true> : (const void*)pair_mfma_bf3_kernel<Cfg, false>;
+            int dev = 0;
+            (void)hipGetDevice(&dev);
+            if (!((ready[h.vecA ? 1 : 0] >> dev) & 1ull)) {
+                const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+                if (e != hipSuccess) return e;
+                ready[h.vecA ? 1 : 0] |= 1ull << dev;
+            }
+            if (h.vecA)
+                hipLaunchKernelGGL((pair_mfma_bf3_kernel<Cfg, true>), grid, dim3(256), smem, stream, p, h, tiles_m, tiles_n, k_chunk, part);
+            else
+                hipLaunchKernelGGL((pair_mfma_bf3_kernel<Cfg, false>), grid, dim3(256), smem, stream, p, h, tiles_m, tiles_n, k_chunk, part);
+            if (S > 1) {
+                int64_t blocks = (p.R * p.N * p.Bt + 31) / 32;
+                if (blocks > 8192) blocks = 8192;
+                hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)blocks, (unsigned)p.nz), dim3(256), 0, stream, p, S,
+                                   tiles_m * BM, 2 * tiles_n * BN, (const float*)scratch);
+            }
+            return hipGetLastError();
+        }
+    }
     if (h.fast) {
         if (h.vecA)
             hipLaunchKernelGGL((pair_mfma_fast_kernel<Cfg, true>), grid, dim3(256), 0, stream, p, h,

@@ -464,6 +464,7 @@ void resolve_args(ctg_exec* e) {
         }
         a.facA = a.facB = nullptr;
         a.check_zero = e->check_zero;
+        a.bf3 = e->stem_bf16x3;
         if (e->strip && r[W_KIND] == KIND_PAIR) {
             auto fac = [&](int w) -> const double* {
                 return (r[w] >= 0 && r[w] < p->n_steps) ? e->d_fac + r[w] : e->d_fac + p->n_steps;
@@ -1699,6 +1700,15 @@ int ctg_exec_set_stem_arithmetic(ctg_exec* e, int bf16x3) {
     HIP_TRY(hipStreamSynchronize(e->stream));
     e->stem_bf16x3 = bf16x3;
     for (auto& q : e->stem_args) q.bf3 = bf16x3;
+    for (auto& a : e->args) a.bf3 = bf16x3;
+    // (a captured slice graph holds the kernels of the old arithmetic, and the slice-invariant steps were computed
+    // with it)
+    if (e->gexec) {
+        (void)hipGraphExecDestroy(e->gexec);
+        e->gexec = nullptr;
+    }
+    e->invariants_ready = false;
+    e->group_key = -1;
     return CTG_OK;
 }
 
