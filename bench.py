@@ -236,6 +236,8 @@ def step_peak_tflops(r, bf16x3=False):
     bf16 matrix cores with three-way split operands: bf16 peak / 6 products (decided per launch
     by the kernel's name when the row carries one)."""
     name = r.get("kernel_name") or r.get("kernel_symbol")
+    if name is not None and name.startswith("pair_mfma_bf3_kernel"):   # (long tiled steps, round 5)
+        return PEAK_BF16X3_TFLOPS
     if name is not None and name.startswith("stem2_kernel<"):
         return PEAK_BF16X3_TFLOPS if is_bf16x3_kernel(name) else PEAK_MFMA_F32_TFLOPS
     return PEAK_BF16X3_TFLOPS if (bf16x3 and r.get("kind") == "stem2") else PEAK_MFMA_F32_TFLOPS

@@ -393,6 +393,10 @@ struct MfmaHints {
     int splitk;        // tiled kernels: number of k-splits (>= 1), fixed when the executor is
                        // built -- a function of the step alone, so that a result does not
                        // depend on how many slices share a launch or on the tile width
+    int bf3;           // round 5: a LONG tiled step (K >= 64, N a multiple of 64, full tiles at bn = 64) --
+                       // its products may run as six bf16 products (pair_mfma_bf3_kernel).  A function of
+                       // the step alone: such a step keeps tiles of >= 64 columns in every launch and stays
+                       // out of the wave-front groups, so that the arithmetic never depends on batching
 };
 
 // k-splits of a tiled step: when the output alone cannot fill the chip but K is long
@@ -516,6 +520,7 @@ size_t stem2_lds_bytes(const StemArgs& p);
 hipError_t launch_stem2(const StemArgs& p, hipStream_t stream);
 void stem2_kernel_name(const StemArgs& p, char* buf, size_t n);
 hipError_t launch_single(int dtype, const StepArgs& p, hipStream_t stream);
+bool pair_bf16x3_on(const StepArgs& p);   // (ctg_pair_mfma.hip) do long tiled steps multiply with bf16 x 3 products right now?
 hipError_t launch_accum(int dtype, const StepArgs& p, const StripState* st, void* wide, const double* inscale, hipStream_t stream);
 // (single-precision trees) inputs far from 1 are brought to [1, 2) by an exact power of two at upload; inscale[0] =
 // the product of the powers taken out, inscale[1] = its log10

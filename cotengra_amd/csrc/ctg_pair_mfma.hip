@@ -864,10 +864,10 @@ __global__ __launch_bounds__(256, Cfg::FAST_BLOCKS) void pair_mfma_fast_kernel(S
 // Same tiles, same gather order, same tile map, same split-K slabs and the same per-thread constants
 // (FastLane / MfmaHints::lane) as pair_mfma_fast_kernel -- what changes is the arithmetic, as in the
 // fused stem kernel (ctg_stem.hip, DESIGN 4.2 / HISTORY 4b): every fp32 operand is split EXACTLY
-// into three bfloat16 limbs, the six cross terms above 2^-24 are accumulated in fp32 by
-// v_mfma_f32_32x32x16_bf16 (16x the fp32 MFMA rate for 6x the products).  The split happens ONCE per
-// element, where a thread stages what it gathered into LDS (two ANDs and two subtractions per value, three
-// 2-byte writes that take the high halves where they are); the LDS tile holds limb planes
+// into three bfloat16 limbs (rounded to nearest: see put3x2), the six cross terms above 2^-24 are accumulated
+// in fp32 by v_mfma_f32_32x32x16_bf16 (16x the fp32 MFMA rate for 6x the products).  The split happens ONCE per
+// element, where a thread stages what it gathered into LDS (five vector instructions per value, three 2-byte
+// writes); the LDS tile holds limb planes
 //     [Re | Im][limb][k-block of 8][row][8 k]        (a lane's 8 values of one limb: 16 contiguous bytes)
 // so a fragment is one ds_read_b128 and the k-step's 16 k are ONE instruction per (component pair, limb pair).
 // Complex on real matrix cores: 32 complex columns per tile, X += Re a Re b + Im a (-Im b), Y += Re a Im b +
@@ -977,29 +977,32 @@ __global__ __launch_bounds__(256, 1) void pair_mfma_bf3_kernel(StepArgs p, MfmaH
 #pragma unroll
         for (int j = 0; j < Cfg::B_PER_T; ++j) b_reg[j] = Bk[b_off[j]];
     };
-    // one value -> its three limbs, planes PL shorts apart
-    auto put3 = [&](unsigned short* d, int PL, float x) __attribute__((always_inline)) {
-        const unsigned u = __builtin_bit_cast(unsigned, x);
-        const float r1 = x - __builtin_bit_cast(float, u & 0xffff0000u);
-        const unsigned u1 = __builtin_bit_cast(unsigned, r1);
-        const float r2 = r1 - __builtin_bit_cast(float, u1 & 0xffff0000u);
-        d[0] = (unsigned short)(u >> 16);
-        d[PL] = (unsigned short)(u1 >> 16);
-        d[2 * PL] = (unsigned short)(__builtin_bit_cast(unsigned, r2) >> 16);
+    // two values -> their three limbs each, planes PL shorts apart.  ROUNDED limbs (v_cvt_pk_bf16_f32: round to
+    // nearest even, two values per instruction): x = l1 + l2 + l3 stays exact -- the remainder after two rounded
+    // limbs has at most 7 significant bits -- and the three cross terms that are not computed (l2 m3, l3 m2, l3 m3)
+    // are below 2^-26 of the product with either sign, where truncated limbs leave up to 2^-23 of one sign: the
+    // products carry the fp32 kernel's error, not 1.2 x it (the split is once per element here: 5 instead of 4
+    // vector instructions per value are nothing next to 96 MFMAs)
+    auto put3x2 = [&](unsigned short* d0, unsigned short* d1, int PL, float x0, float x1) __attribute__((always_inline)) {
+        unsigned p1, p2;
+        asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(p1) : "v"(x0), "v"(x1));
+        const float r0 = x0 - __builtin_bit_cast(float, p1 << 16), r1 = x1 - __builtin_bit_cast(float, p1 & 0xffff0000u);
+        asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(p2) : "v"(r0), "v"(r1));
+        const float s0 = r0 - __builtin_bit_cast(float, p2 << 16), s1 = r1 - __builtin_bit_cast(float, p2 & 0xffff0000u);
+        d0[0] = (unsigned short)p1;
+        d1[0] = (unsigned short)(p1 >> 16);
+        d0[PL] = (unsigned short)p2;
+        d1[PL] = (unsigned short)(p2 >> 16);
+        d0[2 * PL] = (unsigned short)(__builtin_bit_cast(unsigned, s0) >> 16);
+        d1[2 * PL] = (unsigned short)(__builtin_bit_cast(unsigned, s1) >> 16);
     };
     auto stage = [&](int buf) {
         unsigned short* As = lds_q + buf * (ASZ + BSZ);
         unsigned short* Bs = As + ASZ;
 #pragma unroll
-        for (int j = 0; j < Cfg::A_PER_T; ++j) {
-            put3(As + a_q[j], APL, a_reg[j].re);
-            put3(As + 3 * APL + a_q[j], APL, a_reg[j].im);
-        }
+        for (int j = 0; j < Cfg::A_PER_T; ++j) put3x2(As + a_q[j], As + 3 * APL + a_q[j], APL, a_reg[j].re, a_reg[j].im);
 #pragma unroll
-        for (int j = 0; j < Cfg::B_PER_T; ++j) {
-            put3(Bs + b_q[j], BPL, b_reg[j].re);
-            put3(Bs + 3 * BPL + b_q[j], BPL, b_reg[j].im);
-        }
+        for (int j = 0; j < Cfg::B_PER_T; ++j) put3x2(Bs + b_q[j], Bs + 3 * BPL + b_q[j], BPL, b_reg[j].re, b_reg[j].im);
     };
 
     f32x16 ax[FM][FN], ay[FM][FN];
@@ -1159,7 +1162,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(StepArgs p, int64_t 
 // Arithmetic of the long tiled steps: bf16 x 3 products when the executor multiplies its stem pairs that way
 // (StepArgs::bf3: ctg_exec_set_stem_arithmetic, default on) unless CTG_PAIR_BF16X3 / CTG_STEM_BF16X3 in the
 // environment say otherwise ("0" / "" = fp32 products; read at every launch, tests switch within a process).
-static bool pair_bf16x3_on(const StepArgs& p) {
+bool pair_bf16x3_on(const StepArgs& p) {
     auto off = [](const char* v) { return v != nullptr && (v[0] == '\0' || (v[0] == '0' && v[1] == '\0')); };
     const char* v = getenv("CTG_PAIR_BF16X3");
     if (v != nullptr) return !off(v);
@@ -1197,7 +1200,7 @@ static hipError_t launch_cfg(const StepArgs& p, const MfmaHints& h, void* scratc
     float* part = S > 1 ? (float*)scratch : (float*)nullptr;
     if constexpr (Cfg::BN >= 64) {
         // fp32 products as six bf16 products (pair_mfma_bf3_kernel): long contractions on full tiles
-        if (h.fast && p.K >= 64 && pair_bf16x3_on(p)) {
+        if (h.fast && h.bf3 && pair_bf16x3_on(p)) {
             constexpr size_t smem = 2 * 2 * 6 * (size_t)(2 * Cfg::BM * 8 + 2 * Cfg::BN * 8);
             static unsigned long long ready[2] = {0, 0};
             const void* fn = h.vecA ? (const void*)pair_mfma_bf3_kernel<Cfg, true> : (const void*)pair_mfma_bf3_kernel<Cfg, false>;

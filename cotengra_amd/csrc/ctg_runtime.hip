@@ -832,13 +832,17 @@ int build_hints_into(ctg_exec* e, std::vector<MfmaHints>& hints, int64_t zmult,
         // small problems: narrower column tiles until the output alone gives every
         // CU a block -- cheaper than split-K (no slabs to write and reduce); long
         // contractions (K >= 1024) count the k-splits as blocks
+        // long contractions on full 64-column tiles: candidates for bf16 x 3 products (MfmaHints::bf3)
+        h.bf3 = (!h.stream && r[W_K] >= 64 && r[W_N] % 64 == 0 && r[W_R] % MFMA_BM == 0 && r[W_K] % MFMA_BK == 0 &&
+                 r[W_BT] == 1 && mfma_fast_ok(p, r, 64) && !env_on("CTG_NO_PAIR_BF3")) ? 1 : 0;
+        if (h.bf3 && h.bn > 64 && !mfma_fast_ok(p, r, h.bn)) h.bn = 64;
         if (!h.stream) {
             const int64_t tiles_m = (r[W_R] + MFMA_BM - 1) / MFMA_BM;
             const int64_t per_tile = r[W_K] >= 1024 ? splits : 1;
             // (two blocks per CU: a CU with a single block has nothing to overlap its
             // gather latency with -- 8x8 lattice, 4096 x 256 x 256 step: 49 -> 20 us)
             static const int64_t fill = getenv("CTG_TILE_FILL") ? atoll(getenv("CTG_TILE_FILL")) : 512;
-            while (h.bn > 16 && tiles_m * ((r[W_N] + h.bn - 1) / h.bn) * r[W_BT] * per_tile * zmult < fill)
+            while (h.bn > (h.bf3 ? 64 : 16) && tiles_m * ((r[W_N] + h.bn - 1) / h.bn) * r[W_BT] * per_tile * zmult < fill)
                 h.bn /= 2;
             // the number of k-splits belongs to the step: taken from the single-slice
             // hints; a wider tile whose slabs would not fit the scratch is given up
@@ -884,6 +888,7 @@ int build_hints_into(ctg_exec* e, std::vector<MfmaHints>& hints, int64_t zmult,
         }
         build_mfma_order(p, r, h.bn, h.stream ? 32 : MFMA_BM, blob, &offA[s], &offB[s], &h.vecA);
         h.fast = (!h.stream && mfma_fast_ok(p, r, h.bn)) ? 1 : 0;
+        if (!h.fast || h.bn < 64) h.bf3 = 0;
     }
     if (blob.empty()) return CTG_OK;
     HIP_TRY(hipMalloc((void**)d_ord_out, blob.size() * sizeof(uint16_t)));
@@ -1047,6 +1052,7 @@ int build_groups(ctg_exec* e) {
             return it.n_tiles <= kValuGroupMaxTiles ? 0 : -1;
         }
         if (p->dtype != CTG_C64 || fast_off) return -1;
+        if (e->hints[s].bf3) return -1;   // (its arithmetic is its own kernel's: never inside a shared launch)
         const int key = fast_group_key(e->args[s], e->hints[s]);
         // (a launch that carries several slices may prefer a wider tile: such steps stay alone)
         if (key < 0 || (!e->hints_b.empty() && fast_group_key(e->args[s], e->hints_b[s]) != key)) return -1;
@@ -2044,6 +2050,8 @@ int ctg_exec_step_kernel(ctg_exec* e, int64_t step, char* buf, int64_t buflen) {
             snprintf(name, sizeof(name), "pair_mfma_stream_kernel<%d,%s,%s,%s,%d>", h.bn / 16,
                      (h.vecA && h.additive32) ? "true" : "false", h.additive32 ? "true" : "false",
                      r[W_K] < MFMA_BK ? "true" : "false", r[W_K] <= 4 ? 2 : (r[W_K] <= 8 ? 4 : 8));
+        else if (h.bf3 && pair_bf16x3_on(e->args[step]))
+            snprintf(name, sizeof(name), "pair_mfma_bf3_kernel<128,%d,16>,%s", h.bn, h.vecA ? "true" : "false");
         else
             snprintf(name, sizeof(name), "%s<128,%d,16>,%s",
                      h.fast ? "pair_mfma_fast_kernel" : "pair_mfma_c64_kernel", h.bn,

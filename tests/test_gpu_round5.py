@@ -379,3 +379,56 @@ def test_inputs_at_both_ends_of_the_fp32_range(bf16x3, fuse_whatever_fits, monke
     off = np.asarray(fn0(*arrays))
     fn0.close()
     assert np.array_equal(off, plain)
+
+
+# ---------------------------------------------------------------------- #
+# long tiled steps with bf16 x 3 products (csrc/ctg_pair_mfma.hip: pair_mfma_bf3_kernel)
+# ---------------------------------------------------------------------- #
+
+
+def _gemm_tree(R, K, N):
+    import cotengra_amd as ca_
+
+    return ca_.ContractionTree.from_path([("a", "b"), ("b", "c")], ("a", "c"), dict(a=R, b=K, c=N), path=[(0, 1)])
+
+
+@pytest.mark.parametrize("R,K,N", [(1024, 512, 512), (4096, 64, 64), (256, 1024, 128), (128, 256, 64)])
+def test_long_tiled_steps_multiply_on_the_bf16_pipe(R, K, N, monkeypatch):
+    """A GEMM-like complex64 step with K >= 64 on full 64-column tiles runs pair_mfma_bf3_kernel (fp32 operands
+    split exactly into three ROUNDED bf16 limbs where they are staged into LDS, six products on
+    v_mfma_f32_32x32x16_bf16) unless CTG_PAIR_BF16X3 / CTG_STEM_BF16X3 = 0.  Against the complex128 oracle:
+    the fp32 kernel's accuracy -- random data, 2^+-40 of dynamic range across rows and columns (judged per row
+    and column scale), and a contraction that cancels by 2^-12."""
+    monkeypatch.delenv("CTG_STEM_BF16X3", raising=False)
+    tree = _gemm_tree(R, K, N)
+    rng = np.random.default_rng(R + K + N)
+
+    def cplx(*shape):
+        return (rng.standard_normal(shape) + 1j * rng.standard_normal(shape)).astype("complex64")
+
+    a, b = cplx(R, K), cplx(K, N)
+    row = np.exp2(rng.integers(-40, 41, size=R)).astype("float32")
+    col = np.exp2(rng.integers(-40, 41, size=N)).astype("float32")
+    a_wide, b_wide = (a * row[:, None]).astype("complex64"), (b * col[None, :]).astype("complex64")
+    a_canc = a.copy()
+    a_canc[:, K // 2:] = -a[:, : K // 2]
+    b_canc = b.copy()
+    b_canc[K // 2:, :] = b[: K // 2, :] * np.float32(1.0 + 2.0**-12)
+    cases = {"random": (a, b, np.ones(R), np.ones(N)), "wide": (a_wide, b_wide, row, col), "cancelling": (a_canc, b_canc, np.ones(R), np.ones(N))}
+    fn = HipContractor(tree)
+    errs = {}
+    for label, (x, y, rs, cs) in cases.items():
+        ref = x.astype("complex128") @ y.astype("complex128")
+        # error relative to the size of the terms: |a_i| . |b_j| per element
+        terms = np.abs(x.astype("complex128")) @ np.abs(y.astype("complex128"))
+        for mode in ("1", "0"):
+            monkeypatch.setenv("CTG_PAIR_BF16X3", mode)
+            got = np.asarray(fn(x, y)).astype("complex128")
+            names = fn.setup(x, y)["exec"].step_kernels()
+            assert any(n.startswith("pair_mfma_bf3_kernel" if mode == "1" else "pair_mfma_fast_kernel") for n in names), names
+            errs[(label, mode)] = float((np.abs(got - ref) / terms).max())
+    fn.close()
+    print({k: f"{v:.2e}" for k, v in errs.items()})
+    for label in cases:
+        assert errs[(label, "0")] <= 2e-6
+        assert errs[(label, "1")] <= max(1.5 * errs[(label, "0")], 2e-7), label

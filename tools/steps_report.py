@@ -23,6 +23,8 @@ P32, PBF3, BW = 157.3e12, 2500e12 / 6, 8e12
 
 def peak(r):
     name = r.get("kernel_name") or ""
+    if name.startswith("pair_mfma_bf3_kernel"):
+        return PBF3
     if name.startswith("stem2_kernel<"):
         a = name[len("stem2_kernel<"):].rstrip(">").split(",")
         return PBF3 if len(a) >= 10 and a[9].strip() == "true" else P32
