@@ -525,6 +525,9 @@ def small_config(name, tree, arrays, dev, slices, reps, cpu_slices, note, dtype=
     batch = ex.batch
     launches = ex.launch_count()[1]   # independent small steps share launches
     roof_ms = mixed_roofline_ms(rows, 8.0) * slices   # (no fused pairs here: moved = algorithmic bytes)
+    # (round 5: long tiled steps multiply on the bf16 pipe -- pair_mfma_bf3_kernel -- and are priced against bf16
+    # peak / 6 above; the same sum with every step priced on the fp32 pipe is what rounds 1-4 reported)
+    roof32_ms = mixed_roofline_ms(rows, 8.0, moved=False) * slices
     flops = (executed_flops(plan, ids) if ids is not None else
              executed_flops(plan, list(range(slices))) if plan.group_size > 1 else plan.flops_per_slice() * slices)
     # the oracle (numpy, the reference's executor restated) on this node's cores
@@ -545,6 +548,9 @@ def small_config(name, tree, arrays, dev, slices, reps, cpu_slices, note, dtype=
         "tflops": flops / dt / 1e12,
         "mixed_roofline_ms": roof_ms,
         "mixed_roofline_frac": roof_ms / (dt * 1e3),
+        "mixed_roofline_fp32_pipe_ms": roof32_ms,
+        "mixed_roofline_fp32_pipe_frac": roof32_ms / (dt * 1e3),
+        "bf16x3_steps": sum(1 for r in rows if (r.get("kernel_name") or "").startswith("pair_mfma_bf3_kernel")),
         "cpu_oracle_ms": cpu * 1e3,
         "cpu_cores": host_cores(),
         "cpu_sample": f"{cpu_slices} slice(s) with numpy {dtype}, scaled to {slices}",
@@ -768,6 +774,8 @@ def compact_record(out, full_path="bench_full.json"):
         if "mixed_roofline_frac" in c:
             legs[name + "_ms"] = c.get("ms")
             legs[name + "_frac"] = c.get("mixed_roofline_frac")
+            if c.get("bf16x3_steps"):   # (some steps on the bf16 pipe: the fraction with every step priced at 157.3 TF next to it)
+                legs[name + "_frac_fp32_pipe"] = c.get("mixed_roofline_fp32_pipe_frac")
         elif "amplitudes_per_sec" in c:
             legs[name + "_per_sec"] = c.get("amplitudes_per_sec")
         elif "ms" in c:

@@ -532,13 +532,13 @@ hipError_t launch_widen(int dtype, void* wide, const void* result, int64_t n, hi
 // ------------------------------------------------------------------------- //
 
 // Single-precision trees.  An input whose largest |element| lies outside [2^-32, 2^32) is multiplied by the
-// power of two that brings it to [1, 2) -- exact -- and the powers taken out are summed; the accumulate step
+// power of two that brings it back to the edge of that window -- exact -- and the powers taken out are summed; the accumulate step
 // multiplies them back in (double precision), a strip_exponent run adds them to its exponent.  Inputs in the
 // range are not touched (bit-identical results).  What this buys: the reference normalises after EVERY step
 // under strip_exponent (contract.py:816-829); here normalisation is lazy -- the consumer's epilogue scales --
 // so two raw inputs below 2^-40 meeting in one fused pair would underflow the fp32 intermediate before any
 // scale is applied, and the bf16 x 3 split loses its third limb on an operand below 2^-110.  After this pass
-// every input is O(1) or within 2^+-32 of it.  One workgroup per input (they are KBs).
+// every input's largest element is within 2^+-32 of 1.  One workgroup per input (they are KBs).
 __device__ __forceinline__ double abs_max_part(float a) { return fabs((double)a); }
 __device__ __forceinline__ double abs_max_part(c64 a) { return fmax(fabs((double)a.re), fabs((double)a.im)); }
 
@@ -565,9 +565,13 @@ __global__ __launch_bounds__(256) void prescale_inputs_kernel(T* inputs, const i
     (void)frexp(mx, &ex);
     ex -= 1;   // mx = m 2^ex with m in [1, 2)
     if (ex >= -32 && ex < 32) return;
-    const double f = ldexp(1.0, -ex);
+    // the SMALLEST shift that brings the largest element into the window -- to [2^31, 2^32) from above, to
+    // [2^-32, 2^-31) from below: an input with a wide range of its own (rows 2^80 apart) keeps as many of its
+    // small elements -- and of the products they enter -- inside the fp32 range as the window allows
+    const int shift = ex >= 32 ? ex - 31 : ex + 32;
+    const double f = ldexp(1.0, -shift);
     for (int64_t i = threadIdx.x; i < n; i += 256) x[i] = scale_of(x[i], f);
-    if (threadIdx.x == 0) atomicAdd(shift_total, ex);
+    if (threadIdx.x == 0) atomicAdd(shift_total, shift);
 }
 
 __global__ void prescale_finish_kernel(const int* shift_total, double* inscale) {

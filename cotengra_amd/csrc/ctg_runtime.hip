@@ -833,8 +833,11 @@ int build_hints_into(ctg_exec* e, std::vector<MfmaHints>& hints, int64_t zmult,
         // CU a block -- cheaper than split-K (no slabs to write and reduce); long
         // contractions (K >= 1024) count the k-splits as blocks
         // long contractions on full 64-column tiles: candidates for bf16 x 3 products (MfmaHints::bf3)
+        // (... of a size that fills the chip with 64-column tiles in a launch of the plan's nominal batch -- a
+        // function of the plan, like the k-splits: a small tree's steps keep their narrow tiles and shared launches)
         h.bf3 = (!h.stream && r[W_K] >= 64 && r[W_N] % 64 == 0 && r[W_R] % MFMA_BM == 0 && r[W_K] % MFMA_BK == 0 &&
-                 r[W_BT] == 1 && mfma_fast_ok(p, r, 64) && !env_on("CTG_NO_PAIR_BF3")) ? 1 : 0;
+                 r[W_BT] == 1 && (r[W_R] / MFMA_BM) * (r[W_N] / 64) * std::max<int64_t>(e->batch_nominal, 1) >= 512 &&
+                 mfma_fast_ok(p, r, 64) && !env_on("CTG_NO_PAIR_BF3")) ? 1 : 0;
         if (h.bf3 && h.bn > 64 && !mfma_fast_ok(p, r, h.bn)) h.bn = 64;
         if (!h.stream) {
             const int64_t tiles_m = (r[W_R] + MFMA_BM - 1) / MFMA_BM;

@@ -119,10 +119,10 @@ __device__ __forceinline__ void load_b_planes(float* P, const c64* __restrict__ 
 
 
 // ---- fp32 products on the bf16 matrix cores (template argument BF3) ------------------------
-// An fp32 value splits EXACTLY into three bfloat16 values (8 + 8 + 8 mantissa bits: two ANDs,
-// two subtractions); products of bf16 values are exact in fp32, so a real multiply-add becomes
-// the 6 cross terms above 2^-24 (the three smallest of the nine are dropped: truncation error
-// 4e-8 against the 1e-6 of fp32 accumulation itself, tools/exp_bf16x3.py) accumulated in fp32 by
+// An fp32 value splits EXACTLY into three bfloat16 values (rounded limbs since round 5 -- split3 below; truncated
+// ones, 8 + 8 + 8 mantissa bits, before); products of bf16 values are exact in fp32, so a real multiply-add becomes
+// the 6 cross terms above 2^-24 (the three smallest of the nine are dropped: below 2^-26 of the product with
+// rounded limbs, tools/exp_bf16x3.py) accumulated in fp32 by
 // v_mfma_f32_32x32x16_bf16 -- 16 k per instruction at 16x the fp32 MFMA rate, i.e. 2.7x the fp32
 // matrix peak (measured with the splitting: 1.7x, tools/exp_bf16x3_rate.py).  A lane holds 8
 // values of k per operand; which 8 is the same function of (lane half, position) for both
@@ -135,31 +135,35 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ constexpr int bf3_ta(int t) { return t < 3 ? 0 : (t == 5 ? 2 : 1); }
 __device__ __forceinline__ constexpr int bf3_tb(int t) { return t == 1 || t == 4 ? 1 : (t == 2 ? 2 : 0); }
 
+// Two values -> the packed pair of their bf16 roundings (round to nearest even; lo = a, hi = b).
+__device__ __forceinline__ unsigned cvt_pk_bf16(float a, float b) {
+    unsigned r;
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
 __device__ __forceinline__ void split3(const float (&x)[8], bf16x8 (&o)[3]) {
-    // Per value: two ANDs and two subtractions.  A limb's bf16 pattern is the HIGH half of an fp32
-    // word whose low half does not matter (x itself for the first limb: truncation IS the limb; the
-    // remainders r1, r2 for the others -- r2 has at most 8 significant bits, its low half is zero), so
-    // two limbs are packed by ONE byte permute (v_perm_b32: bytes 2, 3 of each word) instead of
-    // shift + mask + or: 5.5 instead of 7 vector instructions per value (round 4: the bf16 x 3 kernel
-    // runs at the board's power limit, every instruction removed is clock).
-    unsigned w[3][8];
+    // Round 5: ROUNDED limbs.  l1 = rn(x), l2 = rn(x - l1), l3 = x - l1 - l2: the remainder after two rounded limbs
+    // has at most 7 significant bits, so x = l1 + l2 + l3 stays EXACT, and the three cross terms that are not
+    // computed (l2 m3, l3 m2, l3 m3) are below 2^-26 of the product with either sign -- truncated limbs (round 3-4)
+    // leave up to 2^-23 of ONE sign there, which is where the bf16 x 3 kernels' 1.1-1.2 x the fp32 kernel's error
+    // came from.  Same instruction count as the truncating split (5.5 per value): v_cvt_pk_bf16_f32 rounds and packs two
+    // values at once (no byte permute for the first two limbs), a shift / a mask turn the pair back into floats for
+    // the subtractions, one permute packs the third limbs.  (|x| within 2^-9 of the largest float rounds to inf:
+    // inputs that large lost a power of two at upload, ctg_kernels_valu.hip: prescale_inputs_kernel.)
+    u32x4 p1, p2, p3;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const unsigned u = __builtin_bit_cast(unsigned, x[i]);
-        const float r1 = x[i] - __builtin_bit_cast(float, u & 0xffff0000u);
-        const unsigned u1 = __builtin_bit_cast(unsigned, r1);
-        const float r2 = r1 - __builtin_bit_cast(float, u1 & 0xffff0000u);
-        w[0][i] = u;
-        w[1][i] = u1;
-        w[2][i] = __builtin_bit_cast(unsigned, r2);
+    for (int i = 0; i < 4; ++i) {
+        const float a = x[2 * i], b = x[2 * i + 1];
+        p1[i] = cvt_pk_bf16(a, b);
+        const float ra = a - __builtin_bit_cast(float, p1[i] << 16), rb = b - __builtin_bit_cast(float, p1[i] & 0xffff0000u);
+        p2[i] = cvt_pk_bf16(ra, rb);
+        const float sa = ra - __builtin_bit_cast(float, p2[i] << 16), sb = rb - __builtin_bit_cast(float, p2[i] & 0xffff0000u);
+        p3[i] = __builtin_amdgcn_perm(__builtin_bit_cast(unsigned, sb), __builtin_bit_cast(unsigned, sa), 0x07060302u);
     }
-#pragma unroll
-    for (int q = 0; q < 3; ++q) {
-        u32x4 pk;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) pk[i] = __builtin_amdgcn_perm(w[q][2 * i + 1], w[q][2 * i], 0x07060302u);
-        o[q] = __builtin_bit_cast(bf16x8, pk);
-    }
+    o[0] = __builtin_bit_cast(bf16x8, p1);
+    o[1] = __builtin_bit_cast(bf16x8, p2);
+    o[2] = __builtin_bit_cast(bf16x8, p3);
 }
 
 __device__ __forceinline__ f32x16 mfma_bf(bf16x8 a, bf16x8 b, f32x16 c) {
@@ -197,10 +201,10 @@ __device__ __forceinline__ void load_b_planes_bf3(unsigned short* Q, const c64* 
 #pragma unroll
         for (int pl = 0; pl < 3; ++pl) {
             if (pl >= planes) break;
-            const float x = vals[pl];
-            const unsigned h1 = __builtin_bit_cast(unsigned, x) & 0xffff0000u;
+            const float x = vals[pl];   // (rounded limbs, as split3)
+            const unsigned h1 = cvt_pk_bf16(x, 0.f) << 16;
             const float r1 = x - __builtin_bit_cast(float, h1);
-            const unsigned h2 = __builtin_bit_cast(unsigned, r1) & 0xffff0000u;
+            const unsigned h2 = cvt_pk_bf16(r1, 0.f) << 16;
             const float r2 = r1 - __builtin_bit_cast(float, h2);
             unsigned short* d = Q + (pl * N + n) * ROW + at;
             d[0] = (unsigned short)(h1 >> 16);
@@ -943,10 +947,10 @@ __global__ __launch_bounds__(SW * 64, 1) void stem2_kernel(StemArgs p) {
     // LM: one value -> its three limbs at dst[0], dst[8], dst[16] (the high halves of x, x - limb 1, and of
     // what is left of that)
     auto put3 = [&](unsigned short* dst, float x) __attribute__((always_inline)) {
-        const unsigned u = __builtin_bit_cast(unsigned, x);
-        const float r1 = x - __builtin_bit_cast(float, u & 0xffff0000u);
-        const unsigned u1 = __builtin_bit_cast(unsigned, r1);
-        const float r2 = r1 - __builtin_bit_cast(float, u1 & 0xffff0000u);
+        const unsigned u = cvt_pk_bf16(x, 0.f) << 16;
+        const float r1 = x - __builtin_bit_cast(float, u);
+        const unsigned u1 = cvt_pk_bf16(r1, 0.f) << 16;
+        const float r2 = r1 - __builtin_bit_cast(float, u1);
         dst[0] = (unsigned short)(u >> 16);
         dst[8] = (unsigned short)(u1 >> 16);
         dst[16] = (unsigned short)(__builtin_bit_cast(unsigned, r2) >> 16);
