@@ -74,9 +74,11 @@ def test_narrowed_trees_against_oracle(fixture, log2_width):
         fn.close()
         assert rel(got128, ref) <= 1e-10
         # (a slice amplitude is a cancelling sum: numpy's complex64 run and the HIP path round it
-        # independently, and on slices that cancel hard the ratio of their errors scatters between
-        # 0.3 and 12 -- profiles/r3_single_precision_errors.txt; hence 16 x here, 8 x elsewhere)
-        gate = max(NORTH_STAR, 16.0 * rel(np64, ref))
+        # independently.  Round 5 -- rounded limbs in every bf16 x 3 split -- 23 of these 24 slices are below
+        # 1e-5 outright (worst 4.6e-6) and the remaining one is at 1.7 x numpy's own error:
+        # profiles/r5_single_precision_errors.txt; the gate is the 8 x of every other single-precision test,
+        # where rounds 3-4 needed 16 x here)
+        gate = max(NORTH_STAR, 8.0 * rel(np64, ref))
         assert rel(got64, ref) <= gate, (rel(got64, ref), gate, rel(np64, ref))
 
 
