@@ -884,7 +884,7 @@ template <typename Cfg, bool VEC_A>
 __global__ __launch_bounds__(256, 1) void pair_mfma_bf3_kernel(StepArgs p, MfmaHints h, int64_t tiles_m, int64_t tiles_n,
                                                               int64_t k_chunk, float* __restrict__ partial) {
     constexpr int BM = Cfg::BM, BN = Cfg::BN, BK = Cfg::BK;
-    static_assert(BK == 16 && BM == 128 && (BN == 64 || BN == 128), "one bf16 MFMA k-step per tile step");
+    static_assert(BK == 16 && BM == 128 && (BN == 64 || BN == 128), "one bf16 MFMA k-step per tile step");   // (the product uses 64)
     constexpr int WTM = 64, WTN = BN / 2;        // 2 x 2 waves: 64 rows x (32 | 64) complex columns each
     constexpr int FM = 2, FN = WTN / 32;
     constexpr int NA = VEC_A ? Cfg::A_PER_T / 2 : Cfg::A_PER_T;
@@ -1198,8 +1198,8 @@ static hipError_t launch_cfg(const StepArgs& p, const MfmaHints& h, void* scratc
     if (gx > 0x7fffffffll || p.nz > 65535) return hipErrorInvalidValue;
     const dim3 grid((unsigned)gx, (unsigned)p.nz, (unsigned)p.Bt);
     float* part = S > 1 ? (float*)scratch : (float*)nullptr;
-    if constexpr (Cfg::BN >= 64) {
-        // fp32 products as six bf16 products (pair_mfma_bf3_kernel): long contractions on full tiles
+    if constexpr (Cfg::BN == 64) {
+        // fp32 products as six bf16 products (pair_mfma_bf3_kernel): long contractions on full 64-column tiles
         if (h.fast && h.bf3 && pair_bf16x3_on(p)) {
             constexpr size_t smem = 2 * 2 * 6 * (size_t)(2 * Cfg::BM * 8 + 2 * Cfg::BN * 8);
             static unsigned long long ready[2] = {0, 0};

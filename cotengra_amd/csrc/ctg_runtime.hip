@@ -838,14 +838,17 @@ int build_hints_into(ctg_exec* e, std::vector<MfmaHints>& hints, int64_t zmult,
         h.bf3 = (!h.stream && r[W_K] >= 64 && r[W_N] % 64 == 0 && r[W_R] % MFMA_BM == 0 && r[W_K] % MFMA_BK == 0 &&
                  r[W_BT] == 1 && (r[W_R] / MFMA_BM) * (r[W_N] / 64) * std::max<int64_t>(e->batch_nominal, 1) >= 512 &&
                  mfma_fast_ok(p, r, 64) && !env_on("CTG_NO_PAIR_BF3")) ? 1 : 0;
-        if (h.bf3 && h.bn > 64 && !mfma_fast_ok(p, r, h.bn)) h.bn = 64;
+        // (such a step runs on 64-column tiles: 74 KB of limb planes, two workgroups per CU -- one workgroup's
+        // staging under the other's MFMAs; the 128-column tile the fp32 kernel prefers for K >= 256 was measured
+        // 16 % slower per launch here: 98 KB, one workgroup of four waves per CU)
+        if (h.bf3) h.bn = 64;
         if (!h.stream) {
             const int64_t tiles_m = (r[W_R] + MFMA_BM - 1) / MFMA_BM;
             const int64_t per_tile = r[W_K] >= 1024 ? splits : 1;
             // (two blocks per CU: a CU with a single block has nothing to overlap its
             // gather latency with -- 8x8 lattice, 4096 x 256 x 256 step: 49 -> 20 us)
             static const int64_t fill = getenv("CTG_TILE_FILL") ? atoll(getenv("CTG_TILE_FILL")) : 512;
-            while (h.bn > (h.bf3 ? 64 : 16) && tiles_m * ((r[W_N] + h.bn - 1) / h.bn) * r[W_BT] * per_tile * zmult < fill)
+            while (h.bn > 16 && !h.bf3 && tiles_m * ((r[W_N] + h.bn - 1) / h.bn) * r[W_BT] * per_tile * zmult < fill)
                 h.bn /= 2;
             // the number of k-splits belongs to the step: taken from the single-slice
             // hints; a wider tile whose slabs would not fit the scratch is given up
@@ -854,7 +857,7 @@ int build_hints_into(ctg_exec* e, std::vector<MfmaHints>& hints, int64_t zmult,
                                                      e->batch_nominal));
             if (like) {
                 const int64_t slab = tiles_m * MFMA_BM * ((r[W_N] + h.bn - 1) / h.bn) * h.bn * 8 * r[W_BT];
-                if ((int64_t)h.splitk * slab > kScratchBytes) h.bn = (*like)[s].bn;
+                if ((int64_t)h.splitk * slab > kScratchBytes && !h.bf3) h.bn = (*like)[s].bn;
             }
         }
         h.additive32 = (h.stream && tile_additive(p, r[W_ROWA_LO], r[W_ROW_LO], r[W_R], 32) &&
