@@ -2009,12 +2009,34 @@ int ctg_exec_profile_slice(ctg_exec* e, int64_t slice_id, float* ms) {
     if (const char* v = getenv("CTG_PROFILE_SLICES"))
         nb = (int)std::max<int64_t>(1, std::min<int64_t>({(int64_t)atoll(v), (int64_t)(e->strip ? 1 : e->batch),
                                                           p->nslices - slice_id}));
-    hipError_t err = launch_prologue(e->meta, e->d_state, e->d_soff, slice_id, e->stream, nb, 1);
+    // (an executor that batches whole slice groups: the batch is the groups from slice_id's on, slice-in-batch
+    // z = group * d + member as in run_grouped, and what a group shares goes out once per group)
+    const int d = e->group_d > 1 ? e->group_d : 1;
+    std::vector<int64_t> ids;
+    if (d > 1 && nb > 1) {
+        const std::vector<SliceDigit> digits = slice_digits(p);
+        int64_t g = 0, mul = 1;
+        for (const SliceDigit& dg : digits)
+            if (!dg.group) {
+                g += ((slice_id / dg.stride) % dg.size) * mul;
+                mul *= dg.size;
+            }
+        for (const int64_t n_groups = p->nslices / d; g < n_groups && (int64_t)ids.size() + d <= nb; ++g)
+            group_members(digits, g, ids);
+        nb = ids.empty() ? 1 : (int)ids.size();
+    }
+    hipError_t err;
+    if (nb > 1 && d > 1) {
+        HIP_TRY(hipMemcpyAsync(e->d_batch_ids, ids.data(), nb * sizeof(int64_t), hipMemcpyHostToDevice, e->stream));
+        err = launch_prologue(e->meta, e->d_state, e->d_soff, 0, e->stream, nb, 1, e->d_batch_ids);
+    } else {
+        err = launch_prologue(e->meta, e->d_state, e->d_soff, slice_id, e->stream, nb, 1);
+    }
     if (err != hipSuccess) return fail(CTG_E_HIP, "prologue launch failed: %s", hipGetErrorString(err));
     HIP_TRY(hipEventRecord(e->events[0], e->stream));
     for (int64_t s = 0; s < p->n_steps; ++s) {
         if (!e->invariant[s]) {  // invariant steps cost nothing per slice: 0 ms
-            e->args[s].nz = nb;
+            e->args[s].nz = (nb > 1 && d > 1 && e->grouped[s]) ? nb / d : nb;
             const int rc = launch_step(e, s, e->stream);
             e->args[s].nz = 1;
             if (rc != CTG_OK) return rc;

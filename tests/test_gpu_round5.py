@@ -434,3 +434,39 @@ def test_long_tiled_steps_multiply_on_the_bf16_pipe(R, K, N, monkeypatch):
     for label in cases:
         assert errs[(label, "0")] <= 2e-6
         assert errs[(label, "1")] <= max(1.5 * errs[(label, "0")], 2e-7), label
+
+
+@pytest.mark.parametrize("name", ["C5_hyper200", "lattice8x8_sliced"])
+def test_profile_slice_with_batched_launches_on_a_grouped_tree(name, monkeypatch):
+    """``ctg_exec_profile_slice`` under ``CTG_PROFILE_SLICES`` (the per-step table of ``tools/steps_batched.py``)
+    on an executor that batches whole slice groups: the profiled batch is whole groups (z = group * d + member,
+    shared steps once per group) and what it adds to the result is exactly those slices."""
+    from cotengra_amd import plan as P
+    from cotengra_amd.distributed import scatter_slices
+
+    monkeypatch.delenv("CTG_SLICE_GROUPS", raising=False)
+    monkeypatch.setattr(P, "GROUP_MIN_WIDTH", 1)
+    monkeypatch.setattr(P, "GROUP_MIN_SAVING", 0.0)
+    monkeypatch.setattr(P, "GROUP_MIN_SAVING_SMALL", 0.0)
+    case = next(c for c in G.cases("tree") if c["name"] == name)
+    tree = G.tree_of(case)
+    arrays = G.arrays_of(case, "complex128", tree)
+    fn = HipContractor(tree)
+    st = fn.setup(*arrays)
+    ex, plan = st["exec"], st["plan"]
+    gs = int(plan.group_size)
+    if gs < 2 or ex.batch < 2 * gs:
+        fn.close()
+        pytest.skip("no batched slice groups on this tree")
+    nb = 2 * gs
+    monkeypatch.setenv("CTG_PROFILE_SLICES", str(nb))
+    ex.zero_result()
+    ms = ex.profile_slice(0)
+    assert len(ms) == len(plan.steps) and np.all(np.isfinite(ms)) and np.all(np.asarray(ms) >= 0)
+    got = np.asarray(ex.download_result())
+    ids = [int(i) for i in plan.rank_slice_ids(0, 1, 0, 2)]
+    assert len(ids) == nb
+    a128 = [np.asarray(a).astype("complex128") for a in arrays]
+    want = scatter_slices(tree, ids, [np.asarray(orc.contract_slice(tree, a128, i)) for i in ids])
+    assert got.shape == want.shape and np.abs(got - want).max() <= 1e-10 * np.abs(want).max()
+    fn.close()

@@ -38,13 +38,19 @@ for _ in range(5):
 rows = plan.describe_steps()
 names = ex.step_kernels()
 fl = 8.0 if plan.is_complex else 2.0
-ideal = np.array([max(r["macs"] * fl / 157.3e12, r["bytes"] / 6.1e12) * nb * 1e3 for r in rows])
-print("%s: %d slices per launch, sum of step times %.3f ms, sum of bounds %.3f ms" % (which, nb, best.sum(), ideal.sum()))
+# (a step the slices of a group share runs once per group of the launch)
+gs = int(plan.group_size) if getattr(ex, "batch", 1) > 1 else 1
+if gs > 1:
+    nb -= nb % gs
+launches = [nb // gs if (gs > 1 and getattr(st_, "group", False)) else nb for st_ in plan.steps]
+ideal = np.array([max(r["macs"] * fl / 157.3e12, r["bytes"] / 6.1e12) * n * 1e3 for r, n in zip(rows, launches)])
+print("%s: %d slices per launch%s, sum of step times %.3f ms, sum of bounds %.3f ms" % (
+    which, nb, " (slice groups of %d: shared steps once per group)" % gs if gs > 1 else "", best.sum(), ideal.sum()))
 order = np.argsort(-(best - ideal))
 print("%5s %-52s %9s %6s %5s %3s %9s %9s %6s %8s" % ("step", "kernel", "R", "K", "N", "Bt", "ms", "bound", "x", "TB/s"))
 for i in order[:top]:
     r = rows[i]
     print("%5d %-52s %9d %6d %5d %3d %9.3f %9.3f %6.2f %8.2f" % (
         i, names[i][:52], r["R"], r["K"], r["N"], r["Bt"], best[i], ideal[i], best[i] / max(ideal[i], 1e-9),
-        r["bytes"] * nb / (best[i] * 1e-3) / 1e12))
+        r["bytes"] * launches[i] / (best[i] * 1e-3) / 1e12))
 fn.close()
