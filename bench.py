@@ -968,7 +968,17 @@ def main():
     c3_amp = None
     # (CTG_BENCH_C3_AMPLITUDES=1: also at N = 1 under a launcher -- how the one-GPU lease tests this leg)
     if (world > 1 or os.environ.get("CTG_BENCH_C3_AMPLITUDES")) and not args.headline_only:
-        mine3 = m10_amplitudes(dev)
+        try:
+            mine3 = m10_amplitudes(dev)
+        except Exception as e:  # noqa: BLE001  (an extra leg must not cost the headline line)
+            print(f"rank {rank}: C3_amplitudes leg failed: {e!r}", file=sys.stderr)
+            mine3 = None
+        # (all ranks or none: the gather below is a collective)
+        if dist is not None:
+            ok3 = torch.tensor([0 if mine3 is not None else 1], device=dev)
+            dist.all_reduce(ok3)
+            if int(ok3.item()) != 0:
+                mine3 = None
         if mine3 is not None:
             t3 = torch.tensor([mine3["amplitudes"], mine3["seconds"]], dtype=torch.float64, device=dev)
             all3 = [torch.zeros_like(t3) for _ in range(world)]
@@ -989,7 +999,11 @@ def main():
     # BASELINE config 3 as worded: the one 64-slice amplitude over the N ranks (strong scaling)
     c3_strong = None
     if (world > 1 or os.environ.get("CTG_BENCH_C3_AMPLITUDES")) and not args.headline_only:
-        c3_strong = m10_strong(dev, rank, world, comm, dist)
+        try:
+            c3_strong = m10_strong(dev, rank, world, comm, dist)
+        except Exception as e:  # noqa: BLE001
+            print(f"rank {rank}: C3_strong leg failed: {e!r}", file=sys.stderr)
+            c3_strong = None
 
     # (flops really executed: the steps a slice group shares count once per group -- every rank times the
     # same number of whole groups, so rank 0's count x world is the job's)

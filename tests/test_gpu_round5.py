@@ -470,3 +470,31 @@ def test_profile_slice_with_batched_launches_on_a_grouped_tree(name, monkeypatch
     want = scatter_slices(tree, ids, [np.asarray(orc.contract_slice(tree, a128, i)) for i in ids])
     assert got.shape == want.shape and np.abs(got - want).max() <= 1e-10 * np.abs(want).max()
     fn.close()
+
+
+def test_bench_legs_of_the_multi_rank_run_under_a_one_rank_launcher():
+    """``bench.py`` as the driver starts it at N > 1 (``torch.distributed.run``, RCCL process group, the
+    collective behind the C ABI) with ONE rank and ``CTG_BENCH_C3_AMPLITUDES=1``: the legs that otherwise only
+    exist at N > 1 -- m10 amplitudes per second and BASELINE config 3 as worded (one amplitude's 64 slices
+    dealt over the ranks + reduce) -- run on the one-GPU lease and land in the compact line."""
+    import json
+    import subprocess
+    import sys
+
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, CTG_BENCH_C3_AMPLITUDES="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
+           "--master-addr", "127.0.0.1", "--master-port", "29517", os.path.join(ROOT, "bench.py"),
+           "--gpus", "1", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = r.stdout.strip().splitlines()[-1]
+    assert len(line) < 4096
+    rec = json.loads(line)
+    assert rec["n_gpus"] == 1 and rec["roofline"]["frac"] > 0
+    legs = rec["legs"]
+    assert legs["C3_amplitudes_per_sec"] > 50 and legs["C3_strong_ms"] > 0
+    full = json.load(open(os.path.join(ROOT, rec["full_record"])))
+    strong = full["configs"]["C3_strong"]
+    assert strong["nslices"] == 64 and strong["amplitude_rel_diff"] <= 1e-6
+    assert full["config"]["reduce_via"] == "ctg_exec_reduce (RCCL, C ABI)"
