@@ -58,6 +58,8 @@ enum StepWord {
                                    // 2 (round 4): does not depend on the plan's GROUP indices -- run once per
                                    // group of slices (ctg_plan_desc.slice_group)
     W_STEM = 43,                   // KIND_STEM2: word offset of the descriptor in the table blob
+    W_LDS_COMP = 44,               // (round 6) member of an LDS-resident subtree: component id + 1 (0: none)
+    W_LDS_DESC = 45,               // ... word offset of the component's descriptor in the table blob
     STEP_WORDS = 48
 };
 

@@ -8,6 +8,7 @@
 
 #include "../../include/ctg_hip.h"
 #include "ctg_common.h"
+#include "ctg_lds.h"
 
 struct ctg_plan {
     int dtype = 0;
@@ -83,6 +84,12 @@ struct ctg_exec {
     };
     std::vector<Issue> issue;
     std::vector<Issue> issue_reuse;   // ... of a slice that finds the shared steps of its group done
+    // LDS-resident subtrees (round 6; ctg_lds_host.hip / ctg_lds_run.hip): per step the packed component that
+    // runs it (-1: none, the step launches as usual); components sorted [group-shared..., per-slice...]
+    std::vector<int32_t> lds_comp_of;
+    int lds_first[2] = {0, 0}, lds_count[2] = {0, 0}, lds_bytes[2] = {0, 0};   // [0] group-shared, [1] per slice
+    ctg::LdsCompDev* d_lds_comps = nullptr;
+    char* d_lds_blob = nullptr;
     ctg::ValuGroupItem* d_group_items = nullptr;
     ctg::FastGroupItem* d_fast_items = nullptr;
     std::vector<hipEvent_t> events;
@@ -118,3 +125,7 @@ inline int64_t ctg_item_size(int dtype) {
 
 // records `msg` as the calling thread's ctg_last_error() (ctg_runtime.hip)
 extern "C" __attribute__((visibility("hidden"))) void ctg_set_error_(const char* msg);
+
+// LDS-resident subtrees (ctg_lds_host.hip): descriptor validation (host only) and per-executor packing
+__attribute__((visibility("hidden"))) int ctg_lds_validate(const ctg_plan* p);
+__attribute__((visibility("hidden"))) int ctg_lds_build(ctg_exec* e);

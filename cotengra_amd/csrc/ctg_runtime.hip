@@ -1044,13 +1044,20 @@ int build_groups(ctg_exec* e) {
     if (e->d_fast_items) (void)hipFree(e->d_fast_items);
     e->d_group_items = nullptr;
     e->d_fast_items = nullptr;
+    // LDS-resident subtrees: which steps a component's workgroup runs (none under strip_exponent)
+    {
+        const int rc = ctg_lds_build(e);
+        if (rc != CTG_OK) return rc;
+    }
+    bool lds_issued[2] = {false, false};
+    auto lds_member = [&](int64_t s) { return e->lds_comp_of[s] >= 0; };
     // (strip_exponent measures every intermediate right after its step)
     const bool off = e->strip || env_on("CTG_NO_GROUPS");
     const bool fast_off = env_on("CTG_NO_FAST_GROUPS");
     // class of a step: -1 launches alone, 0 thread-per-output, 1 + key tiled fast kernel
     auto class_of = [&](int64_t s) -> int {
         const int64_t* r = &p->steps[s * STEP_WORDS];
-        if (off || r[W_KIND] != KIND_PAIR || e->invariant[s]) return -1;
+        if (off || r[W_KIND] != KIND_PAIR || e->invariant[s] || lds_member(s)) return -1;
         if (r[W_KERNEL] != KERNEL_MFMA) {
             if (!valu_thread_per_output(e->args[s])) return -1;
             ValuGroupItem it;
@@ -1080,6 +1087,22 @@ int build_groups(ctg_exec* e) {
     std::vector<FastGroupItem> fitems;
     for (int64_t s = 0; s < n;) {
         if (e->invariant[s]) {
+            ++s;
+            continue;
+        }
+        if (lds_member(s)) {
+            // all components of the step's sharing class go out as ONE launch, at the first member (members
+            // read leaves, slice-invariant results and -- per-slice ones -- group-shared results only, and the
+            // planner puts them before every other step of their class: cotengra_amd/plan.py)
+            // (a member that is a leaf's preprocessing stands with the other preprocessing steps, before the
+            // pair steps of EVERY class: the launch goes where the first member PAIR stands -- behind all
+            // steps of the classes that run less often)
+            const int cls = e->grouped[s] ? 0 : 1;
+            if (!lds_issued[cls] && p->steps[s * STEP_WORDS + W_KIND] == KIND_PAIR) {
+                lds_issued[cls] = true;
+                e->issue.push_back(ctg_exec::Issue{s, -2, e->lds_first[cls], e->lds_count[cls], (uint32_t)e->lds_count[cls],
+                                                   cls == 0});
+            }
             ++s;
             continue;
         }
@@ -1146,6 +1169,14 @@ int build_groups(ctg_exec* e) {
 int launch_issue(ctg_exec* e, const ctg_exec::Issue& q, int nb, hipStream_t stream) {
     // (batched slice groups: what a group shares goes out once per group of the launch)
     if (e->group_d > 1 && q.shared && nb > 1) nb /= e->group_d;
+    if (q.cls == -2) {
+        const int cls = q.shared ? 0 : 1;
+        const hipError_t err = launch_lds_run(e->plan->dtype, e->d_lds_comps + q.item0, q.n, nb, 0, e->lds_bytes[cls], stream);
+        if (err != hipSuccess)
+            return fail(CTG_E_HIP, "launch of the %d LDS-resident subtrees at step %lld failed: %s", (int)q.n,
+                        (long long)q.step, hipGetErrorString(err));
+        return CTG_OK;
+    }
     if (q.cls < 0) {
         e->args[q.step].nz = nb;
         const int rc = launch_step(e, q.step, stream);
@@ -1373,7 +1404,8 @@ int ctg_plan_create(const ctg_plan_desc* d, ctg_plan** out) {
         delete p;
         return fail(CTG_E_INVALID, "empty buffer in plan");
     }
-    const int rc = validate_plan(p);
+    int rc = validate_plan(p);
+    if (rc == CTG_OK) rc = ctg_lds_validate(p);
     if (rc != CTG_OK) {
         delete p;
         return rc;
@@ -1429,6 +1461,8 @@ int ctg_exec_destroy(ctg_exec* e) {
     if (e->d_lane_b) (void)hipFree(e->d_lane_b);
     if (e->d_group_items) (void)hipFree(e->d_group_items);
     if (e->d_fast_items) (void)hipFree(e->d_fast_items);
+    if (e->d_lds_comps) (void)hipFree(e->d_lds_comps);
+    if (e->d_lds_blob) (void)hipFree(e->d_lds_blob);
     if (e->h_ids) (void)hipHostFree(e->h_ids);
     if (e->ev_ids) (void)hipEventDestroy(e->ev_ids);
     if (e->d_fac) (void)hipFree(e->d_fac);
@@ -1962,7 +1996,12 @@ int ctg_exec_launch_count(ctg_exec* e, int64_t* steps, int64_t* launches) {
     if (!e || !steps || !launches) return fail(CTG_E_INVALID, "null argument");
     int64_t ns = 0, nl = 0;
     for (const ctg_exec::Issue& q : e->issue) {
-        ns += q.n;
+        if (q.cls == -2) {
+            // (one launch of q.n LDS-resident subtrees: its steps are their members)
+            for (int32_t c : e->lds_comp_of) ns += c >= q.item0 && c < q.item0 + q.n;
+        } else {
+            ns += q.n;
+        }
         nl += 1;
     }
     *steps = ns;
@@ -2034,8 +2073,19 @@ int ctg_exec_profile_slice(ctg_exec* e, int64_t slice_id, float* ms) {
     }
     if (err != hipSuccess) return fail(CTG_E_HIP, "prologue launch failed: %s", hipGetErrorString(err));
     HIP_TRY(hipEventRecord(e->events[0], e->stream));
+    bool lds_done[2] = {false, false};
     for (int64_t s = 0; s < p->n_steps; ++s) {
-        if (!e->invariant[s]) {  // invariant steps cost nothing per slice: 0 ms
+        if (!e->invariant[s] && !e->lds_comp_of.empty() && e->lds_comp_of[s] >= 0) {
+            // a member of an LDS-resident subtree: all subtrees of its class are ONE launch, timed under
+            // the first member; the others read 0 ms
+            const int cls = e->grouped[s] ? 0 : 1;
+            if (!lds_done[cls] && p->steps[s * STEP_WORDS + W_KIND] == KIND_PAIR) {
+                lds_done[cls] = true;
+                const ctg_exec::Issue q{s, -2, e->lds_first[cls], e->lds_count[cls], (uint32_t)e->lds_count[cls], cls == 0};
+                const int rc = launch_issue(e, q, nb, e->stream);
+                if (rc != CTG_OK) return rc;
+            }
+        } else if (!e->invariant[s]) {  // invariant steps cost nothing per slice: 0 ms
             e->args[s].nz = (nb > 1 && d > 1 && e->grouped[s]) ? nb / d : nb;
             const int rc = launch_step(e, s, e->stream);
             e->args[s].nz = 1;
@@ -2055,7 +2105,9 @@ int ctg_exec_step_kernel(ctg_exec* e, int64_t step, char* buf, int64_t buflen) {
     if (step < 0 || step >= p->n_steps) return fail(CTG_E_INVALID, "step out of range");
     const int64_t* r = &p->steps[step * STEP_WORDS];
     char name[128];
-    if (r[W_KIND] == KIND_SINGLE) {
+    if (!e->lds_comp_of.empty() && e->lds_comp_of[step] >= 0) {
+        snprintf(name, sizeof(name), "lds_run_kernel[%d]", (int)e->lds_comp_of[step]);
+    } else if (r[W_KIND] == KIND_SINGLE) {
         snprintf(name, sizeof(name), "single_kernel");
     } else if (r[W_KIND] == KIND_ACCUM) {
         snprintf(name, sizeof(name), "accum_kernel");

@@ -70,6 +70,8 @@ SPACE_RESULT = 2
 
 STEP_WORDS = 48  # int64 words per serialised step record
 W_STEM = 43  # STEM2 steps: word offset of the descriptor in the table blob (stem.serialise_stem)
+W_LDS_COMP = 44  # member of an LDS-resident subtree (ldsrun.py): component id + 1
+W_LDS_DESC = 45  # ... word offset of the component's descriptor in the table blob
 LO_MAX = 4096  # target size of the fast ('lo') level of a row table
 ARENA_ALIGN = 64  # elements; keeps every intermediate 256-B aligned
 # trees whose largest intermediate is at most this are emitted level by level (compile_tree)
@@ -173,6 +175,8 @@ class Step:
     b2_prod: int = -1
     stem: dict = None
     elems_moved: int = 0
+    # (round 6) member of an LDS-resident subtree (ldsrun.py): index into Plan.lds_runs, -1 = none
+    lds_comp: int = -1
 
 
 class Arena:
@@ -241,6 +245,8 @@ class Plan:
         self.group_inds = ()
         self.slice_group = []
         self.nslices = 1
+        # LDS-resident subtrees (round 6, ldsrun.py): per component its shadow steps, LDS need and members
+        self.lds_runs = []
         # accounting
         self.macs_per_slice = 0
         self.elems_rw_per_slice = 0
@@ -380,7 +386,10 @@ class Plan:
          40 a.producer step  41 b.producer step   (-1: scale factor 1)
          42 sharing class: 1 slice-invariant (run once per upload, output persistent), 2 shared by the
             slices of a group (Plan.group_inds: run once per group, what per-slice steps read of it kept)
-         43.. reserved (0)
+         43 STEM2: word offset of the stem descriptor
+         44 member of an LDS-resident subtree: component id + 1 (0: none)   45 word offset of the
+            component's descriptor in the table blob (ldsrun.serialise_run)
+         46.. reserved (0)
         """
         blobs = []
         cursor = 0
@@ -394,6 +403,12 @@ class Plan:
             return off
 
         zero = put(np.zeros(1, dtype=np.int64))  # shared all-zero table
+
+        run_desc = []
+        if self.lds_runs:
+            from .ldsrun import serialise_run
+
+            run_desc = [serialise_run(run, put) for run in self.lds_runs]
 
         recs = np.zeros((len(self.steps), STEP_WORDS), dtype=np.int64)
         for i, s in enumerate(self.steps):
@@ -449,6 +464,8 @@ class Plan:
             r[33], r[34], r[35] = s.macs, s.elems_rw, s.node
             r[40], r[41] = s.a_prod, s.b_prod
             r[42] = 1 if s.invariant else (2 if s.group else 0)
+            if s.lds_comp >= 0:
+                r[W_LDS_COMP], r[W_LDS_DESC] = s.lds_comp + 1, run_desc[s.lds_comp]
 
         tables = np.concatenate(blobs) if blobs else np.zeros(1, np.int64)
         n_in = len(self.input_sizes)
@@ -997,7 +1014,37 @@ def compile_tree(tree, dtype, order=None, force_kernel=None, fuse=None, fuse_min
         if not group or dep_g[node] or not depends[node] or node not in parent_of:
             return False
         return dep_g[last_of(parent_of[node])]
-    for i, term in enumerate(tree.inputs):
+    # LDS-resident subtrees (round 6, ldsrun.py): maximal subtrees whose tensors all fit one compute
+    # unit's LDS are run by one workgroup of one launch.  Their ordinary steps stay in the plan -- complete,
+    # FIRST in the step order among the steps of their sharing class (the arena is assigned for the order the
+    # launches really have) -- next to a second lowering on LDS-resident tensors (Plan.lds_runs).
+    comps = []
+    node_class = None
+    leaf_order = range(N)
+    if (order is None and N > 3 and tree.max_size() <= LEVEL_ORDER_MAX_ELEMS and force_kernel is None):
+        from . import ldsrun
+
+        if ldsrun.lds_runs_enabled():
+            for i in range(N):
+                tree.get_legs(i)   # (fills tree.preprocessing)
+            dep_s = dict((i, (i in tree.sliced_inputs) or not use_invariants) for i in range(N))
+            for p_, l_, r_ in tree.traverse():
+                dep_s[p_] = dep_s[l_] or dep_s[r_] or p_ == tree.root
+
+            def node_class(node):
+                # (a leaf: the class of its preprocessing step)
+                if not dep_s[node]:
+                    return "inv"
+                if group and not dep_g[node] and node != tree.root:
+                    return "group"
+                return "slice"
+
+            comps = ldsrun.choose_components(tree, dtype, plan.itemsize, node_class, pairs=pairs)
+        if comps:
+            # (leaf preprocessing steps in the same class order as the pair steps below)
+            leaf_order = sorted(range(N), key=lambda i: ldsrun.CLASS_RANK[node_class(i)])
+    for i in leaf_order:
+        term = tree.inputs[i]
         full_shape = [size_dict[ix] for ix in term]
         st = _row_major_strides(full_shape)
         kept = [(ix, s) for ix, s in zip(term, st) if ix not in tree.sliced_inds]
@@ -1064,6 +1111,17 @@ def compile_tree(tree, dtype, order=None, force_kernel=None, fuse=None, fuse_min
 
             return reorder
 
+    sequence = None
+    if comps and level is not None:
+        rank = ldsrun.CLASS_RANK
+        member_nodes = set(n for c in comps for n in c.nodes)
+        seq = list(tree.traverse(order=order))
+        # What members read from the arena -- results of a class that runs less often -- comes before
+        # them: class by class (each is closed under "child of"), members of a class before its other steps.
+        sequence = sorted(seq, key=lambda x: (rank[node_class(x[0])], x[0] not in member_nodes))
+    operand_node = {}   # id(TensorRef) -> the tree node whose tensor it is (LDS shadows)
+    step_of_node = {}
+
     if N == 1:
         step = build_single_step(
             size_dict, tensors[0], root_order, arena_factory(), node=tree.root
@@ -1073,7 +1131,9 @@ def compile_tree(tree, dtype, order=None, force_kernel=None, fuse=None, fuse_min
     else:
         final = None
         pending, cur_level = [], 0
-        for p, l, r in tree.traverse(order=order):
+        for i_, ref_ in tensors.items():
+            operand_node[id(ref_)] = i_
+        for p, l, r in (sequence if sequence is not None else tree.traverse(order=order)):
             if level is not None and level[p] != cur_level:
                 for ref in pending:
                     release(ref)
@@ -1212,6 +1272,8 @@ def compile_tree(tree, dtype, order=None, force_kernel=None, fuse=None, fuse_min
                         release(ref)
             step = steps_new[-1]
             tensors[p] = step.c
+            operand_node[id(step.c)] = p
+            step_of_node[p] = step
             final = step.c
         for ref in pending:
             release(ref)
@@ -1242,6 +1304,11 @@ def compile_tree(tree, dtype, order=None, force_kernel=None, fuse=None, fuse_min
     acc.elems_rw = 0
     add(acc)
     release(final)
+
+    if comps:
+        from . import ldsrun
+
+        ldsrun.build_shadows(plan, tree, dtype, comps, step_of_node, operand_node)
 
     big_peak = max(arena.peak, ARENA_ALIGN)
     for ref in small_refs:

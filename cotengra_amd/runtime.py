@@ -12,7 +12,7 @@ import os
 import numpy as np
 
 _LIB_PATH = os.environ.get("CTG_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libctg_hip.so")
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 # every symbol include/ctg_hip.h declares
 SYMBOLS = (

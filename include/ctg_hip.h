@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define CTG_ABI_VERSION 6
+#define CTG_ABI_VERSION 7
 
 /* element types of the tensors (reference tests cover all four:
  * tests/test_compute.py:102-115) */
@@ -63,7 +63,20 @@ enum {
  * tile decomposition, the second small operand, 14 offset tables: layout in
  * cotengra_amd/stem.py: serialise_stem, csrc/ctg_common.h: StemWord).  Like every
  * step it is validated by ctg_plan_create: tables inside the blob, every operand
- * address inside its buffer, a tile shape the kernel takes. */
+ * address inside its buffer, a tile shape the kernel takes.
+ *
+ * ABI 7 -- LDS-resident subtrees (the small-tree execution model; the reference's step
+ * loop contract.py:788-832 for a whole subtree at once).  Word 44 of a pair / single
+ * step record: component id + 1 (0: none), word 45: word offset of the component's
+ * descriptor in the table blob (cotengra_amd/ldsrun.py: serialise_run, csrc/ctg_common.h:
+ * LdsHeadWord / LdsRecWord) -- a second lowering of the component's member steps on
+ * tensors that live in one compute unit's LDS.  The member records stay complete and
+ * come first in the step order; an executor runs all components of a plan as ONE launch
+ * (one workgroup per component and slice of the batch) at the position of their first
+ * member, or -- under strip_exponent, CTG_NO_LDS_RUNS=1, or when a component does not
+ * fit the LDS of the device -- the member steps one by one.  ctg_plan_create validates
+ * the descriptors like everything else (tables inside the blob, LDS addresses inside
+ * the component's data area, global addresses inside their space). */
 typedef struct ctg_plan_desc {
     int32_t dtype;                /* CTG_F32 .. CTG_C128 */
     int64_t n_inputs;

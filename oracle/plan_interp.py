@@ -154,9 +154,34 @@ def run_stem2(step, spaces, base, chunk=256):
         C[gc[:, None, None] + out_at[None]] = a2 @ b2
 
 
-def run_plan(plan, arrays, slice_ids=None, result=None):
+def run_lds_component(run, spaces, base, dt):
+    """One LDS-resident subtree (``plan.lds_runs[i]``, cotengra_amd/ldsrun.py) as its workgroup runs
+    it (csrc/ctg_lds_run.hip): the shadow records in order on a private array standing in for the LDS."""
+    from cotengra_amd import ldsrun as L
+
+    lds = np.full(max(int(run["lds_elems"]), 1), np.nan, dtype=dt)
+    where = lambda t: lds if t.space == L.SPACE_LDS else spaces[t.space]  # noqa: E731
+    at = lambda t: t.offset if t.space == L.SPACE_LDS else base(t)  # noqa: E731
+    for sh in run["steps"]:
+        st = sh["step"]
+        if sh["kind"] == L.KIND_LOAD:
+            ia = at(st.a) + _rows(st, "A")[:, None] + _ks(st, "A")[None, :]
+            where(st.c)[at(st.c) + _rows(st, "C")] = where(st.a)[ia].sum(axis=1)
+        else:
+            rA, rB, rC = (_rows(st, k) for k in "ABC")
+            kA, kB = _ks(st, "A"), _ks(st, "B")
+            nB, nC = st.n_tabs["B"], st.n_tabs["C"]
+            ia = at(st.a) + rA[:, None] + kA[None, :]
+            ib = at(st.b) + rB[:, None, None] + kB[None, :, None] + nB[None, None, :]
+            ic = at(st.c) + rC[:, None] + nC[None, :]
+            where(st.c)[ic] = np.einsum("rk,rkn->rn", where(st.a)[ia], where(st.b)[ib])
+
+
+def run_plan(plan, arrays, slice_ids=None, result=None, lds=False):
     """Execute ``plan`` for the given slices, accumulating into ``result``
-    (a flat array of ``plan.result_elems``); returns the result reshaped."""
+    (a flat array of ``plan.result_elems``); returns the result reshaped.
+    ``lds=True``: members of LDS-resident subtrees run through their shadow records
+    (``plan.lds_runs``), all components of a sharing class at the first member -- the executor's order."""
     dt = np.dtype(plan.dtype)
     inputs = np.zeros(plan.inputs_elems, dtype=dt)
     for off, n, x in zip(plan.input_offsets, plan.input_sizes, arrays):
@@ -185,11 +210,21 @@ def run_plan(plan, arrays, slice_ids=None, result=None):
                 b += int(soff[t.leaf])
             return b
 
+        lds_done = set()
         for step in plan.steps:
             if step.invariant and not first:
                 continue  # computed once, output persistent (like the executor)
             if grouped and getattr(step, "group", False) and not fresh:
                 continue  # computed for the first slice of this group, what is read of it kept
+            if lds and getattr(step, "lds_comp", -1) >= 0:
+                cls = plan.lds_runs[step.lds_comp]["cls"]
+                # (at the first member PAIR of the class: behind every step of the classes that run less often)
+                if cls not in lds_done and step.kind == P.KIND_PAIR:
+                    lds_done.add(cls)
+                    for run in plan.lds_runs:
+                        if run["cls"] == cls:
+                            run_lds_component(run, spaces, base, dt)
+                continue
             if step.kind == P.KIND_SINGLE:
                 src, dst = spaces[step.a.space], spaces[step.c.space]
                 ia = base(step.a) + _rows(step, "A")[:, None] + _ks(step, "A")[None, :]
