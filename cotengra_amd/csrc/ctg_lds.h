@@ -24,21 +24,25 @@ enum LdsRecWord {
     LR_WORDS = 40
 };
 constexpr int64_t LR_MAGIC = 0x4C44535231;
-constexpr int LDS_RUN_THREADS = 512;            // one workgroup of 8 waves per component
+constexpr int LDS_RUN_THREADS = 1024;           // one workgroup of 16 waves per component
 constexpr int LDS_RUN_MAX_BYTES = 160 * 1024;   // gfx950: LDS per workgroup
 
 // One shadow step as the kernel reads it from LDS (the component's blob: records, then tables).
 // Offsets of tables are BYTES from the start of the blob.
 struct LdsStepDev {
+    // (the first 16 bytes decide whether a wave takes part in the step at all)
     int32_t kind, phase;
+    int32_t wave;                   // -1: the whole workgroup shares the step; else the wave that runs it alone
+    int32_t mfma;                   // complex64 pair step on the matrix cores (32 x 16 tiles): 1 columns on the lanes, 2 rows
     int32_t R, K, N;
     int32_t row_lo, row_shift;      // rows are two-level: r -> (r / row_lo, r % row_lo); shift = log2 or -1
     uint32_t row_magic;             // floor(2^32 / row_lo) + 1 when row_lo is not a power of two (r < 2^16)
-    int32_t wave;                   // -1: the whole workgroup shares the step; else the wave that runs it alone
+    int32_t rot;                    // matrix-core steps shared by the workgroup: task t goes to wave (t + rot) % waves
     int32_t a_off, b_off, c_off;    // LDS element offsets of the operands (-1: the global side)
     uint32_t t_row_hi, t_row_lo;    // row entries, 8 bytes each: pair {a | b << 16, c}, load {global a, c}
     uint32_t t_k;                   // K entries, 4 bytes: pair ka | kb << 16, load global ka
     uint32_t t_n;                   // N entries, 4 bytes: nb | nc << 16 (pairs)
+    int32_t pad1, pad2;
     // the global side (loads: the source; a component's root: the result): base pointer, per-slice offsets
     const char* gptr;
     const int64_t* gsoff;
@@ -46,6 +50,7 @@ struct LdsStepDev {
     int32_t gzs;                    // stride of gsoff (entries)
     int32_t gzq;                    // > 1: the operand lives with the first slice of its group of gzq
 };
+static_assert(sizeof(LdsStepDev) % 16 == 0, "records are copied and read in 16-byte pieces");
 
 struct LdsCompDev {
     const char* blob;       // records + tables of the component (device memory)

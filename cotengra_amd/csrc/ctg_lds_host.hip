@@ -5,6 +5,7 @@
 #include <algorithm>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <vector>
@@ -189,6 +190,7 @@ int ctg_lds_build(ctg_exec* e) {
     }
     if (comp_desc.empty()) return CTG_OK;
     struct Packed { int64_t cid; std::vector<char> blob; uint32_t n_steps, data_off; int lds_bytes; bool shared; };
+    const bool no_mfma = env_on("CTG_LDS_NO_MFMA");
     std::vector<Packed> packed;
     for (const auto& cd : comp_desc) {
         const int64_t* h = &p->tables[cd.second];
@@ -200,7 +202,7 @@ int ctg_lds_build(ctg_exec* e) {
         std::vector<char> tabs;
         bool ok = true;
         auto put = [&](const void* src, size_t bytes) -> uint32_t {
-            const size_t at = (tabs.size() + 7) / 8 * 8;
+            const size_t at = (tabs.size() + 15) / 16 * 16;
             tabs.resize(at + bytes);
             memcpy(tabs.data() + at, src, bytes);
             return (uint32_t)at;
@@ -208,6 +210,7 @@ int ctg_lds_build(ctg_exec* e) {
         const size_t rec_bytes = (size_t)n_rec * sizeof(LdsStepDev);
         // per phase: small steps are dealt to single waves (least loaded first), large ones shared by all
         std::map<int64_t, std::vector<int64_t>> wave_load;
+        std::map<int64_t, int64_t> mfma_rot;
         pk.shared = false;
         for (int64_t i = 0; i < n_rec && ok; ++i) {
             const int64_t* q = h + LR_HEAD_WORDS + i * LR_WORDS;
@@ -284,10 +287,38 @@ int ctg_lds_build(ctg_exec* e) {
                 else if (gop == 1) { st.gptr = (const char*)a.B; st.gsoff = a.soffB; st.gz = a.zB; st.gzs = (int32_t)a.zsB; st.gzq = a.zqB; }
                 else { st.gptr = (const char*)a.C; st.gsoff = a.soffC; st.gz = a.zC; st.gzs = (int32_t)a.zsC; st.gzq = 0; }
             }
+            // matrix cores: complex64 GEMM-like pair steps with enough rows and columns to fill a good part of a
+            // 32 x 16 tile (B must not depend on the row: no batch index)
+            st.mfma = 0;
+            if (kind == 1 && p->dtype == CTG_C64 && q[LR_N] >= 8 && q[LR_R] >= 16 && !no_mfma) {
+                bool gemm = true;
+                for (int64_t j = 0; j < row_hi && gemm; ++j) gemm = p->tables[q[LR_ROWB_HI] + j] == 0;
+                for (int64_t j = 0; j < row_lo && gemm; ++j) gemm = p->tables[q[LR_ROWB_LO] + j] == 0;
+                st.mfma = gemm ? 1 : 0;
+                if (gemm) {
+                    // which way the result is stored: the lanes of a store run along the index group that is
+                    // denser in C (1: columns on the lanes, 2: rows on the lanes)
+                    auto stride = [&](int64_t w, int64_t len) -> int64_t {
+                        return len > 1 ? std::llabs(p->tables[w + 1] - p->tables[w]) : INT64_MAX;
+                    };
+                    const int64_t srow = stride(q[LR_ROWC_LO], row_lo), scol = stride(q[LR_NC], q[LR_N]);
+                    if (srow <= scol) st.mfma = 2;
+                }
+            }
             // wave assignment
             const int tn = q[LR_N] >= 3 ? 4 : (int)q[LR_N];
-            const int64_t items = kind == 1 ? q[LR_R] * ((q[LR_N] + tn - 1) / tn) : q[LR_R];
+            int64_t items = kind == 1 ? q[LR_R] * ((q[LR_N] + tn - 1) / tn) : q[LR_R];
+            const int64_t tasks = ((q[LR_R] + 31) / 32) * ((q[LR_N] + 15) / 16);
+            if (st.mfma) items = tasks <= 1 ? 1 : 1 << 20;
+            // (loads: one wave each, so that the gathers of a component's leaves are all in flight together)
+            if (kind == 0 && items <= 4096) items = std::min<int64_t>(items, 128);
             st.wave = -1;
+            st.rot = 0;
+            if (st.mfma && tasks > 1) {
+                int64_t& rot = mfma_rot[q[LR_PHASE]];
+                st.rot = (int32_t)(rot % (LDS_RUN_THREADS / 64));
+                rot += tasks;
+            }
             if (items <= 128) {
                 std::vector<int64_t>& load = wave_load[q[LR_PHASE]];
                 if (load.empty()) load.assign(LDS_RUN_THREADS / 64, 0);

@@ -59,7 +59,7 @@ def test_subtrees_in_lds_against_oracle_and_step_path(name, dtype, monkeypatch):
     ids = list(range(0, 6)) if big else None
 
     def run(env):
-        for k in ("CTG_NO_LDS_RUNS",):
+        for k in ("CTG_NO_LDS_RUNS", "CTG_LDS_NO_MFMA"):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)
@@ -107,7 +107,9 @@ def test_subtrees_in_lds_against_oracle_and_step_path(name, dtype, monkeypatch):
     same_order = all(info_old["kernels"][i] in ("pair_valu_kernel", "single_kernel") and plan.steps[i].K < 256 for i in members)
     rest_same = True   # (the steps outside the components are the same launches either way)
     if same_order and rest_same and info["batch"] == 1:
-        assert np.array_equal(got, old), name
+        # (complex64 steps with >= 8 columns run on the matrix cores inside the component: switched off here)
+        plain, _ = run({"CTG_LDS_NO_MFMA": "1"}) if dtype == "complex64" else (got, None)
+        assert np.array_equal(plain, old), name
 
 
 def test_c2_launches_and_result():
