@@ -362,11 +362,18 @@ def slice_ids_from_groups(plan, first_group, count, rank=0, world=1):
     unit is a single slice), starting at the unit that holds group ``first_group + rank`` -- whole groups, so
     that what a group shares is computed once per group INSIDE the timed region, as it is over the whole job."""
     units, gs = plan.share_units(rank, world)
+    if units == 0:
+        # (more ranks than slice groups: this rank has nothing to time -- the callers' "every rank times the
+        # same number of groups" cannot hold)
+        raise ValueError(f"rank {rank} of {world} holds no slice group of this tree")
     u0 = (first_group // world) % max(units, 1)
     need = -(-count // gs)
     ids = []
     while len(ids) < count:
         n = min(need, units - u0)
+        if n <= 0:   # (wrapped around a share smaller than the request: start over at its first unit)
+            u0, need = 0, -(-(count - len(ids)) // gs)
+            n = min(need, units)
         ids += plan.rank_slice_ids(rank, world, u0, n).tolist()
         need -= n
         u0 = 0
@@ -640,10 +647,10 @@ def m10_amplitudes(dev, seconds=2.0):
     return {"amplitudes": n, "seconds": dt, "nslices": int(tree.nslices), "amplitude": complex(amp.item())}
 
 
-def m10_strong(dev, rank, world, comm, dist, reps=20):
-    """BASELINE config 3 as worded: ONE Sycamore m10 amplitude, its 64 slices dealt over the N ranks
-    (``ctg_exec_run_share``) + the RCCL reduce to rank 0, against the same amplitude on one rank.  Strong
-    scaling of a 3 ms job: printed because the configuration names it, not because it scales."""
+def m10_strong_setup(dev):
+    """Everything of ``m10_strong`` that can fail on one rank alone (files, executor, device memory) and
+    involves no collective: ``(fn, st, tree)`` or None.  The caller lets the ranks agree before the first
+    collective (all ranks or none)."""
     import torch
 
     import cotengra_amd as ca
@@ -658,6 +665,17 @@ def m10_strong(dev, rank, world, comm, dist, reps=20):
     xs = [torch.as_tensor(z[f"t{i}"].astype("complex64"), device=dev) for i in range(tree.N)]
     fn = HipContractor(tree, handle_slicing=True)
     st = fn.setup(*xs)
+    return fn, st, tree
+
+
+def m10_strong(dev, rank, world, comm, dist, setup, reps=20):
+    """BASELINE config 3 as worded: ONE Sycamore m10 amplitude, its 64 slices dealt over the N ranks
+    (``ctg_exec_run_share``) + the RCCL reduce to rank 0, against the same amplitude on one rank.  Strong
+    scaling of a 3 ms job: printed because the configuration names it, not because it scales.
+    ``setup`` = ``m10_strong_setup(dev)``, which every rank has completed (the caller checked)."""
+    import torch
+
+    fn, st, tree = setup
     ex, result = st["exec"], st["result"]
 
     def sync_all():
@@ -1000,10 +1018,25 @@ def main():
     c3_strong = None
     if (world > 1 or os.environ.get("CTG_BENCH_C3_AMPLITUDES")) and not args.headline_only:
         try:
-            c3_strong = m10_strong(dev, rank, world, comm, dist)
-        except Exception as e:  # noqa: BLE001
-            print(f"rank {rank}: C3_strong leg failed: {e!r}", file=sys.stderr)
-            c3_strong = None
+            setup3 = m10_strong_setup(dev)
+        except Exception as e:  # noqa: BLE001  (an extra leg must not cost the headline line)
+            print(f"rank {rank}: C3_strong setup failed: {e!r}", file=sys.stderr)
+            setup3 = None
+        # (all ranks or none: the leg barriers and reduces -- a rank that failed above must not leave the
+        # others waiting in a collective before the headline line is printed)
+        if dist is not None:
+            bad3 = torch.tensor([0 if setup3 is not None else 1], device=dev)
+            dist.all_reduce(bad3)
+            if int(bad3.item()) != 0:
+                if setup3 is not None:
+                    setup3[0].close()
+                setup3 = None
+        if setup3 is not None:
+            try:
+                c3_strong = m10_strong(dev, rank, world, comm, dist, setup3)
+            except Exception as e:  # noqa: BLE001
+                print(f"rank {rank}: C3_strong leg failed: {e!r}", file=sys.stderr)
+                c3_strong = None
 
     # (flops really executed: the steps a slice group shares count once per group -- every rank times the
     # same number of whole groups, so rank 0's count x world is the job's)

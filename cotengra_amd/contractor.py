@@ -196,14 +196,29 @@ class HipContractor:
 
     # ------------------------------------------------------------------ #
 
+    def host_plan(self, dtype):
+        """The compiled plan alone -- pure Python, no native library: what a caller needs that only asks how
+        the slices are dealt to ranks (``Plan.rank_slice_ids``)."""
+        try:
+            return self._plans[dtype][0]
+        except KeyError:
+            pass
+        try:
+            return self._host_plans[dtype]
+        except (KeyError, AttributeError):
+            if not hasattr(self, "_host_plans"):
+                self._host_plans = {}
+            plan = self._host_plans[dtype] = compile_tree(
+                self.tree, dtype, order=self.order, force_kernel=self.force_kernel,
+                fuse=self.fuse, fuse_min_elems=self.fuse_min_elems, stem_bf16x3=self.stem_bf16x3,
+            )
+            return plan
+
     def get_plan(self, dtype):
         try:
             return self._plans[dtype]
         except KeyError:
-            plan = compile_tree(
-                self.tree, dtype, order=self.order, force_kernel=self.force_kernel,
-                fuse=self.fuse, fuse_min_elems=self.fuse_min_elems, stem_bf16x3=self.stem_bf16x3,
-            )
+            plan = self.host_plan(dtype)
             entry = self._plans[dtype] = (plan, runtime.DevicePlan(plan))
             return entry
 

@@ -1202,14 +1202,11 @@ static hipError_t launch_cfg(const StepArgs& p, const MfmaHints& h, void* scratc
         // fp32 products as six bf16 products (pair_mfma_bf3_kernel): long contractions on full 64-column tiles
         if (h.fast && h.bf3 && pair_bf16x3_on(p)) {
             constexpr size_t smem = 2 * 2 * 6 * (size_t)(2 * Cfg::BM * 8 + 2 * Cfg::BN * 8);
-            static unsigned long long ready[2] = {0, 0};
+            static unsigned long long ready[2] = {0, 0};   // (per-device bit masks, updated atomically: lds_opt_in)
             const void* fn = h.vecA ? (const void*)pair_mfma_bf3_kernel<Cfg, true> : (const void*)pair_mfma_bf3_kernel<Cfg, false>;
-            int dev = 0;
-            (void)hipGetDevice(&dev);
-            if (!((ready[h.vecA ? 1 : 0] >> dev) & 1ull)) {
-                const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+            {
+                const hipError_t e = lds_opt_in(fn, (int)smem, &ready[h.vecA ? 1 : 0]);
                 if (e != hipSuccess) return e;
-                ready[h.vecA ? 1 : 0] |= 1ull << dev;
             }
             if (h.vecA)
                 hipLaunchKernelGGL((pair_mfma_bf3_kernel<Cfg, true>), grid, dim3(256), smem, stream, p, h, tiles_m, tiles_n, k_chunk, part);

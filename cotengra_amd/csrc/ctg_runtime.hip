@@ -296,6 +296,14 @@ int validate_plan(ctg_plan* p) {
         }
     }
     if (p->has_groups) {
+        // (group indices of extent 1 only: every "group" is one slice -- the plan shares nothing, and
+        // ctg_exec_run_slices / ctg_exec_run_share must not hand the work to each other for ever)
+        int64_t gsize = 1;
+        for (int64_t j = 0; j < p->n_sliced; ++j)
+            if (p->slice_group[j] == 1 && p->slice_fixed[j] < 0) gsize *= p->slice_sizes[j];
+        if (gsize <= 1) p->has_groups = false;
+    }
+    if (p->has_groups) {
         // What a per-slice step reads of a step that its group shares must survive the group: no
         // per-slice step may write into that range of the arena (element ranges of the records; the
         // planner keeps such results out of the recycled part, cotengra_amd/plan.py: kept_for_group).

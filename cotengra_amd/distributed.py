@@ -165,7 +165,8 @@ def contract_distributed(
         # only -- says whether the tree has slice groups)
         from .contractor import _result_dtype, _tree_contractor
 
-        plan = _tree_contractor(tree, order).get_plan(_result_dtype(arrays))[0]
+        # (host_plan: no native plan handle, so this path needs neither a GPU nor the HIP library)
+        plan = _tree_contractor(tree, order).host_plan(_result_dtype(arrays))
         mine = slices_of_rank(tree.multiplicity, rank, world, plan=plan)
         return _reduce_host(
             _injected_partial(tree, arrays, mine, executor_factory), None, tgroup, rank, root

@@ -151,3 +151,75 @@ def test_strip_exponent_runs_the_ordinary_steps():
     assert abs(lg - lg_ref) < 1e-4
     z, z_ref = complex(m) / abs(complex(m)), complex(m_ref) / abs(complex(m_ref))
     assert abs(z - z_ref) < 1e-3
+
+
+# ---------------------------------------------------------------------- #
+# the reference's own input scale at Sycamore depth (missing 2)
+# ---------------------------------------------------------------------- #
+
+TREES = os.path.join(ROOT, "tests", "golden", "trees")
+
+
+def _strip_sum(pairs):
+    """Sum of (mantissa, exponent) pairs as the reference's adder forms it (core.py:125-172), in Python
+    complex: ``(mantissa, exponent)`` with the largest exponent."""
+    emax = max(e for _, e in pairs)
+    return sum(complex(m) * 10.0 ** (e - emax) for m, e in pairs), emax
+
+
+@pytest.mark.parametrize("fixture", ["sycamore_m20_native.json", "sycamore_m10.json"])
+@pytest.mark.parametrize("mode", ["complex64-bf16x3", "complex64-fp32", "complex128"])
+def test_raw_inputs_under_strip_exponent_at_sycamore_depth(fixture, mode, monkeypatch):
+    """The reference normalises after EVERY step under strip_exponent (contract.py:816-829), so its own
+    un-rescaled inputs (Frobenius-normalised, utils.py:1243-1284) go through a 380-step m20 tree in
+    complex64; here normalisation is lazy.  Trees narrowed to width 2^20, ``rescale=False``,
+    ``strip_exponent=True``: 64 slices summed on the device and single slices, both arithmetics and
+    double precision, against the oracle's (mantissa, exponent) in complex128 -- compared as
+    log10|m| + e and as the normalised mantissa."""
+    tree = ca.tree_from_record(ca.load_network(os.path.join(TREES, fixture)))
+    small = tree.slice(target_size=2**20) if tree.max_size() > 2**20 else tree
+    a128 = ca.make_arrays_from_inputs(small.inputs, small.size_dict, seed=42, dtype="complex128", rescale=False)
+    dtype = "complex128" if mode == "complex128" else "complex64"
+    if mode != "complex128":
+        monkeypatch.setenv("CTG_STEM_BF16X3", "1" if mode.endswith("bf16x3") else "0")
+    xs = [a.astype(dtype) for a in a128]
+    n = int(min(small.nslices, 2**40))
+    ids = sorted({int(i) for i in np.linspace(0, n - 1, 64)})
+    assert len(ids) >= min(64, n)
+    ref_pairs = [orc.contract_slice(small, a128, i, strip_exponent=True) for i in ids]
+    s_ref, e_ref = _strip_sum(ref_pairs)
+    assert abs(s_ref) > 0 and e_ref < -30, "the value must lie far below the float32 range for this test to bite"
+    if dtype == "complex64":
+        s_np, e_np = _strip_sum([orc.contract_slice(small, xs, i, strip_exponent=True) for i in ids])
+        np_err = abs(s_np * 10.0 ** (e_np - e_ref) - s_ref) / abs(s_ref)
+        gate = max(1e-5, 8.0 * np_err)
+    else:
+        gate = 1e-10
+
+    def check(m, e, s, es, tol):
+        lg, lg_ref = np.log10(abs(complex(m))) + e, np.log10(abs(s)) + es
+        assert abs(lg - lg_ref) <= max(tol, 1e-12) / np.log(10.0) * 1.5 + 1e-12, (lg, lg_ref)
+        z, z_ref = complex(m) / abs(complex(m)), s / abs(s)
+        assert abs(z - z_ref) <= 1.5 * tol, (abs(z - z_ref), tol)
+
+    fn = HipContractor(small)
+    try:
+        st = fn.setup(*xs)
+        ex = st["exec"]
+        ex.set_strip_exponent(True, False)
+        ex.zero_result()
+        ex.run_slice_list(ids)
+        part, e, zero = ex.get_state()
+        assert not zero
+        check(part, e, s_ref, e_ref, gate)
+        # single slices
+        for k in (0, len(ids) - 1):
+            m1, e1 = fn.contract_slice(xs, ids[k], strip_exponent=True)
+            sm, se = complex(ref_pairs[k][0]), ref_pairs[k][1]
+            tol1 = gate
+            if dtype == "complex64":
+                mn, en = orc.contract_slice(small, xs, ids[k], strip_exponent=True)
+                tol1 = max(1e-5, 8.0 * abs(complex(mn) * 10.0 ** (en - se) - sm) / abs(sm))
+            check(np.asarray(m1), e1, sm, se, tol1)
+    finally:
+        fn.close()
