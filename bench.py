@@ -17,7 +17,8 @@ timed region.
 environment) the script re-executes itself under ``torch.distributed.run`` with
 N ranks on 127.0.0.1; started by a launcher it checks that WORLD_SIZE == N.
 Every rank pins GPU LOCAL_RANK, the ranks verify that they own N distinct GPUs,
-each contracts its own slices (round-robin, no data-path traffic) and the
+each contracts ITS SHARE of the slices (``ctg_exec_run_share``: whole slice groups ``rank, rank + world,
+...`` -- the reference's round-robin, core.py:4070, with the group as the unit; no data-path traffic) and the
 partial amplitudes are combined by ONE RCCL reduce on the executors' streams
 (``ctg_exec_reduce`` of the C ABI) inside the timed region -- weak scaling.
 
@@ -37,6 +38,7 @@ anyway).  The LAST stdout line is a compact record (< 4 KB: the contract's keys,
 """
 import argparse
 import json
+import math
 import os
 import socket
 import subprocess
@@ -201,6 +203,67 @@ def precision_check(tree, arrays, slice_id=3, log2_width=20):
     if out["rel_err"] > gate or out["rel_err_complex128_path"] > 1e-10:
         raise SystemExit(f"precision check failed: {out}")
     return out
+
+
+def precision_sum_check(tree, arrays, slice_id=3, log2_width=22, log2_slices=12):
+    """The quantity ``north_star`` gates is a SUM of slices (core.py:3842-3844).  One slice of ``tree``
+    narrowed to width 2^log2_width is -- exactly -- the sum of the 2^log2_slices slices of the same tree with
+    that many more indices sliced: the complex64 HIP path sums those on the device (double-precision running
+    sum, accum_kernel), the numpy complex128 oracle contracts the one wide slice.  No numpy-relative clause:
+    the number is reported against 1e-5 as it is."""
+    import itertools
+
+    from cotengra_amd.contractor import HipContractor
+    from cotengra_amd.stem import bf16x3_mode
+    from oracle import contract_ref as orc
+
+    coarse = shrink_for_cpu(tree, log2_width)
+    fine = coarse.copy()
+    extra = []
+    while len(extra) < log2_slices:
+        big = max((p for p, _, _ in fine.traverse()), key=fine.get_size)
+        ix = next(iter(fine.get_legs(big)))
+        fine.remove_ind_(ix)
+        extra.append(ix)
+    # ids (in fine's numbering) of the slices of ``fine`` that make up slice ``slice_id`` of ``coarse``
+    import cotengra_amd as ca
+
+    key = coarse.slice_key(slice_id)
+    strides = dict(zip(fine.sliced_inds, ca.get_slice_strides(fine.sliced_inds)))
+    ids = []
+    for combo in itertools.product(*[range(fine.size_dict[ix]) for ix in extra]):
+        k = dict(key)
+        k.update(zip(extra, combo))
+        ids.append(sum(k[ix] * strides[ix] for ix in fine.sliced_inds))
+    ids.sort()
+    lowered = bf16x3_mode() and "CTG_FUSE_MIN_ELEMS" not in os.environ
+    if lowered:
+        os.environ["CTG_FUSE_MIN_ELEMS"] = str(1 << 12)
+    a128 = [a.astype("complex128") for a in arrays]
+    with host_threads():
+        t0 = time.perf_counter()
+        ref = complex(orc.contract_slice(coarse, a128, slice_id))
+        oracle_s = time.perf_counter() - t0
+    fn = HipContractor(fine)
+    try:
+        st = fn.setup(*arrays)
+        ex = st["exec"]
+        ex.zero_result()
+        ex.run_slice_list(ids)
+        got = complex(np.asarray(ex.download_result()))
+        wide = str(ex.state_dtype())
+        fused = sum(1 for s_ in st["plan"].steps if s_.kind == 3)
+    finally:
+        fn.close()
+        if lowered:
+            del os.environ["CTG_FUSE_MIN_ELEMS"]
+    rel = abs(got - ref) / abs(ref)
+    return {
+        "check": f"sum of {len(ids)} complex64 slices (width 2^{math.log2(fine.max_size()):.0f}, device running sum in "
+                 f"{wide}) vs ONE numpy complex128 slice of the same tree at width 2^{log2_width}",
+        "slices": len(ids), "rel_err": rel, "meets_north_star_1e-5": bool(rel <= 1e-5),
+        "fused_pairs_in_check": fused, "oracle_seconds": oracle_s,
+    }
 
 
 def step_table(ex, plan, slice_id=0):
@@ -756,7 +819,7 @@ def compact_record(out, full_path="bench_full.json"):
     rec["dtype"] = out.get("dtype_short", "complex64")
     rec["data"] = out.get("data", "synthetic")
     rec.update(_pick(out, "slices_per_sec", "tflops", "est_time_total_s"))
-    rec["config"] = _pick(cfg, "workload", "tree", "nslices_log2", "macs_per_slice", "flops_per_slice",
+    rec["config"] = _pick(cfg, "workload", "network", "tree", "width_log2", "arena_gib", "nslices_log2", "macs_per_slice", "flops_per_slice",
                           "bytes_moved_per_slice", "algorithmic_bytes_per_slice", "steps_per_slice", "parallelism",
                           "reduce_via", "arithmetic")
     sg = cfg.get("slice_groups")
@@ -768,10 +831,12 @@ def compact_record(out, full_path="bench_full.json"):
     if "matrix_side" in roof:
         rec["roofline"]["matrix_frac"] = roof["matrix_side"].get("frac")
     if "mixed_per_step" in roof:
-        rec["roofline"]["mixed_per_step"] = _pick(roof["mixed_per_step"], "bound_ms", "frac")
+        # (flat: the driver's parser keeps one level below "roofline")
+        rec["roofline"]["mixed_frac"] = roof["mixed_per_step"].get("frac")
+        rec["roofline"]["mixed_bound_ms"] = roof["mixed_per_step"].get("bound_ms")
     if out.get("precision"):
         rec["precision"] = _pick(out["precision"], "rel_err", "gate", "numpy_complex64_rel_err",
-                                 "rel_err_complex128_path")
+                                 "rel_err_complex128_path", "sum_rel_err", "sum_slices")
     if out.get("cpu_baseline"):
         rec["cpu_baseline"] = _pick(out["cpu_baseline"], "value", "unit", "cores", "kind", "sample")
     # one number per extra leg
@@ -792,6 +857,7 @@ def compact_record(out, full_path="bench_full.json"):
         if "mixed_roofline_frac" in c:
             legs[name + "_ms"] = c.get("ms")
             legs[name + "_frac"] = c.get("mixed_roofline_frac")
+            legs[name + "_launches"] = c.get("launches_per_slice")
             if c.get("bf16x3_steps"):   # (some steps on the bf16 pipe: the fraction with every step priced at 157.3 TF next to it)
                 legs[name + "_frac_fp32_pipe"] = c.get("mixed_roofline_fp32_pipe_frac")
         elif "amplitudes_per_sec" in c:
@@ -809,8 +875,8 @@ def compact_record(out, full_path="bench_full.json"):
     rec["full_record"] = full_path
     rec = _sig(rec)
     # never over the limit: drop the least important keys first (none of them is part of the contract)
-    for drop in ("legs", "precision", ("config", "slice_groups"), ("roofline", "mixed_per_step"),
-                 ("config", "workload")):
+    for drop in ("legs", "precision", ("config", "slice_groups"), ("roofline", "mixed_bound_ms"),
+                 ("config", "network")):
         if len(json.dumps(rec, separators=(",", ":"))) < COMPACT_LIMIT:
             break
         if isinstance(drop, tuple):
@@ -982,6 +1048,11 @@ def main():
 
     extras = rank == 0 and world == 1 and not args.no_cpu_baseline
     precision = precision_check(tree, arrays) if (rank == 0 and not args.no_cpu_baseline) else None
+    if precision is not None:
+        # the quantity north_star gates: a sum of slices, without the numpy-relative clause
+        psum = precision_sum_check(tree, arrays)
+        precision["sum"] = psum
+        precision["sum_rel_err"], precision["sum_slices"] = psum["rel_err"], psum["slices"]
     # C3 at N > 1: every rank computes m10 amplitudes (of different bitstrings) on its own
     c3_amp = None
     # (CTG_BENCH_C3_AMPLITUDES=1: also at N = 1 under a launcher -- how the one-GPU lease tests this leg)
@@ -1133,10 +1204,12 @@ def main():
             "cotengra_convention_gigaflops": 4.0 * plan.macs_per_slice * total_slices / dt / 1e9,
             "est_time_total_s": nsl / (total_slices / dt),
             "config": {
-                "workload": "Sycamore circuit_n53_m20 amplitude (examples/benchmarks/"
-                "sycamore_n53_m20_s0_e0_pABCDCDAB.json), tree sliced to width 2^%d, "
-                "one slice per step per GPU" % int(round(np.log2(tree.max_size()))),
+                # (<= 120 characters: the driver's parser cuts fields at 128; file, width and arena have keys of their own)
+                "workload": "Sycamore n53 m20 amplitude, sliced tree, one slice per step per GPU",
+                "network": "examples/benchmarks/sycamore_n53_m20_s0_e0_pABCDCDAB.json",
                 "tree": os.path.basename(args.tree),
+                "width_log2": int(round(np.log2(tree.max_size()))),
+                "arena_gib": round(plan.arena_elems * plan.itemsize / 2**30, 1),
                 "nslices_log2": float(np.log2(nsl)),
                 "macs_per_slice": int(plan.macs_per_slice),
                 "flops_per_slice": float(flops_slice),

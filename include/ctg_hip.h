@@ -284,9 +284,11 @@ int ctg_exec_get_state_wide(ctg_exec* exec, void* host_sum, double* exponent, in
 int ctg_exec_set_state_wide(ctg_exec* exec, const void* host_sum, double exponent, int zero);
 
 /* Multi-GPU: one process (or thread) per GPU, each with its own exec running
- * ctg_exec_run_slices(first = rank, stride = world) -- the round-robin of
- * `contract_mpi` (core.py:4068-4076) -- followed by ONE collective over the
- * result tensor: `comm.Allreduce` / `comm.Reduce` there (core.py:4081, 4089),
+ * ctg_exec_run_share(exec, rank, world, 0, -1) -- ITS SHARE of the slices, dealt by the
+ * library (ABI 6): the units rank, rank + world, ... where a unit is a whole slice group
+ * (what a group shares is then computed once per group, on one rank) and a single slice
+ * for a plan without group indices, which is the round-robin of `contract_mpi`
+ * (core.py:4068-4076) -- followed by ONE collective over the result tensor: `comm.Allreduce` / `comm.Reduce` there (core.py:4081, 4089),
  * RCCL over xGMI here.  The communicator is created from a 128-byte unique id
  * made on one rank and handed to the others by whatever channel the caller has
  * (MPI bcast, a file, torch.distributed's store ...) -- the role of mpi4py's

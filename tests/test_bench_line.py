@@ -68,3 +68,30 @@ def test_pmc_traffic_lookup_normalises_template_arguments():
     assert traffic == pytest.approx(68.7e9, rel=0.01)
     traffic, _ = bench.pmc_traffic_for(bench.TREE, xm[:-1].replace(",", ", ") + ", false>")
     assert traffic == pytest.approx(68.7e9, rel=0.01)
+
+
+def test_no_field_of_the_compact_line_is_cut_by_the_drivers_parser(full):
+    """The driver keeps 128 characters of a string field and one level of nesting below ``roofline``:
+    every string of the compact record stays under 120 characters, the workload included, and the mixed
+    per-step roofline fraction is a flat key next to ``frac``."""
+    full = dict(full)
+    full["config"] = dict(full["config"], workload="Sycamore n53 m20 amplitude, sliced tree, one slice per step per GPU",
+                          network="examples/benchmarks/sycamore_n53_m20_s0_e0_pABCDCDAB.json", width_log2=32, arena_gib=113.0)
+    full["roofline"] = dict(full["roofline"], mixed_per_step={"bound_ms": 107.8, "frac": 0.49})
+    rec = bench.compact_record(full)
+
+    def strings(x, path=""):
+        if isinstance(x, dict):
+            for k, v in x.items():
+                yield from strings(v, path + "/" + str(k))
+        elif isinstance(x, (list, tuple)):
+            for i, v in enumerate(x):
+                yield from strings(v, path + "/" + str(i))
+        elif isinstance(x, str):
+            yield path, x
+
+    for path, text in strings(rec):
+        assert len(text) <= 120, (path, len(text))
+    assert rec["roofline"]["mixed_frac"] == pytest.approx(0.49)
+    assert all(not isinstance(v, dict) for v in rec["roofline"].values())
+    assert rec["config"]["width_log2"] == 32 and rec["config"]["tree"]
