@@ -872,6 +872,13 @@ def compact_record(out, full_path="bench_full.json"):
         rec["distinct_gpus"] = out.get("distinct_gpus")
         rec["slowest_rank_ms"] = max(r["wall_ms"] for r in out["per_rank"])
         rec["reduce_wait_ms_max"] = max(r["reduce_wait_ms"] for r in out["per_rank"])
+        # the spread over the ranks (an 8-GPU run: which rank lags, and whether in its slices or in the reduce)
+        rec["ranks"] = {
+            "slices_ms": [round(r["slices_ms"], 3) for r in out["per_rank"]],
+            "reduce_wait_ms": [round(r["reduce_wait_ms"], 3) for r in out["per_rank"]],
+            "share_units": [r.get("share_units") for r in out["per_rank"]],
+            "slices_per_unit": out["per_rank"][0].get("slices_per_unit"),
+        }
     rec["full_record"] = full_path
     rec = _sig(rec)
     # never over the limit: drop the least important keys first (none of them is part of the contract)
@@ -1042,7 +1049,9 @@ def main():
         dist.all_gather(allr, mine)
         per_rank = [
             {"rank": r, "device": devices[r] if devices else None, "wall_ms": float(v[0]),
-             "slices_ms": float(v[1]), "reduce_wait_ms": float(v[2])}
+             "slices_ms": float(v[1]), "reduce_wait_ms": float(v[2]),
+             # (what the library deals this rank over the WHOLE job: ctg_plan_share_units)
+             "share_units": int(plan.share_units(r, world)[0]), "slices_per_unit": int(plan.share_units(r, world)[1])}
             for r, v in enumerate(allr)
         ]
 

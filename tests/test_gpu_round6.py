@@ -223,3 +223,47 @@ def test_raw_inputs_under_strip_exponent_at_sycamore_depth(fixture, mode, monkey
             check(np.asarray(m1), e1, sm, se, tol1)
     finally:
         fn.close()
+
+
+# ---------------------------------------------------------------------- #
+# multi-GPU path hardened for the day an 8-GPU node exists
+# ---------------------------------------------------------------------- #
+
+
+def test_bench_line_is_complete_when_rccl_cannot_be_loaded():
+    """``bench.py`` under a launcher with ``CTG_RCCL_LIB`` pointing at a file that does not exist:
+    ``ctg_comm_init`` fails loudly (CTG_E_COMM), every rank agrees to reduce through torch.distributed instead,
+    and the line is still complete -- contract keys, per-rank spread, share sizes, the N > 1 legs."""
+    import json
+    import subprocess
+    import sys
+
+    env = dict(os.environ, CTG_BENCH_C3_AMPLITUDES="1", HSA_ENABLE_IPC_MODE_LEGACY="0",
+               CTG_RCCL_LIB="/nonexistent/librccl-missing.so")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
+           "--master-addr", "127.0.0.1", "--master-port", "29519", os.path.join(ROOT, "bench.py"),
+           "--gpus", "1", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert "ctg_comm_init failed" in r.stderr
+    rec = json.loads(r.stdout.strip().splitlines()[-1])
+    assert rec["n_gpus"] == 1 and rec["roofline"]["frac"] > 0 and rec["value"] > 0
+    assert rec["config"]["reduce_via"] == "torch.distributed.reduce (RCCL)"
+    assert rec["ranks"]["share_units"] == [2**20 // rec["ranks"]["slices_per_unit"]]
+    assert len(rec["ranks"]["slices_ms"]) == 1 and rec["ranks"]["reduce_wait_ms"][0] >= 0
+    assert rec["legs"]["C3_strong_ms"] > 0 and rec["legs"]["C3_amplitudes_per_sec"] > 50
+
+
+def test_plain_c_driver_fails_loudly_without_rccl(tmp_path):
+    """``tests/cabi_reduce`` (no Python) with RCCL unloadable: a non-zero exit and the library's message, not a
+    silent single-GPU result."""
+    import subprocess
+
+    exe = os.path.join(ROOT, "tests", "cabi_reduce")
+    plan = os.path.join(ROOT, "tests", "golden", "cabi_plan.bin")
+    if not os.path.exists(exe):
+        pytest.skip("tests/cabi_reduce not built")
+    env = dict(os.environ, CTG_RCCL_LIB="/nonexistent/librccl-missing.so")
+    r = subprocess.run([exe, plan], capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode != 0
+    assert "rccl" in (r.stdout + r.stderr).lower()

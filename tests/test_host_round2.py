@@ -342,11 +342,18 @@ def test_small_trees_are_planned_level_by_level(name):
         level[p] = 1 + max(level.get(l, 0), level.get(r, 0))
     pl = P.compile_tree(tree, "complex64")
     pairs = [s for s in pl.steps if s.kind == P.KIND_PAIR]
-    seq = [level[s.node] for s in pairs]
+    # (round 6: the members of LDS-resident subtrees come first among the steps of their sharing class --
+    # cotengra_amd/ldsrun.py --, level by level; then the other steps of the class, level by level)
+    from cotengra_amd.ldsrun import CLASS_RANK
+
+    def section(s):
+        return (CLASS_RANK["inv" if s.invariant else ("group" if s.group else "slice")], s.lds_comp < 0)
+
+    seq = [(section(s), level[s.node]) for s in pairs]
     assert seq == sorted(seq), "steps are not in level order"
     by_level = {}
     for s in pairs:
-        by_level.setdefault(level[s.node], []).append(s)
+        by_level.setdefault((section(s), level[s.node]), []).append(s)
     for steps in by_level.values():
         for i, x in enumerate(steps):
             for y in steps[i + 1:]:

@@ -539,11 +539,26 @@ def test_slice_groups_plan_semantics(fixture, groups_on_small_trees):
     with pytest.raises((runtime.CtgError, ValueError)):
         runtime.DevicePlan(plan)
     plan.slice_group = keep
-    kept = next(s for s in shared if any(not t.group and not t.invariant and t.kind != P.KIND_ACCUM and
-                                         any(op is s.c for op in (t.a, t.b, getattr(t, "b2", None)))
-                                         for t in plan.steps))
-    victim = next(t for t in plan.steps if not t.group and not t.invariant and t.kind in (P.KIND_PAIR, P.KIND_STEM2)
-                  and t.c.space == P.SPACE_ARENA and t.c.size >= kept.c.size and t.c is not kept.c)
+    # a kept tensor moved onto the output range of a per-slice step that nobody else writes between the shared
+    # step and the kept tensor's first per-slice reader (the value would be alive there): refused
+    def first_writer(g, skip, lo, hi):
+        return next((i for i, t in enumerate(plan.steps) if i > g and t.kind != P.KIND_ACCUM and t.c.space == P.SPACE_ARENA
+                     and t.c is not skip and t.c.offset < hi and lo < t.c.offset + t.c.size), len(plan.steps))
+
+    kept = victim = None
+    for cand in shared:
+        g = plan.steps.index(cand)
+        readers = [i for i, t in enumerate(plan.steps) if i > g and not t.group and not t.invariant and
+                   t.kind != P.KIND_ACCUM and any(op is cand.c for op in (t.a, t.b, getattr(t, "b2", None)))]
+        if not readers or cand.c.space != P.SPACE_ARENA:
+            continue
+        victim = next((t for t in plan.steps if not t.group and not t.invariant and t.kind in (P.KIND_PAIR, P.KIND_STEM2)
+                       and t.c.space == P.SPACE_ARENA and t.c.size >= cand.c.size and t.c is not cand.c
+                       and first_writer(g, cand.c, t.c.offset, t.c.offset + cand.c.size) > readers[0]), None)
+        if victim is not None:
+            kept = cand
+            break
+    assert kept is not None
     old = kept.c.offset
     kept.c.offset = victim.c.offset
     with pytest.raises((runtime.CtgError, ValueError)):
