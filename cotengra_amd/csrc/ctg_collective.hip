@@ -55,7 +55,12 @@ RcclApi g_rccl;
 std::once_flag g_rccl_once;
 
 void bind_rccl() {
-    const char* names[3] = {getenv("CTG_RCCL_LIB"), "librccl.so.1", "librccl.so"};
+    // (an explicit CTG_RCCL_LIB is the ONLY candidate: a library named by the caller that cannot be loaded is an
+    // error -- CTG_E_COMM with dlerror's text --, not a reason to bind some other RCCL silently)
+    const char* named = getenv("CTG_RCCL_LIB");
+    const bool explicit_lib = named != nullptr && *named != '\0';
+    const char* names[3] = {explicit_lib ? named : nullptr, explicit_lib ? nullptr : "librccl.so.1",
+                            explicit_lib ? nullptr : "librccl.so"};
     for (const char* n : names) {
         if (!n || !*n) continue;
         g_rccl.handle = dlopen(n, RTLD_NOW | RTLD_GLOBAL);

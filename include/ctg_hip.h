@@ -293,8 +293,8 @@ int ctg_exec_set_state_wide(ctg_exec* exec, const void* host_sum, double exponen
  * made on one rank and handed to the others by whatever channel the caller has
  * (MPI bcast, a file, torch.distributed's store ...) -- the role of mpi4py's
  * COMM_WORLD in the reference (core.py:4057-4060).  RCCL is bound with dlopen
- * at the first call (CTG_RCCL_LIB overrides the library name); CTG_E_COMM if
- * it is absent. */
+ * at the first call (librccl.so.1, librccl.so; CTG_RCCL_LIB names the one library to
+ * bind instead -- no fallback when it cannot be loaded); CTG_E_COMM if it is absent. */
 #define CTG_UNIQUE_ID_BYTES 128
 int ctg_comm_get_unique_id(void* id_out /* [CTG_UNIQUE_ID_BYTES] */);
 /* collective over all `world` ranks; `device` is this rank's GPU ordinal */
