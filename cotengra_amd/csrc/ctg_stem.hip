@@ -132,6 +132,13 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 // the six products kept, (limb of a, limb of b): those that need only the FIRST limb of the operand
 // being split come first -- it is a byte permute of the words as they arrive, the MFMAs can start while
 // the other two limbs are still being subtracted out
+// (experiment build -DCTG_STEM_KO_HALF: only the three products a TWO-limb split would keep -- t = 0, 1, 3 --, the third
+// limbs dead code: what halving the product count is worth in time; the results lose their third limb)
+#ifdef CTG_STEM_KO_HALF
+#define CTG_STEM_T_STEP(t) ((t) == 1 ? 2 : ((t) == 3 ? 3 : 1))
+#else
+#define CTG_STEM_T_STEP(t) 1
+#endif
 __device__ __forceinline__ constexpr int bf3_ta(int t) { return t < 3 ? 0 : (t == 5 ? 2 : 1); }
 __device__ __forceinline__ constexpr int bf3_tb(int t) { return t == 1 || t == 4 ? 1 : (t == 2 ? 2 : 0); }
 
@@ -872,7 +879,7 @@ __global__ __launch_bounds__(SW * 64, 1) void stem2_kernel(StemArgs p) {
 #pragma unroll
             for (int u = 0; u < 16; ++u) zero16[u] = 0.f;
 #pragma unroll
-            for (int t = 0; t < 6; ++t) {
+            for (int t = 0; t < 6; t += CTG_STEM_T_STEP(t)) {
                 const int ta = bf3_ta(t), tb = bf3_tb(t);
                 if (PACK1) {
                     ax[m] = mfma_bf(r3[ta], bp3[tb], (fresh && t == 0) ? zero16 : ax[m]);
@@ -1120,7 +1127,7 @@ __global__ __launch_bounds__(SW * 64, 1) void stem2_kernel(StemArgs p) {
 #pragma unroll
                 for (int u = 0; u < 16; ++u) zero16[u] = 0.f;
 #pragma unroll
-                for (int t = 0; t < 6; ++t) {
+                for (int t = 0; t < 6; t += CTG_STEM_T_STEP(t)) {
                     const int ta = bf3_ta(t), tb = bf3_tb(t);
                     cx = mfma_bf(F.ar[ta], F.br[tb], (FIRST && t == 0) ? zero16 : cx);
                     cy = mfma_bf(F.ar[ta], F.bi[tb], (FIRST && t == 0) ? zero16 : cy);
@@ -1169,7 +1176,7 @@ __global__ __launch_bounds__(SW * 64, 1) void stem2_kernel(StemArgs p) {
                     bx3[q] = *(const bf16x8*)(q2x + kb * 24 + q * 8);
                 }
 #pragma unroll
-                for (int t = 0; t < 6; ++t) cx = mfma_bf(a3[bf3_ta(t)], bx3[bf3_tb(t)], cx);
+                for (int t = 0; t < 6; t += CTG_STEM_T_STEP(t)) cx = mfma_bf(a3[bf3_ta(t)], bx3[bf3_tb(t)], cx);
             }
         } else if constexpr (BF3) {
             // 8 k per instruction: the row's 8 values of this lane's plane, split; B2 from its planes
@@ -1189,7 +1196,7 @@ __global__ __launch_bounds__(SW * 64, 1) void stem2_kernel(StemArgs p) {
                     if (!PACK2) by3[q] = *(const bf16x8*)(byq + kb * 24 + q * 8);
                 }
 #pragma unroll
-                for (int t = 0; t < 6; ++t) {
+                for (int t = 0; t < 6; t += CTG_STEM_T_STEP(t)) {
                     cx = mfma_bf(ax3[bf3_ta(t)], bx3[bf3_tb(t)], cx);
                     if (!PACK2) cy = mfma_bf(a3[bf3_ta(t)], by3[bf3_tb(t)], cy);
                 }
@@ -1307,7 +1314,7 @@ __global__ __launch_bounds__(SW * 64, 1) void stem2_kernel(StemArgs p) {
                     if (!PACKM) by3[q] = *(const bf16x8*)(qmy[I] + kb * 24 + q * 8);
                 }
 #pragma unroll
-                for (int t = 0; t < 6; ++t) {
+                for (int t = 0; t < 6; t += CTG_STEM_T_STEP(t)) {
                     cx = mfma_bf(ax3[bf3_ta(t)], bx3[bf3_tb(t)], cx);
                     if (!PACKM) cy = mfma_bf(a3[bf3_ta(t)], by3[bf3_tb(t)], cy);
                 }
