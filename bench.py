@@ -55,6 +55,8 @@ PEAK_MFMA_BF16_TFLOPS = 2500.0  # ... dense bf16 matrix peak (~2.5 PF)
 # fp32 products as SIX bf16 products (three-way split operands, csrc/ctg_stem.hip BF3): the peak of
 # that arithmetic in fp32-equivalent flops -- what the bf16 x 3 legs are priced against
 PEAK_BF16X3_TFLOPS = PEAK_MFMA_BF16_TFLOPS / 6.0
+# (round 6) two fp16 limbs, three products per fp32 product on v_mfma_f32_32x32x16_f16 (same dense peak as bf16)
+PEAK_FP16X2_TFLOPS = PEAK_MFMA_BF16_TFLOPS / 3.0
 PEAK_HBM_GBS = 8000.0
 TREES = os.path.join(ROOT, "tests", "golden", "trees")
 TREE = os.path.join(TREES, "sycamore_m20_native.json")        # reaches the amplitude first
@@ -286,24 +288,29 @@ def step_table(ex, plan, slice_id=0):
 
 
 def is_bf16x3_kernel(name):
-    """stem2_kernel<..., BF3, RI2>: the tenth template argument says whether the instantiation
-    multiplies on the bf16 matrix cores (shapes without such an instantiation keep fp32 products)."""
-    if not name or not name.startswith("stem2_kernel<"):
-        return False
-    args = name[len("stem2_kernel<"):].rstrip(">").split(",")
-    return len(args) >= 10 and args[9].strip() == "true"
+    """stem2_kernel<..., BF3, RI2> / stem2h_kernel<...>: the tenth template argument says whether the instantiation
+    multiplies on the 16-bit matrix cores (shapes without such an instantiation keep fp32 products)."""
+    for prefix in ("stem2_kernel<", "stem2h_kernel<"):
+        if name and name.startswith(prefix):
+            args = name[len(prefix):].rstrip(">").split(",")
+            return len(args) >= 10 and args[9].strip() == "true"
+    return False
 
 
 def step_peak_tflops(r, bf16x3=False):
-    """The matrix peak a step is priced against: fp32 MFMA; a fused stem pair running on the
-    bf16 matrix cores with three-way split operands: bf16 peak / 6 products (decided per launch
-    by the kernel's name when the row carries one)."""
+    """The matrix peak a step is priced against: fp32 MFMA; a fused stem pair on the 16-bit matrix cores: the dense
+    bf16 / fp16 peak over its products per fp32 product -- 6 with three bf16 limbs (stem2_kernel), 3 with two fp16
+    limbs (stem2h_kernel, round 6) -- decided per launch by the kernel's name when the row carries one."""
     name = r.get("kernel_name") or r.get("kernel_symbol")
     if name is not None and name.startswith("pair_mfma_bf3_kernel"):   # (long tiled steps, round 5)
         return PEAK_BF16X3_TFLOPS
+    if name is not None and name.startswith("stem2h_kernel<"):
+        return PEAK_FP16X2_TFLOPS if is_bf16x3_kernel(name) else PEAK_MFMA_F32_TFLOPS
     if name is not None and name.startswith("stem2_kernel<"):
         return PEAK_BF16X3_TFLOPS if is_bf16x3_kernel(name) else PEAK_MFMA_F32_TFLOPS
-    return PEAK_BF16X3_TFLOPS if (bf16x3 and r.get("kind") == "stem2") else PEAK_MFMA_F32_TFLOPS
+    if bf16x3 and r.get("kind") == "stem2":
+        return PEAK_FP16X2_TFLOPS if bf16x3 == "fp16x2" else PEAK_BF16X3_TFLOPS
+    return PEAK_MFMA_F32_TFLOPS
 
 
 def mixed_roofline_ms(rows, flops_per_mac, moved=True, bf16x3=False):
@@ -350,12 +357,13 @@ def norm_kernel_name(name):
     if not name:
         return name
     name = name.replace(" ", "")
-    if name.startswith("stem2_kernel<") and name.endswith(">"):
-        targs = name[len("stem2_kernel<"):-1].split(",")
-        full = 10 + len(STEM2_TEMPLATE_DEFAULTS)
-        if 10 <= len(targs) < full:
-            targs += list(STEM2_TEMPLATE_DEFAULTS[len(targs) - 10:])
-        name = "stem2_kernel<" + ",".join(targs) + ">"
+    for prefix in ("stem2_kernel<", "stem2h_kernel<"):   # (stem2h: the same instantiations in the fp16 x 2 arithmetic)
+        if name.startswith(prefix) and name.endswith(">"):
+            targs = name[len(prefix):-1].split(",")
+            full = 10 + len(STEM2_TEMPLATE_DEFAULTS)
+            if 10 <= len(targs) < full:
+                targs += list(STEM2_TEMPLATE_DEFAULTS[len(targs) - 10:])
+            name = prefix + ",".join(targs) + ">"
     return name
 
 
@@ -377,38 +385,57 @@ def pmc_traffic_for(tree_file, kernel):
         return None, None
 
 
+ARITH_ENV = ("CTG_STEM_ARITH", "CTG_STEM_BF16X3", "CTG_STEM_H2")
+
+
 class arithmetic:
-    """``with arithmetic("fp32" | "bf16x3" | None)``: the fused stem pairs' arithmetic for the
-    duration (CTG_STEM_BF16X3, which planner and kernel launcher both read); None = leave it."""
+    """``with arithmetic("fp32" | "bf16x3" | "fp16x2" | None)``: the fused stem pairs' arithmetic for the duration
+    (CTG_STEM_ARITH for the executors created inside; CTG_STEM_BF16X3=0 as well for fp32, which the planner's pairing
+    model reads); None = leave the environment alone."""
 
     def __init__(self, mode):
         self.mode = mode
 
     def __enter__(self):
-        self.old = os.environ.get("CTG_STEM_BF16X3")
+        self.old = {k: os.environ.get(k) for k in ARITH_ENV}
         if self.mode is not None:
-            os.environ["CTG_STEM_BF16X3"] = "1" if self.mode == "bf16x3" else "0"
+            for k in ARITH_ENV:
+                os.environ.pop(k, None)
+            os.environ["CTG_STEM_ARITH"] = self.mode
+            if self.mode == "fp32":
+                os.environ["CTG_STEM_BF16X3"] = "0"
         return self
 
     def __exit__(self, *exc):
         if self.mode is not None:
-            if self.old is None:
-                del os.environ["CTG_STEM_BF16X3"]
-            else:
-                os.environ["CTG_STEM_BF16X3"] = self.old
+            for k, v in self.old.items():
+                if v is None:
+                    os.environ.pop(k, None)
+                else:
+                    os.environ[k] = v
         return False
 
 
 def stem_arithmetic():
-    from cotengra_amd.stem import bf16x3_mode
-
-    return "bf16x3" if bf16x3_mode() else "fp32"
+    """The arithmetic an executor created now multiplies its stem pairs with (csrc/ctg_runtime.hip reads the same
+    variables): CTG_STEM_BF16X3=0 -> fp32; CTG_STEM_ARITH; fp16 x 2 when nothing is said (CTG_STEM_H2=0: bf16 x 3)."""
+    v = os.environ.get("CTG_STEM_BF16X3")
+    if v is not None and v in ("", "0"):
+        return "fp32"
+    a = {"0": "fp32", "1": "bf16x3", "2": "fp16x2"}.get(os.environ.get("CTG_STEM_ARITH", "fp16x2"),
+                                                       os.environ.get("CTG_STEM_ARITH", "fp16x2"))
+    if a == "fp16x2" and os.environ.get("CTG_STEM_H2") in ("", "0"):
+        a = "bf16x3"
+    return a
 
 
 BF16X3_NOTE = ("fused stem pairs: fp32 operands split exactly into 3 bf16 limbs, 6 of the 9 cross terms on "
                "v_mfma_f32_32x32x16_bf16, fp32 accumulation (DESIGN 4b: error bound + adversarial tests); every "
                "other step: fp32 MFMA")
+FP16X2_NOTE = ("fused stem pairs: fp32 operands as 2 rounded fp16 limbs under per-tensor power-of-two scales, 3 products on "
+               "v_mfma_f32_32x32x16_f16, fp32 accumulation (DESIGN 4.5); long tiled steps bf16 x 3; every other step fp32 MFMA")
 FP32_NOTE = "every step on the fp32 matrix cores (v_mfma_f32_32x32x2_f32: an exact-fp32 multiply-add chain)"
+ARITH_NOTE = {"fp32": FP32_NOTE, "bf16x3": BF16X3_NOTE, "fp16x2": FP16X2_NOTE}
 
 
 def time_slices(ex, first, count, stride=1):
@@ -479,7 +506,8 @@ def tree_report(tree_file, dev, steps=5, warmup=1, mode=None):
     if mode is not None:
         with arithmetic(mode):
             return tree_report(tree_file, dev, steps, warmup)
-    bf16x3 = stem_arithmetic() == "bf16x3"
+    arith = stem_arithmetic()
+    bf16x3 = arith if arith != "fp32" else False
     import torch
 
     import cotengra_amd as ca
@@ -537,13 +565,14 @@ def tree_report(tree_file, dev, steps=5, warmup=1, mode=None):
         },
         "precision": precision_check(tree, arrays),
     }
-    out["arithmetic"] = BF16X3_NOTE if bf16x3 else FP32_NOTE
+    out["arithmetic"] = ARITH_NOTE[arith]
     if bf16x3:
         # fp32-equivalent flops; the fused pairs run on the bf16 pipe and are priced against bf16 peak /
         # 6 products (per step, in mixed_bound_ms); the ratio to the fp32 pipe's peak is a comparison
         # with the fp32 arithmetic, not a fraction of a bound
-        out["tflops_are"] = "fp32-equivalent (8 real flops per complex MAC; six bf16 products per fp32 product)"
-        out["bf16x3_peak_tflops"] = PEAK_BF16X3_TFLOPS
+        out["tflops_are"] = ("fp32-equivalent (8 real flops per complex MAC; %s per fp32 product)"
+                             % ("three fp16 products" if arith == "fp16x2" else "six bf16 products"))
+        out["bf16x3_peak_tflops"] = PEAK_FP16X2_TFLOPS if arith == "fp16x2" else PEAK_BF16X3_TFLOPS
         out["ratio_to_fp32_mfma_peak"] = flops / dt / 1e12 / PEAK_MFMA_F32_TFLOPS
     else:
         out["frac_of_mfma_peak"] = flops / dt / 1e12 / PEAK_MFMA_F32_TFLOPS
@@ -1127,7 +1156,8 @@ def main():
     if rank == 0:
         rows = step_table(ex, plan)
         dom_name, dom, by_name = dominant_kernel(rows, 8.0)
-        bf3_run = stem_arithmetic() == "bf16x3"
+        arith_run = stem_arithmetic()
+        bf3_run = arith_run if arith_run != "fp32" else False
         dom_peak = step_peak_tflops(dom, bf3_run)
         achieved_tf = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
         achieved_gbs = dom["moved"] / (dom["ms"] * 1e-3) / 1e9
@@ -1201,7 +1231,7 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": ("complex64, 8 real flops per complex MAC -- " + (BF16X3_NOTE if bf3_run else FP32_NOTE)),
+            "dtype": ("complex64, 8 real flops per complex MAC -- " + ARITH_NOTE[arith_run]),
             "dtype_short": "complex64",
             "data": "synthetic",
             "slices_per_sec": total_slices / dt,
@@ -1230,7 +1260,8 @@ def main():
                 "fused_stem_pairs": sum(1 for s_ in plan.steps if s_.kind == 3),
                 "steps_per_slice": len(plan.steps),
                 "parallelism": f"slice-parallel x{world}, 1 RCCL reduce",
-                "arithmetic": "bf16x3 stem pairs + fp32 MFMA" if bf3_run else "fp32 MFMA",
+                "arithmetic": {"fp32": "fp32 MFMA", "bf16x3": "bf16x3 stem pairs + fp32 MFMA",
+                               "fp16x2": "fp16x2 stem pairs + bf16x3 long steps + fp32 MFMA"}[arith_run],
                 "reduce_via": reduce_via,
                 "partial_amplitude": [float(result.real.item()), float(result.imag.item())]
                 if result.numel() == 1
@@ -1257,11 +1288,14 @@ def main():
             # the other arithmetic of the fused pairs on the same trees (each entry with its own
             # precision check and rooflines): fp32 products on the fp32 matrix cores when the line
             # runs bf16 x 3 (the default), and the other way round
-            other = "fp32" if bf3_run else "bf16x3"
-            out[other + "_arithmetic"] = {
-                os.path.basename(t): tree_report(t, dev, steps=3, mode=other)
-                for t in (args.tree, TTS_TREE, TTS33_TREE) if os.path.exists(t)
-            }
+            # the other arithmetics of the fused pairs on the same trees (each entry with its own precision check and
+            # rooflines): fp32 products on the fp32 matrix cores and the exact bf16 x 3 split when the line runs
+            # fp16 x 2 (the default), ...
+            for other in [a for a in ("fp32", "bf16x3", "fp16x2") if a != arith_run]:
+                trees_o = (args.tree, TTS_TREE, TTS33_TREE) if other == "fp32" or arith_run == "fp32" else (args.tree,)
+                out[other + "_arithmetic"] = {
+                    os.path.basename(t): tree_report(t, dev, steps=3, mode=other) for t in trees_o if os.path.exists(t)
+                }
             out["configs"] = other_configs(dev)
         if c3_amp is not None:
             out.setdefault("configs", {})["C3_amplitudes"] = c3_amp

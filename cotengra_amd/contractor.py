@@ -186,6 +186,12 @@ class HipContractor:
         # arithmetic of the fused pairs: bf16 x 3 -- fp32 operands split exactly three ways, products on
         # the bf16 matrix cores -- unless switched off here (False) or by CTG_STEM_BF16X3=0
         # in the environment, which the kernel launcher reads at every launch and which wins
+        # (round 6) a string names the arithmetic outright: "fp32", "bf16x3" (three exact limbs, six products) or
+        # "fp16x2" (two limbs, three products: what an executor takes when nothing is said); True / False as
+        # before: bf16 x 3 / fp32
+        self.stem_arith = stem_bf16x3 if isinstance(stem_bf16x3, str) else None
+        if isinstance(stem_bf16x3, str):
+            stem_bf16x3 = stem_bf16x3 != "fp32"
         self.stem_bf16x3 = None if stem_bf16x3 is None else bool(stem_bf16x3)
         self._plans = {}  # dtype -> (Plan, DevicePlan)
         self._execs = {}  # (dtype, device, torch?) -> state dict
@@ -283,7 +289,9 @@ class HipContractor:
             )
         else:
             st["exec"] = runtime.Executor(dplan, device=device)
-        if self.stem_bf16x3 is not None:
+        if self.stem_arith is not None:
+            st["exec"].set_stem_arithmetic(self.stem_arith)
+        elif self.stem_bf16x3 is not None:
             st["exec"].set_stem_arithmetic(self.stem_bf16x3)
         return st
 

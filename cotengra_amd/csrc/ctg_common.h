@@ -207,6 +207,10 @@ struct StemArgs {
     int64_t zBM, zsBM;
     int64_t a_elems, c_elems;   // extents of the big operand and of the result (the bounds-checked
                                 // experiment build -DCTG_STEM_BOUNDS tests every gather and store)
+    // (round 6) the fp16 x 2 arithmetic (ctg_stem.hip built with -DCTG_STEM_H2: launch_stem2h): largest |component| of
+    // the big operand as its producer recorded it, and where this launch records that of its result (device floats)
+    const float* amax;
+    float* cmax;
 };
 
 // element offset of an operand for the slice-in-batch this block works on
@@ -521,6 +525,14 @@ bool stem3_supported(const StemArgs& p);   // (a three-step tile: shape, instant
 size_t stem2_lds_bytes(const StemArgs& p);
 hipError_t launch_stem2(const StemArgs& p, hipStream_t stream);
 void stem2_kernel_name(const StemArgs& p, char* buf, size_t n);
+// the same kernels in the fp16 x 2 arithmetic (round 6; StemArgs::amax / cmax)
+bool stem2h_supported(const StemArgs& p);
+bool stem2h_uses_h2(const StemArgs& p);   // (else the launch is the fp32 kernel of that object: no record of the result)
+hipError_t launch_stem2h(const StemArgs& p, hipStream_t stream);
+void stem2h_kernel_name(const StemArgs& p, char* buf, size_t n);
+// largest |re|, |im| of n complex64 values as a float (atomicMax on its bits; *out zeroed by the caller)
+hipError_t launch_maxabs_f32(const void* base, const int64_t* soff, int64_t z, int64_t zs, int64_t zstride, int64_t n,
+                             float* out, hipStream_t stream);
 hipError_t launch_single(int dtype, const StepArgs& p, hipStream_t stream);
 bool pair_bf16x3_on(const StepArgs& p);   // (ctg_pair_mfma.hip) do long tiled steps multiply with bf16 x 3 products right now?
 hipError_t launch_accum(int dtype, const StepArgs& p, const StripState* st, void* wide, const double* inscale, hipStream_t stream);
@@ -547,6 +559,11 @@ struct SliceMeta {
     double* fac;             // strip_exponent: per-step max|.| scalars (or null)
     const int32_t* fac_zero; // [n_fac] 1: zero the scalar at slice start (per-slice pair steps)
     int64_t n_fac;
+    // (round 6) fp16 x 2 stem kernels: the largest element each stem step recorded for its result; the slots of
+    // per-slice steps start every slice at zero (smax_zero[i] = 1), what a group shares or is slice-invariant keeps its own
+    float* smax;
+    const int32_t* smax_zero;
+    int64_t n_smax;
 };
 // soff[n_leaves] receives the per-leaf base offsets of slice `sid`; with sid < 0
 // the id is taken from the device counter state[0], which is then advanced by

@@ -52,6 +52,12 @@ struct ctg_exec {
     std::vector<ctg::StepArgs> args;  // resolved per step
     std::vector<ctg::StemArgs> stem_args;  // KIND_STEM2 steps (fused stem pairs)
     int stem_bf16x3 = 1;                   // ctg_exec_set_stem_arithmetic (default since round 4: bf16 x 3)
+    // (round 6) 2: the stem kernels multiply with two fp16 limbs and three products (ctg_stem.hip built with
+    // -DCTG_STEM_H2) where they took three bf16 limbs and six; stem_bf16x3 stays 1 then (the bf16-pipe kernels are on)
+    int stem_arith = 2;
+    float* d_stem_max = nullptr;           // [2 n_steps]: largest element recorded by step s | of step s's big operand (max-abs pass)
+    int32_t* d_smax_zero = nullptr;        // [2 n_steps] which of them start a slice at zero
+    std::vector<char> stem_h2_ran;         // step s last ran in the fp16 x 2 arithmetic (its record is valid)
     std::vector<ctg::MfmaHints> hints;  // per step kernel hints (MFMA steps)
     // the same for launches that carry several slices (batch > 1): wider column tiles
     // where one slice alone would not fill the chip; same k-splits, same kernels otherwise

@@ -629,6 +629,31 @@ hipError_t launch_maxabs(int dtype, const void* x, int64_t n, double* fac, hipSt
     return hipGetLastError();
 }
 
+// largest |re|, |im| of n complex64 values as a FLOAT (round 6: the power-of-two scale of a big operand of the fp16 x 2 stem
+// kernels whose producer is not one of them); *out must be zero
+__global__ __launch_bounds__(256) void maxabs_f32_kernel(const c64* __restrict__ base, const int64_t* soff, int64_t z,
+                                                         int64_t zs, int64_t zstride, int64_t n, float* out) {
+    const c64* __restrict__ x = base + (soff[z * zs] + z * zstride);
+    float m = 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const c64 v = x[i];
+        m = fmaxf(m, fmaxf(fabsf(v.re), fabsf(v.im)));
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+    if ((threadIdx.x & 63) == 0 && m > 0.f && m < __builtin_bit_cast(float, 0x7f800000u))
+        atomicMax((unsigned*)out, __builtin_bit_cast(unsigned, m));
+}
+
+hipError_t launch_maxabs_f32(const void* base, const int64_t* soff, int64_t z, int64_t zs, int64_t zstride, int64_t n,
+                             float* out, hipStream_t stream) {
+    int64_t blocks = (n + 256 * 16 - 1) / (256 * 16);
+    if (blocks > 4096) blocks = 4096;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(maxabs_f32_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, (const c64*)base, soff, z, zs, zstride, n, out);
+    return hipGetLastError();
+}
+
 // slice exponent and the coefficients of the exponent-aware accumulate
 // (AdderWithMaybeExponentStripped, core.py:125-172): E' = max(E, e),
 // result = result * 10^(E-E') + slice * 10^(e-E') / fac_root
@@ -721,6 +746,9 @@ __global__ __launch_bounds__(256) void prologue_kernel(SliceMeta m, int64_t* sta
     if (m.fac && blockIdx.x == 0)
         for (int64_t i = threadIdx.x; i < m.n_fac; i += blockDim.x)
             if (m.fac_zero[i]) m.fac[i] = 0.0;
+    if (m.smax && blockIdx.x == 0)
+        for (int64_t i = threadIdx.x; i < m.n_smax; i += blockDim.x)
+            if (m.smax_zero[i]) m.smax[i] = 0.f;
     __syncthreads();
     // (the device-side slice counter of a graph replay: always a single workgroup)
     if (threadIdx.x == 0 && sid_arg < 0) state[0] = sid0 + state[1];

@@ -1005,11 +1005,36 @@ int launch_step(ctg_exec* e, int64_t s, hipStream_t stream) {
         case KIND_STEM2: {
             // (slices of a batch one after the other: the workgroups are persistent)
             const int nz = e->args[s].nz;
+            // fp16 x 2 (round 6): the executor's arithmetic, not under strip_exponent (a scale per step there), where
+            // the shape has a bf16-pipe kernel; CTG_STEM_H2=0 in the environment (read per launch) says no
+            bool h2 = e->stem_arith == 2 && !e->strip && e->d_stem_max != nullptr && stem2h_uses_h2(e->stem_args[s]);
+            if (h2)
+                if (const char* v = getenv("CTG_STEM_H2")) h2 = !(v[0] == '\0' || (v[0] == '0' && v[1] == '\0'));
+            e->stem_h2_ran[s] = h2 ? 1 : 0;
             for (int z = 0; z < nz && err == hipSuccess; ++z) {
                 StemArgs q = e->stem_args[s];
                 q.z0 = e->args[s].z0 + z;
                 q.nz = 1;
-                err = launch_stem2(q, stream);
+                q.amax = nullptr;
+                q.cmax = nullptr;
+                if (!h2) {
+                    err = launch_stem2(q, stream);
+                    continue;
+                }
+                q.cmax = e->d_stem_max + s;
+                const int64_t prod = r[W_A_PROD];
+                if (prod >= 0 && prod < p->n_steps && p->steps[prod * STEP_WORDS + W_KIND] == KIND_STEM2 && e->stem_h2_ran[prod]) {
+                    q.amax = e->d_stem_max + prod;   // the producer recorded it
+                } else {
+                    // a big operand of any other origin: a max-abs pass (it is the FIRST pair of a stem that meets
+                    // one; the operand is small next to what the stem then builds)
+                    float* slot = e->d_stem_max + p->n_steps + s;
+                    err = hipMemsetAsync(slot, 0, sizeof(float), stream);
+                    if (err == hipSuccess)
+                        err = launch_maxabs_f32(q.A, q.soffA, q.z0, q.zsA, q.zA, q.a_elems, slot, stream);
+                    q.amax = slot;
+                }
+                if (err == hipSuccess) err = launch_stem2h(q, stream);
             }
             break;
         }
@@ -1469,6 +1494,8 @@ int ctg_exec_destroy(ctg_exec* e) {
     if (e->d_lane_b) (void)hipFree(e->d_lane_b);
     if (e->d_group_items) (void)hipFree(e->d_group_items);
     if (e->d_fast_items) (void)hipFree(e->d_fast_items);
+    if (e->d_stem_max) (void)hipFree(e->d_stem_max);
+    if (e->d_smax_zero) (void)hipFree(e->d_smax_zero);
     if (e->d_lds_comps) (void)hipFree(e->d_lds_comps);
     if (e->d_lds_blob) (void)hipFree(e->d_lds_blob);
     if (e->h_ids) (void)hipHostFree(e->h_ids);
@@ -1621,7 +1648,7 @@ int ctg_exec_create(const ctg_plan* p, int device, void* stream, void* ext_resul
     HIP_TRY_E(hipMemcpy(e->d_tables, p->tables.data(), p->tables.size() * 8, hipMemcpyHostToDevice));
     HIP_TRY_E(hipMemsetAsync(e->d_inputs, 0, p->inputs_elems * isz, e->stream));
     HIP_TRY_E(hipMemsetAsync(e->d_result, 0, p->result_elems * isz, e->stream));
-    e->meta = SliceMeta{n_leaves, p->n_sliced, d_sizes, d_fixed, d_strides, nullptr, nullptr, 0};
+    e->meta = SliceMeta{n_leaves, p->n_sliced, d_sizes, d_fixed, d_strides, nullptr, nullptr, 0, nullptr, nullptr, 0};
     {
         std::vector<double> fac(p->n_steps + 1, 0.0);
         fac[p->n_steps] = 1.0;
@@ -1641,6 +1668,26 @@ int ctg_exec_create(const ctg_plan* p, int device, void* stream, void* ext_resul
                 e->root_step = st;  // the last pair step produces the slice output
             }
         }
+        {
+            // fp16 x 2 stem kernels: per step the largest element it recorded | of its big operand
+            bool stems = false;
+            std::vector<int32_t> sz((size_t)(2 * std::max<int64_t>(p->n_steps, 1)), 1);
+            for (int64_t st = 0; st < p->n_steps; ++st) {
+                stems = stems || p->steps[st * STEP_WORDS + W_KIND] == KIND_STEM2;
+                // (slice-invariant steps and what a slice group shares keep their record across slices)
+                if (e->invariant[st] || e->grouped[st]) sz[(size_t)st] = 0;
+            }
+            e->stem_h2_ran.assign(p->n_steps, 0);
+            if (stems && p->dtype == CTG_C64) {
+                HIP_TRY_E(hipMalloc((void**)&e->d_stem_max, sz.size() * sizeof(float)));
+                HIP_TRY_E(hipMemset(e->d_stem_max, 0, sz.size() * sizeof(float)));
+                HIP_TRY_E(hipMalloc((void**)&e->d_smax_zero, sz.size() * sizeof(int32_t)));
+                HIP_TRY_E(hipMemcpy(e->d_smax_zero, sz.data(), sz.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+                e->meta.smax = e->d_stem_max;
+                e->meta.smax_zero = e->d_smax_zero;
+                e->meta.n_smax = (int64_t)sz.size();
+            }
+        }
         HIP_TRY_E(hipMalloc((void**)&e->d_fac_zero, fac_zero.size() * sizeof(int32_t)));
         HIP_TRY_E(hipMemcpy(e->d_fac_zero, fac_zero.data(), fac_zero.size() * sizeof(int32_t),
                             hipMemcpyHostToDevice));
@@ -1658,6 +1705,15 @@ int ctg_exec_create(const ctg_plan* p, int device, void* stream, void* ext_resul
     // kernels are bound by their dependent-load latency, not by launch cost.
     // The path stays available behind CTG_GRAPH=1.
     e->graph_off = !env_on("CTG_GRAPH");
+    // arithmetic of the stem kernels: fp16 x 2 (round 6) unless CTG_STEM_ARITH names another one
+    // (fp32 | bf16x3 | fp16x2, or 0 | 1 | 2); ctg_exec_set_stem_arithmetic changes it later
+    if (const char* v = getenv("CTG_STEM_ARITH")) {
+        const std::string a(v);
+        if (a == "fp32" || a == "0") e->stem_arith = 0;
+        else if (a == "bf16x3" || a == "1") e->stem_arith = 1;
+        else if (a == "fp16x2" || a == "2") e->stem_arith = 2;
+        e->stem_bf16x3 = e->stem_arith ? 1 : 0;
+    }
     resolve_args(e);
     {
         int rc = build_hints(e);
@@ -1746,12 +1802,14 @@ int ctg_exec_zero_result(ctg_exec* e) {
     return CTG_OK;
 }
 
-int ctg_exec_set_stem_arithmetic(ctg_exec* e, int bf16x3) {
+int ctg_exec_set_stem_arithmetic(ctg_exec* e, int mode) {
     if (!e) return fail(CTG_E_INVALID, "null argument");
-    bf16x3 = bf16x3 ? 1 : 0;
-    if (bf16x3 == e->stem_bf16x3) return CTG_OK;
+    if (mode < 0 || mode > 2) return fail(CTG_E_INVALID, "stem arithmetic %d (0 fp32, 1 bf16 x 3, 2 fp16 x 2)", mode);
+    const int bf16x3 = mode ? 1 : 0;
+    if (bf16x3 == e->stem_bf16x3 && mode == e->stem_arith) return CTG_OK;
     HIP_TRY(hipSetDevice(e->device));
     HIP_TRY(hipStreamSynchronize(e->stream));
+    e->stem_arith = mode;
     e->stem_bf16x3 = bf16x3;
     for (auto& q : e->stem_args) q.bf3 = bf16x3;
     for (auto& a : e->args) a.bf3 = bf16x3;
@@ -2120,7 +2178,11 @@ int ctg_exec_step_kernel(ctg_exec* e, int64_t step, char* buf, int64_t buflen) {
     } else if (r[W_KIND] == KIND_ACCUM) {
         snprintf(name, sizeof(name), "accum_kernel");
     } else if (r[W_KIND] == KIND_STEM2) {
-        stem2_kernel_name(e->stem_args[step], name, sizeof(name));
+        bool h2 = e->stem_arith == 2 && !e->strip && e->d_stem_max != nullptr && stem2h_uses_h2(e->stem_args[step]);
+        if (h2)
+            if (const char* v = getenv("CTG_STEM_H2")) h2 = !(v[0] == '\0' || (v[0] == '0' && v[1] == '\0'));
+        if (h2) stem2h_kernel_name(e->stem_args[step], name, sizeof(name));
+        else stem2_kernel_name(e->stem_args[step], name, sizeof(name));
     } else if (r[W_KERNEL] == KERNEL_MFMA && p->dtype == CTG_C128) {
         snprintf(name, sizeof(name), "pair_mfma_c128_kernel");
     } else if (r[W_KERNEL] == KERNEL_MFMA && p->dtype != CTG_C64) {

@@ -44,6 +44,34 @@
 #include <cstdlib>
 #include <type_traits>
 
+// Round 6 -- the SECOND ARITHMETIC of the bf16-pipe kernels, compiled from this same source with -DCTG_STEM_H2
+// into a second object (its externals and its kernel renamed: both objects live in one library):
+// every fp32 operand as TWO ROUNDED fp16 limbs (22 bits) under a per-tensor power-of-two scale and THREE
+// products (h1 h1', h1 h2', h2 h1') on v_mfma_f32_32x32x16_f16, where the bf16 x 3 arithmetic spends three
+// limbs and six products.  The pairs are bound by their matrix + split work (profiles/r6_stem_half_products.txt:
+// half the products = 222 -> 150 ms per headline slice), so this is where their time goes.  What fp16 lacks is
+// RANGE (5 exponent bits): every operand is brought to [2^13, 2^14) by an exact power of two before it is
+// split -- the small operands by their largest element (found in-kernel, as before), the big operand A by the
+// largest element its PRODUCER recorded (StemArgs::amax: every stem kernel tracks max |re|, |im| of what it
+// stores, one v_max3 per value and one atomic per wave; a big operand of any other origin gets a max-abs pass,
+// ctg_runtime.hip), the intermediate tile by its own largest element (a wave reduction and eight LDS words per
+// tile) -- and the powers go back in where the result is stored.  Elements more than 2^-14 below their tensor's
+// largest lose low bits gradually (absolute error <= 2^-24 of the largest): the error is norm-wise, like that
+// of any blocked floating-point format; tools/exp_product_levers.py measures it on the narrowed m20 trees.
+#ifdef CTG_STEM_H2
+#define CTG_STEM_KNAME "stem2h_kernel"
+#define stem2_kernel stem2h_kernel
+#define stem2_lds_bytes stem2h_lds_bytes
+#define stem3_instantiated_c stem3h_instantiated_c
+#define stem3_supported stem3h_supported
+#define stem2_supported stem2h_supported
+#define stem2_variant stem2h_variant
+#define stem2_kernel_name stem2h_kernel_name
+#define launch_stem2 launch_stem2h
+#else
+#define CTG_STEM_KNAME "stem2_kernel"
+#endif
+
 namespace ctg {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -134,10 +162,14 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 // the other two limbs are still being subtracted out
 // (experiment build -DCTG_STEM_KO_HALF: only the three products a TWO-limb split would keep -- t = 0, 1, 3 --, the third
 // limbs dead code: what halving the product count is worth in time; the results lose their third limb)
-#ifdef CTG_STEM_KO_HALF
+#if defined(CTG_STEM_KO_HALF) || defined(CTG_STEM_H2)   // (H2: limbs 0, 1 only -- products (0, 0), (0, 1), (1, 0))
 #define CTG_STEM_T_STEP(t) ((t) == 1 ? 2 : ((t) == 3 ? 3 : 1))
+#define CTG_STEM_T_COUNT 3                        // products per k-block, and which of them t is (deferred stores go
+#define CTG_STEM_T_INDEX(t) ((t) == 3 ? 2 : (t))  // out in as many portions)
 #else
 #define CTG_STEM_T_STEP(t) 1
+#define CTG_STEM_T_COUNT 6
+#define CTG_STEM_T_INDEX(t) (t)
 #endif
 __device__ __forceinline__ constexpr int bf3_ta(int t) { return t < 3 ? 0 : (t == 5 ? 2 : 1); }
 __device__ __forceinline__ constexpr int bf3_tb(int t) { return t == 1 || t == 4 ? 1 : (t == 2 ? 2 : 0); }
@@ -149,7 +181,29 @@ __device__ __forceinline__ unsigned cvt_pk_bf16(float a, float b) {
     return r;
 }
 
-__device__ __forceinline__ void split3(const float (&x)[8], bf16x8 (&o)[3]) {
+#ifdef CTG_STEM_H2
+// H2: x * scale as two rounded fp16 limbs (v_cvt_pk_f16_f32 rounds to nearest even and packs two values; the
+// residual x s - h1 is exact in fp32); o[2] is not used by any product.  4 vector instructions per value.
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ unsigned pack_f16(float a, float b) {
+    const _Float16 ha = (_Float16)a, hb = (_Float16)b;
+    return (unsigned)__builtin_bit_cast(unsigned short, ha) | ((unsigned)__builtin_bit_cast(unsigned short, hb) << 16);
+}
+__device__ __forceinline__ void split3(const float (&x)[8], bf16x8 (&o)[3], float scale = 1.f) {
+    u32x4 p1, p2;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float a = x[2 * i] * scale, b = x[2 * i + 1] * scale;
+        const _Float16 ha = (_Float16)a, hb = (_Float16)b;
+        p1[i] = (unsigned)__builtin_bit_cast(unsigned short, ha) | ((unsigned)__builtin_bit_cast(unsigned short, hb) << 16);
+        p2[i] = pack_f16(a - (float)ha, b - (float)hb);
+    }
+    o[0] = __builtin_bit_cast(bf16x8, p1);
+    o[1] = __builtin_bit_cast(bf16x8, p2);
+    o[2] = o[1];
+}
+#else
+__device__ __forceinline__ void split3(const float (&x)[8], bf16x8 (&o)[3], float = 1.f) {
     // Round 5: ROUNDED limbs.  l1 = rn(x), l2 = rn(x - l1), l3 = x - l1 - l2: the remainder after two rounded limbs
     // has at most 7 significant bits, so x = l1 + l2 + l3 stays EXACT, and the three cross terms that are not
     // computed (l2 m3, l3 m2, l3 m3) are below 2^-26 of the product with either sign -- truncated limbs (round 3-4)
@@ -172,11 +226,14 @@ __device__ __forceinline__ void split3(const float (&x)[8], bf16x8 (&o)[3]) {
     o[1] = __builtin_bit_cast(bf16x8, p2);
     o[2] = __builtin_bit_cast(bf16x8, p3);
 }
+#endif
 
 __device__ __forceinline__ f32x16 mfma_bf(bf16x8 a, bf16x8 b, f32x16 c) {
 #ifdef CTG_STEM_KO_MFMA
     c[0] = fmaf((float)a[0], (float)b[0], c[0]);
     return c;
+#elif defined(CTG_STEM_H2)
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
 #else
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
 #endif
@@ -209,6 +266,16 @@ __device__ __forceinline__ void load_b_planes_bf3(unsigned short* Q, const c64* 
         for (int pl = 0; pl < 3; ++pl) {
             if (pl >= planes) break;
             const float x = vals[pl];   // (rounded limbs, as split3)
+#ifdef CTG_STEM_H2
+            {
+                const _Float16 f1 = (_Float16)x, f2 = (_Float16)(x - (float)f1);
+                unsigned short* dh = Q + (pl * N + n) * ROW + at;
+                dh[0] = __builtin_bit_cast(unsigned short, f1);
+                dh[8] = __builtin_bit_cast(unsigned short, f2);
+                dh[16] = 0;
+                continue;
+            }
+#endif
             const unsigned h1 = cvt_pk_bf16(x, 0.f) << 16;
             const float r1 = x - __builtin_bit_cast(float, h1);
             const unsigned h2 = cvt_pk_bf16(r1, 0.f) << 16;
@@ -243,8 +310,22 @@ __device__ __forceinline__ int bf3_operand_exponent(const c64* __restrict__ B, c
     for (int w = 1; w < SW; ++w) mx = fmaxf(mx, red[w]);
     __syncthreads();   // (red is reused for the other operand)
     int ex = (int)((__builtin_bit_cast(unsigned, mx) >> 23) & 255u) - 127;
+#ifdef CTG_STEM_H2
+    // fp16 limbs: the largest element always goes to [2^13, 2^14) (fp16 holds up to 2^16; the rounding of the first
+    // limb and the sums of a few terms stay clear of it)
+    if (mx == 0.f || ex == 128) return 0;
+    ex -= 13;
+    return ex < -126 ? -126 : (ex > 126 ? 126 : ex);
+#endif
     if (mx == 0.f || ex == 128 || (ex >= -64 && ex < 64)) return 0;   // (zero, inf / nan, or fine as it is)
     return ex < -126 ? -126 : (ex > 126 ? 126 : ex);
+}
+// H2: the exponent to REMOVE from a tensor whose largest |component| is mx (its producer's record)
+__device__ __forceinline__ int h2_exponent_of(float mx) {
+    const int ex = (int)((__builtin_bit_cast(unsigned, mx) >> 23) & 255u) - 127;
+    if (mx == 0.f || ex == 128 || ex == -127) return 0;   // (zero / inf / nan / subnormal: left alone)
+    const int e = ex - 13;
+    return e < -126 ? -126 : (e > 126 ? 126 : e);
 }
 __device__ __forceinline__ float pow2f(int ex) {   // 2^ex, -126 <= ex <= 127
     return __builtin_bit_cast(float, (unsigned)(ex + 127) << 23);
@@ -449,8 +530,23 @@ __global__ __launch_bounds__(SW * 64, 1) void stem2_kernel(StemArgs p) {
     const c64* __restrict__ BM = TRI ? (const c64*)p.BM + (sload64(p.soffBM + z * p.zsBM) + z * p.zBM) : nullptr;
 
     int bf3_ex = 0;   // BF3: power of two taken out of the small operands (goes back in through alpha)
+    float* const bf3_red = (float*)(oc_s + (ONE ? N1 : N2));   // (64 bytes behind the column table: stem2_lds_bytes_bf3)
+#ifdef CTG_STEM_H2
+    static_assert(!BF3 || (!TRI && !LM && !WS), "fp16 x 2: pairs and single steps of the symmetric kernel");
+    // H2: the big operand's power of two, from the largest element its producer recorded
+    float h2_sa = 1.f;
+    int h2_exa = 0;
     if constexpr (BF3) {
-        float* bf3_red = (float*)(oc_s + (ONE ? N1 : N2));   // (64 bytes behind the column table: stem2_lds_bytes_bf3)
+        h2_exa = p.amax != nullptr ? h2_exponent_of(*p.amax) : 0;
+        h2_exa = __builtin_amdgcn_readfirstlane(h2_exa);
+        h2_sa = pow2f(-h2_exa);
+    }
+    float h2_st = 1.f;    // ... and the intermediate tile's (per tile)
+    float h2_vmax = 0.f;  // largest |component| this lane has stored (-> StemArgs::cmax)
+#else
+    constexpr float h2_sa = 1.f, h2_st = 1.f;
+#endif
+    if constexpr (BF3) {
         const int ex1 = bf3_operand_exponent(B1, p.b1_off, K1 * N1, tid, bf3_red);
         const int ex2 = ONE ? 0 : bf3_operand_exponent(B2, p.b2_off, K2 * N2, tid, bf3_red);
         int exm = 0;
@@ -639,7 +735,24 @@ __global__ __launch_bounds__(SW * 64, 1) void stem2_kernel(StemArgs p) {
         }
         if (BF3 && e2 != 0) alpha2 = pow2f(e2);
     }
+#ifdef CTG_STEM_H2
+    // H2: the stores always scale -- by 2^(exponents taken out of A, B1, B2 and, per tile, of the intermediate), as two
+    // factors inside the float range (set per tile: h2_set_alpha).  strip_exponent runs do not take this arithmetic
+    // (ctg_runtime.hip): alpha carries no other factor.
+    const int h2_e0 = BF3 ? bf3_ex + h2_exa : 0;
+    auto h2_set_alpha = [&](int et) __attribute__((always_inline)) {
+        const int E = h2_e0 + et;
+        const int e1 = E < -126 ? -126 : (E > 126 ? 126 : E);
+        int e2 = E - e1;
+        e2 = e2 < -126 ? -126 : (e2 > 126 ? 126 : e2);
+        alpha = pow2f(e1);
+        alpha2 = pow2f(e2);
+    };
+    if constexpr (BF3) h2_set_alpha(0);
+    const bool scaled = BF3 ? true : __builtin_amdgcn_readfirstlane(alpha != 1.f || alpha2 != 1.f);
+#else
     const bool scaled = __builtin_amdgcn_readfirstlane(alpha != 1.f || alpha2 != 1.f);   // (strip_exponent runs, rescaled operands)
+#endif
     __syncthreads();
 
 #ifdef CTG_STEM_KO_BFRAG
@@ -855,8 +968,8 @@ __global__ __launch_bounds__(SW * 64, 1) void stem2_kernel(StemArgs p) {
                 im[j] = r[j].im;
             }
             bf16x8 r3[3], i3[3], n3[3], bp3[3], bq3[3];
-            split3(re, r3);
-            split3(im, i3);
+            split3(re, r3, h2_sa);
+            split3(im, i3, h2_sa);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int q = 0; q < 4; ++q) fire2(r, q, base, always_tag);
@@ -896,7 +1009,8 @@ __global__ __launch_bounds__(SW * 64, 1) void stem2_kernel(StemArgs p) {
                     ay[m] = mfma_bf(i3[ta], bp3[tb], ay[m]);
                 }
                 __builtin_amdgcn_sched_barrier(0);
-                if constexpr (DRAIN) drain(t * NST / 6, (t + 1) * NST / 6, drain_tag, scaled_tag);
+                if constexpr (DRAIN)
+                    drain(CTG_STEM_T_INDEX(t) * NST / CTG_STEM_T_COUNT, (CTG_STEM_T_INDEX(t) + 1) * NST / CTG_STEM_T_COUNT, drain_tag, scaled_tag);
             }
             __builtin_amdgcn_sched_barrier(0);
             prep(always_tag);
@@ -1111,8 +1225,8 @@ __global__ __launch_bounds__(SW * 64, 1) void stem2_kernel(StemArgs p) {
                     const f32x4 i0 = *(const f32x4*)(aRf + PLANE + 16 * c), i1 = *(const f32x4*)(aRf + PLANE + 16 * c + 4);
                     const float re8[8] = {r0[0], r0[1], r0[2], r0[3], r1[0], r1[1], r1[2], r1[3]};
                     const float im8[8] = {i0[0], i0[1], i0[2], i0[3], i1[0], i1[1], i1[2], i1[3]};
-                    split3(re8, F.ar);
-                    split3(im8, F.ai);
+                    split3(re8, F.ar, h2_st);
+                    split3(im8, F.ai, h2_st);
                 }
 #pragma unroll
                 for (int q = 0; q < 3; ++q) {
@@ -1186,7 +1300,7 @@ __global__ __launch_bounds__(SW * 64, 1) void stem2_kernel(StemArgs p) {
                 const f32x4 lo = *(const f32x4*)(a_base + 8 * kb), hi = *(const f32x4*)(a_base + 8 * kb + 4);
                 const float a8[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
                 bf16x8 a3[3], ax3[3], bx3[3], by3[3];
-                split3(a8, a3);
+                split3(a8, a3, h2_st);
 #pragma unroll
                 for (int q = 0; q < 3; ++q) {
                     // (the X tile takes -Im a: the lanes of the second k-row flip the sign)
@@ -1273,6 +1387,9 @@ __global__ __launch_bounds__(SW * 64, 1) void stem2_kernel(StemArgs p) {
                         v.x = v.x * alpha * alpha2;
                         v.y = v.y * alpha * alpha2;
                     }
+#ifdef CTG_STEM_H2
+                    if constexpr (BF3) h2_vmax = fmaxf(h2_vmax, fmaxf(fabsf(v.x), fabsf(v.y)));
+#endif
                     pv[t >> 1] = v;
                 }
             } else {
@@ -1282,6 +1399,9 @@ __global__ __launch_bounds__(SW * 64, 1) void stem2_kernel(StemArgs p) {
                     const float xr = XM2 ? cx[t] - cxm[t] : cx[t];
                     v.x = SC ? xr * alpha * alpha2 : xr;
                     v.y = SC ? cy[t] * alpha * alpha2 : cy[t];
+#ifdef CTG_STEM_H2
+                    if constexpr (BF3) h2_vmax = fmaxf(h2_vmax, fmaxf(fabsf(v.x), fabsf(v.y)));
+#endif
                     pv[t] = v;
                 }
             }
@@ -1369,10 +1489,50 @@ __global__ __launch_bounds__(SW * 64, 1) void stem2_kernel(StemArgs p) {
             const float xr = XM1 ? ax[m][t] - axm[m][t] : ax[m][t];
             v.x = SC ? xr * alpha * alpha2 : xr;
             v.y = SC ? ay[m][t] * alpha * alpha2 : ay[m][t];
+#ifdef CTG_STEM_H2
+            if constexpr (BF3) h2_vmax = fmaxf(h2_vmax, fmaxf(fabsf(v.x), fabsf(v.y)));
+#endif
             pv[RI2 ? 0 : t] = v;
         }
         pdst = C + 2 * (c_tile + one_rt[m] + out_lane + one_col);
     };
+#ifdef CTG_STEM_H2
+    // H2: the intermediate tile's power of two.  publish (step 1 of the tile done, before the barrier): this wave's
+    // largest |component| of its accumulators -> LDS (two sets of eight words, alternating by tile: a fast wave's next
+    // tile never overwrites what a slow one still reads); consume (after the scatter's barrier): the tile's largest
+    // -> the scale step 2 splits with, and the factors its stores apply.
+    int h2_par = 0;
+    auto h2_publish = [&]() __attribute__((always_inline)) {
+        if constexpr (BF3 && !ONE) {
+            float mx = 0.f;
+#pragma unroll
+            for (int m = 0; m < RT1; ++m)
+#pragma unroll
+                for (int t = 0; t < 16; ++t) {
+                    const float xr = XM1 ? ax[m][t] - axm[m][t] : ax[m][t];
+                    mx = fmaxf(mx, fabsf(xr));
+                    if (!PACK1) mx = fmaxf(mx, fabsf(ay[m][t]));
+                }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+            if (lane == 0) bf3_red[h2_par * 8 + wave] = mx;
+        }
+    };
+    auto h2_consume = [&]() __attribute__((always_inline)) {
+        if constexpr (BF3 && !ONE) {
+            float mx = bf3_red[h2_par * 8];
+#pragma unroll
+            for (int w = 1; w < SW; ++w) mx = fmaxf(mx, bf3_red[h2_par * 8 + w]);
+            const int et = __builtin_amdgcn_readfirstlane(h2_exponent_of(mx));
+            h2_st = pow2f(-et);
+            h2_set_alpha(et);
+            h2_par ^= 1;
+        }
+    };
+#else
+    auto h2_publish = [&]() __attribute__((always_inline)) {};
+    auto h2_consume = [&]() __attribute__((always_inline)) {};
+#endif
     auto tile_c = [&](int64_t g) __attribute__((always_inline)) -> int64_t {
         const int64_t gh = g >> p.g_lo_shift, gl = g & (p.g_lo - 1);
         return sload64(p.gC_hi + uniform64(gh)) + sload64(p.gC_lo + uniform64(gl));
@@ -1480,6 +1640,7 @@ __global__ __launch_bounds__(SW * 64, 1) void stem2_kernel(StemArgs p) {
                 });
             });
             CTG_TL_STAMP(1);
+            h2_publish();
             CTG_STEM_SYNC();   // all waves have finished step 2 of the previous tile
             CTG_TL_STAMP(2);
             scatter();
@@ -1497,6 +1658,7 @@ __global__ __launch_bounds__(SW * 64, 1) void stem2_kernel(StemArgs p) {
                 }
             });
             CTG_STEM_SYNC();
+            h2_consume();
             CTG_TL_STAMP(4);
             if constexpr (TRI) {
                 static_for<0, ITM>([&](auto ii) __attribute__((always_inline)) { item_mid(ii); });
@@ -1554,9 +1716,11 @@ __global__ __launch_bounds__(SW * 64, 1) void stem2_kernel(StemArgs p) {
                 }
             }
             if constexpr (ONE) continue;
+            h2_publish();
             CTG_STEM_SYNC();
             scatter();
             CTG_STEM_SYNC();
+            h2_consume();
             const int64_t c_tile = tile_c(g);
             for (int item = wave; item < n_items; item += SW)
                 item2(item, item_row(item, c_tile), scaled_tag, std::false_type{}, std::false_type{});
@@ -1565,6 +1729,18 @@ __global__ __launch_bounds__(SW * 64, 1) void stem2_kernel(StemArgs p) {
     };
     if (scaled) run(std::true_type{});
     else run(std::false_type{});
+#ifdef CTG_STEM_H2
+    // the largest |component| this launch stored: what the consumer of the result scales its split with
+    if constexpr (BF3) {
+        if (p.cmax != nullptr) {
+            float mx = h2_vmax;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+            if (lane == 0 && mx > 0.f && mx < __builtin_bit_cast(float, 0x7f800000u))
+                atomicMax((unsigned*)p.cmax, __builtin_bit_cast(unsigned, mx));
+        }
+    }
+#endif
 }
 
 #ifdef CTG_STEM_TIMELINE
@@ -2010,36 +2186,41 @@ void stem2_kernel_name(const StemArgs& p, char* buf, size_t n) {
     auto tf = [](bool b) { return b ? "true" : "false"; };
     if (p.tri) {
         const Stem3Shape t = stem3_shape(p);
-        snprintf(buf, n, "stem2_kernel<%s,%s,%d,%d,%d,%d,%s,0,%s,%s,false,false,%d,%s>", tf(t.p1), tf(t.p2), t.rt1, t.cs1,
+        snprintf(buf, n, CTG_STEM_KNAME "<%s,%s,%d,%d,%d,%d,%s,0,%s,%s,false,false,%d,%s>", tf(t.p1), tf(t.p2), t.rt1, t.cs1,
                  t.nch, t.it2, tf(t.nch <= 2), tf(t.vec), tf(stem3_bf3(p)), t.itm, tf(t.pm));
         return;
     }
     if (p.one) {
         const bool st = stem1_static(s), b3 = stem2_bf3(p);
         if (st && b3 && CTG_STEM_FORM >= 1)
-            snprintf(buf, n, "stem2_kernel<false,false,%d,%d,%d,0,%s,0,%s,true,false,true,0,false,true,false>", s.rt1, s.cs1,
+            snprintf(buf, n, CTG_STEM_KNAME "<false,false,%d,%d,%d,0,%s,0,%s,true,false,true,0,false,true,false>", s.rt1, s.cs1,
                      s.nch, tf(s.nch <= 2), tf(s.vec));
         else
-            snprintf(buf, n, "stem2_kernel<false,false,%d,%d,%d,0,%s,0,%s,%s,false,true>", s.rt1, s.cs1, st ? s.nch : 0,
+            snprintf(buf, n, CTG_STEM_KNAME "<false,false,%d,%d,%d,0,%s,0,%s,%s,false,true>", s.rt1, s.cs1, st ? s.nch : 0,
                      tf(st && (b3 ? s.nch <= 2 : p.K1 <= 64)), tf(s.vec), tf(b3));
         return;
     }
     if (stem2_bf3(p)) {
         const int form = stem2_bf3_form(p);
         if (form == 0)
-            snprintf(buf, n, "stem2_kernel<%s,%s,%d,%d,%d,%d,%s,0,%s,true,false,false>", tf(s.p1), tf(s.p2), s.rt1, s.cs1,
+            snprintf(buf, n, CTG_STEM_KNAME "<%s,%s,%d,%d,%d,%d,%s,0,%s,true,false,false>", tf(s.p1), tf(s.p2), s.rt1, s.cs1,
                      s.nch, s.it2, tf(s.nch <= 2), tf(s.vec));
         else
-            snprintf(buf, n, "stem2_kernel<%s,%s,%d,%d,%d,%d,%s,0,%s,true,false,false,0,false,true,%s,%s>", tf(s.p1), tf(s.p2),
+            snprintf(buf, n, CTG_STEM_KNAME "<%s,%s,%d,%d,%d,%d,%s,0,%s,true,false,false,0,false,true,%s,%s>", tf(s.p1), tf(s.p2),
                      s.rt1, s.cs1, s.nch, s.it2, tf(s.nch <= 2), tf(s.vec), tf(form == 2), tf(form == 3));
     }
     else if (stem2_variant(p))
-        snprintf(buf, n, "stem2_kernel<%s,%s,%d,%d,%d,%d,%s,%d,%s,false,%s,false>", tf(s.p1), tf(s.p2), s.rt1, s.cs1, s.nch,
+        snprintf(buf, n, CTG_STEM_KNAME "<%s,%s,%d,%d,%d,%d,%s,%d,%s,false,%s,false>", tf(s.p1), tf(s.p2), s.rt1, s.cs1, s.nch,
                  s.it2, tf(s.br1), s.k2q, tf(s.vec), tf(s.ri2));
     else
-        snprintf(buf, n, "stem2_kernel<%s,%s,%d,%d,0,0,false,0,%s,false,false,false>", tf(s.p1), tf(s.p2), s.rt1, s.cs1,
+        snprintf(buf, n, CTG_STEM_KNAME "<%s,%s,%d,%d,0,0,false,0,%s,false,false,false>", tf(s.p1), tf(s.p2), s.rt1, s.cs1,
                  tf(s.vec));
 }
+
+#ifdef CTG_STEM_H2
+// does this launch multiply in the fp16 x 2 arithmetic (and record the largest element of its result)?
+bool stem2h_uses_h2(const StemArgs& p) { return !p.tri && stem2_supported(p) && stem2_bf3(p); }
+#endif
 
 hipError_t launch_stem2(const StemArgs& p, hipStream_t stream) {
     if (!stem2_supported(p)) return hipErrorInvalidValue;
@@ -2146,7 +2327,7 @@ hipError_t launch_stem2(const StemArgs& p, hipStream_t stream) {
 #endif   // CTG_STEM_DEV_ONE
 }  // namespace ctg
 
-#ifndef CTG_STEM_DEV_ONE
+#if !defined(CTG_STEM_DEV_ONE) && !defined(CTG_STEM_H2)
 // (include/ctg_hip.h) is there a three-step tile kernel for this shape?  A pure function of the shape.
 extern "C" int ctg_stem_triple_instantiated(int p1, int pm, int p2, int rt1, int cs1, int nch, int itm, int it2, int vec) {
     return ctg::stem3_instantiated_c(p1 != 0, pm != 0, p2 != 0, rt1, cs1, nch, itm, it2, vec != 0) ? 1 : 0;

@@ -325,10 +325,20 @@ class Executor:
     def set_strip_exponent(self, strip, check_zero=False):
         _check(load().ctg_exec_set_strip_exponent(self.handle, int(bool(strip)), int(bool(check_zero))))
 
-    def set_stem_arithmetic(self, bf16x3):
-        """Fused stem pairs on the bf16 matrix cores with exactly split fp32 operands (True) or on
-        the fp32 matrix cores (False, the default); include/ctg_hip.h."""
-        _check(load().ctg_exec_set_stem_arithmetic(self.handle, int(bool(bf16x3))))
+    STEM_ARITHMETICS = {"fp32": 0, "bf16x3": 1, "fp16x2": 2}
+
+    def set_stem_arithmetic(self, mode):
+        """Arithmetic of the fused stem pairs (include/ctg_hip.h): ``"fp32"`` / ``False`` / 0 -- fp32 products on
+        the fp32 matrix cores; ``"bf16x3"`` / 1 -- operands split exactly into three bf16 limbs, six products;
+        ``"fp16x2"`` / 2 -- two fp16 limbs under per-tensor power-of-two scales, three products (the
+        executor's default since round 6).  ``True`` keeps its old meaning, ``"bf16x3"``."""
+        if mode is True:
+            mode = 1
+        elif mode is False:
+            mode = 0
+        elif isinstance(mode, str):
+            mode = self.STEM_ARITHMETICS[mode]
+        _check(load().ctg_exec_set_stem_arithmetic(self.handle, int(mode)))
 
     def get_exponent(self):
         e, z = C.c_double(), C.c_int()

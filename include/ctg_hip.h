@@ -165,8 +165,16 @@ int ctg_exec_set_strip_exponent(ctg_exec* exec, int strip_exponent, int check_ze
  * a double-precision reference as 0, not the same bits, 11-13 % less time per slice.  0: complex64 on
  * the fp32 matrix cores, an exact-fp32 multiply-add chain like every other step.  The environment
  * variable CTG_STEM_BF16X3, when set, overrides the option ("0" = fp32).  No reference counterpart
- * (the reference computes in whatever its array library does).  Takes effect from the next run. */
-int ctg_exec_set_stem_arithmetic(ctg_exec* exec, int bf16x3);
+ * (the reference computes in whatever its array library does).  Takes effect from the next run.
+ * 2 (ABI 7, the default of a new executor unless CTG_STEM_ARITH = fp32 | bf16x3 | fp16x2 says otherwise):
+ * two ROUNDED fp16 limbs per operand (22 bits) under per-tensor power-of-two scales and THREE products --
+ * half the matrix work of 1, the stem pairs at 0.7 instead of 0.45 of the HBM roofline.  The scales: the
+ * small operands' largest elements (found in-kernel), the big operand's as its producer recorded it (every
+ * such kernel tracks the largest element it stores; a big operand of other origin gets a max-abs pass), the
+ * intermediate tile's own; an element more than 2^-14 below its tensor's largest loses low bits gradually
+ * (absolute error <= 2^-24 of the largest: norm-wise accuracy).  strip_exponent runs
+ * and CTG_STEM_H2=0 fall back to 1. */
+int ctg_exec_set_stem_arithmetic(ctg_exec* exec, int mode);
 int ctg_exec_get_exponent(ctg_exec* exec, double* exponent, int* zero);
 
 /* Contract slices first, first+stride, ... (count of them) and ACCUMULATE each

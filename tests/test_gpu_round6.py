@@ -267,3 +267,143 @@ def test_plain_c_driver_fails_loudly_without_rccl(tmp_path):
     r = subprocess.run([exe, plan], capture_output=True, text=True, timeout=300, env=env)
     assert r.returncode != 0
     assert "rccl" in (r.stdout + r.stderr).lower()
+
+
+# ---------------------------------------------------------------------- #
+# the fp16 x 2 arithmetic of the stem kernels (csrc/ctg_stem.hip built with -DCTG_STEM_H2): two rounded fp16 limbs
+# per operand under per-tensor power-of-two scales, three products -- what a new executor multiplies its pairs with
+# ---------------------------------------------------------------------- #
+
+
+@pytest.fixture
+def fuse_whatever_fits(monkeypatch):
+    from cotengra_amd import stem
+    monkeypatch.setattr(stem, "gather_rate", lambda run_bytes: 5.4e12)
+    for k in ("CTG_STEM_ARITH", "CTG_STEM_BF16X3", "CTG_STEM_H2"):
+        monkeypatch.delenv(k, raising=False)
+
+
+def _stem_names(fn, arrays):
+    return [n for n in fn.setup(*arrays)["exec"].step_kernels() if n.startswith(("stem2_kernel", "stem2h_kernel"))]
+
+
+@pytest.mark.parametrize("sliced", [0, 2])
+@pytest.mark.parametrize("case", range(len(G.STEM_CASES)))
+def test_stem_pairs_in_fp16x2(case, sliced, fuse_whatever_fits, monkeypatch):
+    """Every instantiation of the fused kernel: the default arithmetic is fp16 x 2 wherever the shape has a
+    16-bit-pipe kernel (names stem2h_kernel<..., BF3 = true ...>), within the single-precision gate of the oracle;
+    "bf16x3" / "fp32" by option give the other arithmetics' bits, CTG_STEM_H2=0 the bf16 x 3 bits; strip_exponent
+    falls back to bf16 x 3 (a scale per step there)."""
+    nq, gates = G.STEM_CASES[case]
+    tree = G.stem_network(nq, gates, 100 * case, sliced=sliced)
+    arrays = ca.make_arrays_from_inputs(tree.inputs, tree.size_dict, seed=case, dtype="complex64")
+    ref = np.asarray(orc.contract(tree, [a.astype("complex128") for a in arrays]))
+    gate = G.single_gate(ref, orc.contract(tree, arrays))
+    fn = HipContractor(tree, fuse=True, fuse_min_elems=1 << 10)
+    got = np.asarray(fn(*arrays))
+    names = _stem_names(fn, arrays)
+    assert names
+    h2 = [n for n in names if n.startswith("stem2h_kernel")]
+    assert all(G.stem_flags(n)["bf3"] for n in h2)
+    assert G.relerr(got, ref) <= gate, (G.relerr(got, ref), gate)
+    fb = HipContractor(tree, fuse=True, fuse_min_elems=1 << 10, stem_bf16x3="bf16x3")
+    bf3 = np.asarray(fb(*arrays))
+    names_b = _stem_names(fb, arrays)
+    fb.close()
+    assert not any(n.startswith("stem2h_kernel") for n in names_b)
+    assert [n.replace("stem2h_kernel", "stem2_kernel") for n in names] == names_b   # (the same instantiations)
+    assert G.relerr(bf3, ref) <= gate
+    if h2:
+        assert not np.array_equal(got, bf3)   # (it really ran)
+    monkeypatch.setenv("CTG_STEM_H2", "0")
+    assert np.array_equal(np.asarray(fn(*arrays)), bf3)
+    monkeypatch.delenv("CTG_STEM_H2")
+    m, e = fn(*arrays, strip_exponent=True)
+    assert not any(n.startswith("stem2h_kernel") for n in _stem_names(fn, arrays))
+    assert G.relerr(np.asarray(m).astype("complex128") * 10.0**e, ref) <= gate
+    assert np.array_equal(np.asarray(fn(*arrays)), got)     # (and back)
+    if tree.nslices > 1:
+        a128 = [a.astype("complex128") for a in arrays]
+        for i in range(tree.nslices):
+            ri = np.asarray(orc.contract_slice(tree, a128, i))
+            gi = max(gate, G.single_gate(ri, orc.contract_slice(tree, arrays, i)))
+            assert G.relerr(np.asarray(fn.contract_slice(arrays, i)), ri) <= gi
+    fn.close()
+
+
+@pytest.mark.parametrize("seed", range(48))
+def test_random_stems_in_fp16x2(seed, fuse_whatever_fits):
+    tree = G.random_stem(seed)
+    arrays = ca.make_arrays_from_inputs(tree.inputs, tree.size_dict, seed=seed, dtype="complex64")
+    ref = np.asarray(orc.contract(tree, [a.astype("complex128") for a in arrays]))
+    gate = G.single_gate(ref, orc.contract(tree, arrays))
+    fn = HipContractor(tree, fuse=True, fuse_min_elems=1 << 9)
+    got = np.asarray(fn(*arrays))
+    fn.close()
+    assert G.relerr(got, ref) <= gate, (G.relerr(got, ref), gate)
+
+
+@pytest.mark.parametrize("case", range(len(G.ONE_CASES)))
+def test_single_stem_steps_in_fp16x2(case, fuse_whatever_fits, monkeypatch):
+    # (the pairing model takes a single step only where it pays; here: wherever the kernel can)
+    from cotengra_amd import stem
+    monkeypatch.setattr(stem, "single_seconds", lambda *a, **k: 0.0)
+    nq, gates = G.ONE_CASES[case]
+    tree = G.stem_network(nq, gates, 300 + case)
+    arrays = ca.make_arrays_from_inputs(tree.inputs, tree.size_dict, seed=case, dtype="complex64")
+    ref = np.asarray(orc.contract(tree, [a.astype("complex128") for a in arrays]))
+    gate = G.single_gate(ref, orc.contract(tree, arrays))
+    fn = HipContractor(tree, fuse=True, fuse_min_elems=1 << 10)
+    got = np.asarray(fn(*arrays))
+    names = _stem_names(fn, arrays)
+    fn.close()
+    assert names
+    assert G.relerr(got, ref) <= gate, (G.relerr(got, ref), gate)
+
+
+def test_fp16x2_scales_are_exact_powers_of_two(fuse_whatever_fits):
+    """Inputs alternately scaled by 2^+40 and 2^-40, the big state by 2^-90: every scale the kernels take out is a
+    power of two found from the data, so the limbs -- and the result, up to the power put back in -- are the SAME
+    BITS as in the plain run; a chain of pairs whose intermediates' magnitudes differ by 2^40 from one pair to the
+    next also checks that every pair scales with ITS operand's record, not a stale one."""
+    nq, gates = G.STEM_CASES[10]
+    tree = G.stem_network(nq, gates, 1000)
+    arrays = ca.make_arrays_from_inputs(tree.inputs, tree.size_dict, seed=10, dtype="complex64", rescale=True)
+    ref = np.asarray(orc.contract(tree, [a.astype("complex128") for a in arrays]))
+    fn = HipContractor(tree, fuse=True, fuse_min_elems=1 << 10)
+    plain = np.asarray(fn(*arrays))
+    assert any(n.startswith("stem2h_kernel") for n in _stem_names(fn, arrays))
+    shifts = [(-90 if i == 0 else (40 if i % 2 else -40)) for i in range(len(arrays))]
+    scaled = [(a * np.float32(2.0**s)).astype("complex64") for a, s in zip(arrays, shifts)]
+    got = np.asarray(fn(*scaled))
+    fn.close()
+    total = sum(shifts)
+    assert np.array_equal(got * np.float32(2.0 ** -total) if abs(total) < 120 else got, plain) or \
+        G.relerr(got.astype("complex128") * 2.0 ** -total, ref) <= 1e-5
+    assert G.relerr(got.astype("complex128") * 2.0 ** -total, ref) <= G.single_gate(ref, orc.contract(tree, arrays))
+
+
+def test_fp16x2_wide_dynamic_range_is_norm_wise(fuse_whatever_fits):
+    """fp16 limbs cover 2^-24 ... 2^16 of a tensor's largest element: an operand whose elements span 2^120 keeps its
+    large ones to 22 bits and loses the small ones gradually.  What holds is the NORM-WISE bound (error relative to the
+    largest element of the result) -- the exact three-way bf16 split keeps every element to fp32 accuracy and is the
+    arithmetic for such data (stem_bf16x3="bf16x3", CTG_STEM_ARITH)."""
+    nq, gates = G.STEM_CASES[4]
+    tree = G.stem_network(nq, gates, 404)
+    arrays = ca.make_arrays_from_inputs(tree.inputs, tree.size_dict, seed=4, dtype="complex64")
+    rng = np.random.default_rng(7)
+    big = arrays[0]
+    arrays[0] = (big * np.exp2(rng.integers(-60, 61, size=big.shape)).astype("float32")).astype("complex64")
+    ref = np.asarray(orc.contract(tree, [a.astype("complex128") for a in arrays]))
+    fn = HipContractor(tree, fuse=True, fuse_min_elems=1 << 10)
+    got = np.asarray(fn(*arrays)).astype("complex128")
+    assert any(n.startswith("stem2h_kernel") for n in _stem_names(fn, arrays))
+    fn.close()
+    fb = HipContractor(tree, fuse=True, fuse_min_elems=1 << 10, stem_bf16x3="bf16x3")
+    bf3 = np.asarray(fb(*arrays)).astype("complex128")
+    fb.close()
+    top = np.abs(ref).max()
+    assert np.abs(got - ref).max() <= 1e-5 * top          # norm-wise: fp16 x 2
+    assert np.abs(bf3 - ref).max() <= 1e-5 * top
+    # (on THIS data the outputs are sums dominated by their large terms and the two arithmetics are equally good
+    # element by element -- median relative error 2e-7 either way; the difference is in what is promised)

@@ -32,9 +32,9 @@ def step_kernel_name(rocprof_name):
     m = re.match(r"pair_rowwise_kernel<(\d+), (?:true|false)>", rocprof_name)
     if m:
         return f"pair_rowwise_kernel<{m.group(1)}>"
-    m = re.match(r"stem2_kernel<([^>]*)>", rocprof_name)
-    if m:   # (nine template arguments, spelled as csrc/ctg_stem.hip: stem2_kernel_name spells them)
-        return "stem2_kernel<%s>" % m.group(1).replace(" ", "")
+    m = re.match(r"(stem2h?_kernel)<([^>]*)>", rocprof_name)
+    if m:   # (template arguments spelled as csrc/ctg_stem.hip: stem2_kernel_name spells them; stem2h: fp16 x 2)
+        return "%s<%s>" % (m.group(1), m.group(2).replace(" ", ""))
     m = re.match(r"pair_skinny_kernel<(\d+), (\d+)>", rocprof_name)
     if m:
         return f"pair_skinny_kernel<{m.group(1)},{m.group(2)}>"
