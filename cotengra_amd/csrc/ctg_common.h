@@ -528,11 +528,10 @@ void stem2_kernel_name(const StemArgs& p, char* buf, size_t n);
 // the same kernels in the fp16 x 2 arithmetic (round 6; StemArgs::amax / cmax)
 bool stem2h_supported(const StemArgs& p);
 bool stem2h_uses_h2(const StemArgs& p);   // (else the launch is the fp32 kernel of that object: no record of the result)
+bool stem2_uses_bf3(const StemArgs& p);   // the same question for launch_stem2 (bf16 x 3: records the result's largest element too)
 hipError_t launch_stem2h(const StemArgs& p, hipStream_t stream);
 void stem2h_kernel_name(const StemArgs& p, char* buf, size_t n);
-// largest |re|, |im| of n complex64 values as a float (atomicMax on its bits; *out zeroed by the caller)
-hipError_t launch_maxabs_f32(const void* base, const int64_t* soff, int64_t z, int64_t zs, int64_t zstride, int64_t n,
-                             float* out, hipStream_t stream);
+
 hipError_t launch_single(int dtype, const StepArgs& p, hipStream_t stream);
 bool pair_bf16x3_on(const StepArgs& p);   // (ctg_pair_mfma.hip) do long tiled steps multiply with bf16 x 3 products right now?
 hipError_t launch_accum(int dtype, const StepArgs& p, const StripState* st, void* wide, const double* inscale, hipStream_t stream);

@@ -132,6 +132,12 @@ inline int64_t ctg_item_size(int dtype) {
 // records `msg` as the calling thread's ctg_last_error() (ctg_runtime.hip)
 extern "C" __attribute__((visibility("hidden"))) void ctg_set_error_(const char* msg);
 
+namespace ctg {
+// (ctg_kernels_valu.hip) largest |re|, |im| of n complex64 values as a float; *out zeroed by the caller
+hipError_t launch_maxabs_f32(const void* base, const int64_t* soff, int64_t z, int64_t zs, int64_t zstride, int64_t n,
+                             float* out, hipStream_t stream);
+}
+
 // LDS-resident subtrees (ctg_lds_host.hip): descriptor validation (host only) and per-executor packing
 __attribute__((visibility("hidden"))) int ctg_lds_validate(const ctg_plan* p);
 __attribute__((visibility("hidden"))) int ctg_lds_build(ctg_exec* e);

@@ -629,8 +629,9 @@ hipError_t launch_maxabs(int dtype, const void* x, int64_t n, double* fac, hipSt
     return hipGetLastError();
 }
 
-// largest |re|, |im| of n complex64 values as a FLOAT (round 6: the power-of-two scale of a big operand of the fp16 x 2 stem
-// kernels whose producer is not one of them); *out must be zero
+// largest |re|, |im| of n complex64 values as a FLOAT: the power-of-two scale of a big operand of the fp16 x 2 stem
+// kernels that no producer recorded (CTG_STEM_H2_ALL=1: tests and diagnostics -- by default such a pair is multiplied in
+// bf16 x 3 instead, ctg_runtime.hip); *out must be zero
 __global__ __launch_bounds__(256) void maxabs_f32_kernel(const c64* __restrict__ base, const int64_t* soff, int64_t z,
                                                          int64_t zs, int64_t zstride, int64_t n, float* out) {
     const c64* __restrict__ x = base + (soff[z * zs] + z * zstride);

@@ -1005,36 +1005,36 @@ int launch_step(ctg_exec* e, int64_t s, hipStream_t stream) {
         case KIND_STEM2: {
             // (slices of a batch one after the other: the workgroups are persistent)
             const int nz = e->args[s].nz;
-            // fp16 x 2 (round 6): the executor's arithmetic, not under strip_exponent (a scale per step there), where
-            // the shape has a bf16-pipe kernel; CTG_STEM_H2=0 in the environment (read per launch) says no
-            bool h2 = e->stem_arith == 2 && !e->strip && e->d_stem_max != nullptr && stem2h_uses_h2(e->stem_args[s]);
+            // fp16 x 2 (round 6): the executor's arithmetic, not under strip_exponent (a scale per step there), for a
+            // shape with a 16-bit-pipe kernel whose big operand was produced by a 16-bit-pipe stem launch (that launch
+            // recorded the operand's largest element: the power of two the split needs).  A big operand of any other
+            // origin -- the first pair of a stem -- is multiplied in bf16 x 3, which needs no scale and records its
+            // result's largest element as well.  CTG_STEM_H2=0 in the environment (read per launch) says no.
+            const bool rec = e->stem_arith != 0 && !e->strip && e->d_stem_max != nullptr;
+            const int64_t prod = r[W_A_PROD];
+            const bool prod_rec = prod >= 0 && prod < p->n_steps && p->steps[prod * STEP_WORDS + W_KIND] == KIND_STEM2 &&
+                                  e->stem_h2_ran[prod];
+            // (CTG_STEM_H2_ALL=1, tests and diagnostics: fp16 x 2 for EVERY capable pair -- a max-abs pass over the
+            // big operand supplies the scale where no producer recorded it)
+            const bool h2_all = env_on("CTG_STEM_H2_ALL");
+            bool h2 = e->stem_arith == 2 && rec && (prod_rec || h2_all) && stem2h_uses_h2(e->stem_args[s]);
             if (h2)
                 if (const char* v = getenv("CTG_STEM_H2")) h2 = !(v[0] == '\0' || (v[0] == '0' && v[1] == '\0'));
-            e->stem_h2_ran[s] = h2 ? 1 : 0;
+            const bool records = h2 || (rec && stem2_uses_bf3(e->stem_args[s]));
+            e->stem_h2_ran[s] = records ? 1 : 0;
             for (int z = 0; z < nz && err == hipSuccess; ++z) {
                 StemArgs q = e->stem_args[s];
                 q.z0 = e->args[s].z0 + z;
                 q.nz = 1;
-                q.amax = nullptr;
-                q.cmax = nullptr;
-                if (!h2) {
-                    err = launch_stem2(q, stream);
-                    continue;
-                }
-                q.cmax = e->d_stem_max + s;
-                const int64_t prod = r[W_A_PROD];
-                if (prod >= 0 && prod < p->n_steps && p->steps[prod * STEP_WORDS + W_KIND] == KIND_STEM2 && e->stem_h2_ran[prod]) {
-                    q.amax = e->d_stem_max + prod;   // the producer recorded it
-                } else {
-                    // a big operand of any other origin: a max-abs pass (it is the FIRST pair of a stem that meets
-                    // one; the operand is small next to what the stem then builds)
+                q.amax = h2 ? e->d_stem_max + prod : nullptr;
+                q.cmax = records ? e->d_stem_max + s : nullptr;
+                if (h2 && !prod_rec) {
                     float* slot = e->d_stem_max + p->n_steps + s;
                     err = hipMemsetAsync(slot, 0, sizeof(float), stream);
-                    if (err == hipSuccess)
-                        err = launch_maxabs_f32(q.A, q.soffA, q.z0, q.zsA, q.zA, q.a_elems, slot, stream);
+                    if (err == hipSuccess) err = launch_maxabs_f32(q.A, q.soffA, q.z0, q.zsA, q.zA, q.a_elems, slot, stream);
                     q.amax = slot;
                 }
-                if (err == hipSuccess) err = launch_stem2h(q, stream);
+                if (err == hipSuccess) err = h2 ? launch_stem2h(q, stream) : launch_stem2(q, stream);
             }
             break;
         }
@@ -2178,7 +2178,13 @@ int ctg_exec_step_kernel(ctg_exec* e, int64_t step, char* buf, int64_t buflen) {
     } else if (r[W_KIND] == KIND_ACCUM) {
         snprintf(name, sizeof(name), "accum_kernel");
     } else if (r[W_KIND] == KIND_STEM2) {
-        bool h2 = e->stem_arith == 2 && !e->strip && e->d_stem_max != nullptr && stem2h_uses_h2(e->stem_args[step]);
+        // (the arithmetic of the step's NEXT launch: fp16 x 2 needs the producer of its big operand to be a stem
+        // launch of the 16-bit pipe -- decided on the shapes here, as launch_step decides it on what ran)
+        const int64_t prod = r[W_A_PROD];
+        const bool prod16 = prod >= 0 && prod < p->n_steps && p->steps[prod * STEP_WORDS + W_KIND] == KIND_STEM2 &&
+                            (stem2_uses_bf3(e->stem_args[prod]) || stem2h_uses_h2(e->stem_args[prod]));
+        bool h2 = e->stem_arith == 2 && !e->strip && e->d_stem_max != nullptr && (prod16 || env_on("CTG_STEM_H2_ALL")) &&
+                  stem2h_uses_h2(e->stem_args[step]);
         if (h2)
             if (const char* v = getenv("CTG_STEM_H2")) h2 = !(v[0] == '\0' || (v[0] == '0' && v[1] == '\0'));
         if (h2) stem2h_kernel_name(e->stem_args[step], name, sizeof(name));

@@ -68,6 +68,7 @@
 #define stem2_variant stem2h_variant
 #define stem2_kernel_name stem2h_kernel_name
 #define launch_stem2 launch_stem2h
+#define stem2_uses_bf3 stem2h_uses_h2
 #else
 #define CTG_STEM_KNAME "stem2_kernel"
 #endif
@@ -542,10 +543,12 @@ __global__ __launch_bounds__(SW * 64, 1) void stem2_kernel(StemArgs p) {
         h2_sa = pow2f(-h2_exa);
     }
     float h2_st = 1.f;    // ... and the intermediate tile's (per tile)
-    float h2_vmax = 0.f;  // largest |component| this lane has stored (-> StemArgs::cmax)
 #else
     constexpr float h2_sa = 1.f, h2_st = 1.f;
 #endif
+    // (both 16-bit arithmetics) largest |component| this lane has stored -> StemArgs::cmax: what a consumer in the
+    // fp16 x 2 arithmetic scales its split of this result with
+    float h2_vmax = 0.f;
     if constexpr (BF3) {
         const int ex1 = bf3_operand_exponent(B1, p.b1_off, K1 * N1, tid, bf3_red);
         const int ex2 = ONE ? 0 : bf3_operand_exponent(B2, p.b2_off, K2 * N2, tid, bf3_red);
@@ -1387,9 +1390,7 @@ __global__ __launch_bounds__(SW * 64, 1) void stem2_kernel(StemArgs p) {
                         v.x = v.x * alpha * alpha2;
                         v.y = v.y * alpha * alpha2;
                     }
-#ifdef CTG_STEM_H2
                     if constexpr (BF3) h2_vmax = fmaxf(h2_vmax, fmaxf(fabsf(v.x), fabsf(v.y)));
-#endif
                     pv[t >> 1] = v;
                 }
             } else {
@@ -1399,9 +1400,7 @@ __global__ __launch_bounds__(SW * 64, 1) void stem2_kernel(StemArgs p) {
                     const float xr = XM2 ? cx[t] - cxm[t] : cx[t];
                     v.x = SC ? xr * alpha * alpha2 : xr;
                     v.y = SC ? cy[t] * alpha * alpha2 : cy[t];
-#ifdef CTG_STEM_H2
                     if constexpr (BF3) h2_vmax = fmaxf(h2_vmax, fmaxf(fabsf(v.x), fabsf(v.y)));
-#endif
                     pv[t] = v;
                 }
             }
@@ -1489,9 +1488,7 @@ __global__ __launch_bounds__(SW * 64, 1) void stem2_kernel(StemArgs p) {
             const float xr = XM1 ? ax[m][t] - axm[m][t] : ax[m][t];
             v.x = SC ? xr * alpha * alpha2 : xr;
             v.y = SC ? ay[m][t] * alpha * alpha2 : ay[m][t];
-#ifdef CTG_STEM_H2
             if constexpr (BF3) h2_vmax = fmaxf(h2_vmax, fmaxf(fabsf(v.x), fabsf(v.y)));
-#endif
             pv[RI2 ? 0 : t] = v;
         }
         pdst = C + 2 * (c_tile + one_rt[m] + out_lane + one_col);
@@ -1729,8 +1726,7 @@ __global__ __launch_bounds__(SW * 64, 1) void stem2_kernel(StemArgs p) {
     };
     if (scaled) run(std::true_type{});
     else run(std::false_type{});
-#ifdef CTG_STEM_H2
-    // the largest |component| this launch stored: what the consumer of the result scales its split with
+    // the largest |component| this launch stored: what a consumer of the result scales its split with (fp16 x 2)
     if constexpr (BF3) {
         if (p.cmax != nullptr) {
             float mx = h2_vmax;
@@ -1740,7 +1736,6 @@ __global__ __launch_bounds__(SW * 64, 1) void stem2_kernel(StemArgs p) {
                 atomicMax((unsigned*)p.cmax, __builtin_bit_cast(unsigned, mx));
         }
     }
-#endif
 }
 
 #ifdef CTG_STEM_TIMELINE
@@ -2217,10 +2212,9 @@ void stem2_kernel_name(const StemArgs& p, char* buf, size_t n) {
                  tf(s.vec));
 }
 
-#ifdef CTG_STEM_H2
-// does this launch multiply in the fp16 x 2 arithmetic (and record the largest element of its result)?
-bool stem2h_uses_h2(const StemArgs& p) { return !p.tri && stem2_supported(p) && stem2_bf3(p); }
-#endif
+// does this launch run an instantiation of the 16-bit matrix cores (which records the largest element of its result,
+// StemArgs::cmax)?  In the object built with -DCTG_STEM_H2: in the fp16 x 2 arithmetic.
+bool stem2_uses_bf3(const StemArgs& p) { return !p.tri && stem2_supported(p) && stem2_bf3(p); }
 
 hipError_t launch_stem2(const StemArgs& p, hipStream_t stream) {
     if (!stem2_supported(p)) return hipErrorInvalidValue;

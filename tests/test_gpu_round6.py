@@ -281,6 +281,9 @@ def fuse_whatever_fits(monkeypatch):
     monkeypatch.setattr(stem, "gather_rate", lambda run_bytes: 5.4e12)
     for k in ("CTG_STEM_ARITH", "CTG_STEM_BF16X3", "CTG_STEM_H2"):
         monkeypatch.delenv(k, raising=False)
+    # (by default the FIRST pair of a stem -- its big operand comes from a kernel that records no maximum -- is
+    # multiplied in bf16 x 3; the kernel tests want every capable pair in fp16 x 2: a max-abs pass supplies the scale)
+    monkeypatch.setenv("CTG_STEM_H2_ALL", "1")
 
 
 def _stem_names(fn, arrays):
@@ -407,3 +410,29 @@ def test_fp16x2_wide_dynamic_range_is_norm_wise(fuse_whatever_fits):
     assert np.abs(bf3 - ref).max() <= 1e-5 * top
     # (on THIS data the outputs are sums dominated by their large terms and the two arithmetics are equally good
     # element by element -- median relative error 2e-7 either way; the difference is in what is promised)
+
+
+def test_first_pair_of_a_stem_runs_bf16x3_and_records_its_maximum(monkeypatch):
+    """The default rule: fp16 x 2 needs the largest element of the big operand, which only a stem launch of the 16-bit
+    pipe records -- the first pair of a chain (operand of other origin) runs bf16 x 3 and records, every later pair runs
+    fp16 x 2 on its producer's record.  Against the oracle; and with CTG_STEM_H2_ALL=1 (a max-abs pass for the first
+    pair) the result changes only in the last bits."""
+    from cotengra_amd import stem
+    monkeypatch.setattr(stem, "gather_rate", lambda run_bytes: 5.4e12)
+    for k in ("CTG_STEM_ARITH", "CTG_STEM_BF16X3", "CTG_STEM_H2", "CTG_STEM_H2_ALL"):
+        monkeypatch.delenv(k, raising=False)
+    nq, gates = G.STEM_CASES[10]     # a longer stem: pairs + leftovers
+    tree = G.stem_network(nq, gates, 1000)
+    arrays = ca.make_arrays_from_inputs(tree.inputs, tree.size_dict, seed=10, dtype="complex64")
+    ref = np.asarray(orc.contract(tree, [a.astype("complex128") for a in arrays]))
+    gate = G.single_gate(ref, orc.contract(tree, arrays))
+    fn = HipContractor(tree, fuse=True, fuse_min_elems=1 << 10)
+    got = np.asarray(fn(*arrays))
+    names = _stem_names(fn, arrays)
+    assert names[0].startswith("stem2_kernel<") and any(n.startswith("stem2h_kernel<") for n in names[1:]), names
+    assert G.relerr(got, ref) <= gate
+    monkeypatch.setenv("CTG_STEM_H2_ALL", "1")
+    allh = np.asarray(fn(*arrays))
+    assert _stem_names(fn, arrays)[0].startswith("stem2h_kernel<")
+    fn.close()
+    assert G.relerr(allh, ref) <= gate and G.relerr(allh, got) <= 1e-5
