@@ -176,6 +176,11 @@ def precision_check(tree, arrays, slice_id=3, log2_width=20):
     lowered = bf16x3_mode() and "CTG_FUSE_MIN_ELEMS" not in os.environ
     if lowered:
         os.environ["CTG_FUSE_MIN_ELEMS"] = str(1 << 12)
+    # (fp16 x 2: on the full-width tree every pair of a stem but its first runs it; the narrowed tree's stems are one or
+    # two pairs long, so the check asks for EVERY capable pair in fp16 x 2 -- CTG_STEM_H2_ALL: a max-abs pass scales a first pair)
+    h2_all = stem_arithmetic() == "fp16x2" and "CTG_STEM_H2_ALL" not in os.environ
+    if h2_all:
+        os.environ["CTG_STEM_H2_ALL"] = "1"
     a128 = [a.astype("complex128") for a in arrays]
     with host_threads():
         ref = complex(orc.contract_slice(small, a128, slice_id))
@@ -194,6 +199,9 @@ def precision_check(tree, arrays, slice_id=3, log2_width=20):
         "rel_err_complex128_path": abs(got128 - ref) / abs(ref),
         "gate_complex128_path": 1e-10,
     }
+    if h2_all:
+        del os.environ["CTG_STEM_H2_ALL"]
+        out["check"] += "; every capable pair in fp16 x 2"
     if lowered:
         del os.environ["CTG_FUSE_MIN_ELEMS"]
         out["check"] += "; stem pairs fused from 2^12 elements, on the bf16 matrix cores"
@@ -241,6 +249,9 @@ def precision_sum_check(tree, arrays, slice_id=3, log2_width=22, log2_slices=12)
     lowered = bf16x3_mode() and "CTG_FUSE_MIN_ELEMS" not in os.environ
     if lowered:
         os.environ["CTG_FUSE_MIN_ELEMS"] = str(1 << 12)
+    h2_all = stem_arithmetic() == "fp16x2" and "CTG_STEM_H2_ALL" not in os.environ
+    if h2_all:   # (as in precision_check: every capable pair of the narrowed tree in fp16 x 2)
+        os.environ["CTG_STEM_H2_ALL"] = "1"
     a128 = [a.astype("complex128") for a in arrays]
     with host_threads():
         t0 = time.perf_counter()
@@ -259,12 +270,14 @@ def precision_sum_check(tree, arrays, slice_id=3, log2_width=22, log2_slices=12)
         fn.close()
         if lowered:
             del os.environ["CTG_FUSE_MIN_ELEMS"]
+        if h2_all:
+            del os.environ["CTG_STEM_H2_ALL"]
     rel = abs(got - ref) / abs(ref)
     return {
         "check": f"sum of {len(ids)} complex64 slices (width 2^{math.log2(fine.max_size()):.0f}, device running sum in "
                  f"{wide}) vs ONE numpy complex128 slice of the same tree at width 2^{log2_width}",
         "slices": len(ids), "rel_err": rel, "meets_north_star_1e-5": bool(rel <= 1e-5),
-        "fused_pairs_in_check": fused, "oracle_seconds": oracle_s,
+        "fused_pairs_in_check": fused, "oracle_seconds": oracle_s, "every_capable_pair_in_fp16x2": bool(h2_all),
     }
 
 

@@ -1022,6 +1022,10 @@ int launch_step(ctg_exec* e, int64_t s, hipStream_t stream) {
                 if (const char* v = getenv("CTG_STEM_H2")) h2 = !(v[0] == '\0' || (v[0] == '0' && v[1] == '\0'));
             const bool records = h2 || (rec && stem2_uses_bf3(e->stem_args[s]));
             e->stem_h2_ran[s] = records ? 1 : 0;
+            if (env_on("CTG_STEM_DEBUG"))
+                fprintf(stderr, "stem step %lld: arith %d rec %d prod %lld prod_rec %d uses_h2 %d uses_bf3 %d -> h2 %d records %d\n",
+                        (long long)s, e->stem_arith, (int)rec, (long long)prod, (int)prod_rec, (int)stem2h_uses_h2(e->stem_args[s]),
+                        (int)stem2_uses_bf3(e->stem_args[s]), (int)h2, (int)records);
             for (int z = 0; z < nz && err == hipSuccess; ++z) {
                 StemArgs q = e->stem_args[s];
                 q.z0 = e->args[s].z0 + z;

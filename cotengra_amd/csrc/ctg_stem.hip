@@ -69,6 +69,11 @@
 #define stem2_kernel_name stem2h_kernel_name
 #define launch_stem2 launch_stem2h
 #define stem2_uses_bf3 stem2h_uses_h2
+#define ctg_debug_stem_timeline ctg_debug_stem_timeline_h2   // (experiment builds: the same hooks, this object's kernels)
+#define ctg_debug_stem_oob ctg_debug_stem_oob_h2
+#define ctg_stem_tl ctg_stem_tl_h2
+#define ctg_stem_tl_on ctg_stem_tl_on_h2
+#define ctg_stem_oob ctg_stem_oob_h2
 #else
 #define CTG_STEM_KNAME "stem2_kernel"
 #endif

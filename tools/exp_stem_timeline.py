@@ -33,8 +33,10 @@ ex.sync()
 lib = runtime.load()
 T = 256
 buf = np.zeros((8, T, 6), dtype=np.uint64)
-lib.ctg_debug_stem_timeline.argtypes = [C.c_void_p, C.c_int]
-rc = lib.ctg_debug_stem_timeline(C.c_void_p(buf.ctypes.data), 1)
+# (the fp16 x 2 object has its own copy of the hook: CTG_TL_H2=1 reads that one)
+hook = lib.ctg_debug_stem_timeline_h2 if os.environ.get("CTG_TL_H2") else lib.ctg_debug_stem_timeline
+hook.argtypes = [C.c_void_p, C.c_int]
+rc = hook(C.c_void_p(buf.ctypes.data), 1)
 assert rc == 0
 fn.close()
 ok = buf[:, :, 5] > 0
