@@ -61,9 +61,11 @@ def test_pmc_traffic_lookup_normalises_template_arguments():
     short = "stem2_kernel<false,false,1,1,2,1,true,0,false,true,false,false>"
     long_ = "stem2_kernel<false, false, 1, 1, 2, 1, true, 0, false, true, false, false, 0, false>"
     assert bench.norm_kernel_name(short) == bench.norm_kernel_name(long_)
-    # the committed counter passes are the round-5 build's: the dominant pair in its two-accumulator form, spelled
-    # with 16 of its 17 template arguments by the executor and with all of them (and blanks) by rocprof
-    xm = "stem2_kernel<false,false,1,1,2,1,true,0,false,true,false,false,0,false,true,false>"
+    assert bench.norm_kernel_name(short.replace("stem2_", "stem2h_")) == bench.norm_kernel_name(long_.replace("stem2_", "stem2h_"))
+    assert bench.norm_kernel_name(short.replace("stem2_", "stem2h_")) != bench.norm_kernel_name(short)
+    # the committed counter passes are the round-6 build's: the dominant pair in the fp16 x 2 arithmetic (stem2h_kernel),
+    # spelled with 16 of its 17 template arguments by the executor and with all of them (and blanks) by rocprof
+    xm = "stem2h_kernel<false,false,1,1,2,1,true,0,false,true,false,false,0,false,true,false>"
     traffic, _ = bench.pmc_traffic_for(bench.TREE, xm)
     assert traffic == pytest.approx(68.7e9, rel=0.01)
     traffic, _ = bench.pmc_traffic_for(bench.TREE, xm[:-1].replace(",", ", ") + ", false>")
