@@ -66,7 +66,7 @@ def main():
         kernels[step_kernel_name(k)] = {"rocprof_name": k, "launches": f[k][0],
                                         "fetch_bytes_corrected": fb, "write_bytes": wb,
                                         "hbm_bytes_per_launch": (fb + wb) / f[k][0]}
-        if "pair_mfma" in k or "pair_skinny" in k or "stem2_kernel" in k:
+        if "pair_mfma" in k or "pair_skinny" in k or "stem2_kernel" in k or "stem2h_kernel" in k:
             tot_f += fb
             tot_w += wb
             launches += f[k][0]

@@ -18,16 +18,17 @@ args = [a for a in sys.argv[1:] if not a.startswith("--")]
 BF3 = "--bf16x3" in sys.argv
 rows = [r for r in json.load(open(args[0])) if r["ms"] > 0]   # (slice-invariant steps show 0 ms)
 tot = sum(r["ms"] for r in rows)
-P32, PBF3, BW = 157.3e12, 2500e12 / 6, 8e12
+P32, PBF3, PH2, BW = 157.3e12, 2500e12 / 6, 2500e12 / 3, 8e12
 
 
 def peak(r):
     name = r.get("kernel_name") or ""
     if name.startswith("pair_mfma_bf3_kernel"):
         return PBF3
-    if name.startswith("stem2_kernel<"):
-        a = name[len("stem2_kernel<"):].rstrip(">").split(",")
-        return PBF3 if len(a) >= 10 and a[9].strip() == "true" else P32
+    for prefix, pk in (("stem2h_kernel<", PH2), ("stem2_kernel<", PBF3)):   # (stem2h: fp16 x 2, three products)
+        if name.startswith(prefix):
+            a = name[len(prefix):].rstrip(">").split(",")
+            return pk if len(a) >= 10 and a[9].strip() == "true" else P32
     return PBF3 if (BF3 and r.get("kind") == "stem2") else P32
 
 
