@@ -74,8 +74,13 @@
 #define ctg_stem_tl ctg_stem_tl_h2
 #define ctg_stem_tl_on ctg_stem_tl_on_h2
 #define ctg_stem_oob ctg_stem_oob_h2
+// B1's fragments live in registers up to this many 16-deep chunks of the first contraction (24 registers per chunk with
+// three limbs, 16 with two).  Four chunks under H2 -- the K1 = 64 pairs, whose fragments come from LDS for every task --
+// were measured (same box, alternating): 199.5 against 198.3 ms per slice, 0.6 % SLOWER; two it stays.
+#define CTG_STEM_BR1_MAX 2
 #else
 #define CTG_STEM_KNAME "stem2_kernel"
+#define CTG_STEM_BR1_MAX 2
 #endif
 
 namespace ctg {
@@ -538,7 +543,7 @@ __global__ __launch_bounds__(SW * 64, 1) void stem2_kernel(StemArgs p) {
     int bf3_ex = 0;   // BF3: power of two taken out of the small operands (goes back in through alpha)
     float* const bf3_red = (float*)(oc_s + (ONE ? N1 : N2));   // (64 bytes behind the column table: stem2_lds_bytes_bf3)
 #ifdef CTG_STEM_H2
-    static_assert(!BF3 || (!TRI && !LM && !WS), "fp16 x 2: pairs and single steps of the symmetric kernel");
+    static_assert(!BF3 || (!TRI && !LM), "fp16 x 2: pairs and single steps, fp32 intermediate");
     // H2: the big operand's power of two, from the largest element its producer recorded
     float h2_sa = 1.f;
     int h2_exa = 0;
@@ -1517,14 +1522,15 @@ __global__ __launch_bounds__(SW * 64, 1) void stem2_kernel(StemArgs p) {
                 }
 #pragma unroll
             for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
-            if (lane == 0) bf3_red[h2_par * 8 + wave] = mx;
+            if (lane == 0) bf3_red[h2_par * 8 + wave1] = mx;
+            if constexpr (WS) h2_par ^= 1;   // (specialised waves: only the producers publish, only the consumers consume)
         }
     };
     auto h2_consume = [&]() __attribute__((always_inline)) {
         if constexpr (BF3 && !ONE) {
             float mx = bf3_red[h2_par * 8];
 #pragma unroll
-            for (int w = 1; w < SW; ++w) mx = fmaxf(mx, bf3_red[h2_par * 8 + w]);
+            for (int w = 1; w < PW; ++w) mx = fmaxf(mx, bf3_red[h2_par * 8 + w]);
             const int et = __builtin_amdgcn_readfirstlane(h2_exponent_of(mx));
             h2_st = pow2f(-et);
             h2_set_alpha(et);
@@ -1586,6 +1592,7 @@ __global__ __launch_bounds__(SW * 64, 1) void stem2_kernel(StemArgs p) {
                 static_for<0, U>([&](auto ui) __attribute__((always_inline)) {
                     constexpr int UI = decltype(ui)::value;
                     if (t + UI < my_tiles) {
+                        h2_publish();
                         CTG_STEM_SYNC();   // the consumers have read tile t - 1's intermediate; tile t's accumulators are complete
                         scatter();
                         CTG_STEM_SYNC();
@@ -1598,6 +1605,7 @@ __global__ __launch_bounds__(SW * 64, 1) void stem2_kernel(StemArgs p) {
                 CTG_STEM_SYNC();
                 if (t > 0) drain(0, NST, std::integral_constant<int, 0>{}, scaled_tag);   // the last item's stores: while the producers scatter
                 CTG_STEM_SYNC();
+                h2_consume();
                 step2(tile0 + t * tile_step);
             }
             drain(0, NST, std::integral_constant<int, 0>{}, scaled_tag);
@@ -1843,6 +1851,10 @@ static hipError_t launch_stem2_t(const StemArgs& p_, hipStream_t stream) {
 // (tools/build_variants.py lm=-DCTG_STEM_FORM=2,-DCTG_STEM_LM  ws=-DCTG_STEM_FORM=3,-DCTG_STEM_WS; profiles/r5_forms_*.txt):
 // 2 the intermediate as bf16 limbs (40 % fewer vector instructions, 3-4 % SLOWER: the split moves into the scatter
 // between the two barriers, where no wave has MFMAs to hide it), 3 specialised waves (same time as form 1 to 1 %).
+// The fp16 x 2 object (-DCTG_STEM_H2) is built with form 3 (-DCTG_STEM_FORM=3 -DCTG_STEM_WS, __graft_entry__.py): with
+// half the matrix work per tile, the scatter between the barriers is a larger share of it, and producers one tile ahead
+// of the consumers hide it -- every pair shape of the headline tree 1-8 % faster, 199 -> 193 ms/slice
+// (profiles/r6_forms_h2_xm_vs_ws.txt).
 #ifndef CTG_STEM_FORM
 #define CTG_STEM_FORM 1
 #endif
@@ -2187,27 +2199,27 @@ void stem2_kernel_name(const StemArgs& p, char* buf, size_t n) {
     if (p.tri) {
         const Stem3Shape t = stem3_shape(p);
         snprintf(buf, n, CTG_STEM_KNAME "<%s,%s,%d,%d,%d,%d,%s,0,%s,%s,false,false,%d,%s>", tf(t.p1), tf(t.p2), t.rt1, t.cs1,
-                 t.nch, t.it2, tf(t.nch <= 2), tf(t.vec), tf(stem3_bf3(p)), t.itm, tf(t.pm));
+                 t.nch, t.it2, tf(t.nch <= CTG_STEM_BR1_MAX), tf(t.vec), tf(stem3_bf3(p)), t.itm, tf(t.pm));
         return;
     }
     if (p.one) {
         const bool st = stem1_static(s), b3 = stem2_bf3(p);
         if (st && b3 && CTG_STEM_FORM >= 1)
             snprintf(buf, n, CTG_STEM_KNAME "<false,false,%d,%d,%d,0,%s,0,%s,true,false,true,0,false,true,false>", s.rt1, s.cs1,
-                     s.nch, tf(s.nch <= 2), tf(s.vec));
+                     s.nch, tf(s.nch <= CTG_STEM_BR1_MAX), tf(s.vec));
         else
             snprintf(buf, n, CTG_STEM_KNAME "<false,false,%d,%d,%d,0,%s,0,%s,%s,false,true>", s.rt1, s.cs1, st ? s.nch : 0,
-                     tf(st && (b3 ? s.nch <= 2 : p.K1 <= 64)), tf(s.vec), tf(b3));
+                     tf(st && (b3 ? s.nch <= CTG_STEM_BR1_MAX : p.K1 <= 64)), tf(s.vec), tf(b3));
         return;
     }
     if (stem2_bf3(p)) {
         const int form = stem2_bf3_form(p);
         if (form == 0)
             snprintf(buf, n, CTG_STEM_KNAME "<%s,%s,%d,%d,%d,%d,%s,0,%s,true,false,false>", tf(s.p1), tf(s.p2), s.rt1, s.cs1,
-                     s.nch, s.it2, tf(s.nch <= 2), tf(s.vec));
+                     s.nch, s.it2, tf(s.nch <= CTG_STEM_BR1_MAX), tf(s.vec));
         else
             snprintf(buf, n, CTG_STEM_KNAME "<%s,%s,%d,%d,%d,%d,%s,0,%s,true,false,false,0,false,true,%s,%s>", tf(s.p1), tf(s.p2),
-                     s.rt1, s.cs1, s.nch, s.it2, tf(s.nch <= 2), tf(s.vec), tf(form == 2), tf(form == 3));
+                     s.rt1, s.cs1, s.nch, s.it2, tf(s.nch <= CTG_STEM_BR1_MAX), tf(s.vec), tf(form == 2), tf(form == 3));
     }
     else if (stem2_variant(p))
         snprintf(buf, n, CTG_STEM_KNAME "<%s,%s,%d,%d,%d,%d,%s,%d,%s,false,%s,false>", tf(s.p1), tf(s.p2), s.rt1, s.cs1, s.nch,
@@ -2241,7 +2253,7 @@ hipError_t launch_stem2(const StemArgs& p, hipStream_t stream) {
         if (stem1_static(s)) {
 #define CTG_STEM_GO1(R, CS, NC, V)                                                           \
     if (s.rt1 == R && s.cs1 == CS && s.nch == NC && s.vec == V)                              \
-        return b3 ? launch_stem1_t<R, CS, NC, (NC <= 2), V, true>(p, stream)                 \
+        return b3 ? launch_stem1_t<R, CS, NC, (NC <= CTG_STEM_BR1_MAX), V, true>(p, stream)                 \
                   : launch_stem1_t<R, CS, NC, (NC <= 4), V, false>(p, stream);
             CTG_STEM_ONE(CTG_STEM_GO1)
 #undef CTG_STEM_GO1
@@ -2260,28 +2272,28 @@ hipError_t launch_stem2(const StemArgs& p, hipStream_t stream) {
         const int form = stem2_bf3_form(p);
 #if CTG_STEM_FORM >= 3 && defined(CTG_STEM_WS)
 #define CTG_STEM_GO3_WS(P1, P2, R, CS, NC, IT, V) \
-        if constexpr (IT <= 2 && (P1 || R == 1)) { if (form == 3) return launch_stem2_t<P1, P2, R, CS, NC, IT, (NC <= 2), 0, V, true, false, true, false, true>(p, stream); }
+        if constexpr (IT <= 2 && (P1 || R == 1)) { if (form == 3) return launch_stem2_t<P1, P2, R, CS, NC, IT, (NC <= CTG_STEM_BR1_MAX), 0, V, true, false, true, false, true>(p, stream); }
 #else
 #define CTG_STEM_GO3_WS(P1, P2, R, CS, NC, IT, V)
 #endif
 #if CTG_STEM_FORM >= 2 && defined(CTG_STEM_LM)
 #define CTG_STEM_GO3_LM(P1, P2, R, CS, NC, IT, V) \
-        if constexpr (IT < 4) { if (form == 2) return launch_stem2_t<P1, P2, R, CS, NC, IT, (NC <= 2), 0, V, true, false, true, true>(p, stream); }
+        if constexpr (IT < 4) { if (form == 2) return launch_stem2_t<P1, P2, R, CS, NC, IT, (NC <= CTG_STEM_BR1_MAX), 0, V, true, false, true, true>(p, stream); }
 #else
 #define CTG_STEM_GO3_LM(P1, P2, R, CS, NC, IT, V)
 #endif
 #if CTG_STEM_FORM >= 1
 #define CTG_STEM_GO3_XM(P1, P2, R, CS, NC, IT, V) \
-        if constexpr (IT < 4) { if (form == 1) return launch_stem2_t<P1, P2, R, CS, NC, IT, (NC <= 2), 0, V, true, false, true, false>(p, stream); }
+        if constexpr (IT < 4) { if (form == 1) return launch_stem2_t<P1, P2, R, CS, NC, IT, (NC <= CTG_STEM_BR1_MAX), 0, V, true, false, true, false>(p, stream); }
 #else
 #define CTG_STEM_GO3_XM(P1, P2, R, CS, NC, IT, V)
 #endif
 #if CTG_STEM_FORM == 0 || defined(CTG_STEM_FORM_ALL)
 #define CTG_STEM_GO3_R4(P1, P2, R, CS, NC, IT, V) \
-        if (form == 0) return launch_stem2_t<P1, P2, R, CS, NC, IT, (NC <= 2), 0, V, true>(p, stream);
+        if (form == 0) return launch_stem2_t<P1, P2, R, CS, NC, IT, (NC <= CTG_STEM_BR1_MAX), 0, V, true>(p, stream);
 #else
 #define CTG_STEM_GO3_R4(P1, P2, R, CS, NC, IT, V) \
-        if constexpr (IT >= 4) { if (form == 0) return launch_stem2_t<P1, P2, R, CS, NC, IT, (NC <= 2), 0, V, true>(p, stream); }
+        if constexpr (IT >= 4) { if (form == 0) return launch_stem2_t<P1, P2, R, CS, NC, IT, (NC <= CTG_STEM_BR1_MAX), 0, V, true>(p, stream); }
 #endif
 #define CTG_STEM_GO3(P1, P2, R, CS, NC, IT, V)                                                          \
     if (s.p1 == P1 && s.p2 == P2 && s.rt1 == R && s.cs1 == CS && s.nch == NC && s.it2 == IT && s.vec == V) { \

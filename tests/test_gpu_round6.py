@@ -314,7 +314,11 @@ def test_stem_pairs_in_fp16x2(case, sliced, fuse_whatever_fits, monkeypatch):
     names_b = _stem_names(fb, arrays)
     fb.close()
     assert not any(n.startswith("stem2h_kernel") for n in names_b)
-    assert [n.replace("stem2h_kernel", "stem2_kernel") for n in names] == names_b   # (the same instantiations)
+    # (the same instantiations -- but for the form of a pair: specialised waves under two limbs, where they win;
+    # the symmetric kernel under three, where they lose: the last template argument)
+    def shape_of(n):
+        return n[n.index("<") + 1: n.rindex(">")].split(",")[:16]
+    assert [shape_of(n) for n in names] == [shape_of(n) for n in names_b]
     assert G.relerr(bf3, ref) <= gate
     if h2:
         assert not np.array_equal(got, bf3)   # (it really ran)
