@@ -439,6 +439,9 @@ __device__ __forceinline__ void settle(T& v) {
 // LDS; the only serial part left is the producers' scatter between the two barriers (the consumers drain
 // their pending stores there).  A consumer has the registers for two fragment sets: the loads and splits of
 // chunk c + 1 go out before the MFMAs of chunk c.
+#ifndef CTG_STEM_WS_DEPTH
+#define CTG_STEM_WS_DEPTH 2
+#endif
 template <bool PACK1, bool PACK2, int RT1_, int CS1, int NCH, int IT2_, bool BR1 = false, int K2Q = 0, bool VEC = false,
           bool BF3 = false, bool RI2 = false, bool ONE = false, int ITM = 0, bool PACKM = false, bool XM = false,
           bool LM = false, bool WS = false>
@@ -822,7 +825,9 @@ __global__ __launch_bounds__(SW * 64, 1) void stem2_kernel(StemArgs p) {
     const int64_t last_tile = tile0 + (my_tiles - 1) * tile_step;
 
     // ---- gather pipeline: tasks (tile, unit m, chunk) in order, two in flight --------
-    c64 regs[2][8];
+    // (specialised waves: a producer keeps GD tasks in flight -- CTG_STEM_WS_DEPTH, a power of two)
+    constexpr int GD = WS ? CTG_STEM_WS_DEPTH : 2;
+    c64 regs[GD][8];
     int64_t ig = tile0;   // cursor of the next task to issue
     int im = 0, ic = 0;
     // prep: address of the next task to gather -- scalar loads, issued early (behind the
@@ -1553,7 +1558,8 @@ __global__ __launch_bounds__(SW * 64, 1) void stem2_kernel(StemArgs p) {
     if constexpr (WS) {
         // ---- specialised waves: producers one tile ahead of the consumers ---------------------------------
         constexpr int NT = RT1 * NCH;            // tasks per tile and producer
-        constexpr int U = (NT & 1) ? 2 : 1;      // tiles per pass: the gather register sets alternate
+        constexpr int U = (NT % GD == 0) ? 1 : ((2 * NT) % GD == 0 ? 2 : 4);   // tiles per pass: the gather register sets rotate
+        static_assert((U * NT) % GD == 0, "a pass of U tiles returns to gather set 0");
         // step 1 of the producer's next tile: every unit, every chunk (no stores on this side: a wait for a
         // gather counts gathers only)
         auto step1 = [&](auto slot0_tag) __attribute__((always_inline)) {
@@ -1562,7 +1568,7 @@ __global__ __launch_bounds__(SW * 64, 1) void stem2_kernel(StemArgs p) {
                 constexpr int M = decltype(mi)::value;
                 static_for<0, NCH>([&](auto ci) __attribute__((always_inline)) {
                     constexpr int CH = decltype(ci)::value;
-                    consume(regs[(SLOT0 + M * NCH + CH) & 1], M, CH, std::true_type{}, std::integral_constant<int, -1>{}, scaled_tag);
+                    consume(regs[(SLOT0 + M * NCH + CH) & (GD - 1)], M, CH, std::true_type{}, std::integral_constant<int, -1>{}, scaled_tag);
                 });
             });
         };
@@ -1583,8 +1589,7 @@ __global__ __launch_bounds__(SW * 64, 1) void stem2_kernel(StemArgs p) {
         // registers and B1 fragments; the consumers' pending stores -- must not be live in the other's loop.  Both
         // loops pass the same two barriers per tile.)
         if (producer) {
-            issue(regs[0], std::true_type{});
-            issue(regs[1], std::true_type{});
+            static_for<0, GD>([&](auto gi) __attribute__((always_inline)) { issue(regs[decltype(gi)::value], std::true_type{}); });
             prep(std::true_type{});
             step1(std::integral_constant<int, 0>{});
             // tiles t, t + 1 (U = 2: the gather register sets swap roles from one tile to the next)
@@ -1596,7 +1601,7 @@ __global__ __launch_bounds__(SW * 64, 1) void stem2_kernel(StemArgs p) {
                         CTG_STEM_SYNC();   // the consumers have read tile t - 1's intermediate; tile t's accumulators are complete
                         scatter();
                         CTG_STEM_SYNC();
-                        if (t + UI + 1 < my_tiles) step1(std::integral_constant<int, ((UI + 1) * NT) & 1>{});
+                        if (t + UI + 1 < my_tiles) step1(std::integral_constant<int, ((UI + 1) * NT) & (GD - 1)>{});
                     }
                 });
             }
@@ -2186,6 +2191,9 @@ static int stem2_bf3_form(const StemArgs& p) {
     // specialised waves: a producer takes two of the symmetric kernel's shares of step 1, a consumer two of step 2 --
     // at most two items per wave there, and one unit per wave unless step 1 has 16 columns (one accumulator per unit)
     if (form == 3 && !(items <= 2 * SW && (p.N1 == 16 || units == SW))) form = 1;
+    // (... and a consumer with four items of 32 columns keeps three accumulator pairs next to its pending stores: the
+    // compiler spills 46-51 registers there -- the symmetric kernel)
+    if (form == 3 && items == 2 * SW && p.N2 >= 32) form = 1;
     // four items of step 2 per wave and tile: the pending stores of one item, three accumulators and the fragments
     // of the next do not fit the registers next to B1's fragments (the compiler spills 12-46 of them): round-4 form
     if (items >= 4 * SW) form = 0;
@@ -2272,7 +2280,7 @@ hipError_t launch_stem2(const StemArgs& p, hipStream_t stream) {
         const int form = stem2_bf3_form(p);
 #if CTG_STEM_FORM >= 3 && defined(CTG_STEM_WS)
 #define CTG_STEM_GO3_WS(P1, P2, R, CS, NC, IT, V) \
-        if constexpr (IT <= 2 && (P1 || R == 1)) { if (form == 3) return launch_stem2_t<P1, P2, R, CS, NC, IT, (NC <= CTG_STEM_BR1_MAX), 0, V, true, false, true, false, true>(p, stream); }
+        if constexpr (IT <= 2 && (P1 || R == 1) && (P2 || IT < 2)) { if (form == 3) return launch_stem2_t<P1, P2, R, CS, NC, IT, (NC <= CTG_STEM_BR1_MAX), 0, V, true, false, true, false, true>(p, stream); }
 #else
 #define CTG_STEM_GO3_WS(P1, P2, R, CS, NC, IT, V)
 #endif
