@@ -1193,11 +1193,12 @@ def main():
             "frac": achieved_gbs / PEAK_HBM_GBS if hbm_bound else achieved_tf / dom_peak,
             "bound_is": "the longer of flops / matrix peak and MOVED bytes / 8 TB/s for this kernel's launches; "
                         "both sides follow",
-            # the matrix side: a bf16 x 3 pair is priced against bf16 peak / 6 products (fp32-equivalent
-            # flops), an fp32 kernel against the fp32 matrix peak
+            # the matrix side: an fp16 x 2 pair is priced against fp16 peak / 3 products, a bf16 x 3 pair against
+            # bf16 peak / 6 (fp32-equivalent flops), an fp32 kernel against the fp32 matrix peak
             "matrix_side": {"achieved_tflops": achieved_tf, "peak_tflops": dom_peak, "frac": achieved_tf / dom_peak,
-                            "pipe": "bf16 MFMA, 6 products per fp32 product" if dom_peak != PEAK_MFMA_F32_TFLOPS
-                            else "fp32 MFMA"},
+                            "pipe": ("fp16 MFMA, 3 products per fp32 product" if dom_peak == PEAK_FP16X2_TFLOPS
+                                     else "bf16 MFMA, 6 products per fp32 product" if dom_peak == PEAK_BF16X3_TFLOPS
+                                     else "fp32 MFMA")},
             "hbm_side": {"achieved_gbs": achieved_gbs, "peak_gbs": PEAK_HBM_GBS, "frac": achieved_gbs / PEAK_HBM_GBS},
             "launches_per_slice": dom["n"],
             "avg_launch_ms": dom["ms"] / dom["n"],
@@ -1219,8 +1220,9 @@ def main():
             },
             "mixed_per_step": {
                 "definition": "THE BOUND: sum over steps of max(flops_i / matrix peak_i, MOVED bytes_i / 8 TB/s) -- a "
-                              "fused pair is priced on the bytes it moves (big operand in, result out) and, in the "
-                              "bf16 x 3 arithmetic, against bf16 peak / 6; every other step against 157.3 TF",
+                              "fused pair is priced on the bytes it moves (big operand in, result out) and against "
+                              "its own pipe (fp16 x 2: fp16 peak / 3; bf16 x 3: bf16 peak / 6); every other step "
+                              "against 157.3 TF",
                 "bound_ms": bound_ms,
                 "frac": bound_ms / step_ms,
                 "unfused_roofline_ms": unfused_ms,

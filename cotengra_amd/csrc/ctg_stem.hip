@@ -442,6 +442,9 @@ __device__ __forceinline__ void settle(T& v) {
 #ifndef CTG_STEM_WS_DEPTH
 #define CTG_STEM_WS_DEPTH 2
 #endif
+#ifndef CTG_STEM_DEPTH
+#define CTG_STEM_DEPTH 2
+#endif
 template <bool PACK1, bool PACK2, int RT1_, int CS1, int NCH, int IT2_, bool BR1 = false, int K2Q = 0, bool VEC = false,
           bool BF3 = false, bool RI2 = false, bool ONE = false, int ITM = 0, bool PACKM = false, bool XM = false,
           bool LM = false, bool WS = false>
@@ -826,7 +829,8 @@ __global__ __launch_bounds__(SW * 64, 1) void stem2_kernel(StemArgs p) {
 
     // ---- gather pipeline: tasks (tile, unit m, chunk) in order, two in flight --------
     // (specialised waves: a producer keeps GD tasks in flight -- CTG_STEM_WS_DEPTH, a power of two)
-    constexpr int GD = WS ? CTG_STEM_WS_DEPTH : 2;
+    // (symmetric static kernels: CTG_STEM_DEPTH = 4 where a tile has an even number of tasks -- experiment builds)
+    constexpr int GD = WS ? CTG_STEM_WS_DEPTH : ((NCH > 0 && CTG_STEM_DEPTH == 4 && ((RT1 * NCH) & 1) == 0) ? 4 : 2);
     c64 regs[GD][8];
     int64_t ig = tile0;   // cursor of the next task to issue
     int im = 0, ic = 0;
@@ -1617,10 +1621,10 @@ __global__ __launch_bounds__(SW * 64, 1) void stem2_kernel(StemArgs p) {
         }
     } else if constexpr (STATIC) {
         constexpr int NT = RT1 * NCH;            // tasks per tile and wave
-        constexpr int U = (NT & 1) ? 2 : 1;      // tiles per pass: the register sets alternate
+        constexpr int U = (NT % GD) ? 2 : 1;     // tiles per pass: the register sets rotate
+        static_assert((U * NT) % GD == 0, "a pass of U tiles returns to gather set 0");
         constexpr int LASTSET = RI2 ? ((IT2 > 0 ? IT2 - 1 : 0) & (NSET - 1)) : 0;
-        issue(regs[0], std::true_type{});
-        issue(regs[1], std::true_type{});
+        static_for<0, GD>([&](auto gi) __attribute__((always_inline)) { issue(regs[decltype(gi)::value], std::true_type{}); });
         prep(std::true_type{});
         int64_t g = tile0;
         auto tile = [&](auto slot0_tag, auto first_tag) __attribute__((always_inline)) {
@@ -1634,7 +1638,7 @@ __global__ __launch_bounds__(SW * 64, 1) void stem2_kernel(StemArgs p) {
                     static_for<0, NCH>([&](auto ci) __attribute__((always_inline)) {
                         constexpr int CH = decltype(ci)::value;
                         // (the first task of a unit issues the stores of the unit before)
-                        consume(regs[(SLOT0 + M * NCH + CH) & 1], M, CH, std::true_type{},
+                        consume(regs[(SLOT0 + M * NCH + CH) & (GD - 1)], M, CH, std::true_type{},
                                 std::integral_constant<int, (CH == 0 && !(FIRST && M == 0)) ? 0 : -1>{}, scaled_tag);
                     });
                     emit_one(M, c_tile, scaled_tag);
@@ -1650,7 +1654,7 @@ __global__ __launch_bounds__(SW * 64, 1) void stem2_kernel(StemArgs p) {
                     constexpr int CH = decltype(ci)::value;
                     // (the first task of a tile issues the stores the tile before left pending:
                     // those of its last item, accumulator set LASTSET)
-                    consume(regs[(SLOT0 + M * NCH + CH) & 1], M, CH, std::true_type{},
+                    consume(regs[(SLOT0 + M * NCH + CH) & (GD - 1)], M, CH, std::true_type{},
                             std::integral_constant<int, (!FIRST && M == 0 && CH == 0) ? LASTSET : -1>{}, scaled_tag);
                 });
             });
@@ -1694,7 +1698,7 @@ __global__ __launch_bounds__(SW * 64, 1) void stem2_kernel(StemArgs p) {
         };
         auto pass = [&](auto peel_tag) __attribute__((always_inline)) {
             static_for<0, U>([&](auto ui) __attribute__((always_inline)) {
-                tile(std::integral_constant<int, (decltype(ui)::value * NT) & 1>{},
+                tile(std::integral_constant<int, (decltype(ui)::value * NT) & (GD - 1)>{},
                      std::integral_constant<bool, decltype(peel_tag)::value && decltype(ui)::value == 0>{});
             });
         };
