@@ -317,6 +317,8 @@ def step_peak_tflops(r, bf16x3=False):
     name = r.get("kernel_name") or r.get("kernel_symbol")
     if name is not None and name.startswith("pair_mfma_bf3_kernel"):   # (long tiled steps, round 5)
         return PEAK_BF16X3_TFLOPS
+    if name is not None and name.startswith("pair_mfma_h2_kernel"):    # (... in the fp16 x 2 arithmetic, round 6)
+        return PEAK_FP16X2_TFLOPS
     if name is not None and name.startswith("stem2h_kernel<"):
         return PEAK_FP16X2_TFLOPS if is_bf16x3_kernel(name) else PEAK_MFMA_F32_TFLOPS
     if name is not None and name.startswith("stem2_kernel<"):
@@ -662,7 +664,7 @@ def small_config(name, tree, arrays, dev, slices, reps, cpu_slices, note, dtype=
         "mixed_roofline_frac": roof_ms / (dt * 1e3),
         "mixed_roofline_fp32_pipe_ms": roof32_ms,
         "mixed_roofline_fp32_pipe_frac": roof32_ms / (dt * 1e3),
-        "bf16x3_steps": sum(1 for r in rows if (r.get("kernel_name") or "").startswith("pair_mfma_bf3_kernel")),
+        "bf16x3_steps": sum(1 for r in rows if (r.get("kernel_name") or "").startswith(("pair_mfma_bf3_kernel", "pair_mfma_h2_kernel"))),
         "cpu_oracle_ms": cpu * 1e3,
         "cpu_cores": host_cores(),
         "cpu_sample": f"{cpu_slices} slice(s) with numpy {dtype}, scaled to {slices}",

@@ -403,6 +403,11 @@ struct MfmaHints {
                        // its products may run as six bf16 products (pair_mfma_bf3_kernel).  A function of
                        // the step alone: such a step keeps tiles of >= 64 columns in every launch and stays
                        // out of the wave-front groups, so that the arithmetic never depends on batching
+    // round 6, set PER LAUNCH by the executor on its copy of a bf3 step's hints (ctg_runtime.hip: KIND_PAIR):
+    int h2;             // 1: this launch multiplies with two fp16 limbs (pair_mfma_h2_kernel)
+    const float* amax;  // h2: the largest |component| of the operands (device memory; recorded by their producers,
+    const float* bmax;  //     or found by a max-abs pass): the power of two each operand is split under
+    float* cmax;        // either 16-bit arithmetic: where the launch records its result's largest |component| (or null)
 };
 
 // k-splits of a tiled step: when the output alone cannot fill the chip but K is long

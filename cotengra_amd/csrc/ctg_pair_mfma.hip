@@ -880,17 +880,33 @@ typedef unsigned pu32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ constexpr int pbf3_ta(int t) { return t < 3 ? 0 : (t == 5 ? 2 : 1); }
 __device__ __forceinline__ constexpr int pbf3_tb(int t) { return t == 1 || t == 4 ? 1 : (t == 2 ? 2 : 0); }
 
-template <typename Cfg, bool VEC_A>
-__global__ __launch_bounds__(256, 1) void pair_mfma_bf3_kernel(StepArgs p, MfmaHints h, int64_t tiles_m, int64_t tiles_n,
-                                                              int64_t k_chunk, float* __restrict__ partial) {
+// H2 (round 6; pair_mfma_h2_kernel): the same kernel in the stem kernels' second arithmetic (ctg_stem.hip) --
+// TWO rounded fp16 limbs per value under a power-of-two scale per OPERAND TENSOR (MfmaHints::amax / bmax: the largest
+// |component|, recorded by the operand's producer or found by a max-abs pass; brought to [2^13, 2^14) before the split),
+// THREE products on v_mfma_f32_32x32x16_f16, the two powers of two back in where the result is stored.  4 instead of 5
+// vector instructions and 2 instead of 3 LDS writes per value staged, 2 / 3 of the LDS, half the matrix instructions.
+// Both arithmetics record the largest |component| they store (MfmaHints::cmax) for a consumer that splits this way.
+typedef _Float16 pf16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ int pair_h2_exponent_of(float mx) {
+    const int ex = (int)((__builtin_bit_cast(unsigned, mx) >> 23) & 255u) - 127;
+    if (mx == 0.f || ex == 128 || ex == -127) return 0;   // (zero / inf / nan / subnormal: left alone)
+    const int e = ex - 13;
+    return e < -126 ? -126 : (e > 126 ? 126 : e);
+}
+__device__ __forceinline__ float pair_pow2f(int ex) { return __builtin_bit_cast(float, (unsigned)(ex + 127) << 23); }
+
+template <typename Cfg, bool VEC_A, bool H2>
+__device__ __forceinline__ void pair_mfma_16bit_body(const StepArgs& p, const MfmaHints& h, int64_t tiles_m, int64_t tiles_n,
+                                                     int64_t k_chunk, float* __restrict__ partial) {
     constexpr int BM = Cfg::BM, BN = Cfg::BN, BK = Cfg::BK;
     static_assert(BK == 16 && BM == 128 && (BN == 64 || BN == 128), "one bf16 MFMA k-step per tile step");   // (the product uses 64)
     constexpr int WTM = 64, WTN = BN / 2;        // 2 x 2 waves: 64 rows x (32 | 64) complex columns each
     constexpr int FM = 2, FN = WTN / 32;
     constexpr int NA = VEC_A ? Cfg::A_PER_T / 2 : Cfg::A_PER_T;
-    // limb planes, in shorts: [buf][comp 2][limb 3][kb 2][rows][8]
+    constexpr int NL = H2 ? 2 : 3;               // limbs per value
+    // limb planes, in shorts: [buf][comp 2][limb NL][kb 2][rows][8]
     constexpr int APL = 2 * BM * 8, BPL = 2 * BN * 8;          // one (comp, limb) plane of A / B
-    constexpr int ASZ = 6 * APL, BSZ = 6 * BPL;
+    constexpr int ASZ = 2 * NL * APL, BSZ = 2 * NL * BPL;
     extern __shared__ __attribute__((aligned(16))) unsigned short lds_q[];
     typedef FastLane<Cfg, VEC_A> Lane;
 
@@ -996,9 +1012,36 @@ __global__ __launch_bounds__(256, 1) void pair_mfma_bf3_kernel(StepArgs p, MfmaH
         d0[2 * PL] = (unsigned short)(__builtin_bit_cast(unsigned, s0) >> 16);
         d1[2 * PL] = (unsigned short)(__builtin_bit_cast(unsigned, s1) >> 16);
     };
+    // H2: x s -> two rounded fp16 limbs (the residual x s - h1 is exact in fp32)
+    int h2_e = 0;
+    float h2_sa = 1.f, h2_sb = 1.f;
+    if constexpr (H2) {
+        int ea = h.amax != nullptr ? pair_h2_exponent_of(*h.amax) : 0;
+        int eb = h.bmax != nullptr ? pair_h2_exponent_of(*h.bmax) : 0;
+        ea = __builtin_amdgcn_readfirstlane(ea);
+        eb = __builtin_amdgcn_readfirstlane(eb);
+        h2_sa = pair_pow2f(-ea);
+        h2_sb = pair_pow2f(-eb);
+        h2_e = ea + eb;
+    }
+    auto put2x2 = [&](unsigned short* d0, unsigned short* d1, int PL, float x0, float x1) __attribute__((always_inline)) {
+        const _Float16 g0 = (_Float16)x0, g1 = (_Float16)x1;
+        const _Float16 r0 = (_Float16)(x0 - (float)g0), r1 = (_Float16)(x1 - (float)g1);
+        d0[0] = __builtin_bit_cast(unsigned short, g0);
+        d1[0] = __builtin_bit_cast(unsigned short, g1);
+        d0[PL] = __builtin_bit_cast(unsigned short, r0);
+        d1[PL] = __builtin_bit_cast(unsigned short, r1);
+    };
     auto stage = [&](int buf) {
         unsigned short* As = lds_q + buf * (ASZ + BSZ);
         unsigned short* Bs = As + ASZ;
+        if constexpr (H2) {
+#pragma unroll
+            for (int j = 0; j < Cfg::A_PER_T; ++j) put2x2(As + a_q[j], As + NL * APL + a_q[j], APL, a_reg[j].re * h2_sa, a_reg[j].im * h2_sa);
+#pragma unroll
+            for (int j = 0; j < Cfg::B_PER_T; ++j) put2x2(Bs + b_q[j], Bs + NL * BPL + b_q[j], BPL, b_reg[j].re * h2_sb, b_reg[j].im * h2_sb);
+            return;
+        }
 #pragma unroll
         for (int j = 0; j < Cfg::A_PER_T; ++j) put3x2(As + a_q[j], As + 3 * APL + a_q[j], APL, a_reg[j].re, a_reg[j].im);
 #pragma unroll
@@ -1017,35 +1060,43 @@ __global__ __launch_bounds__(256, 1) void pair_mfma_bf3_kernel(StepArgs p, MfmaH
         f32x16 zero16;
 #pragma unroll
         for (int u = 0; u < 16; ++u) zero16[u] = 0.f;
-        pbf16x8 aR[FM][3], aI[FM][3];
+        pbf16x8 aR[FM][NL], aI[FM][NL];
 #pragma unroll
         for (int i = 0; i < FM; ++i)
 #pragma unroll
-            for (int q = 0; q < 3; ++q) {
+            for (int q = 0; q < NL; ++q) {
                 aR[i][q] = *(const pbf16x8*)(As + q * APL + a_frag + i * 32 * 8);
-                aI[i][q] = *(const pbf16x8*)(As + (3 + q) * APL + a_frag + i * 32 * 8);
+                aI[i][q] = *(const pbf16x8*)(As + (NL + q) * APL + a_frag + i * 32 * 8);
             }
+        // (the sign bit of a bf16 and of an fp16 value is the same bit: one mask negates either)
+        auto mm = [](pbf16x8 a, pbf16x8 b, f32x16 c) __attribute__((always_inline)) -> f32x16 {
+            if constexpr (H2)
+                return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(pf16x8, a), __builtin_bit_cast(pf16x8, b), c, 0, 0, 0);
+            else
+                return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+        };
 #pragma unroll
         for (int j = 0; j < FN; ++j) {
-            pbf16x8 bR[3], bI[3], nI[3];
+            pbf16x8 bR[NL], bI[NL], nI[NL];
 #pragma unroll
-            for (int q = 0; q < 3; ++q) {
+            for (int q = 0; q < NL; ++q) {
                 bR[q] = *(const pbf16x8*)(Bs + q * BPL + b_frag + j * 32 * 8);
-                bI[q] = *(const pbf16x8*)(Bs + (3 + q) * BPL + b_frag + j * 32 * 8);
+                bI[q] = *(const pbf16x8*)(Bs + (NL + q) * BPL + b_frag + j * 32 * 8);
                 nI[q] = __builtin_bit_cast(pbf16x8, __builtin_bit_cast(pu32x4, bI[q]) ^ 0x80008000u);
             }
+            // (H2: limbs 0, 1 only -- the products (0, 0), (0, 1), (1, 0): t = 0, 1, 3)
 #pragma unroll
-            for (int t = 0; t < 6; ++t) {
+            for (int t = 0; t < 6; t += (H2 ? (t == 1 ? 2 : (t == 3 ? 3 : 1)) : 1)) {
                 const int ta = pbf3_ta(t), tb = pbf3_tb(t);
 #pragma unroll
                 for (int i = 0; i < FM; ++i) {
-                    ax[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aR[i][ta], bR[tb], (FIRST && t == 0) ? zero16 : ax[i][j], 0, 0, 0);
-                    ay[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aR[i][ta], bI[tb], (FIRST && t == 0) ? zero16 : ay[i][j], 0, 0, 0);
+                    ax[i][j] = mm(aR[i][ta], bR[tb], (FIRST && t == 0) ? zero16 : ax[i][j]);
+                    ay[i][j] = mm(aR[i][ta], bI[tb], (FIRST && t == 0) ? zero16 : ay[i][j]);
                 }
 #pragma unroll
                 for (int i = 0; i < FM; ++i) {
-                    ax[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aI[i][ta], nI[tb], ax[i][j], 0, 0, 0);
-                    ay[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aI[i][ta], bR[tb], ay[i][j], 0, 0, 0);
+                    ax[i][j] = mm(aI[i][ta], nI[tb], ax[i][j]);
+                    ay[i][j] = mm(aI[i][ta], bR[tb], ay[i][j]);
                 }
             }
         }
@@ -1096,6 +1147,17 @@ __global__ __launch_bounds__(256, 1) void pair_mfma_bf3_kernel(StepArgs p, MfmaH
     unsigned co[FN];
 #pragma unroll
     for (int j = 0; j < FN; ++j) co[j] = (unsigned)p.nC[wn * WTN + j * 32 + l31];
+    // H2: the operands' powers of two back in, as two factors inside the float range (the executor does not take this
+    // arithmetic under strip_exponent: alpha is 1 there)
+    float f1 = alpha, f2 = 1.f;
+    if constexpr (H2) {
+        const int e1 = h2_e < -126 ? -126 : (h2_e > 126 ? 126 : h2_e);
+        int e2 = h2_e - e1;
+        e2 = e2 < -126 ? -126 : (e2 > 126 ? 126 : e2);
+        f1 = alpha * pair_pow2f(e1);
+        f2 = pair_pow2f(e2);
+    }
+    float vmax = 0.f;
 #pragma unroll
     for (int i = 0; i < FM; ++i)
 #pragma unroll
@@ -1104,11 +1166,29 @@ __global__ __launch_bounds__(256, 1) void pair_mfma_bf3_kernel(StepArgs p, MfmaH
 #pragma unroll
             for (int j = 0; j < FN; ++j) {
                 float2 v;
-                v.x = ax[i][j][t] * alpha;
-                v.y = ay[i][j][t] * alpha;
+                v.x = H2 ? ax[i][j][t] * f1 * f2 : ax[i][j][t] * alpha;
+                v.y = H2 ? ay[i][j][t] * f1 * f2 : ay[i][j][t] * alpha;
+                vmax = fmaxf(vmax, fmaxf(fabsf(v.x), fabsf(v.y)));
                 *(float2*)(C + 2 * (size_t)(ro + co[j])) = v;
             }
         }
+    if (h.cmax != nullptr) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, o));
+        if (lane == 0 && vmax > 0.f && vmax < __builtin_bit_cast(float, 0x7f800000u))
+            atomicMax((unsigned*)h.cmax, __builtin_bit_cast(unsigned, vmax));
+    }
+}
+
+template <typename Cfg, bool VEC_A>
+__global__ __launch_bounds__(256, 1) void pair_mfma_bf3_kernel(StepArgs p, MfmaHints h, int64_t tiles_m, int64_t tiles_n,
+                                                              int64_t k_chunk, float* __restrict__ partial) {
+    pair_mfma_16bit_body<Cfg, VEC_A, false>(p, h, tiles_m, tiles_n, k_chunk, partial);
+}
+template <typename Cfg, bool VEC_A>
+__global__ __launch_bounds__(256, 1) void pair_mfma_h2_kernel(StepArgs p, MfmaHints h, int64_t tiles_m, int64_t tiles_n,
+                                                             int64_t k_chunk, float* __restrict__ partial) {
+    pair_mfma_16bit_body<Cfg, VEC_A, true>(p, h, tiles_m, tiles_n, k_chunk, partial);
 }
 
 // sum the split-K slabs in a fixed order and scatter into C.  A block reduces
@@ -1201,14 +1281,23 @@ static hipError_t launch_cfg(const StepArgs& p, const MfmaHints& h, void* scratc
     if constexpr (Cfg::BN == 64) {
         // fp32 products as six bf16 products (pair_mfma_bf3_kernel): long contractions on full 64-column tiles
         if (h.fast && h.bf3 && pair_bf16x3_on(p)) {
-            constexpr size_t smem = 2 * 2 * 6 * (size_t)(2 * Cfg::BM * 8 + 2 * Cfg::BN * 8);
-            static unsigned long long ready[2] = {0, 0};   // (per-device bit masks, updated atomically: lds_opt_in)
-            const void* fn = h.vecA ? (const void*)pair_mfma_bf3_kernel<Cfg, true> : (const void*)pair_mfma_bf3_kernel<Cfg, false>;
+            // (h.h2: this launch in the fp16 x 2 arithmetic -- the executor's decision, ctg_runtime.hip; never with
+            // k-splits: the slabs hold unscaled sums)
+            if (h.h2 && S > 1) return hipErrorInvalidValue;
+            const bool h2 = h.h2 != 0;
+            const size_t smem = 2 * 2 * (h2 ? 4 : 6) * (size_t)(2 * Cfg::BM * 8 + 2 * Cfg::BN * 8);
+            static unsigned long long ready[4] = {0, 0, 0, 0};   // (per-device bit masks, updated atomically: lds_opt_in)
+            const void* fn = h2 ? (h.vecA ? (const void*)pair_mfma_h2_kernel<Cfg, true> : (const void*)pair_mfma_h2_kernel<Cfg, false>)
+                                : (h.vecA ? (const void*)pair_mfma_bf3_kernel<Cfg, true> : (const void*)pair_mfma_bf3_kernel<Cfg, false>);
             {
-                const hipError_t e = lds_opt_in(fn, (int)smem, &ready[h.vecA ? 1 : 0]);
+                const hipError_t e = lds_opt_in(fn, (int)smem, &ready[(h2 ? 2 : 0) + (h.vecA ? 1 : 0)]);
                 if (e != hipSuccess) return e;
             }
-            if (h.vecA)
+            if (h2 && h.vecA)
+                hipLaunchKernelGGL((pair_mfma_h2_kernel<Cfg, true>), grid, dim3(256), smem, stream, p, h, tiles_m, tiles_n, k_chunk, part);
+            else if (h2)
+                hipLaunchKernelGGL((pair_mfma_h2_kernel<Cfg, false>), grid, dim3(256), smem, stream, p, h, tiles_m, tiles_n, k_chunk, part);
+            else if (h.vecA)
                 hipLaunchKernelGGL((pair_mfma_bf3_kernel<Cfg, true>), grid, dim3(256), smem, stream, p, h, tiles_m, tiles_n, k_chunk, part);
             else
                 hipLaunchKernelGGL((pair_mfma_bf3_kernel<Cfg, false>), grid, dim3(256), smem, stream, p, h, tiles_m, tiles_n, k_chunk, part);

@@ -977,6 +977,18 @@ void* wide_of_step(const ctg_exec* e, int64_t s) {
     return e->d_wide + r[W_C_OFF] * 2 * kItemSize[e->plan->dtype];
 }
 
+
+// a long tiled complex64 step that multiplies on the 16-bit matrix cores right now (MfmaHints::bf3; round 6: such a
+// launch records its result's largest |component| and may run in the fp16 x 2 arithmetic, see launch_step)
+static bool tiled16_step(const ctg_exec* e, int64_t s) {
+    const ctg_plan* p = e->plan;
+    const int64_t* r = &p->steps[s * STEP_WORDS];
+    if (r[W_KIND] != KIND_PAIR || r[W_KERNEL] != KERNEL_MFMA || p->dtype != CTG_C64) return false;
+    const MfmaHints& h = e->hints[s];
+    return !h.stream && h.fast && h.bf3 && e->stem_arith != 0 && !e->strip && e->d_stem_max != nullptr &&
+           pair_bf16x3_on(e->args[s]);
+}
+
 int launch_step(ctg_exec* e, int64_t s, hipStream_t stream) {
     const ctg_plan* p = e->plan;
     const int64_t* r = &p->steps[s * STEP_WORDS];
@@ -1012,8 +1024,8 @@ int launch_step(ctg_exec* e, int64_t s, hipStream_t stream) {
             // result's largest element as well.  CTG_STEM_H2=0 in the environment (read per launch) says no.
             const bool rec = e->stem_arith != 0 && !e->strip && e->d_stem_max != nullptr;
             const int64_t prod = r[W_A_PROD];
-            const bool prod_rec = prod >= 0 && prod < p->n_steps && p->steps[prod * STEP_WORDS + W_KIND] == KIND_STEM2 &&
-                                  e->stem_h2_ran[prod];
+            // (a recording producer: a stem launch of the 16-bit pipe or a long tiled step of it, see KIND_PAIR below)
+            const bool prod_rec = prod >= 0 && prod < p->n_steps && e->stem_h2_ran[prod];
             // (CTG_STEM_H2_ALL=1, tests and diagnostics: fp16 x 2 for EVERY capable pair -- a max-abs pass over the
             // big operand supplies the scale where no producer recorded it)
             const bool h2_all = env_on("CTG_STEM_H2_ALL");
@@ -1047,11 +1059,49 @@ int launch_step(ctg_exec* e, int64_t s, hipStream_t stream) {
                 err = launch_pair_mfma_c128(e->args[s], e->hints[s].vecA /* = stride flags */, stream);
             else if (r[W_KERNEL] == KERNEL_MFMA && p->dtype != CTG_C64)
                 err = launch_pair_mfma_real(p->dtype, e->args[s], e->hints[s].vecA, stream);
-            else if (r[W_KERNEL] == KERNEL_MFMA)
-                err = launch_pair_mfma(p->dtype, e->args[s],
-                                       (e->args[s].nz > 1 && !e->hints_b.empty()) ? e->hints_b[s] : e->hints[s],
-                                       e->d_scratch, kScratchBytes, stream);
-            else
+            else if (r[W_KERNEL] == KERNEL_MFMA) {
+                const MfmaHints& h0 = (e->args[s].nz > 1 && !e->hints_b.empty()) ? e->hints_b[s] : e->hints[s];
+                // Long tiled steps on the 16-bit matrix cores (MfmaHints::bf3, pair_mfma_bf3_kernel), round 6: a launch of
+                // one slice without k-splits records the largest |component| it stores, like a stem launch does, and --
+                // the executor's arithmetic being fp16 x 2 -- multiplies with two fp16 limbs (pair_mfma_h2_kernel) under
+                // the operands' recorded maxima; an operand whose producer recorded nothing gets a max-abs pass (its
+                // bytes once more, against K >= 64 products per element).  CTG_PAIR_H2=0 in the environment says no.
+                const bool tiled16 = tiled16_step(e, s) && !h0.stream && h0.fast && h0.bf3;
+                if (tiled16) {
+                    MfmaHints h = h0;
+                    const bool single = e->args[s].nz == 1 && e->args[s].z0 == 0 && h0.splitk <= 1;
+                    bool h2 = e->stem_arith == 2 && single;
+                    if (h2)
+                        if (const char* v = getenv("CTG_PAIR_H2")) h2 = !(v[0] == '\0' || (v[0] == '0' && v[1] == '\0'));
+                    h.h2 = h2 ? 1 : 0;
+                    h.cmax = single ? e->d_stem_max + s : nullptr;
+                    e->stem_h2_ran[s] = single ? 1 : 0;
+                    for (int side = 0; side < 2 && h2 && err == hipSuccess; ++side) {
+                        const int64_t prod = r[side == 0 ? W_A_PROD : W_B_PROD];
+                        const float* mx = nullptr;
+                        if (prod >= 0 && prod < p->n_steps && e->stem_h2_ran[prod]) {
+                            mx = e->d_stem_max + prod;
+                        } else {
+                            float* slot = e->d_stem_max + (1 + side) * p->n_steps + s;
+                            const StepArgs& a = e->args[s];
+                            err = hipMemsetAsync(slot, 0, sizeof(float), stream);
+                            if (err == hipSuccess)
+                                err = side == 0 ? launch_maxabs_f32(a.A, a.soffA, 0, a.zsA, a.zA, r[W_A_SIZE], slot, stream)
+                                                : launch_maxabs_f32(a.B, a.soffB, 0, a.zsB, a.zB, r[W_B_SIZE], slot, stream);
+                            mx = slot;
+                        }
+                        (side == 0 ? h.amax : h.bmax) = mx;
+                    }
+                    if (env_on("CTG_STEM_DEBUG"))
+                        fprintf(stderr, "tiled step %lld: arith %d single %d -> h2 %d records %d (A prod %lld, B prod %lld)\n",
+                                (long long)s, e->stem_arith, (int)single, (int)h2, (int)single, (long long)r[W_A_PROD],
+                                (long long)r[W_B_PROD]);
+                    if (err == hipSuccess) err = launch_pair_mfma(p->dtype, e->args[s], h, e->d_scratch, kScratchBytes, stream);
+                } else {
+                    if (!e->stem_h2_ran.empty()) e->stem_h2_ran[s] = 0;
+                    err = launch_pair_mfma(p->dtype, e->args[s], h0, e->d_scratch, kScratchBytes, stream);
+                }
+            } else
                 err = launch_pair_valu(p->dtype, e->args[s], e->d_scratch, kScratchBytes, stream);
             break;
     }
@@ -1675,14 +1725,16 @@ int ctg_exec_create(const ctg_plan* p, int device, void* stream, void* ext_resul
         {
             // fp16 x 2 stem kernels: per step the largest element it recorded | of its big operand
             bool stems = false;
-            std::vector<int32_t> sz((size_t)(2 * std::max<int64_t>(p->n_steps, 1)), 1);
+            // (three banks of n_steps: recorded by the step | max-abs pass over its operand A | ... B)
+            std::vector<int32_t> sz((size_t)(3 * std::max<int64_t>(p->n_steps, 1)), 1);
             for (int64_t st = 0; st < p->n_steps; ++st) {
                 stems = stems || p->steps[st * STEP_WORDS + W_KIND] == KIND_STEM2;
                 // (slice-invariant steps and what a slice group shares keep their record across slices)
                 if (e->invariant[st] || e->grouped[st]) sz[(size_t)st] = 0;
             }
             e->stem_h2_ran.assign(p->n_steps, 0);
-            if (stems && p->dtype == CTG_C64) {
+            (void)stems;
+            if (p->dtype == CTG_C64) {   // (plans without a stem may still have long tiled steps)
                 HIP_TRY_E(hipMalloc((void**)&e->d_stem_max, sz.size() * sizeof(float)));
                 HIP_TRY_E(hipMemset(e->d_stem_max, 0, sz.size() * sizeof(float)));
                 HIP_TRY_E(hipMalloc((void**)&e->d_smax_zero, sz.size() * sizeof(int32_t)));
@@ -2185,8 +2237,10 @@ int ctg_exec_step_kernel(ctg_exec* e, int64_t step, char* buf, int64_t buflen) {
         // (the arithmetic of the step's NEXT launch: fp16 x 2 needs the producer of its big operand to be a stem
         // launch of the 16-bit pipe -- decided on the shapes here, as launch_step decides it on what ran)
         const int64_t prod = r[W_A_PROD];
-        const bool prod16 = prod >= 0 && prod < p->n_steps && p->steps[prod * STEP_WORDS + W_KIND] == KIND_STEM2 &&
-                            (stem2_uses_bf3(e->stem_args[prod]) || stem2h_uses_h2(e->stem_args[prod]));
+        const bool prod16 = prod >= 0 && prod < p->n_steps &&
+                            ((p->steps[prod * STEP_WORDS + W_KIND] == KIND_STEM2 &&
+                              (stem2_uses_bf3(e->stem_args[prod]) || stem2h_uses_h2(e->stem_args[prod]))) ||
+                             (tiled16_step(e, prod) && e->hints[prod].splitk <= 1 && e->batch <= 1));
         bool h2 = e->stem_arith == 2 && !e->strip && e->d_stem_max != nullptr && (prod16 || env_on("CTG_STEM_H2_ALL")) &&
                   stem2h_uses_h2(e->stem_args[step]);
         if (h2)
@@ -2210,8 +2264,13 @@ int ctg_exec_step_kernel(ctg_exec* e, int64_t step, char* buf, int64_t buflen) {
             snprintf(name, sizeof(name), "pair_mfma_stream_kernel<%d,%s,%s,%s,%d>", h.bn / 16,
                      (h.vecA && h.additive32) ? "true" : "false", h.additive32 ? "true" : "false",
                      r[W_K] < MFMA_BK ? "true" : "false", r[W_K] <= 4 ? 2 : (r[W_K] <= 8 ? 4 : 8));
-        else if (h.bf3 && pair_bf16x3_on(e->args[step]))
-            snprintf(name, sizeof(name), "pair_mfma_bf3_kernel<128,%d,16>,%s", h.bn, h.vecA ? "true" : "false");
+        else if (h.bf3 && pair_bf16x3_on(e->args[step])) {
+            bool h2 = tiled16_step(e, step) && e->stem_arith == 2 && h.splitk <= 1 && e->batch <= 1;
+            if (h2)
+                if (const char* v = getenv("CTG_PAIR_H2")) h2 = !(v[0] == '\0' || (v[0] == '0' && v[1] == '\0'));
+            snprintf(name, sizeof(name), "%s<128,%d,16>,%s", h2 ? "pair_mfma_h2_kernel" : "pair_mfma_bf3_kernel", h.bn,
+                     h.vecA ? "true" : "false");
+        }
         else
             snprintf(name, sizeof(name), "%s<128,%d,16>,%s",
                      h.fast ? "pair_mfma_fast_kernel" : "pair_mfma_c64_kernel", h.bn,

@@ -440,3 +440,81 @@ def test_first_pair_of_a_stem_runs_bf16x3_and_records_its_maximum(monkeypatch):
     assert _stem_names(fn, arrays)[0].startswith("stem2h_kernel<")
     fn.close()
     assert G.relerr(allh, ref) <= gate and G.relerr(allh, got) <= 1e-5
+
+
+# ---------------------------------------------------------------------- #
+# long tiled steps in the fp16 x 2 arithmetic (csrc/ctg_pair_mfma.hip: pair_mfma_h2_kernel)
+# ---------------------------------------------------------------------- #
+
+
+def _chain_tree(R, K, N, N2=None):
+    """a[R, K] b[K, N] (c[N, N2]): one long tiled step, or two of them in a chain (the second one's big operand
+    produced -- and its largest element recorded -- by the first)."""
+    if N2 is None:
+        return ca.ContractionTree.from_path([("a", "b"), ("b", "c")], ("a", "c"), dict(a=R, b=K, c=N), path=[(0, 1)])
+    return ca.ContractionTree.from_path([("a", "b"), ("b", "c"), ("c", "d")], ("a", "d"), dict(a=R, b=K, c=N, d=N2),
+                                        path=[(0, 1), (0, 1)])
+
+
+def _cplx(rng, *shape):
+    return (rng.standard_normal(shape) + 1j * rng.standard_normal(shape)).astype("complex64")
+
+
+@pytest.mark.parametrize("R,K,N", [(8192, 512, 512), (65536, 64, 64), (32768, 256, 128)])
+def test_long_tiled_steps_in_fp16x2(R, K, N, monkeypatch):
+    """A new executor's arithmetic is fp16 x 2: a GEMM-like complex64 step with K >= 64 on full 64-column tiles runs
+    pair_mfma_h2_kernel -- both operands split into two rounded fp16 limbs under a power of two per TENSOR (a max-abs
+    pass here: the operands are inputs), three products.  Against the complex128 oracle, error relative to the size of
+    the terms: random data and a contraction that cancels by 2^-12 within 3 x the bf16 x 3 kernel's error (same data,
+    CTG_PAIR_H2=0); operands scaled by 2^+40 / 2^-37 give the same bits up to the power put back in."""
+    for k in ("CTG_STEM_ARITH", "CTG_STEM_BF16X3", "CTG_PAIR_BF16X3", "CTG_PAIR_H2"):
+        monkeypatch.delenv(k, raising=False)
+    tree = _chain_tree(R, K, N)
+    rng = np.random.default_rng(R + K + N)
+    a, b = _cplx(rng, R, K), _cplx(rng, K, N)
+    a_canc = a.copy()
+    a_canc[:, K // 2:] = -a[:, : K // 2]
+    b_canc = b.copy()
+    b_canc[K // 2:, :] = b[: K // 2, :] * np.float32(1.0 + 2.0**-12)
+    fn = HipContractor(tree)
+    for label, (x, y) in {"random": (a, b), "cancelling": (a_canc, b_canc)}.items():
+        ref = x.astype("complex128") @ y.astype("complex128")
+        terms = np.abs(x.astype("complex128")) @ np.abs(y.astype("complex128"))
+        got = np.asarray(fn(x, y))
+        names = fn.setup(x, y)["exec"].step_kernels()
+        assert any(n.startswith("pair_mfma_h2_kernel") for n in names), names
+        monkeypatch.setenv("CTG_PAIR_H2", "0")
+        bf3 = np.asarray(fn(x, y))
+        assert any(n.startswith("pair_mfma_bf3_kernel") for n in fn.setup(x, y)["exec"].step_kernels())
+        monkeypatch.delenv("CTG_PAIR_H2")
+        e_h2 = float((np.abs(got - ref) / terms).max())
+        e_b3 = float((np.abs(bf3 - ref) / terms).max())
+        print(label, f"fp16x2 {e_h2:.2e} bf16x3 {e_b3:.2e}")
+        assert not np.array_equal(got, bf3)          # (it really ran)
+        assert e_h2 <= max(3.0 * e_b3, 5e-7), (label, e_h2, e_b3)
+    plain = np.asarray(fn(a, b))
+    scaled = np.asarray(fn((a * np.float32(2.0**40)).astype("complex64"), (b * np.float32(2.0**-37)).astype("complex64")))
+    fn.close()
+    assert np.array_equal(scaled * np.float32(2.0**-3), plain)
+
+
+def test_chained_tiled_steps_take_the_producers_record(monkeypatch):
+    """Two long tiled steps in a chain: the first one records the largest element it stores, the second one splits
+    its big operand under that record (no max-abs pass over it) -- with the first result 2^50 away from the inputs'
+    magnitude, a stale or missing record would overflow or flush the limbs.  Against the oracle, norm-wise."""
+    for k in ("CTG_STEM_ARITH", "CTG_STEM_BF16X3", "CTG_PAIR_BF16X3", "CTG_PAIR_H2"):
+        monkeypatch.delenv(k, raising=False)
+    R, K, N, N2 = 16384, 256, 256, 256
+    tree = _chain_tree(R, K, N, N2)
+    rng = np.random.default_rng(5)
+    a, b, c = _cplx(rng, R, K), _cplx(rng, K, N), _cplx(rng, N, N2)
+    a = (a * np.float32(2.0**25)).astype("complex64")
+    b = (b * np.float32(2.0**25)).astype("complex64")
+    c = (c * np.float32(2.0**-45)).astype("complex64")
+    ref = (a.astype("complex128") @ b.astype("complex128")) @ c.astype("complex128")
+    fn = HipContractor(tree)
+    got = np.asarray(fn(a, b, c))
+    names = fn.setup(a, b, c)["exec"].step_kernels()
+    fn.close()
+    assert sum(n.startswith("pair_mfma_h2_kernel") for n in names) == 2, names
+    assert G.relerr(got, ref) <= 2e-6, G.relerr(got, ref)

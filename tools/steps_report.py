@@ -25,6 +25,8 @@ def peak(r):
     name = r.get("kernel_name") or ""
     if name.startswith("pair_mfma_bf3_kernel"):
         return PBF3
+    if name.startswith("pair_mfma_h2_kernel"):
+        return PH2
     for prefix, pk in (("stem2h_kernel<", PH2), ("stem2_kernel<", PBF3)):   # (stem2h: fp16 x 2, three products)
         if name.startswith(prefix):
             a = name[len(prefix):].rstrip(">").split(",")
