@@ -886,6 +886,9 @@ __device__ __forceinline__ constexpr int pbf3_tb(int t) { return t == 1 || t == 
 // THREE products on v_mfma_f32_32x32x16_f16, the two powers of two back in where the result is stored.  4 instead of 5
 // vector instructions and 2 instead of 3 LDS writes per value staged, 2 / 3 of the LDS, half the matrix instructions.
 // Both arithmetics record the largest |component| they store (MfmaHints::cmax) for a consumer that splits this way.
+#ifndef CTG_PAIR16_KBPAD
+#define CTG_PAIR16_KBPAD 32   // shorts
+#endif
 typedef _Float16 pf16x8 __attribute__((ext_vector_type(8)));
 __device__ __forceinline__ int pair_h2_exponent_of(float mx) {
     const int ex = (int)((__builtin_bit_cast(unsigned, mx) >> 23) & 255u) - 127;
@@ -905,7 +908,12 @@ __device__ __forceinline__ void pair_mfma_16bit_body(const StepArgs& p, const Mf
     constexpr int NA = VEC_A ? Cfg::A_PER_T / 2 : Cfg::A_PER_T;
     constexpr int NL = H2 ? 2 : 3;               // limbs per value
     // limb planes, in shorts: [buf][comp 2][limb NL][kb 2][rows][8]
-    constexpr int APL = 2 * BM * 8, BPL = 2 * BN * 8;          // one (comp, limb) plane of A / B
+    // (KBP: the second k-block of a plane starts 64 bytes -- 16 banks -- behind a multiple of the bank period: the 2-byte
+    // writes of the lanes that stage k and k + 8 of one row no longer meet in a bank.  SQ counters of the unpadded
+    // layout, 65536 x 512 x 512: half of the LDS array's active cycles were bank conflicts, profiles/r6_pair_sq_counters.txt)
+    constexpr int KBP = CTG_PAIR16_KBPAD;
+    constexpr int AKB = BM * 8 + KBP, BKB = BN * 8 + KBP;      // one k-block of a plane, in shorts
+    constexpr int APL = 2 * AKB, BPL = 2 * BKB;                // one (comp, limb) plane of A / B
     constexpr int ASZ = 2 * NL * APL, BSZ = 2 * NL * BPL;
     extern __shared__ __attribute__((aligned(16))) unsigned short lds_q[];
     typedef FastLane<Cfg, VEC_A> Lane;
@@ -956,7 +964,7 @@ __device__ __forceinline__ void pair_mfma_16bit_body(const StepArgs& p, const Mf
     auto slot_of = [](unsigned o, int rows, int rowscale) {
         const int r = (int)(o / Lane::LD), sl = (int)(o % Lane::LD);
         const int c = (((sl >> 1) ^ Lane::fsw(r)) << 1) | (sl & 1);
-        return (unsigned)((c >> 3) * rows * 8 + (r / rowscale) * 8 + (c & 7));
+        return (unsigned)((c >> 3) * (rows * 8 + KBP) + (r / rowscale) * 8 + (c & 7));
     };
     unsigned short a_q[Cfg::A_PER_T], b_q[Cfg::B_PER_T];
 #pragma unroll
@@ -1051,8 +1059,8 @@ __device__ __forceinline__ void pair_mfma_16bit_body(const StepArgs& p, const Mf
     f32x16 ax[FM][FN], ay[FM][FN];
     const float alpha = (float)step_alpha(p);
     // fragment bases: lane = (row | column l31, k-block kk)
-    const int a_frag = kk * BM * 8 + (wm * WTM + l31) * 8;
-    const int b_frag = kk * BN * 8 + (wn * WTN + l31) * 8;
+    const int a_frag = kk * AKB + (wm * WTM + l31) * 8;
+    const int b_frag = kk * BKB + (wn * WTN + l31) * 8;
     auto k_step = [&](int buf, auto first_tag) {
         constexpr bool FIRST = decltype(first_tag)::value;
         const unsigned short* As = lds_q + buf * (ASZ + BSZ);
@@ -1285,7 +1293,7 @@ static hipError_t launch_cfg(const StepArgs& p, const MfmaHints& h, void* scratc
             // k-splits: the slabs hold unscaled sums)
             if (h.h2 && S > 1) return hipErrorInvalidValue;
             const bool h2 = h.h2 != 0;
-            const size_t smem = 2 * 2 * (h2 ? 4 : 6) * (size_t)(2 * Cfg::BM * 8 + 2 * Cfg::BN * 8);
+            const size_t smem = 2 * 2 * (h2 ? 4 : 6) * (size_t)(2 * (Cfg::BM * 8 + CTG_PAIR16_KBPAD) + 2 * (Cfg::BN * 8 + CTG_PAIR16_KBPAD));
             static unsigned long long ready[4] = {0, 0, 0, 0};   // (per-device bit masks, updated atomically: lds_opt_in)
             const void* fn = h2 ? (h.vecA ? (const void*)pair_mfma_h2_kernel<Cfg, true> : (const void*)pair_mfma_h2_kernel<Cfg, false>)
                                 : (h.vecA ? (const void*)pair_mfma_bf3_kernel<Cfg, true> : (const void*)pair_mfma_bf3_kernel<Cfg, false>);

@@ -850,6 +850,10 @@ int build_hints_into(ctg_exec* e, std::vector<MfmaHints>& hints, int64_t zmult,
         // staging under the other's MFMAs; the 128-column tile the fp32 kernel prefers for K >= 256 was measured
         // 16 % slower per launch here: 98 KB, one workgroup of four waves per CU)
         if (h.bf3) h.bn = 64;
+        // (experiment, CTG_PAIR_BF3_BN=128: the 128-column tile for such steps -- two limbs leave it 64 KB of planes)
+        if (h.bf3 && r[W_N] % 128 == 0 && env_on("CTG_PAIR_BF3_BN128") && mfma_fast_ok(p, r, 128) &&
+            (r[W_R] / MFMA_BM) * (r[W_N] / 128) * std::max<int64_t>(e->batch_nominal, 1) >= 512)
+            h.bn = 128;
         if (!h.stream) {
             const int64_t tiles_m = (r[W_R] + MFMA_BM - 1) / MFMA_BM;
             const int64_t per_tile = r[W_K] >= 1024 ? splits : 1;
