@@ -215,6 +215,19 @@ struct StemArgs {
 
 // element offset of an operand for the slice-in-batch this block works on
 __device__ __forceinline__ int64_t zid(const StepArgs& p) { return (int64_t)p.z0 + blockIdx.y; }
+// A record of a largest |component| is kMaxSub floats (one 64-byte line): a wave records into one of them, picked by its
+// workgroup and wave -- 500 K waves of a launch on ONE address cost a 60 us kernel 20-60 us of atomics --, a reader takes
+// the largest of the kMaxSub.  (lane 0 calls record_max; v > 0, finite)
+constexpr int kMaxSub = 16;
+__device__ __forceinline__ void record_max(float* slot, float v) {
+    atomicMax((unsigned*)slot + ((blockIdx.x + (threadIdx.x >> 6)) & (kMaxSub - 1)), __builtin_bit_cast(unsigned, v));
+}
+__device__ __forceinline__ float read_max(const float* slot) {
+    float m = slot[0];
+#pragma unroll
+    for (int i = 1; i < kMaxSub; ++i) m = fmaxf(m, slot[i]);
+    return m;
+}
 __device__ __forceinline__ int64_t zgroup(int64_t z, int32_t q) { return q > 1 ? z / q * q : z; }
 __device__ __forceinline__ int64_t zoffA(const StepArgs& p) { const int64_t z = zgroup(zid(p), p.zqA); return p.soffA[z * p.zsA] + z * p.zA; }
 __device__ __forceinline__ int64_t zoffB(const StepArgs& p) { const int64_t z = zgroup(zid(p), p.zqB); return p.soffB[z * p.zsB] + z * p.zB; }
@@ -408,6 +421,10 @@ struct MfmaHints {
     const float* amax;  // h2: the largest |component| of the operands (device memory; recorded by their producers,
     const float* bmax;  //     or found by a max-abs pass): the power of two each operand is split under
     float* cmax;        // either 16-bit arithmetic: where the launch records its result's largest |component| (or null)
+    // slice z of a launch (StepArgs::z0 + blockIdx.y) reads the records at amax + z * amax_zs * kMaxSub, bmax + ..., and
+    // records into cmax + z * cmax_zs * kMaxSub: a record per slice of a batch (stride 1), one for all of them where the
+    // tensor is slice-invariant (0)
+    int amax_zs, bmax_zs, cmax_zs;
 };
 
 // k-splits of a tiled step: when the output alone cannot fill the chip but K is long

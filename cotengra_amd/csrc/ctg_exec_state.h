@@ -55,8 +55,15 @@ struct ctg_exec {
     // (round 6) 2: the stem kernels multiply with two fp16 limbs and three products (ctg_stem.hip built with
     // -DCTG_STEM_H2) where they took three bf16 limbs and six; stem_bf16x3 stays 1 then (the bf16-pipe kernels are on)
     int stem_arith = 2;
-    float* d_stem_max = nullptr;           // [2 n_steps]: largest element recorded by step s | of step s's big operand (max-abs pass)
-    int32_t* d_smax_zero = nullptr;        // [2 n_steps] which of them start a slice at zero
+    // [3 banks][n_steps][batch][kMaxSub]: largest |component| recorded by step s in slice z of a launch sequence | of step s's
+    // operand A | B (max-abs pass): smax_slot().  A slice-invariant step records into z = 0.
+    float* d_stem_max = nullptr;
+    int32_t* d_smax_zero = nullptr;        // (same shape) which of them start a slice at zero
+    float* smax_slot(int bank, int64_t s, int64_t z) const {
+        return d_stem_max + (((int64_t)bank * plan_steps + s) * (batch > 1 ? batch : 1) + z) * ctg::kMaxSub;
+    }
+    int64_t plan_steps = 0;                // (= plan->n_steps, for smax_slot)
+    std::vector<char> wave_member;         // step s is launched inside a wave-front group (it never records its maximum)
     std::vector<char> stem_h2_ran;         // step s last ran in the fp16 x 2 arithmetic (its record is valid)
     std::vector<ctg::MfmaHints> hints;  // per step kernel hints (MFMA steps)
     // the same for launches that carry several slices (batch > 1): wider column tiles
@@ -134,8 +141,9 @@ extern "C" __attribute__((visibility("hidden"))) void ctg_set_error_(const char*
 
 namespace ctg {
 // (ctg_kernels_valu.hip) largest |re|, |im| of n complex64 values as a float; *out zeroed by the caller
+// (nz slices from z on: the record (kMaxSub floats, zeroed by the caller) at out + i * out_zs for slice z + i)
 hipError_t launch_maxabs_f32(const void* base, const int64_t* soff, int64_t z, int64_t zs, int64_t zstride, int64_t n,
-                             float* out, hipStream_t stream);
+                             float* out, hipStream_t stream, int nz = 1, int out_zs = 0);
 }
 
 // LDS-resident subtrees (ctg_lds_host.hip): descriptor validation (host only) and per-executor packing

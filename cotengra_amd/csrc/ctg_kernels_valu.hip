@@ -632,26 +632,52 @@ hipError_t launch_maxabs(int dtype, const void* x, int64_t n, double* fac, hipSt
 // largest |re|, |im| of n complex64 values as a FLOAT: the power-of-two scale of a big operand of the fp16 x 2 stem
 // kernels that no producer recorded (CTG_STEM_H2_ALL=1: tests and diagnostics -- by default such a pair is multiplied in
 // bf16 x 3 instead, ctg_runtime.hip); *out must be zero
+// (gridDim.y slices from z on, one record of kMaxSub floats each: out + blockIdx.y * out_zs)
 __global__ __launch_bounds__(256) void maxabs_f32_kernel(const c64* __restrict__ base, const int64_t* soff, int64_t z,
-                                                         int64_t zs, int64_t zstride, int64_t n, float* out) {
+                                                         int64_t zs, int64_t zstride, int64_t n, float* out, int out_zs) {
+    z += blockIdx.y;
+    out += (int64_t)blockIdx.y * out_zs;
     const c64* __restrict__ x = base + (soff[z * zs] + z * zstride);
     float m = 0.f;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
-        const c64 v = x[i];
-        m = fmaxf(m, fmaxf(fabsf(v.re), fabsf(v.im)));
+    if ((((uintptr_t)x) & 15) == 0) {
+        // 16-byte loads, four in flight per thread
+        typedef float f4 __attribute__((ext_vector_type(4)));
+        const f4* __restrict__ x4 = (const f4*)x;
+        const int64_t n4 = n >> 1, step = (int64_t)gridDim.x * 256;
+        int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+        for (; i + 3 * step < n4; i += 4 * step) {
+            const f4 a = x4[i], b = x4[i + step], c = x4[i + 2 * step], d = x4[i + 3 * step];
+            m = fmaxf(m, fmaxf(fmaxf(fabsf(a[0]), fabsf(a[1])), fmaxf(fabsf(a[2]), fabsf(a[3]))));
+            m = fmaxf(m, fmaxf(fmaxf(fabsf(b[0]), fabsf(b[1])), fmaxf(fabsf(b[2]), fabsf(b[3]))));
+            m = fmaxf(m, fmaxf(fmaxf(fabsf(c[0]), fabsf(c[1])), fmaxf(fabsf(c[2]), fabsf(c[3]))));
+            m = fmaxf(m, fmaxf(fmaxf(fabsf(d[0]), fabsf(d[1])), fmaxf(fabsf(d[2]), fabsf(d[3]))));
+        }
+        for (; i < n4; i += step) {
+            const f4 a = x4[i];
+            m = fmaxf(m, fmaxf(fmaxf(fabsf(a[0]), fabsf(a[1])), fmaxf(fabsf(a[2]), fabsf(a[3]))));
+        }
+        if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) m = fmaxf(m, fmaxf(fabsf(x[n - 1].re), fabsf(x[n - 1].im)));
+    } else {
+        for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+            const c64 v = x[i];
+            m = fmaxf(m, fmaxf(fabsf(v.re), fabsf(v.im)));
+        }
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
     if ((threadIdx.x & 63) == 0 && m > 0.f && m < __builtin_bit_cast(float, 0x7f800000u))
-        atomicMax((unsigned*)out, __builtin_bit_cast(unsigned, m));
+        record_max(out, m);
 }
 
 hipError_t launch_maxabs_f32(const void* base, const int64_t* soff, int64_t z, int64_t zs, int64_t zstride, int64_t n,
-                             float* out, hipStream_t stream) {
+                             float* out, hipStream_t stream, int nz, int out_zs) {
     int64_t blocks = (n + 256 * 16 - 1) / (256 * 16);
-    if (blocks > 4096) blocks = 4096;
+    const int64_t cap = nz > 1 ? std::max<int64_t>(8192 / nz, 16) : 8192;
+    if (blocks > cap) blocks = cap;
     if (blocks < 1) blocks = 1;
-    hipLaunchKernelGGL(maxabs_f32_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, (const c64*)base, soff, z, zs, zstride, n, out);
+    if (nz < 1 || nz > 65535) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(maxabs_f32_kernel, dim3((unsigned)blocks, (unsigned)nz), dim3(256), 0, stream, (const c64*)base, soff, z, zs,
+                       zstride, n, out, out_zs);
     return hipGetLastError();
 }
 
@@ -747,8 +773,8 @@ __global__ __launch_bounds__(256) void prologue_kernel(SliceMeta m, int64_t* sta
     if (m.fac && blockIdx.x == 0)
         for (int64_t i = threadIdx.x; i < m.n_fac; i += blockDim.x)
             if (m.fac_zero[i]) m.fac[i] = 0.0;
-    if (m.smax && blockIdx.x == 0)
-        for (int64_t i = threadIdx.x; i < m.n_smax; i += blockDim.x)
+    if (m.smax)   // (every block its share: a batch of 64 slices has 3 x steps x 64 of them)
+        for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < m.n_smax; i += (int64_t)gridDim.x * blockDim.x)
             if (m.smax_zero[i]) m.smax[i] = 0.f;
     __syncthreads();
     // (the device-side slice counter of a graph replay: always a single workgroup)

@@ -823,6 +823,9 @@ __global__ __launch_bounds__(256, Cfg::FAST_BLOCKS) void pair_mfma_fast_kernel(S
         }
         return;
     }
+    // (round 6: the largest |component| stored -> MfmaHints::cmax, where the executor asks for it: a consumer in the
+    // fp16 x 2 arithmetic splits this result under it)
+    float vmax = 0.f;
     auto store_tile = [&](auto scaled_tag) __attribute__((always_inline)) {
 #pragma unroll
         for (int i = 0; i < Cfg::FM; ++i) {
@@ -835,6 +838,7 @@ __global__ __launch_bounds__(256, Cfg::FAST_BLOCKS) void pair_mfma_fast_kernel(S
                     if constexpr (decltype(scaled_tag)::value) v = pair_rows(acc[i][j][t], acc[i][j][t + 1], odd, alpha);
                     else v = pair_rows(acc[i][j][t], acc[i][j][t + 1], odd);
                     CTG_STORE_GUARD(alpha)
+                    if constexpr (!GROUPED) vmax = fmaxf(vmax, fmaxf(fabsf(v.x), fabsf(v.y)));
                     *(float2*)(C + 2 * (size_t)(ro[i][u] + co[j])) = v;
                 }
             }
@@ -843,6 +847,14 @@ __global__ __launch_bounds__(256, Cfg::FAST_BLOCKS) void pair_mfma_fast_kernel(S
     // (alpha != 1 only in strip_exponent runs: two multiplies per store otherwise saved)
     if (alpha != 1.f) store_tile(std::true_type{});
     else store_tile(std::false_type{});
+    if constexpr (!GROUPED) {
+        if (h.cmax != nullptr) {
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, o));
+            if ((threadIdx.x & 63) == 0 && vmax > 0.f && vmax < __builtin_bit_cast(float, 0x7f800000u))
+                record_max(h.cmax + ((int64_t)p.z0 + blockIdx.y) * h.cmax_zs * kMaxSub, vmax);
+        }
+    }
 #ifdef CTG_TIMING
     CTG_STAMP(T4);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // all stores acknowledged
@@ -1024,8 +1036,9 @@ __device__ __forceinline__ void pair_mfma_16bit_body(const StepArgs& p, const Mf
     int h2_e = 0;
     float h2_sa = 1.f, h2_sb = 1.f;
     if constexpr (H2) {
-        int ea = h.amax != nullptr ? pair_h2_exponent_of(*h.amax) : 0;
-        int eb = h.bmax != nullptr ? pair_h2_exponent_of(*h.bmax) : 0;
+        const int64_t zz = (int64_t)p.z0 + blockIdx.y;   // (the slice of the launch this workgroup belongs to)
+        int ea = h.amax != nullptr ? pair_h2_exponent_of(read_max(h.amax + zz * h.amax_zs * kMaxSub)) : 0;
+        int eb = h.bmax != nullptr ? pair_h2_exponent_of(read_max(h.bmax + zz * h.bmax_zs * kMaxSub)) : 0;
         ea = __builtin_amdgcn_readfirstlane(ea);
         eb = __builtin_amdgcn_readfirstlane(eb);
         h2_sa = pair_pow2f(-ea);
@@ -1184,7 +1197,7 @@ __device__ __forceinline__ void pair_mfma_16bit_body(const StepArgs& p, const Mf
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, o));
         if (lane == 0 && vmax > 0.f && vmax < __builtin_bit_cast(float, 0x7f800000u))
-            atomicMax((unsigned*)h.cmax, __builtin_bit_cast(unsigned, vmax));
+            record_max(h.cmax + ((int64_t)p.z0 + blockIdx.y) * h.cmax_zs * kMaxSub, vmax);
     }
 }
 
@@ -1451,6 +1464,7 @@ __global__ __launch_bounds__(256, (FN == 1 ? 4 : FN == 2 ? CTG_STREAM_OCC2 : CTG
             if (ADD) a_delta[j] = (int)p.rowA.lo[r];
         }
     }
+    float rec_max = 0.f;   // (round 6) largest |component| stored by this lane
     // rows this lane stores in the epilogue: 8 (paired) rows per MFMA tile
     int c_delta[8];
     if (ADD) {
@@ -1703,7 +1717,10 @@ __global__ __launch_bounds__(256, (FN == 1 ? 4 : FN == 2 ? CTG_STREAM_OCC2 : CTG
                         if constexpr (decltype(scaled_tag)::value) v = pair_rows(acc[j][t], acc[j][t + 1], odd, alpha);
                         else v = pair_rows(acc[j][t], acc[j][t + 1], odd);
                         CTG_STORE_GUARD(alpha)
-                        if (STEADY || (n_ok[j] && ro >= 0)) *(float2*)(C + 2 * (ro + ncol[j])) = v;
+                        if (STEADY || (n_ok[j] && ro >= 0)) {
+                            rec_max = fmaxf(rec_max, fmaxf(fabsf(v.x), fabsf(v.y)));
+                            *(float2*)(C + 2 * (ro + ncol[j])) = v;
+                        }
                     }
                 }
             };
@@ -1796,6 +1813,13 @@ __global__ __launch_bounds__(256, (FN == 1 ? 4 : FN == 2 ? CTG_STREAM_OCC2 : CTG
 #pragma unroll
         for (int d = 0; d < DEPTH; ++d)
             if (t + d < n_tasks) consume(regs[d], std::false_type{}, std::false_type{}, std::false_type{}, nullptr);
+    }
+    // (round 6) the largest |component| this wave stored -> MfmaHints::cmax, where the executor asks for it
+    if (h.cmax != nullptr) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) rec_max = fmaxf(rec_max, __shfl_xor(rec_max, o));
+        if ((threadIdx.x & 63) == 0 && rec_max > 0.f && rec_max < __builtin_bit_cast(float, 0x7f800000u))
+            record_max(h.cmax + ((int64_t)p.z0 + blockIdx.y) * h.cmax_zs * kMaxSub, rec_max);
     }
 }
 

@@ -993,6 +993,18 @@ static bool tiled16_step(const ctg_exec* e, int64_t s) {
            pair_bf16x3_on(e->args[s]);
 }
 
+// does a launch of pair step s record its result's largest |component| (what launch_step decides, on the shapes)?
+static bool pair_records(const ctg_exec* e, int64_t s) {
+    const ctg_plan* p = e->plan;
+    const int64_t* r = &p->steps[s * STEP_WORDS];
+    if (r[W_KIND] != KIND_PAIR || r[W_KERNEL] != KERNEL_MFMA || p->dtype != CTG_C64) return false;
+    if (e->stem_arith == 0 || e->strip || e->d_stem_max == nullptr || e->grouped[s]) return false;
+    const MfmaHints& h = e->hints[s];
+    if (tiled16_step(e, s)) return h.splitk <= 1 && e->args[s].zqA <= 1 && e->args[s].zqB <= 1;
+    if (e->stem_arith != 2 || e->wave_member[s]) return false;
+    return h.stream == 1 || (!h.stream && h.fast && !h.bf3 && h.splitk <= 1);
+}
+
 int launch_step(ctg_exec* e, int64_t s, hipStream_t stream) {
     const ctg_plan* p = e->plan;
     const int64_t* r = &p->steps[s * STEP_WORDS];
@@ -1046,11 +1058,14 @@ int launch_step(ctg_exec* e, int64_t s, hipStream_t stream) {
                 StemArgs q = e->stem_args[s];
                 q.z0 = e->args[s].z0 + z;
                 q.nz = 1;
-                q.amax = h2 ? e->d_stem_max + prod : nullptr;
-                q.cmax = records ? e->d_stem_max + s : nullptr;
+                // (a slot per slice of the batch; a slice-invariant tensor's record lives in slot 0)
+                const int64_t zc = (e->invariant[s] || e->grouped[s]) ? 0 : q.z0;
+                const int64_t za = (prod_rec && (e->invariant[prod] || e->grouped[prod])) ? 0 : q.z0;
+                q.amax = h2 ? e->smax_slot(0, prod_rec ? prod : 0, za) : nullptr;
+                q.cmax = records ? e->smax_slot(0, s, zc) : nullptr;
                 if (h2 && !prod_rec) {
-                    float* slot = e->d_stem_max + p->n_steps + s;
-                    err = hipMemsetAsync(slot, 0, sizeof(float), stream);
+                    float* slot = e->smax_slot(1, s, q.z0);
+                    err = hipMemsetAsync(slot, 0, sizeof(float) * kMaxSub, stream);
                     if (err == hipSuccess) err = launch_maxabs_f32(q.A, q.soffA, q.z0, q.zsA, q.zA, q.a_elems, slot, stream);
                     q.amax = slot;
                 }
@@ -1073,28 +1088,37 @@ int launch_step(ctg_exec* e, int64_t s, hipStream_t stream) {
                 const bool tiled16 = tiled16_step(e, s) && !h0.stream && h0.fast && h0.bf3;
                 if (tiled16) {
                     MfmaHints h = h0;
-                    const bool single = e->args[s].nz == 1 && e->args[s].z0 == 0 && h0.splitk <= 1;
+                    // (no k-splits: the slabs hold unscaled sums; no operand that a slice group shares: its replica
+                    // is not the slice's own)
+                    const StepArgs& a = e->args[s];
+                    const bool single = h0.splitk <= 1 && a.zqA <= 1 && a.zqB <= 1 && !e->grouped[s] &&
+                                        a.z0 + a.nz <= std::max(e->batch, 1);
                     bool h2 = e->stem_arith == 2 && single;
                     if (h2)
                         if (const char* v = getenv("CTG_PAIR_H2")) h2 = !(v[0] == '\0' || (v[0] == '0' && v[1] == '\0'));
                     h.h2 = h2 ? 1 : 0;
-                    h.cmax = single ? e->d_stem_max + s : nullptr;
+                    // (the kernel adds z0 + blockIdx.y times the stride: pointers to slot 0 of the step)
+                    h.cmax = single ? e->smax_slot(0, s, 0) : nullptr;
+                    h.cmax_zs = e->invariant[s] ? 0 : 1;
                     e->stem_h2_ran[s] = single ? 1 : 0;
                     for (int side = 0; side < 2 && h2 && err == hipSuccess; ++side) {
                         const int64_t prod = r[side == 0 ? W_A_PROD : W_B_PROD];
                         const float* mx = nullptr;
-                        if (prod >= 0 && prod < p->n_steps && e->stem_h2_ran[prod]) {
-                            mx = e->d_stem_max + prod;
+                        int zs = 1;
+                        if (prod >= 0 && prod < p->n_steps && e->stem_h2_ran[prod] && !e->grouped[prod]) {
+                            mx = e->smax_slot(0, prod, 0);
+                            zs = e->invariant[prod] ? 0 : 1;
                         } else {
-                            float* slot = e->d_stem_max + (1 + side) * p->n_steps + s;
-                            const StepArgs& a = e->args[s];
-                            err = hipMemsetAsync(slot, 0, sizeof(float), stream);
+                            float* slot = e->smax_slot(1 + side, s, 0);
+                            float* at = slot + (int64_t)a.z0 * kMaxSub;
+                            err = hipMemsetAsync(at, 0, sizeof(float) * kMaxSub * (size_t)a.nz, stream);
                             if (err == hipSuccess)
-                                err = side == 0 ? launch_maxabs_f32(a.A, a.soffA, 0, a.zsA, a.zA, r[W_A_SIZE], slot, stream)
-                                                : launch_maxabs_f32(a.B, a.soffB, 0, a.zsB, a.zB, r[W_B_SIZE], slot, stream);
+                                err = side == 0 ? launch_maxabs_f32(a.A, a.soffA, a.z0, a.zsA, a.zA, r[W_A_SIZE], at, stream, a.nz, kMaxSub)
+                                                : launch_maxabs_f32(a.B, a.soffB, a.z0, a.zsB, a.zB, r[W_B_SIZE], at, stream, a.nz, kMaxSub);
                             mx = slot;
                         }
                         (side == 0 ? h.amax : h.bmax) = mx;
+                        (side == 0 ? h.amax_zs : h.bmax_zs) = zs;
                     }
                     if (env_on("CTG_STEM_DEBUG"))
                         fprintf(stderr, "tiled step %lld: arith %d single %d -> h2 %d records %d (A prod %lld, B prod %lld)\n",
@@ -1102,8 +1126,22 @@ int launch_step(ctg_exec* e, int64_t s, hipStream_t stream) {
                                 (long long)r[W_B_PROD]);
                     if (err == hipSuccess) err = launch_pair_mfma(p->dtype, e->args[s], h, e->d_scratch, kScratchBytes, stream);
                 } else {
-                    if (!e->stem_h2_ran.empty()) e->stem_h2_ran[s] = 0;
-                    err = launch_pair_mfma(p->dtype, e->args[s], h0, e->d_scratch, kScratchBytes, stream);
+                    // (the fp32 tiled kernel without k-splits and the streaming kernel record as well, so that a tiled
+                    // 16-bit step or a stem pair behind them needs no max-abs pass -- not inside a wave-front group,
+                    // not what a slice group shares)
+                    const StepArgs& a = e->args[s];
+                    const bool can = e->stem_arith == 2 && !e->strip && e->d_stem_max != nullptr && !e->grouped[s] &&
+                                     !e->wave_member[s] && a.z0 + a.nz <= std::max(e->batch, 1) &&
+                                     ((h0.stream == 1) || (!h0.stream && h0.fast && !h0.bf3 && h0.splitk <= 1));
+                    if (!e->stem_h2_ran.empty()) e->stem_h2_ran[s] = can ? 1 : 0;
+                    if (can) {
+                        MfmaHints h = h0;
+                        h.cmax = e->smax_slot(0, s, 0);
+                        h.cmax_zs = e->invariant[s] ? 0 : 1;
+                        err = launch_pair_mfma(p->dtype, a, h, e->d_scratch, kScratchBytes, stream);
+                    } else {
+                        err = launch_pair_mfma(p->dtype, a, h0, e->d_scratch, kScratchBytes, stream);
+                    }
                 }
             } else
                 err = launch_pair_valu(p->dtype, e->args[s], e->d_scratch, kScratchBytes, stream);
@@ -1128,6 +1166,7 @@ int launch_step(ctg_exec* e, int64_t s, hipStream_t stream) {
 // interleaves dependent steps simply forms no groups.  Within a run the steps
 // are mutually independent, so issuing them shape by shape is a legal reorder.
 int build_groups(ctg_exec* e) {
+    std::fill(e->wave_member.begin(), e->wave_member.end(), 0);
     const ctg_plan* p = e->plan;
     const int64_t n = p->n_steps;
     e->issue.clear();
@@ -1226,6 +1265,7 @@ int build_groups(ctg_exec* e) {
             uint32_t blocks = 0;
             const int32_t item0 = (int32_t)(cls == 0 ? vitems.size() : fitems.size());
             for (int64_t m : members) {
+                if ((size_t)m < e->wave_member.size()) e->wave_member[m] = 1;
                 if (cls == 0) {
                     vitems.emplace_back();
                     blocks += valu_group_fill(e->args[m], &vitems.back(), blocks);
@@ -1730,13 +1770,21 @@ int ctg_exec_create(const ctg_plan* p, int device, void* stream, void* ext_resul
             // fp16 x 2 stem kernels: per step the largest element it recorded | of its big operand
             bool stems = false;
             // (three banks of n_steps: recorded by the step | max-abs pass over its operand A | ... B)
-            std::vector<int32_t> sz((size_t)(3 * std::max<int64_t>(p->n_steps, 1)), 1);
+            const int64_t nb = std::max<int64_t>(e->batch, 1);
+            e->plan_steps = p->n_steps;
+            // (what the slice prologue resets: the records of bank 0 of the steps that can record -- stem launches and
+            // matrix-core pair steps --; the max-abs banks are cleared where a pass is launched)
+            std::vector<int32_t> sz((size_t)(3 * std::max<int64_t>(p->n_steps, 1) * nb * kMaxSub), 0);
             for (int64_t st = 0; st < p->n_steps; ++st) {
-                stems = stems || p->steps[st * STEP_WORDS + W_KIND] == KIND_STEM2;
+                const int64_t* rs = &p->steps[st * STEP_WORDS];
+                stems = stems || rs[W_KIND] == KIND_STEM2;
+                const bool can = rs[W_KIND] == KIND_STEM2 || (rs[W_KIND] == KIND_PAIR && rs[W_KERNEL] == KERNEL_MFMA);
                 // (slice-invariant steps and what a slice group shares keep their record across slices)
-                if (e->invariant[st] || e->grouped[st]) sz[(size_t)st] = 0;
+                if (can && !e->invariant[st] && !e->grouped[st])
+                    for (int64_t z = 0; z < nb * kMaxSub; ++z) sz[(size_t)(st * nb * kMaxSub + z)] = 1;
             }
             e->stem_h2_ran.assign(p->n_steps, 0);
+            if (e->wave_member.size() != (size_t)p->n_steps) e->wave_member.assign(p->n_steps, 0);
             (void)stems;
             if (p->dtype == CTG_C64) {   // (plans without a stem may still have long tiled steps)
                 HIP_TRY_E(hipMalloc((void**)&e->d_stem_max, sz.size() * sizeof(float)));
@@ -1745,7 +1793,7 @@ int ctg_exec_create(const ctg_plan* p, int device, void* stream, void* ext_resul
                 HIP_TRY_E(hipMemcpy(e->d_smax_zero, sz.data(), sz.size() * sizeof(int32_t), hipMemcpyHostToDevice));
                 e->meta.smax = e->d_stem_max;
                 e->meta.smax_zero = e->d_smax_zero;
-                e->meta.n_smax = (int64_t)sz.size();
+                e->meta.n_smax = (int64_t)(sz.size() / 3);   // (bank 0 only: see above)
             }
         }
         HIP_TRY_E(hipMalloc((void**)&e->d_fac_zero, fac_zero.size() * sizeof(int32_t)));
@@ -2244,7 +2292,7 @@ int ctg_exec_step_kernel(ctg_exec* e, int64_t step, char* buf, int64_t buflen) {
         const bool prod16 = prod >= 0 && prod < p->n_steps &&
                             ((p->steps[prod * STEP_WORDS + W_KIND] == KIND_STEM2 &&
                               (stem2_uses_bf3(e->stem_args[prod]) || stem2h_uses_h2(e->stem_args[prod]))) ||
-                             (tiled16_step(e, prod) && e->hints[prod].splitk <= 1 && e->batch <= 1));
+                             pair_records(e, prod));
         bool h2 = e->stem_arith == 2 && !e->strip && e->d_stem_max != nullptr && (prod16 || env_on("CTG_STEM_H2_ALL")) &&
                   stem2h_uses_h2(e->stem_args[step]);
         if (h2)
@@ -2269,7 +2317,8 @@ int ctg_exec_step_kernel(ctg_exec* e, int64_t step, char* buf, int64_t buflen) {
                      (h.vecA && h.additive32) ? "true" : "false", h.additive32 ? "true" : "false",
                      r[W_K] < MFMA_BK ? "true" : "false", r[W_K] <= 4 ? 2 : (r[W_K] <= 8 ? 4 : 8));
         else if (h.bf3 && pair_bf16x3_on(e->args[step])) {
-            bool h2 = tiled16_step(e, step) && e->stem_arith == 2 && h.splitk <= 1 && e->batch <= 1;
+            bool h2 = tiled16_step(e, step) && e->stem_arith == 2 && h.splitk <= 1 && !e->grouped[step] &&
+                      e->args[step].zqA <= 1 && e->args[step].zqB <= 1;
             if (h2)
                 if (const char* v = getenv("CTG_PAIR_H2")) h2 = !(v[0] == '\0' || (v[0] == '0' && v[1] == '\0'));
             snprintf(name, sizeof(name), "%s<128,%d,16>,%s", h2 ? "pair_mfma_h2_kernel" : "pair_mfma_bf3_kernel", h.bn,

@@ -554,7 +554,7 @@ __global__ __launch_bounds__(SW * 64, 1) void stem2_kernel(StemArgs p) {
     float h2_sa = 1.f;
     int h2_exa = 0;
     if constexpr (BF3) {
-        h2_exa = p.amax != nullptr ? h2_exponent_of(*p.amax) : 0;
+        h2_exa = p.amax != nullptr ? h2_exponent_of(read_max(p.amax)) : 0;
         h2_exa = __builtin_amdgcn_readfirstlane(h2_exa);
         h2_sa = pow2f(-h2_exa);
     }
@@ -1755,7 +1755,7 @@ __global__ __launch_bounds__(SW * 64, 1) void stem2_kernel(StemArgs p) {
 #pragma unroll
             for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
             if (lane == 0 && mx > 0.f && mx < __builtin_bit_cast(float, 0x7f800000u))
-                atomicMax((unsigned*)p.cmax, __builtin_bit_cast(unsigned, mx));
+                record_max(p.cmax, mx);
         }
     }
 }
