@@ -63,6 +63,7 @@ struct ctg_exec {
         return d_stem_max + (((int64_t)bank * plan_steps + s) * (batch > 1 ? batch : 1) + z) * ctg::kMaxSub;
     }
     int64_t plan_steps = 0;                // (= plan->n_steps, for smax_slot)
+    std::vector<char> rec_wanted;          // the record of step s's largest |component| has a reader (build_hints)
     std::vector<char> wave_member;         // step s is launched inside a wave-front group (it never records its maximum)
     std::vector<char> stem_h2_ran;         // step s last ran in the fp16 x 2 arithmetic (its record is valid)
     std::vector<ctg::MfmaHints> hints;  // per step kernel hints (MFMA steps)

@@ -637,7 +637,7 @@ __global__ __launch_bounds__(256) void maxabs_f32_kernel(const c64* __restrict__
                                                          int64_t zs, int64_t zstride, int64_t n, float* out, int out_zs) {
     z += blockIdx.y;
     out += (int64_t)blockIdx.y * out_zs;
-    const c64* __restrict__ x = base + (soff[z * zs] + z * zstride);
+    const c64* __restrict__ x = base + ((soff != nullptr ? soff[z * zs] : 0) + z * zstride);   // (no table: the tensor at `base`)
     float m = 0.f;
     if ((((uintptr_t)x) & 15) == 0) {
         // 16-byte loads, four in flight per thread

@@ -941,6 +941,19 @@ int build_hints_into(ctg_exec* e, std::vector<MfmaHints>& hints, int64_t zmult,
 
 int build_hints(ctg_exec* e) {
     int rc = build_hints_into(e, e->hints, 1, nullptr, &e->d_ord, &e->d_lane);
+    // whose record of its largest |component| has a reader: the producers of a stem launch's big operand and of a
+    // long tiled step's operands (fp16 x 2 splits them under it) -- the fp32 tiled / streaming kernels record only then
+    e->rec_wanted.assign(e->plan->n_steps, 0);
+    if (rc == CTG_OK && e->plan->dtype == CTG_C64)
+        for (int64_t t = 0; t < e->plan->n_steps; ++t) {
+            const int64_t* r = &e->plan->steps[t * STEP_WORDS];
+            auto want = [&](int64_t prod) { if (prod >= 0 && prod < e->plan->n_steps) e->rec_wanted[prod] = 1; };
+            if (r[W_KIND] == KIND_STEM2) want(r[W_A_PROD]);
+            if (r[W_KIND] == KIND_PAIR && r[W_KERNEL] == KERNEL_MFMA && e->hints[t].bf3) {
+                want(r[W_A_PROD]);
+                want(r[W_B_PROD]);
+            }
+        }
     if (rc != CTG_OK || e->batch <= 1 || e->plan->dtype != CTG_C64) return rc;
     e->hints_b.assign(e->plan->n_steps, MfmaHints{nullptr, nullptr, 0, 0, 0, 0, 0, nullptr, 0});
     return build_hints_into(e, e->hints_b, e->batch, &e->hints, &e->d_ord_b, &e->d_lane_b);
@@ -1001,7 +1014,7 @@ static bool pair_records(const ctg_exec* e, int64_t s) {
     if (e->stem_arith == 0 || e->strip || e->d_stem_max == nullptr || e->grouped[s]) return false;
     const MfmaHints& h = e->hints[s];
     if (tiled16_step(e, s)) return h.splitk <= 1 && e->args[s].zqA <= 1 && e->args[s].zqB <= 1;
-    if (e->stem_arith != 2 || e->wave_member[s]) return false;
+    if (e->stem_arith != 2 || e->wave_member[s] || !e->rec_wanted[s]) return false;
     return h.stream == 1 || (!h.stream && h.fast && !h.bf3 && h.splitk <= 1);
 }
 
@@ -1066,7 +1079,10 @@ int launch_step(ctg_exec* e, int64_t s, hipStream_t stream) {
                 if (h2 && !prod_rec) {
                     float* slot = e->smax_slot(1, s, q.z0);
                     err = hipMemsetAsync(slot, 0, sizeof(float) * kMaxSub, stream);
-                    if (err == hipSuccess) err = launch_maxabs_f32(q.A, q.soffA, q.z0, q.zsA, q.zA, q.a_elems, slot, stream);
+                    // (an input tensor read in place: the whole leaf, see the tiled steps below)
+                    if (err == hipSuccess)
+                        err = r[W_A_LEAF] >= 0 ? launch_maxabs_f32(q.A, nullptr, 0, 0, 0, q.a_elems, slot, stream)
+                                               : launch_maxabs_f32(q.A, q.soffA, q.z0, q.zsA, q.zA, q.a_elems, slot, stream);
                     q.amax = slot;
                 }
                 if (err == hipSuccess) err = h2 ? launch_stem2h(q, stream) : launch_stem2(q, stream);
@@ -1108,6 +1124,16 @@ int launch_step(ctg_exec* e, int64_t s, hipStream_t stream) {
                         if (prod >= 0 && prod < p->n_steps && e->stem_h2_ran[prod] && !e->grouped[prod]) {
                             mx = e->smax_slot(0, prod, 0);
                             zs = e->invariant[prod] ? 0 : 1;
+                        } else if (r[side == 0 ? W_A_LEAF : W_B_LEAF] >= 0) {
+                            // an input tensor read in place: W_x_SIZE is the whole leaf, a slice of it need not be
+                            // contiguous -- the largest element of the WHOLE leaf bounds every slice's (one record for
+                            // all slices of the launch)
+                            float* slot = e->smax_slot(1 + side, s, 0);
+                            err = hipMemsetAsync(slot, 0, sizeof(float) * kMaxSub, stream);
+                            if (err == hipSuccess)
+                                err = launch_maxabs_f32(side == 0 ? a.A : a.B, nullptr, 0, 0, 0, r[side == 0 ? W_A_SIZE : W_B_SIZE], slot, stream);
+                            mx = slot;
+                            zs = 0;
                         } else {
                             float* slot = e->smax_slot(1 + side, s, 0);
                             float* at = slot + (int64_t)a.z0 * kMaxSub;
@@ -1131,7 +1157,7 @@ int launch_step(ctg_exec* e, int64_t s, hipStream_t stream) {
                     // not what a slice group shares)
                     const StepArgs& a = e->args[s];
                     const bool can = e->stem_arith == 2 && !e->strip && e->d_stem_max != nullptr && !e->grouped[s] &&
-                                     !e->wave_member[s] && a.z0 + a.nz <= std::max(e->batch, 1) &&
+                                     !e->wave_member[s] && e->rec_wanted[s] && a.z0 + a.nz <= std::max(e->batch, 1) &&
                                      ((h0.stream == 1) || (!h0.stream && h0.fast && !h0.bf3 && h0.splitk <= 1));
                     if (!e->stem_h2_ran.empty()) e->stem_h2_ran[s] = can ? 1 : 0;
                     if (can) {

@@ -175,9 +175,9 @@ int ctg_exec_set_strip_exponent(ctg_exec* exec, int strip_exponent, int check_ze
  * (absolute error <= 2^-24 of the largest: norm-wise accuracy).  strip_exponent runs
  * and CTG_STEM_H2=0 fall back to 1.  The LONG TILED steps (K >= 64 on full 64-column tiles: the GEMM-like steps of
  * a tree) follow the same mode: 1 = six bf16 products, 2 = two fp16 limbs per value under ONE power of two per
- * operand tensor, three products -- for a launch of one slice without k-splits (its operands' largest elements
- * as their producers recorded them, else a max-abs pass); launches of several slices, k-split launches and
- * CTG_PAIR_H2=0 keep 1. */
+ * operand tensor and slice, three products -- for a launch without k-splits (its operands' largest elements as
+ * their producers recorded them per slice of the batch, else a max-abs pass); k-split launches and CTG_PAIR_H2=0
+ * keep 1. */
 int ctg_exec_set_stem_arithmetic(ctg_exec* exec, int mode);
 int ctg_exec_get_exponent(ctg_exec* exec, double* exponent, int* zero);
 

@@ -518,3 +518,60 @@ def test_chained_tiled_steps_take_the_producers_record(monkeypatch):
     fn.close()
     assert sum(n.startswith("pair_mfma_h2_kernel") for n in names) == 2, names
     assert G.relerr(got, ref) <= 2e-6, G.relerr(got, ref)
+
+
+def test_batched_tiled_steps_scale_every_slice_by_its_own_record(monkeypatch):
+    """Four slices of (a0[s, R, j] m[j, K]) b[K, N] w[s] in ONE launch sequence, slice s larger than slice s - 1 by
+    2^30: the long tiled step of the batch splits every slice's intermediate under THAT slice's largest element (a
+    record per step and slice of the batch) -- one record for the whole batch would leave the small slices' limbs in
+    fp16's subnormals.  Every slice against the oracle; and the same bits whatever the batch size.  (An INPUT read in
+    place by a tiled step is scaled by the largest element of the whole leaf: the second tree.)"""
+    for k in ("CTG_STEM_ARITH", "CTG_STEM_BF16X3", "CTG_PAIR_BF16X3", "CTG_PAIR_H2"):
+        monkeypatch.delenv(k, raising=False)
+    S, R, J, K, N = 4, 4096, 4, 256, 256
+    rng = np.random.default_rng(11)
+    a0 = _cplx(rng, S, R, J)
+    for s in range(S):
+        a0[s] *= np.float32(2.0 ** (30 * s - 60))
+    m, b = _cplx(rng, J, K), _cplx(rng, K, N)
+    w = np.ones(S, dtype="complex64")
+    outs = {}
+    for cap in ("4", "1"):
+        monkeypatch.setenv("CTG_SLICE_BATCH", cap)
+        tree = ca.ContractionTree.from_path([("s", "a", "j"), ("j", "b"), ("b", "c"), ("s",)], ("a", "c"),
+                                            dict(s=S, a=R, j=J, b=K, c=N), path=[(0, 1), (0, 2), (0, 1)])
+        tree.remove_ind_("s")
+        assert tree.nslices == S
+        fn = HipContractor(tree)
+        ex = fn.setup(a0, m, b, w)["exec"]
+        assert any(n.startswith("pair_mfma_h2_kernel") for n in ex.step_kernels()), ex.step_kernels()
+        per_slice = []
+        for i in range(S):
+            ex.zero_result()
+            ex.run_slices(i, 1, 1)
+            per_slice.append(np.asarray(ex.download_result()).copy())
+        ex.zero_result()
+        ex.run_slices(0, S, 1)
+        outs[cap] = (per_slice, np.asarray(ex.download_result()).copy())
+        fn.close()
+    for i in range(S):
+        ref = (a0[i].astype("complex128") @ m.astype("complex128")) @ b.astype("complex128")
+        assert G.relerr(outs["4"][0][i], ref) <= 2e-6, (i, G.relerr(outs["4"][0][i], ref))
+        assert np.array_equal(outs["4"][0][i], outs["1"][0][i])
+    assert np.array_equal(outs["4"][1], outs["1"][1])
+    # a sliced input as the tiled step's own operand
+    monkeypatch.setenv("CTG_SLICE_BATCH", "4")
+    a = _cplx(rng, S, R, K)
+    tree = ca.ContractionTree.from_path([("s", "a", "b"), ("b", "c"), ("s",)], ("a", "c"), dict(s=S, a=R, b=K, c=N),
+                                        path=[(0, 1), (0, 1)])
+    tree.remove_ind_("s")
+    fn = HipContractor(tree)
+    ex = fn.setup(a, b, w)["exec"]
+    assert any(n.startswith("pair_mfma_h2_kernel") for n in ex.step_kernels())
+    for ids in ((1, 1), (0, S)):
+        ex.zero_result()
+        ex.run_slices(ids[0], ids[1], 1)
+        got = np.asarray(ex.download_result())
+        ref = sum(a[i].astype("complex128") @ b.astype("complex128") for i in range(ids[0], ids[0] + ids[1]))
+        assert G.relerr(got, ref) <= 2e-6
+    fn.close()
