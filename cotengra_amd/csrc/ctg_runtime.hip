@@ -1157,6 +1157,7 @@ int launch_step(ctg_exec* e, int64_t s, hipStream_t stream) {
                     // not what a slice group shares)
                     const StepArgs& a = e->args[s];
                     const bool can = e->stem_arith == 2 && !e->strip && e->d_stem_max != nullptr && !e->grouped[s] &&
+                                     !env_on("CTG_NO_PAIR_RECORD") &&
                                      !e->wave_member[s] && e->rec_wanted[s] && a.z0 + a.nz <= std::max(e->batch, 1) &&
                                      ((h0.stream == 1) || (!h0.stream && h0.fast && !h0.bf3 && h0.splitk <= 1));
                     if (!e->stem_h2_ran.empty()) e->stem_h2_ran[s] = can ? 1 : 0;
