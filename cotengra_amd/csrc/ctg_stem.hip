@@ -173,6 +173,11 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 // the other two limbs are still being subtracted out
 // (experiment build -DCTG_STEM_KO_HALF: only the three products a TWO-limb split would keep -- t = 0, 1, 3 --, the third
 // limbs dead code: what halving the product count is worth in time; the results lose their third limb)
+#ifdef CTG_STEM_H2
+#define CTG_STEM_LIMBS 2
+#else
+#define CTG_STEM_LIMBS 3
+#endif
 #if defined(CTG_STEM_KO_HALF) || defined(CTG_STEM_H2)   // (H2: limbs 0, 1 only -- products (0, 0), (0, 1), (1, 0))
 #define CTG_STEM_T_STEP(t) ((t) == 1 ? 2 : ((t) == 3 ? 3 : 1))
 #define CTG_STEM_T_COUNT 3                        // products per k-block, and which of them t is (deferred stores go
@@ -450,7 +455,7 @@ template <bool PACK1, bool PACK2, int RT1_, int CS1, int NCH, int IT2_, bool BR1
           bool LM = false, bool WS = false>
 __global__ __launch_bounds__(SW * 64, 1) void stem2_kernel(StemArgs p) {
     constexpr bool TRI = ITM > 0;
-    static_assert(!WS || (XM && !LM && !ONE && IT2_ > 0 && IT2_ <= 2 && (PACK1 || RT1_ == 1)), "specialised waves: a static bf16 x 3 pair, fp32 intermediate");
+    static_assert(!WS || (XM && !ONE && IT2_ > 0 && IT2_ <= 2 && (PACK1 || RT1_ == 1)), "specialised waves: a static 16-bit pair");
     constexpr int PW = WS ? 4 : SW;               // waves that run step 1 (and, symmetric kernel, step 2)
     constexpr int RT1 = WS ? 2 * RT1_ : RT1_;     // units of step 1 per such wave
     constexpr int IT2 = WS ? 2 * IT2_ : IT2_;     // work items of step 2 per consumer (symmetric: per wave)
@@ -549,7 +554,7 @@ __global__ __launch_bounds__(SW * 64, 1) void stem2_kernel(StemArgs p) {
     int bf3_ex = 0;   // BF3: power of two taken out of the small operands (goes back in through alpha)
     float* const bf3_red = (float*)(oc_s + (ONE ? N1 : N2));   // (64 bytes behind the column table: stem2_lds_bytes_bf3)
 #ifdef CTG_STEM_H2
-    static_assert(!BF3 || (!TRI && !LM), "fp16 x 2: pairs and single steps, fp32 intermediate");
+    static_assert(!BF3 || (!TRI && (!LM || WS)), "fp16 x 2: pairs and single steps; a limb intermediate only on specialised waves");
     // H2: the big operand's power of two, from the largest element its producer recorded
     float h2_sa = 1.f;
     int h2_exa = 0;
@@ -1098,6 +1103,16 @@ __global__ __launch_bounds__(SW * 64, 1) void stem2_kernel(StemArgs p) {
         dst[8] = (unsigned short)(u1 >> 16);
         dst[16] = (unsigned short)(__builtin_bit_cast(unsigned, r2) >> 16);
     };
+#ifdef CTG_STEM_H2
+    // H2 + LM (specialised waves): x * (the tile's scale) -> its two rounded fp16 limbs at dst[0], dst[8]
+    auto put2 = [&](unsigned short* dst, float x) __attribute__((always_inline)) {
+        const float a = x * h2_st;
+        const _Float16 h = (_Float16)a;
+        const _Float16 l = (_Float16)(a - (float)h);
+        dst[0] = __builtin_bit_cast(unsigned short, h);
+        dst[8] = __builtin_bit_cast(unsigned short, l);
+    };
+#endif
     auto scatter = [&]() __attribute__((always_inline)) {
         if constexpr (LM) {
 #pragma unroll
@@ -1105,8 +1120,13 @@ __global__ __launch_bounds__(SW * 64, 1) void stem2_kernel(StemArgs p) {
                 unsigned short* dst = midq + (mid_lane + mid_rt[m]);
 #pragma unroll
                 for (int t = 0; t < 16; ++t) {
+#ifdef CTG_STEM_H2
+                    put2(dst + mid_t(t), XM1 ? ax[m][t] - axm[m][t] : ax[m][t]);
+                    if (!PACK1) put2(dst + PLS + mid_t(t), ay[m][t]);
+#else
                     put3(dst + mid_t(t), XM1 ? ax[m][t] - axm[m][t] : ax[m][t]);
                     if (!PACK1) put3(dst + PLS + mid_t(t), ay[m][t]);
+#endif
                 }
             }
             return;
@@ -1238,7 +1258,7 @@ __global__ __launch_bounds__(SW * 64, 1) void stem2_kernel(StemArgs p) {
             auto load_frag = [&](Frag& F, int c) __attribute__((always_inline)) {
                 if constexpr (LM) {
 #pragma unroll
-                    for (int q = 0; q < 3; ++q) {
+                    for (int q = 0; q < CTG_STEM_LIMBS; ++q) {
                         F.ar[q] = *(const bf16x8*)(aRq + c * 96 + q * 8);
                         F.ai[q] = *(const bf16x8*)(aRq + PLS + c * 96 + q * 8);
                     }
@@ -1308,7 +1328,7 @@ __global__ __launch_bounds__(SW * 64, 1) void stem2_kernel(StemArgs p) {
                 bf16x8 a3[3], bx3[3];
 #pragma unroll
                 for (int q = 0; q < 3; ++q) {
-                    a3[q] = *(const bf16x8*)(aq + kb * 48 + q * 8);
+                    if (q < CTG_STEM_LIMBS) a3[q] = *(const bf16x8*)(aq + kb * 48 + q * 8);
                     bx3[q] = *(const bf16x8*)(q2x + kb * 24 + q * 8);
                 }
 #pragma unroll
@@ -1532,7 +1552,18 @@ __global__ __launch_bounds__(SW * 64, 1) void stem2_kernel(StemArgs p) {
 #pragma unroll
             for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
             if (lane == 0) bf3_red[h2_par * 8 + wave1] = mx;
-            if constexpr (WS) h2_par ^= 1;   // (specialised waves: only the producers publish, only the consumers consume)
+            if constexpr (WS && !LM) h2_par ^= 1;   // (specialised waves: only the producers publish, only the consumers consume)
+        }
+    };
+    // (limb intermediate on specialised waves: the PRODUCERS split -- after the barrier that follows their publish they
+    // read the tile's largest themselves)
+    auto h2_producer_scale = [&]() __attribute__((always_inline)) {
+        if constexpr (BF3 && !ONE && WS && LM) {
+            float mx = bf3_red[h2_par * 8];
+#pragma unroll
+            for (int w = 1; w < PW; ++w) mx = fmaxf(mx, bf3_red[h2_par * 8 + w]);
+            h2_st = pow2f(-__builtin_amdgcn_readfirstlane(h2_exponent_of(mx)));
+            h2_par ^= 1;
         }
     };
     auto h2_consume = [&]() __attribute__((always_inline)) {
@@ -1549,6 +1580,7 @@ __global__ __launch_bounds__(SW * 64, 1) void stem2_kernel(StemArgs p) {
 #else
     auto h2_publish = [&]() __attribute__((always_inline)) {};
     auto h2_consume = [&]() __attribute__((always_inline)) {};
+    auto h2_producer_scale = [&]() __attribute__((always_inline)) {};
 #endif
     auto tile_c = [&](int64_t g) __attribute__((always_inline)) -> int64_t {
         const int64_t gh = g >> p.g_lo_shift, gl = g & (p.g_lo - 1);
@@ -1603,6 +1635,7 @@ __global__ __launch_bounds__(SW * 64, 1) void stem2_kernel(StemArgs p) {
                     if (t + UI < my_tiles) {
                         h2_publish();
                         CTG_STEM_SYNC();   // the consumers have read tile t - 1's intermediate; tile t's accumulators are complete
+                        h2_producer_scale();
                         scatter();
                         CTG_STEM_SYNC();
                         if (t + UI + 1 < my_tiles) step1(std::integral_constant<int, ((UI + 1) * NT) & (GD - 1)>{});
@@ -2184,16 +2217,23 @@ static int stem2_bf3_form(const StemArgs& p) {
 #if !(CTG_STEM_FORM == 0 || defined(CTG_STEM_FORM_ALL))
     if (form < 1) form = 1;   // (the round-4 form of these shapes exists in experiment builds only)
 #endif
+#if !defined(CTG_STEM_WSLM) || !defined(CTG_STEM_WS)
+    if (form >= 4) form = 3;  // (limb intermediate on specialised waves: -DCTG_STEM_WS -DCTG_STEM_WSLM)
+#endif
 #ifndef CTG_STEM_LM
     if (form == 2) form = 1;  // (the limb intermediate: experiment builds, -DCTG_STEM_LM)
 #endif
 #ifndef CTG_STEM_WS
     if (form == 3) form = 1;  // (specialised waves: experiment builds, -DCTG_STEM_WS)
 #endif
+    // form 4: where step 2 has two or more column groups (every consumer of a row re-splits it otherwise), one item per
+    // consumer wave pair, and the limb planes fit
+    if (form == 4 && !(p.ng2 >= 2 && p.N2 >= 32 && stem2_lds_bytes_lm(p) <= 160 * 1024)) form = 3;
     if (form == 2 && stem2_lds_bytes_lm(p) > 160 * 1024) form = 1;
     const int items = (p.rows2 / 32) * p.ng2, units = (1 << (p.nr1 - 5)) * (p.N1 >= 32 ? p.N1 / 32 : 1);
     // specialised waves: a producer takes two of the symmetric kernel's shares of step 1, a consumer two of step 2 --
     // at most two items per wave there, and one unit per wave unless step 1 has 16 columns (one accumulator per unit)
+    if (form == 4 && !(items <= SW && (p.N1 == 16 || units == SW))) form = 3;
     if (form == 3 && !(items <= 2 * SW && (p.N1 == 16 || units == SW))) form = 1;
     // (... and a consumer with four items of 32 columns keeps three accumulator pairs next to its pending stores: the
     // compiler spills 46-51 registers there -- the symmetric kernel)
@@ -2231,7 +2271,7 @@ void stem2_kernel_name(const StemArgs& p, char* buf, size_t n) {
                      s.nch, s.it2, tf(s.nch <= CTG_STEM_BR1_MAX), tf(s.vec));
         else
             snprintf(buf, n, CTG_STEM_KNAME "<%s,%s,%d,%d,%d,%d,%s,0,%s,true,false,false,0,false,true,%s,%s>", tf(s.p1), tf(s.p2),
-                     s.rt1, s.cs1, s.nch, s.it2, tf(s.nch <= CTG_STEM_BR1_MAX), tf(s.vec), tf(form == 2), tf(form == 3));
+                     s.rt1, s.cs1, s.nch, s.it2, tf(s.nch <= CTG_STEM_BR1_MAX), tf(s.vec), tf(form == 2 || form == 4), tf(form >= 3));
     }
     else if (stem2_variant(p))
         snprintf(buf, n, CTG_STEM_KNAME "<%s,%s,%d,%d,%d,%d,%s,%d,%s,false,%s,false>", tf(s.p1), tf(s.p2), s.rt1, s.cs1, s.nch,
@@ -2288,6 +2328,12 @@ hipError_t launch_stem2(const StemArgs& p, hipStream_t stream) {
 #else
 #define CTG_STEM_GO3_WS(P1, P2, R, CS, NC, IT, V)
 #endif
+#if CTG_STEM_FORM >= 4 && defined(CTG_STEM_WS) && defined(CTG_STEM_WSLM)
+#define CTG_STEM_GO3_WSLM(P1, P2, R, CS, NC, IT, V) \
+        if constexpr (IT <= 2 && (P1 || R == 1) && !P2 && IT < 2) { if (form == 4) return launch_stem2_t<P1, P2, R, CS, NC, IT, (NC <= CTG_STEM_BR1_MAX), 0, V, true, false, true, true, true>(p, stream); }
+#else
+#define CTG_STEM_GO3_WSLM(P1, P2, R, CS, NC, IT, V)
+#endif
 #if CTG_STEM_FORM >= 2 && defined(CTG_STEM_LM)
 #define CTG_STEM_GO3_LM(P1, P2, R, CS, NC, IT, V) \
         if constexpr (IT < 4) { if (form == 2) return launch_stem2_t<P1, P2, R, CS, NC, IT, (NC <= CTG_STEM_BR1_MAX), 0, V, true, false, true, true>(p, stream); }
@@ -2309,6 +2355,7 @@ hipError_t launch_stem2(const StemArgs& p, hipStream_t stream) {
 #endif
 #define CTG_STEM_GO3(P1, P2, R, CS, NC, IT, V)                                                          \
     if (s.p1 == P1 && s.p2 == P2 && s.rt1 == R && s.cs1 == CS && s.nch == NC && s.it2 == IT && s.vec == V) { \
+        CTG_STEM_GO3_WSLM(P1, P2, R, CS, NC, IT, V)                                                     \
         CTG_STEM_GO3_WS(P1, P2, R, CS, NC, IT, V)                                                       \
         CTG_STEM_GO3_LM(P1, P2, R, CS, NC, IT, V)                                                       \
         CTG_STEM_GO3_XM(P1, P2, R, CS, NC, IT, V)                                                       \
