@@ -448,7 +448,8 @@ BF16X3_NOTE = ("fused stem pairs: fp32 operands split exactly into 3 bf16 limbs,
                "v_mfma_f32_32x32x16_bf16, fp32 accumulation (DESIGN 4b: error bound + adversarial tests); every "
                "other step: fp32 MFMA")
 FP16X2_NOTE = ("fused stem pairs: fp32 operands as 2 rounded fp16 limbs under per-tensor power-of-two scales, 3 products on "
-               "v_mfma_f32_32x32x16_f16, fp32 accumulation (DESIGN 4.5); long tiled steps bf16 x 3; every other step fp32 MFMA")
+               "v_mfma_f32_32x32x16_f16, fp32 accumulation (DESIGN 4.5); long tiled steps likewise (DESIGN 4.3; k-split launches: bf16 x 3); "
+               "every other step fp32 MFMA")
 FP32_NOTE = "every step on the fp32 matrix cores (v_mfma_f32_32x32x2_f32: an exact-fp32 multiply-add chain)"
 ARITH_NOTE = {"fp32": FP32_NOTE, "bf16x3": BF16X3_NOTE, "fp16x2": FP16X2_NOTE}
 
@@ -1278,7 +1279,7 @@ def main():
                 "steps_per_slice": len(plan.steps),
                 "parallelism": f"slice-parallel x{world}, 1 RCCL reduce",
                 "arithmetic": {"fp32": "fp32 MFMA", "bf16x3": "bf16x3 stem pairs + fp32 MFMA",
-                               "fp16x2": "fp16x2 stem pairs + bf16x3 long steps + fp32 MFMA"}[arith_run],
+                               "fp16x2": "fp16x2 stem pairs and long tiled steps + fp32 MFMA"}[arith_run],
                 "reduce_via": reduce_via,
                 "partial_amplitude": [float(result.real.item()), float(result.imag.item())]
                 if result.numel() == 1
