@@ -1708,6 +1708,8 @@ int ctg_exec_create(const ctg_plan* p, int device, void* stream, void* ext_resul
     }
     HIP_TRY_E(hipMalloc((void**)&e->d_inputs, p->inputs_elems * isz));
     HIP_TRY_E(hipMalloc((void**)&e->d_arena, p->arena_elems * isz * e->batch));
+    if (env_on("CTG_ARENA_DEBUG"))
+        fprintf(stderr, "arena %p (%lld bytes)\n", e->d_arena, (long long)(p->arena_elems * isz * e->batch));
     if (ext_result) {
         e->d_result = (char*)ext_result;
     } else {
