@@ -23,7 +23,12 @@ keep = []
 for rep in range(int(sys.argv[2]) if len(sys.argv) > 2 else 4):
     if rep in dummies:
         st = ctypes.c_void_p()
-        print("  (dummy hipStreamCreate ->", hip.hipStreamCreate(ctypes.byref(st)), ")", flush=True)
+        rc = hip.hipStreamCreate(ctypes.byref(st))
+        # (used once: a stream is bound to a hardware queue at its first operation)
+        buf = torch.zeros(1024, device="cuda")
+        rc2 = hip.hipMemsetAsync(ctypes.c_void_p(buf.data_ptr()), 0, ctypes.c_size_t(4096), st)
+        rc3 = hip.hipStreamSynchronize(st)
+        print("  (dummy stream, used once ->", rc, rc2, rc3, ")", flush=True)
         keep.append(st)
     fn = HipContractor(tree)
     ex = fn.setup(*dev)["exec"]
