@@ -995,6 +995,63 @@ void* wide_of_step(const ctg_exec* e, int64_t s) {
 }
 
 
+
+// Where the arena lies in physical HBM is worth 2-3 % of a slice of a big tree (profiles/r6_process_alternation.txt: the
+// memory of this part is not uniform, and consecutive allocations of an arena that fills more than a third of it alternate
+// between two physical regions).  A big single-slice arena is therefore allocated TWICE where the memory allows, the
+// ranges of the plan's largest tensors are read once in either copy (a streaming read, timed), and the copy that reads them
+// faster is kept.  CTG_ARENA_PLACE=0: the first allocation, as before.  Results do not depend on it.
+static void place_arena(ctg_exec* e) {
+    const ctg_plan* p = e->plan;
+    const int64_t isz = kItemSize[p->dtype];
+    const int64_t bytes = p->arena_elems * isz * e->batch;
+    if (p->dtype != CTG_C64 || e->batch != 1 || bytes < ((int64_t)32 << 30)) return;
+    if (const char* v = getenv("CTG_ARENA_PLACE"))
+        if (v[0] == '\0' || (v[0] == '0' && v[1] == '\0')) return;
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || (int64_t)free_b < bytes + ((int64_t)8 << 30)) return;
+    // the operands and results of the steps that move the most data
+    std::vector<std::pair<int64_t, std::pair<int64_t, int64_t>>> cand;   // (bytes moved, (offset, elements))
+    for (int64_t s = 0; s < p->n_steps; ++s) {
+        const int64_t* r = &p->steps[s * STEP_WORDS];
+        if (r[W_KIND] != KIND_PAIR && r[W_KIND] != KIND_STEM2) continue;
+        const int64_t moved = r[W_A_SIZE] + r[W_C_SIZE];
+        if (r[W_A_SPACE] == SPACE_ARENA) cand.push_back({moved, {r[W_A_OFF], r[W_A_SIZE]}});
+        if (r[W_C_SPACE] == SPACE_ARENA) cand.push_back({moved, {r[W_C_OFF], r[W_C_SIZE]}});
+    }
+    if (cand.empty()) return;
+    std::sort(cand.begin(), cand.end(), [](const auto& a, const auto& b) { return a.first > b.first; });
+    if (cand.size() > 8) cand.resize(8);
+    char* other = nullptr;
+    float* slot = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    if (hipMalloc((void**)&other, (size_t)bytes) != hipSuccess) { (void)hipGetLastError(); return; }
+    bool ok = hipMalloc((void**)&slot, sizeof(float) * kMaxSub) == hipSuccess && hipEventCreate(&ev0) == hipSuccess &&
+              hipEventCreate(&ev1) == hipSuccess;
+    float ms[2] = {0.f, 0.f};
+    char* base[2] = {e->d_arena, other};
+    for (int pass = 0; ok && pass < 3; ++pass)          // (first pass: untimed; then the two copies in turn, twice)
+        for (int c = 0; ok && c < 2; ++c) {
+            ok = hipMemsetAsync(slot, 0, sizeof(float) * kMaxSub, e->stream) == hipSuccess &&
+                 hipEventRecord(ev0, e->stream) == hipSuccess;
+            for (const auto& q : cand)
+                if (ok) ok = launch_maxabs_f32(base[c] + q.second.first * isz, nullptr, 0, 0, 0, q.second.second, slot, e->stream) == hipSuccess;
+            ok = ok && hipEventRecord(ev1, e->stream) == hipSuccess && hipEventSynchronize(ev1) == hipSuccess;
+            float t = 0.f;
+            if (ok) ok = hipEventElapsedTime(&t, ev0, ev1) == hipSuccess;
+            if (pass > 0) ms[c] += t;
+        }
+    const bool take_other = ok && ms[1] < 0.995f * ms[0];
+    if (env_on("CTG_ARENA_DEBUG"))
+        fprintf(stderr, "arena placement: %d ranges, first copy %.3f ms, second copy %.3f ms -> %s\n", (int)cand.size(), ms[0], ms[1],
+                ok ? (take_other ? "second" : "first") : "probe failed: first");
+    if (take_other) std::swap(e->d_arena, other);
+    (void)hipFree(other);
+    if (slot) (void)hipFree(slot);
+    if (ev0) (void)hipEventDestroy(ev0);
+    if (ev1) (void)hipEventDestroy(ev1);
+}
+
 // a long tiled complex64 step that multiplies on the 16-bit matrix cores right now (MfmaHints::bf3; round 6: such a
 // launch records its result's largest |component| and may run in the fp16 x 2 arithmetic, see launch_step)
 static bool tiled16_step(const ctg_exec* e, int64_t s) {
@@ -1710,6 +1767,7 @@ int ctg_exec_create(const ctg_plan* p, int device, void* stream, void* ext_resul
     HIP_TRY_E(hipMalloc((void**)&e->d_arena, p->arena_elems * isz * e->batch));
     if (env_on("CTG_ARENA_DEBUG"))
         fprintf(stderr, "arena %p (%lld bytes)\n", e->d_arena, (long long)(p->arena_elems * isz * e->batch));
+    place_arena(e);
     if (ext_result) {
         e->d_result = (char*)ext_result;
     } else {
