@@ -126,7 +126,11 @@ int ctg_plan_workspace_bytes(const ctg_plan* plan, int64_t bytes[4]);
 /* Exec: one per GPU.  Owns inputs space, arena, tables; the result buffer is
  * either owned or caller-provided device memory (`ext_result`, e.g. memory a
  * collective library will reduce in place).  Replaces the lazy `setup(*arrays)`
- * of the whole-tree backend (contract.py:883-899). */
+ * of the whole-tree backend (contract.py:883-899).
+ * A single-slice arena of 32 GiB or more is allocated twice where the free device memory allows
+ * (peak: twice its size for a moment), the plan's largest tensors' ranges are read in both copies and
+ * the faster copy is kept -- physical placement in HBM is worth 2-3 % of a slice on MI355X
+ * (profiles/r6_process_alternation.txt); results do not depend on it.  CTG_ARENA_PLACE=0: off. */
 int ctg_exec_create(const ctg_plan* plan, int device, void* stream,
                     void* ext_result, ctg_exec** out);
 int ctg_exec_destroy(ctg_exec* exec);
