@@ -1009,7 +1009,10 @@ static void place_arena(ctg_exec* e) {
     if (const char* v = getenv("CTG_ARENA_PLACE"))
         if (v[0] == '\0' || (v[0] == '0' && v[1] == '\0')) return;
     size_t free_b = 0, total_b = 0;
-    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || (int64_t)free_b < bytes + ((int64_t)8 << 30)) return;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) return;
+    // (an arena that does not fit twice -- 169 GiB of 288 -- is tried one allocation after the other: a freed arena is not
+    // what the next hipMalloc of its size gets, the allocator alternates between the two regions)
+    const bool side_by_side = (int64_t)free_b >= bytes + ((int64_t)8 << 30);
     // the operands and results of the steps that move the most data
     std::vector<std::pair<int64_t, std::pair<int64_t, int64_t>>> cand;   // (bytes moved, (offset, elements))
     for (int64_t s = 0; s < p->n_steps; ++s) {
@@ -1022,31 +1025,65 @@ static void place_arena(ctg_exec* e) {
     if (cand.empty()) return;
     std::sort(cand.begin(), cand.end(), [](const auto& a, const auto& b) { return a.first > b.first; });
     if (cand.size() > 8) cand.resize(8);
-    char* other = nullptr;
     float* slot = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    if (hipMalloc((void**)&other, (size_t)bytes) != hipSuccess) { (void)hipGetLastError(); return; }
     bool ok = hipMalloc((void**)&slot, sizeof(float) * kMaxSub) == hipSuccess && hipEventCreate(&ev0) == hipSuccess &&
               hipEventCreate(&ev1) == hipSuccess;
+    // one timed reading of the ranges in the copy at `base` (ms; < 0: failed)
+    auto probe = [&](char* base) -> float {
+        bool good = hipMemsetAsync(slot, 0, sizeof(float) * kMaxSub, e->stream) == hipSuccess &&
+                    hipEventRecord(ev0, e->stream) == hipSuccess;
+        for (const auto& q : cand)
+            if (good) good = launch_maxabs_f32(base + q.second.first * isz, nullptr, 0, 0, 0, q.second.second, slot, e->stream) == hipSuccess;
+        good = good && hipEventRecord(ev1, e->stream) == hipSuccess && hipEventSynchronize(ev1) == hipSuccess;
+        float t = 0.f;
+        if (good) good = hipEventElapsedTime(&t, ev0, ev1) == hipSuccess;
+        return good ? t : -1.f;
+    };
     float ms[2] = {0.f, 0.f};
-    char* base[2] = {e->d_arena, other};
-    for (int pass = 0; ok && pass < 3; ++pass)          // (first pass: untimed; then the two copies in turn, twice)
-        for (int c = 0; ok && c < 2; ++c) {
-            ok = hipMemsetAsync(slot, 0, sizeof(float) * kMaxSub, e->stream) == hipSuccess &&
-                 hipEventRecord(ev0, e->stream) == hipSuccess;
-            for (const auto& q : cand)
-                if (ok) ok = launch_maxabs_f32(base[c] + q.second.first * isz, nullptr, 0, 0, 0, q.second.second, slot, e->stream) == hipSuccess;
-            ok = ok && hipEventRecord(ev1, e->stream) == hipSuccess && hipEventSynchronize(ev1) == hipSuccess;
-            float t = 0.f;
-            if (ok) ok = hipEventElapsedTime(&t, ev0, ev1) == hipSuccess;
-            if (pass > 0) ms[c] += t;
+    const char* verdict = "first";
+    if (ok && side_by_side) {
+        char* other = nullptr;
+        if (hipMalloc((void**)&other, (size_t)bytes) == hipSuccess) {
+            char* base[2] = {e->d_arena, other};
+            for (int pass = 0; ok && pass < 3; ++pass)          // (first pass: untimed; then the two copies in turn, twice)
+                for (int c = 0; ok && c < 2; ++c) {
+                    const float t = probe(base[c]);
+                    ok = t >= 0.f;
+                    if (pass > 0) ms[c] += t;
+                }
+            if (ok && ms[1] < 0.995f * ms[0]) {
+                std::swap(e->d_arena, other);
+                verdict = "second";
+            }
+            (void)hipFree(other);
+        } else {
+            (void)hipGetLastError();
         }
-    const bool take_other = ok && ms[1] < 0.995f * ms[0];
+    } else if (ok) {
+        // one after the other: first (probe), free, second (probe); back to the first's region by a third allocation if
+        // that one read faster
+        auto timed = [&](char* base) { float t = probe(base); if (t >= 0.f) { const float a = probe(base), b = probe(base); t = (a >= 0.f && b >= 0.f) ? a + b : -1.f; } return t; };
+        ms[0] = timed(e->d_arena);
+        char* again = nullptr;
+        if (ms[0] >= 0.f && hipFree(e->d_arena) == hipSuccess) {
+            e->d_arena = nullptr;
+            if (hipMalloc((void**)&again, (size_t)bytes) == hipSuccess) {
+                e->d_arena = again;
+                ms[1] = timed(e->d_arena);
+                verdict = "second";
+                if (ms[1] >= 0.f && ms[0] < 0.995f * ms[1] && hipFree(e->d_arena) == hipSuccess) {
+                    e->d_arena = nullptr;
+                    if (hipMalloc((void**)&again, (size_t)bytes) == hipSuccess) e->d_arena = again;
+                    verdict = "third (the first's region)";
+                }
+            }
+        }
+    }
     if (env_on("CTG_ARENA_DEBUG"))
-        fprintf(stderr, "arena placement: %d ranges, first copy %.3f ms, second copy %.3f ms -> %s\n", (int)cand.size(), ms[0], ms[1],
-                ok ? (take_other ? "second" : "first") : "probe failed: first");
-    if (take_other) std::swap(e->d_arena, other);
-    (void)hipFree(other);
+        fprintf(stderr, "arena placement (%s): %d ranges, first %.3f ms, second %.3f ms -> %s, arena %p\n",
+                side_by_side ? "side by side" : "one after the other", (int)cand.size(), ms[0], ms[1], ok ? verdict : "probe failed",
+                e->d_arena);
     if (slot) (void)hipFree(slot);
     if (ev0) (void)hipEventDestroy(ev0);
     if (ev1) (void)hipEventDestroy(ev1);
@@ -1768,6 +1805,7 @@ int ctg_exec_create(const ctg_plan* p, int device, void* stream, void* ext_resul
     if (env_on("CTG_ARENA_DEBUG"))
         fprintf(stderr, "arena %p (%lld bytes)\n", e->d_arena, (long long)(p->arena_elems * isz * e->batch));
     place_arena(e);
+    if (e->d_arena == nullptr) HIP_TRY_E(hipMalloc((void**)&e->d_arena, p->arena_elems * isz * e->batch));   // (a failed re-allocation)
     if (ext_result) {
         e->d_result = (char*)ext_result;
     } else {
