@@ -1005,14 +1005,16 @@ static void place_arena(ctg_exec* e) {
     const ctg_plan* p = e->plan;
     const int64_t isz = kItemSize[p->dtype];
     const int64_t bytes = p->arena_elems * isz * e->batch;
-    if (p->dtype != CTG_C64 || e->batch != 1 || bytes < ((int64_t)32 << 30)) return;
+    // (tests: CTG_ARENA_PLACE_MIN = smallest arena in bytes, CTG_ARENA_PLACE_SEQ=1 = one allocation after the other)
+    const int64_t min_bytes = getenv("CTG_ARENA_PLACE_MIN") ? atoll(getenv("CTG_ARENA_PLACE_MIN")) : ((int64_t)32 << 30);
+    if (p->dtype != CTG_C64 || e->batch != 1 || bytes < min_bytes) return;
     if (const char* v = getenv("CTG_ARENA_PLACE"))
         if (v[0] == '\0' || (v[0] == '0' && v[1] == '\0')) return;
     size_t free_b = 0, total_b = 0;
     if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) return;
     // (an arena that does not fit twice -- 169 GiB of 288 -- is tried one allocation after the other: a freed arena is not
     // what the next hipMalloc of its size gets, the allocator alternates between the two regions)
-    const bool side_by_side = (int64_t)free_b >= bytes + ((int64_t)8 << 30);
+    const bool side_by_side = (int64_t)free_b >= bytes + ((int64_t)8 << 30) && !env_on("CTG_ARENA_PLACE_SEQ");
     // the operands and results of the steps that move the most data
     std::vector<std::pair<int64_t, std::pair<int64_t, int64_t>>> cand;   // (bytes moved, (offset, elements))
     for (int64_t s = 0; s < p->n_steps; ++s) {

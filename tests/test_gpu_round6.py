@@ -575,3 +575,32 @@ def test_batched_tiled_steps_scale_every_slice_by_its_own_record(monkeypatch):
         ref = sum(a[i].astype("complex128") @ b.astype("complex128") for i in range(ids[0], ids[0] + ids[1]))
         assert G.relerr(got, ref) <= 2e-6
     fn.close()
+
+
+@pytest.mark.parametrize("mode", ["side_by_side", "one_after_the_other"])
+def test_arena_placement_does_not_change_a_bit(mode, monkeypatch, capfd):
+    """A big single-slice arena is allocated twice (or, where it does not fit twice, one allocation after the other) and
+    the copy that reads the plan's largest tensors faster is kept (ctg_runtime.hip: place_arena).  With the size threshold
+    lowered to a small tree: the probe runs, an arena comes out of it, and the result is the same bits as without it."""
+    rec = ca.load_network(os.path.join(ROOT, "tests", "golden", "trees", "sycamore_m10.json"))
+    z = np.load(os.path.join(ROOT, "tests", "golden", "sycamore_m10_arrays.npz"))
+    monkeypatch.setenv("CTG_SLICE_BATCH", "1")
+    outs = {}
+    for place in ("0", "1"):
+        monkeypatch.setenv("CTG_ARENA_PLACE", place)
+        monkeypatch.setenv("CTG_ARENA_PLACE_MIN", "1024")
+        monkeypatch.setenv("CTG_ARENA_DEBUG", "1")
+        if mode == "one_after_the_other":
+            monkeypatch.setenv("CTG_ARENA_PLACE_SEQ", "1")
+        tree = ca.tree_from_record(rec)
+        xs = [z[f"t{i}"].astype("complex64") for i in range(tree.N)]
+        fn = HipContractor(tree)
+        outs[place] = complex(np.asarray(fn(*xs)))
+        fn.close()
+        err = capfd.readouterr().err
+        assert ("arena placement" in err) == (place == "1"), err
+        if place == "1":
+            assert ("side by side" if mode == "side_by_side" else "one after the other") in err and "probe failed" not in err, err
+    assert outs["0"] == outs["1"]
+    ref = complex(np.load(os.path.join(ROOT, "tests", "golden", "sycamore_m10_expected.npz"))["amplitude"])
+    assert abs(outs["1"] - ref) <= 1e-5 * abs(ref)
